@@ -1,0 +1,235 @@
+"""ctypes wrapper around oracle/libredmax_oracle.so (the CPU restatement of the reference).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from redmax_amd/ (the product).  See redmax_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libredmax_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class _Desc(C.Structure):
+    _fields_ = [
+        ("njoints", C.c_int),
+        ("parent", _ip), ("type", _ip),
+        ("axis", _dp), ("E0_pj", _dp), ("E0_ji", _dp), ("I_i", _dp),
+        ("q", _dp), ("qdot", _dp), ("tau", _dp), ("stiffness", _dp), ("damping", _dp),
+        ("qLimL", _dp), ("qLimU", _dp), ("qLimK", _dp), ("qLimD", _dp),
+        ("grav", C.c_double * 3),
+        ("normalize_axis", C.c_int),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("newton_iters", C.c_int), ("ls_halvings", C.c_int), ("residual_evals", C.c_int),
+                ("hessian_evals", C.c_int), ("diverged", C.c_int), ("not_converged", C.c_int)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "redmax_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(_Desc)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        for f in ("orc_nr", "orc_nm"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_int
+        L.orc_idxR.argtypes = [C.c_void_p, _ip]
+        L.orc_reset.argtypes = [C.c_void_p]
+        L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_set_state.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_set_qrest.argtypes = [C.c_void_p, _dp]
+        L.orc_energy.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_jacobian.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.orc_compute_values.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        L.orc_eval_residual.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, _dp, _dp]
+        L.orc_step_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(Stats), _dp, _dp]
+        L.orc_step_bdf2.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.POINTER(Stats), _dp, _dp]
+        L.orc_step_euler_simple.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp]
+        L.orc_batch_step_bdf1.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int]
+        L.orc_batch_step_bdf1.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def make_desc(d, normalize_axis=1):
+    """d: the dict produced by redmax_amd.redmax.Scene.desc(). Returns (struct, keepalive)."""
+    keep = {}
+
+    def f64(k):
+        keep[k] = np.ascontiguousarray(d[k], dtype=np.float64)
+        return keep[k].ctypes.data_as(_dp)
+
+    def i32(k):
+        keep[k] = np.ascontiguousarray(d[k], dtype=np.int32)
+        return keep[k].ctypes.data_as(_ip)
+
+    s = _Desc()
+    s.njoints = int(d["njoints"])
+    s.parent, s.type = i32("parent"), i32("type")
+    for k in ("axis", "E0_pj", "E0_ji", "I_i", "q", "qdot", "tau", "stiffness", "damping", "qLimL", "qLimU", "qLimK", "qLimD"):
+        setattr(s, k, f64(k))
+    for i in range(3):
+        s.grav[i] = float(d["grav"][i])
+    s.normalize_axis = normalize_axis
+    return s, keep
+
+
+class Oracle:
+    """One reference scene on the CPU oracle."""
+
+    def __init__(self, desc_dict, normalize_axis=1):
+        self._L = lib()
+        self._d, self._keep = make_desc(desc_dict, normalize_axis)
+        self._h = C.c_void_p(self._L.orc_create(C.byref(self._d)))
+        self.nr = self._L.orc_nr(self._h)
+        self.nm = self._L.orc_nm(self._h)
+        if "qRest" in desc_dict:
+            self.set_qrest_joint_order(desc_dict["qRest"])
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.orc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def idxR(self):
+        a = np.zeros(self._d.njoints, dtype=np.int32)
+        self._L.orc_idxR(self._h, a.ctypes.data_as(_ip))
+        return a
+
+    def set_qrest_joint_order(self, qrest_per_joint):
+        idx = self.idxR()
+        r = np.zeros(max(self.nr, 1))
+        for i, k in enumerate(idx):
+            if k >= 0:
+                r[k] = qrest_per_joint[i]
+        self._L.orc_set_qrest(self._h, _p(r))
+
+    def reset(self):
+        self._L.orc_reset(self._h)
+
+    def get_state(self):
+        q = np.zeros(self.nr)
+        qd = np.zeros(self.nr)
+        self._L.orc_get_state(self._h, _p(q), _p(qd))
+        return q, qd
+
+    def set_state(self, q, qdot):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        qdot = np.ascontiguousarray(qdot, dtype=np.float64)
+        self._L.orc_set_state(self._h, _p(q), _p(qdot))
+
+    def energy(self):
+        T = C.c_double()
+        V = C.c_double()
+        self._L.orc_energy(self._h, C.byref(T), C.byref(V))
+        return T.value, V.value
+
+    def jacobian(self, deriv=False):
+        nm, nr = self.nm, self.nr
+        J = np.zeros(nm * nr)
+        Jd = np.zeros(nm * nr)
+        if deriv:
+            dJ = np.zeros(nm * nr * nr)
+            dJd = np.zeros(nm * nr * nr)
+            self._L.orc_jacobian(self._h, _p(J), _p(Jd), _p(dJ), _p(dJd))
+            return (J.reshape((nm, nr), order="F"), Jd.reshape((nm, nr), order="F"),
+                    dJ.reshape((nm, nr, nr), order="F"), dJd.reshape((nm, nr, nr), order="F"))
+        self._L.orc_jacobian(self._h, _p(J), _p(Jd), None, None)
+        return J.reshape((nm, nr), order="F"), Jd.reshape((nm, nr), order="F")
+
+    def compute_values(self, deriv=True):
+        nr = self.nr
+        M = np.zeros(nr * nr)
+        f = np.zeros(nr)
+        if not deriv:
+            self._L.orc_compute_values(self._h, _p(M), _p(f), None, None, None)
+            return M.reshape((nr, nr), order="F"), f
+        dM = np.zeros(nr * nr * nr)
+        K = np.zeros(nr * nr)
+        D = np.zeros(nr * nr)
+        self._L.orc_compute_values(self._h, _p(M), _p(f), _p(dM), _p(K), _p(D))
+        return (M.reshape((nr, nr), order="F"), f, dM.reshape((nr, nr, nr), order="F"),
+                K.reshape((nr, nr), order="F"), D.reshape((nr, nr), order="F"))
+
+    def eval_residual(self, q, qA, qB, eta, want_H=True):
+        nr = self.nr
+        q, qA, qB = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, qA, qB))
+        g = np.zeros(nr)
+        if want_H:
+            H = np.zeros(nr * nr)
+            self._L.orc_eval_residual(self._h, _p(q), _p(qA), _p(qB), float(eta), _p(g), _p(H))
+            return g, H.reshape((nr, nr), order="F")
+        self._L.orc_eval_residual(self._h, _p(q), _p(qA), _p(qB), float(eta), _p(g), None)
+        return g
+
+    def eval_bdf1(self, q1, q0, qdot0, h, want_H=True):
+        """evalBDF1 (driverRedMaxBDF1.m:160-187)."""
+        q0 = np.asarray(q0, dtype=np.float64)
+        return self.eval_residual(q1, q0, q0 + h * np.asarray(qdot0, dtype=np.float64), h, want_H)
+
+    def step_bdf1(self, h, nsteps, history=False):
+        st = Stats()
+        if history:
+            T = np.zeros(nsteps)
+            V = np.zeros(nsteps)
+            self._L.orc_step_bdf1(self._h, float(h), int(nsteps), C.byref(st), _p(T), _p(V))
+            return st, T, V
+        self._L.orc_step_bdf1(self._h, float(h), int(nsteps), C.byref(st), None, None)
+        return st
+
+    def step_bdf2(self, h, nsteps, step0=0, history=False):
+        st = Stats()
+        if history:
+            T = np.zeros(nsteps)
+            V = np.zeros(nsteps)
+            self._L.orc_step_bdf2(self._h, float(h), int(step0), int(nsteps), C.byref(st), _p(T), _p(V))
+            return st, T, V
+        self._L.orc_step_bdf2(self._h, float(h), int(step0), int(nsteps), C.byref(st), None, None)
+        return st
+
+    def step_euler_simple(self, h, nsteps):
+        T = np.zeros(nsteps)
+        V = np.zeros(nsteps)
+        self._L.orc_step_euler_simple(self._h, float(h), int(nsteps), _p(T), _p(V))
+        return T, V
+
+
+def batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0):
+    """B independent rollouts on the host cores (OpenMP over trajectories): the cpu_baseline leg.
+    q, qdot: [B][nr] arrays, updated in place.  Returns total Newton iterations."""
+    L = lib()
+    d, keep = make_desc(desc_dict)
+    assert q.flags.c_contiguous and qdot.flags.c_contiguous and q.dtype == np.float64
+    # qRest: the batch helper takes it from the descriptor's q (model constant)
+    return int(L.orc_batch_step_bdf1(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads)))

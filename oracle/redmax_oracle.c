@@ -1,0 +1,920 @@
+/*
+ * redmax_oracle.c -- CPU restatement (plain C, fp64, single trajectory) of the
+ * sueda/redmax matlab-diff BDF1/BDF2 forward-dynamics path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see redmax_oracle.h).  Literal restatement: same data
+ * flow as the reference .m files, including the dense dJ/dq, dJdot/dq tensors and the
+ * O(n^3) ancestor loops of Joint.computeJacobian.  The only liberty taken is that the
+ * block-diagonal maximal matrices Mm/Km/Dm are multiplied block-wise and exact-zero
+ * tensor entries are skipped (adds of exact zeros are omitted; values are unchanged).
+ *
+ * Reference files restated (paths relative to /root/reference/):
+ *   matlab-diff/se3.m, matlab-diff/+redmax/{Scene,Joint,JointRevolute,JointPrismatic,
+ *   JointFixed,Body,BodyCuboid}.m, matlab-diff/driverRedMaxBDF1.m, driverRedMaxBDF2.m,
+ *   matlab-simple/testRedMax.m (euler) with matlab-simple/+redmax/{Joint,Body}.m.
+ *
+ * Internal matrices are row-major C arrays; everything crossing the API is
+ * column-major (MATLAB layout).
+ */
+#include "redmax_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef double m4[4][4];
+typedef double m6[6][6];
+typedef double v6[6];
+
+/* ------------------------------------------------------------------ se3.m */
+
+static void m4_eye(m4 E) { memset(E, 0, sizeof(m4)); for (int i = 0; i < 4; i++) E[i][i] = 1.0; }
+static void m4_copy(m4 D, const m4 S) { memcpy(D, S, sizeof(m4)); }
+static void m4_mul(m4 C, const m4 A, const m4 B) {
+    m4 T;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        double s = 0; for (int k = 0; k < 4; k++) s += A[i][k] * B[k][j]; T[i][j] = s;
+    }
+    memcpy(C, T, sizeof(m4));
+}
+static void m6_zero(m6 A) { memset(A, 0, sizeof(m6)); }
+static void m6_mul(m6 C, const m6 A, const m6 B) {
+    m6 T;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+        double s = 0; for (int k = 0; k < 6; k++) s += A[i][k] * B[k][j]; T[i][j] = s;
+    }
+    memcpy(C, T, sizeof(m6));
+}
+static void m6_mulv(v6 y, const m6 A, const v6 x) {
+    v6 t;
+    for (int i = 0; i < 6; i++) { double s = 0; for (int k = 0; k < 6; k++) s += A[i][k] * x[k]; t[i] = s; }
+    memcpy(y, t, sizeof(v6));
+}
+
+/* se3.inv  (se3.m:11-16) */
+static void se3_inv(m4 Ei, const m4 E) {
+    m4 T; m4_eye(T);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i][j] = E[j][i];
+    for (int i = 0; i < 3; i++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += E[k][i] * E[k][3];
+        T[i][3] = -s;
+    }
+    memcpy(Ei, T, sizeof(m4));
+}
+/* se3.brac, 3-vector form (se3.m:89-98) */
+static void se3_brac3(double S[3][3], const double x[3]) {
+    S[0][0] = 0;     S[0][1] = -x[2]; S[0][2] = x[1];
+    S[1][0] = x[2];  S[1][1] = 0;     S[1][2] = -x[0];
+    S[2][0] = -x[1]; S[2][1] = x[0];  S[2][2] = 0;
+}
+/* se3.Ad (se3.m:44-52) */
+static void se3_Ad(m6 A, const m4 E) {
+    double pb[3][3], p[3] = { E[0][3], E[1][3], E[2][3] };
+    m6_zero(A);
+    se3_brac3(pb, p);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        A[i][j] = E[i][j];
+        A[3 + i][3 + j] = E[i][j];
+        double s = 0; for (int k = 0; k < 3; k++) s += pb[i][k] * E[k][j];
+        A[3 + i][j] = s;
+    }
+}
+/* se3.ad, 6-vector form (se3.m:55-69) */
+static void se3_ad(m6 a, const v6 phi) {
+    double W[3][3], Vb[3][3];
+    m6_zero(a);
+    se3_brac3(W, phi); se3_brac3(Vb, phi + 3);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        a[i][j] = W[i][j]; a[3 + i][j] = Vb[i][j]; a[3 + i][3 + j] = W[i][j];
+    }
+}
+/* se3.Addot (se3.m:72-86) */
+static void se3_Addot(m6 dA, const m4 E, const v6 phi) {
+    double wb[3][3], vb[3][3], pb[3][3], Rw[3][3];
+    double p[3] = { E[0][3], E[1][3], E[2][3] };
+    m6_zero(dA);
+    se3_brac3(wb, phi); se3_brac3(vb, phi + 3); se3_brac3(pb, p);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += E[i][k] * wb[k][j]; Rw[i][j] = s;
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        dA[i][j] = Rw[i][j]; dA[3 + i][3 + j] = Rw[i][j];
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += E[i][k] * vb[k][j] + pb[i][k] * Rw[k][j];
+        dA[3 + i][j] = s;
+    }
+}
+/* se3.aaToMat (se3.m:111-176), THRESH = 1e-9 (se3.m:5) */
+static void se3_aaToMat(double R[3][3], const double axis[3], double angle) {
+    const double THRESH = 1e-9;
+    double ax = axis[0], ay = axis[1], az = axis[2];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = (i == j);
+    double mag = sqrt(ax * ax + ay * ay + az * az);
+    if (mag > THRESH) {
+        mag = 1.0 / mag; ax *= mag; ay *= mag; az *= mag;
+        if (fabs(ax) < THRESH && fabs(ay) < THRESH) {          /* about Z */
+            if (az < 0) angle = -angle;
+            double s = sin(angle), c = cos(angle);
+            R[0][0] = c; R[0][1] = -s; R[1][0] = s; R[1][1] = c;
+        } else if (fabs(ay) < THRESH && fabs(az) < THRESH) {   /* about X */
+            if (ax < 0) angle = -angle;
+            double s = sin(angle), c = cos(angle);
+            R[1][1] = c; R[1][2] = -s; R[2][1] = s; R[2][2] = c;
+        } else if (fabs(az) < THRESH && fabs(ax) < THRESH) {   /* about Y */
+            if (ay < 0) angle = -angle;
+            double s = sin(angle), c = cos(angle);
+            R[0][0] = c; R[0][2] = s; R[2][0] = -s; R[2][2] = c;
+        } else {                                               /* general */
+            double s = sin(angle), c = cos(angle), t = 1.0 - c;
+            double xz = ax * az, xy = ax * ay, yz = ay * az;
+            R[0][0] = t * ax * ax + c;  R[0][1] = t * xy - s * az;  R[0][2] = t * xz + s * ay;
+            R[1][0] = t * xy + s * az;  R[1][1] = t * ay * ay + c;  R[1][2] = t * yz - s * ax;
+            R[2][0] = t * xz - s * ay;  R[2][1] = t * yz + s * ax;  R[2][2] = t * az * az + c;
+        }
+    }
+}
+
+/* ------------------------------------------------------------ scene state */
+
+typedef struct {
+    /* constants */
+    int parent, type, ndof, idxR, idxM;
+    double axis[3];
+    int has_E0_pj;
+    m4 E0_pj, E0_jp;            /* Joint.setJointTransform Joint.m:95-99 */
+    m4 E0_ji, E0_ij; m6 A0_ij;  /* Body.setBodyTransform  Body.m:46-51  */
+    double I_i[6];
+    double tau, stiffness, damping, qRest, qLimL, qLimU, qLimK, qLimD;
+    /* state */
+    double q, qdot, q0, qdot0, q1, qdot1;
+    /* Joint.update outputs */
+    m4 Q, invQ, E_pj, E_jp, E_wj;
+    m6 A, Adot, dAdq, dAdotdq, invA, A_jp;
+    v6 S, V;
+    /* Body.update outputs */
+    m4 E_wi, E_iw; v6 phi;
+    /* matlab-simple extras */
+    m6 Ad_wi, Ad_iw, Ad_ip, Addot_wi;
+} onode;
+
+struct orc_scene {
+    int n, nr, nm;
+    int normalize_axis;
+    double grav[3];
+    onode* nd;
+    double* qInit; double* qdotInit;
+    double T0, V0;
+    /* workspaces */
+    double *J, *Jdot, *dJdq, *dJdotdq;   /* col-major nm x nr (x nr) */
+    double *Mm, *Km, *Dm;                /* n blocks of 36 (row-major 6x6), in idxM/6 order */
+    double *fm;                          /* nm */
+    double *fr, *Kr, *Dr;                /* nr, nr (diagonals)      */
+};
+
+#define JX(s, r, c) ((s)->J[(size_t)(c) * (s)->nm + (r)])
+#define JDX(s, r, c) ((s)->Jdot[(size_t)(c) * (s)->nm + (r)])
+#define T3(p, s, r, c, k) ((p)[((size_t)(k) * (s)->nr + (c)) * (s)->nm + (r)])
+
+static void cm16_to_m4(m4 E, const double* cm) { for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) E[i][j] = cm[j * 4 + i]; }
+
+int orc_nr(const orc_scene* s) { return s->nr; }
+int orc_nm(const orc_scene* s) { return s->nm; }
+void orc_idxR(const orc_scene* s, int* idx) { for (int i = 0; i < s->n; i++) idx[i] = s->nd[i].ndof ? s->nd[i].idxR : -1; }
+
+/* JointRevolute.update_ (JointRevolute.m:29-53), JointPrismatic.update_ (JointPrismatic.m:28-42),
+ * JointFixed (no update_: Q=I, A=I, Adot=0). */
+static void joint_update_(orc_scene* s, onode* j) {
+    (void)s;
+    m4_eye(j->Q);
+    m6_zero(j->A); for (int i = 0; i < 6; i++) j->A[i][i] = 1.0;
+    m6_zero(j->Adot); m6_zero(j->dAdq); m6_zero(j->dAdotdq);
+    for (int i = 0; i < 6; i++) j->S[i] = 0.0;
+    if (j->type == ORC_JOINT_REVOLUTE) {
+        double R[3][3], ab[3][3], dRdq[3][3], d2R[3][3];
+        se3_aaToMat(R, j->axis, j->q);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) j->Q[a][b] = R[a][b];
+        se3_Ad(j->A, j->Q);
+        for (int a = 0; a < 3; a++) j->S[a] = j->axis[a];
+        se3_brac3(ab, j->axis);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            double t = 0; for (int k = 0; k < 3; k++) t += R[a][k] * ab[k][b]; dRdq[a][b] = t;
+        }
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            double t = 0; for (int k = 0; k < 3; k++) t += dRdq[a][k] * ab[k][b]; d2R[a][b] = t;
+        }
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            double Rdot = dRdq[a][b] * j->qdot;
+            j->Adot[a][b] = Rdot; j->Adot[3 + a][3 + b] = Rdot;
+            j->dAdq[a][b] = dRdq[a][b]; j->dAdq[3 + a][3 + b] = dRdq[a][b];
+            double t = d2R[a][b] * j->qdot;
+            j->dAdotdq[a][b] = t; j->dAdotdq[3 + a][3 + b] = t;
+        }
+    } else if (j->type == ORC_JOINT_PRISMATIC) {
+        double ab[3][3];
+        for (int a = 0; a < 3; a++) j->Q[a][3] = j->axis[a] * j->q;
+        se3_Ad(j->A, j->Q);
+        for (int a = 0; a < 3; a++) j->S[3 + a] = j->axis[a];
+        se3_brac3(ab, j->axis);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            j->Adot[3 + a][b] = ab[a][b] * j->qdot;
+            j->dAdq[3 + a][b] = ab[a][b];
+        }
+    }
+}
+
+/* Joint.update (Joint.m:382-434) + Body.update (Body.m:70-80); the extra Ad_* fields are the
+ * matlab-simple Body.update additions (matlab-simple/+redmax/Body.m:89-104). */
+static void scene_update(orc_scene* s) {
+    for (int i = 0; i < s->n; i++) {
+        onode* j = &s->nd[i];
+        joint_update_(s, j);
+        se3_inv(j->invQ, j->Q);
+        se3_Ad(j->invA, j->invQ);
+        if (!j->has_E0_pj) m4_copy(j->E_pj, j->Q); else m4_mul(j->E_pj, j->E0_pj, j->Q);
+        se3_inv(j->E_jp, j->E_pj);
+        se3_Ad(j->A_jp, j->E_jp);
+        if (j->parent < 0) m4_copy(j->E_wj, j->E_pj);
+        else m4_mul(j->E_wj, s->nd[j->parent].E_wj, j->E_pj);
+        for (int a = 0; a < 6; a++) j->V[a] = j->ndof ? j->S[a] * j->qdot : 0.0;
+        if (j->parent >= 0) {
+            v6 t; m6_mulv(t, j->A_jp, s->nd[j->parent].V);
+            for (int a = 0; a < 6; a++) j->V[a] += t[a];
+        }
+        /* Body.update */
+        m4_mul(j->E_wi, j->E_wj, j->E0_ji);
+        se3_inv(j->E_iw, j->E_wi);
+        m6_mulv(j->phi, j->A0_ij, j->V);
+        /* matlab-simple extras */
+        se3_Ad(j->Ad_wi, j->E_wi);
+        se3_Ad(j->Ad_iw, j->E_iw);
+        if (j->parent >= 0) { m4 E_ip; m4_mul(E_ip, j->E_iw, s->nd[j->parent].E_wi); se3_Ad(j->Ad_ip, E_ip); }
+        se3_Addot(j->Addot_wi, j->E_wi, j->phi);
+    }
+}
+
+/* Joint.computeEnergies (Joint.m:616-637) + Body.computeEnergies (Body.m:167-173) */
+void orc_energy(const orc_scene* s, double* T, double* V) {
+    double t = 0, v = 0;
+    for (int i = 0; i < s->n; i++) {
+        const onode* j = &s->nd[i];
+        double tt = 0; for (int a = 0; a < 6; a++) tt += j->phi[a] * j->I_i[a] * j->phi[a];
+        t += 0.5 * tt;
+        double gp = 0; for (int a = 0; a < 3; a++) gp += s->grav[a] * j->E_wi[a][3];
+        v -= j->I_i[5] * gp;
+        if (j->ndof) {
+            double dq = j->q - j->qRest;
+            v += 0.5 * j->stiffness * (dq * dq);
+            double dqL = (j->q < j->qLimL) ? (j->qLimL - j->q) : 0.0;
+            double dqU = (j->q > j->qLimU) ? (j->qLimU - j->q) : 0.0;
+            v += 0.5 * j->qLimK * (dqL * dqL + dqU * dqU);
+        }
+    }
+    *T = t; *V = v;
+}
+
+void orc_get_state(const orc_scene* s, double* q, double* qdot) {
+    for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) {
+        if (q) q[s->nd[i].idxR] = s->nd[i].q;
+        if (qdot) qdot[s->nd[i].idxR] = s->nd[i].qdot;
+    }
+}
+static void set_q(orc_scene* s, const double* q, const double* qdot) {
+    for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) {
+        if (q) s->nd[i].q = q[s->nd[i].idxR];
+        if (qdot) s->nd[i].qdot = qdot[s->nd[i].idxR];
+    }
+}
+void orc_set_state(orc_scene* s, const double* q, const double* qdot) { set_q(s, q, qdot); scene_update(s); }
+void orc_set_qrest(orc_scene* s, const double* qrest) {
+    for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) s->nd[i].qRest = qrest[s->nd[i].idxR];
+}
+
+/* Scene.reset (Scene.m:122-131) */
+void orc_reset(orc_scene* s) {
+    set_q(s, s->qInit, s->qdotInit);
+    scene_update(s);   /* the reference relies on init()'s update(); restated explicitly so reset is re-usable */
+    orc_energy(s, &s->T0, &s->V0);
+}
+
+/* Scene.init (Scene.m:59-119), Joint.countDofs (Joint.m:149-158), Body.countDofs (Body.m:54-60) */
+orc_scene* orc_create(const orc_desc* d) {
+    orc_scene* s = (orc_scene*)calloc(1, sizeof(orc_scene));
+    int n = d->njoints;
+    s->n = n; s->normalize_axis = d->normalize_axis;
+    memcpy(s->grav, d->grav, sizeof(s->grav));
+    s->nd = (onode*)calloc((size_t)n, sizeof(onode));
+    for (int i = 0; i < n; i++) {
+        onode* j = &s->nd[i];
+        j->parent = d->parent[i]; j->type = d->type[i];
+        j->ndof = (j->type == ORC_JOINT_FIXED) ? 0 : 1;
+        double ax[3] = { d->axis[3 * i], d->axis[3 * i + 1], d->axis[3 * i + 2] };
+        if (d->normalize_axis && j->ndof) {    /* JointRevolute.m:14, JointPrismatic.m:15 */
+            double nn = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            for (int a = 0; a < 3; a++) ax[a] /= nn;
+        }
+        memcpy(j->axis, ax, sizeof(ax));
+        j->has_E0_pj = (d->E0_pj != NULL);
+        if (d->E0_pj) cm16_to_m4(j->E0_pj, d->E0_pj + 16 * i); else m4_eye(j->E0_pj);
+        se3_inv(j->E0_jp, j->E0_pj);
+        cm16_to_m4(j->E0_ji, d->E0_ji + 16 * i);
+        se3_inv(j->E0_ij, j->E0_ji);
+        se3_Ad(j->A0_ij, j->E0_ij);
+        memcpy(j->I_i, d->I_i + 6 * i, 6 * sizeof(double));
+        j->tau = d->tau ? d->tau[i] : 0.0;
+        j->stiffness = d->stiffness ? d->stiffness[i] : 0.0;
+        j->damping = d->damping ? d->damping[i] : 0.0;
+        j->qLimL = d->qLimL ? d->qLimL[i] : -1e8;     /* Joint.m:77-80 defaults */
+        j->qLimU = d->qLimU ? d->qLimU[i] : 1e8;
+        j->qLimK = d->qLimK ? d->qLimK[i] : 1e8;
+        j->qLimD = d->qLimD ? d->qLimD[i] : 0.0;
+        j->q = (j->ndof && d->q) ? d->q[i] : 0.0;
+        j->qdot = (j->ndof && d->qdot) ? d->qdot[i] : 0.0;
+    }
+    /* leaf-to-root counting: Scene.m:69-71 */
+    int nr = 0, nm = 0;
+    for (int i = n - 1; i >= 0; i--) {
+        onode* j = &s->nd[i];
+        j->idxR = nr; nr += j->ndof;
+        j->idxM = nm; nm += 6;
+        j->qRest = j->q;                 /* Joint.m:157 */
+    }
+    s->nr = nr; s->nm = nm;
+    for (int i = 0; i < n; i++) {        /* Scene.m:92-97 */
+        onode* j = &s->nd[i];
+        j->q0 = j->q1 = j->q; j->qdot0 = j->qdot1 = j->qdot;
+    }
+    s->qInit = (double*)calloc((size_t)(nr > 0 ? nr : 1), sizeof(double));
+    s->qdotInit = (double*)calloc((size_t)(nr > 0 ? nr : 1), sizeof(double));
+    size_t snr = (size_t)(nr > 0 ? nr : 1);
+    s->J = (double*)calloc((size_t)nm * snr, sizeof(double));
+    s->Jdot = (double*)calloc((size_t)nm * snr, sizeof(double));
+    s->dJdq = (double*)calloc((size_t)nm * snr * snr, sizeof(double));
+    s->dJdotdq = (double*)calloc((size_t)nm * snr * snr, sizeof(double));
+    s->Mm = (double*)calloc((size_t)n * 36, sizeof(double));
+    s->Km = (double*)calloc((size_t)n * 36, sizeof(double));
+    s->Dm = (double*)calloc((size_t)n * 36, sizeof(double));
+    s->fm = (double*)calloc((size_t)nm, sizeof(double));
+    s->fr = (double*)calloc(snr, sizeof(double));
+    s->Kr = (double*)calloc(snr, sizeof(double));
+    s->Dr = (double*)calloc(snr, sizeof(double));
+    scene_update(s);                               /* Scene.m:100 */
+    orc_get_state(s, s->qInit, s->qdotInit);       /* Scene.m:101 */
+    orc_reset(s);                                  /* Scene.m:118 */
+    return s;
+}
+
+void orc_destroy(orc_scene* s) {
+    if (!s) return;
+    free(s->nd); free(s->qInit); free(s->qdotInit);
+    free(s->J); free(s->Jdot); free(s->dJdq); free(s->dJdotdq);
+    free(s->Mm); free(s->Km); free(s->Dm); free(s->fm); free(s->fr); free(s->Kr); free(s->Dr);
+    free(s);
+}
+
+/* -------------------------------------------------- Joint.computeJacobian */
+
+static void blk_mul_col(double* out, const m6 A, const double* in) {   /* out(6) = A*in(6) */
+    for (int r = 0; r < 6; r++) { double t = 0; for (int k = 0; k < 6; k++) t += A[r][k] * in[k]; out[r] = t; }
+}
+
+/* Joint.computeJacobian (Joint.m:490-613). deriv=0: the 2-output O(n^2) branch (:493-532);
+ * deriv=1: the 4-output O(n^3) branch (:533-612). Traversal = listing order (next links). */
+static void compute_jacobian(orc_scene* s, int deriv) {
+    const int nm = s->nm, nr = s->nr;
+    memset(s->J, 0, sizeof(double) * (size_t)nm * nr);
+    memset(s->Jdot, 0, sizeof(double) * (size_t)nm * nr);
+    if (deriv) {
+        memset(s->dJdq, 0, sizeof(double) * (size_t)nm * nr * nr);
+        memset(s->dJdotdq, 0, sizeof(double) * (size_t)nm * nr * nr);
+    }
+    for (int i = 0; i < s->n; i++) {
+        onode* ji = &s->nd[i];
+        const int rI = ji->idxM;
+        if (ji->ndof) {
+            /* J(idxmI,idxrI) = A0_BiJi*S ; Jdot(idxmI,idxrI) = A0_BiJi*Sdot (=0)   Joint.m:508-509,553-554 */
+            double col[6]; blk_mul_col(col, ji->A0_ij, ji->S);
+            for (int r = 0; r < 6; r++) { JX(s, rI + r, ji->idxR) = col[r]; JDX(s, rI + r, ji->idxR) = 0.0; }
+            /* dJdq(idxmI,idxrI,idxrI(ii)) = A0_BiJi*dSdq = 0 for revolute/prismatic     Joint.m:555-558 */
+        }
+        if (ji->parent < 0) continue;
+        onode* jp = &s->nd[ji->parent];
+        const int rP = jp->idxM;
+        m4 E0_JiBp, E_BiBp, T1, T2;
+        m6 A_BiBp, Aleft, Aright, Adot_BiBp, dAdq_BiBp, dAdotdq_BiBp, T6;
+        m4_mul(E0_JiBp, ji->E0_jp, jp->E0_ji);          /* Joint.m:512-514 */
+        m4_mul(T1, ji->E0_ij, ji->invQ);                /* E0_BiJi*invQ    */
+        m4_mul(E_BiBp, T1, E0_JiBp);                    /* Joint.m:515     */
+        se3_Ad(A_BiBp, E_BiBp);
+        se3_Ad(Aleft, T1);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) Aleft[a][b] = -Aleft[a][b];   /* :517 */
+        m4_mul(T2, ji->invQ, E0_JiBp);
+        se3_Ad(Aright, T2);                             /* :518 */
+        m6_mul(T6, Aleft, ji->Adot); m6_mul(Adot_BiBp, T6, Aright);   /* :519 */
+        if (deriv && ji->ndof) {                        /* Joint.m:573-580 (ndof==1) */
+            m6 tmp1, tmp2, U;
+            m6_mul(T6, ji->dAdq, ji->invA); m6_mul(tmp1, T6, ji->Adot);
+            m6_mul(T6, ji->Adot, ji->invA); m6_mul(tmp2, T6, ji->dAdq);
+            m6_mul(T6, Aleft, ji->dAdq); m6_mul(dAdq_BiBp, T6, Aright);
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) U[a][b] = ji->dAdotdq[a][b] - tmp1[a][b] - tmp2[a][b];
+            m6_mul(T6, Aleft, U); m6_mul(dAdotdq_BiBp, T6, Aright);
+        }
+        for (int a = ji->parent; a >= 0; a = s->nd[a].parent) {    /* jointA loop :520-529 / :582-606 */
+            onode* ja = &s->nd[a];
+            if (!ja->ndof) continue;                     /* idxrA empty */
+            const int cA = ja->idxR;
+            double JPA[6], JdPA[6], o1[6], o2[6], o3[6];
+            for (int r = 0; r < 6; r++) { JPA[r] = JX(s, rP + r, cA); JdPA[r] = JDX(s, rP + r, cA); }
+            blk_mul_col(o1, A_BiBp, JPA);
+            blk_mul_col(o2, A_BiBp, JdPA);
+            blk_mul_col(o3, Adot_BiBp, JPA);
+            for (int r = 0; r < 6; r++) { JX(s, rI + r, cA) = o1[r]; JDX(s, rI + r, cA) = o2[r] + o3[r]; }
+            if (!deriv) continue;
+            if (ji->ndof) {                              /* :588-593 */
+                const int k = ji->idxR;
+                blk_mul_col(o1, dAdq_BiBp, JPA);
+                blk_mul_col(o2, dAdq_BiBp, JdPA);
+                blk_mul_col(o3, dAdotdq_BiBp, JPA);
+                for (int r = 0; r < 6; r++) { T3(s->dJdq, s, rI + r, cA, k) = o1[r]; T3(s->dJdotdq, s, rI + r, cA, k) = o2[r] + o3[r]; }
+            }
+            for (int kk = ji->parent; kk >= 0; kk = s->nd[kk].parent) {   /* jointK loop :594-604 */
+                onode* jk = &s->nd[kk];
+                if (!jk->ndof) continue;
+                const int k = jk->idxR;
+                double dP[6], ddP[6];
+                for (int r = 0; r < 6; r++) { dP[r] = T3(s->dJdq, s, rP + r, cA, k); ddP[r] = T3(s->dJdotdq, s, rP + r, cA, k); }
+                blk_mul_col(o1, A_BiBp, dP);
+                blk_mul_col(o2, A_BiBp, ddP);
+                blk_mul_col(o3, Adot_BiBp, dP);
+                for (int r = 0; r < 6; r++) { T3(s->dJdq, s, rI + r, cA, k) = o1[r]; T3(s->dJdotdq, s, rI + r, cA, k) = o2[r] + o3[r]; }
+            }
+        }
+    }
+}
+
+void orc_jacobian(orc_scene* s, double* J, double* Jdot, double* dJdq, double* dJdotdq) {
+    int deriv = (dJdq || dJdotdq);
+    compute_jacobian(s, deriv);
+    size_t a = (size_t)s->nm * s->nr;
+    if (J) memcpy(J, s->J, a * sizeof(double));
+    if (Jdot) memcpy(Jdot, s->Jdot, a * sizeof(double));
+    if (dJdq) memcpy(dJdq, s->dJdq, a * s->nr * sizeof(double));
+    if (dJdotdq) memcpy(dJdotdq, s->dJdotdq, a * s->nr * sizeof(double));
+}
+
+/* ----------------------------------- Body.computeMassGrav, Joint.computeForce */
+
+/* Body.computeMassGrav (Body.m:83-135).  Blocks stored per body (block index = joint index). */
+static void compute_mass_grav(orc_scene* s, int deriv) {
+    for (int i = 0; i < s->n; i++) {
+        onode* j = &s->nd[i];
+        double* Mb = s->Mm + 36 * i; double* Kb = s->Km + 36 * i; double* Db = s->Dm + 36 * i;
+        memset(Mb, 0, 36 * sizeof(double)); memset(Kb, 0, 36 * sizeof(double)); memset(Db, 0, 36 * sizeof(double));
+        for (int a = 0; a < 6; a++) Mb[a * 6 + a] = j->I_i[a];
+        m6 adm; se3_ad(adm, j->phi);
+        /* adt = ad(phi)' ; fcor = adt*M_i*phi */
+        double Mphi[6], fcor[6];
+        for (int a = 0; a < 6; a++) Mphi[a] = j->I_i[a] * j->phi[a];
+        for (int a = 0; a < 6; a++) { double t = 0; for (int k = 0; k < 6; k++) t += adm[k][a] * Mphi[k]; fcor[a] = t; }
+        double mass = j->I_i[3];
+        double grav_i[3];
+        for (int a = 0; a < 3; a++) { double t = 0; for (int k = 0; k < 3; k++) t += j->E_wi[k][a] * s->grav[k]; grav_i[a] = t; }
+        double fgrav[6] = { 0, 0, 0, mass * grav_i[0], mass * grav_i[1], mass * grav_i[2] };
+        for (int a = 0; a < 6; a++) s->fm[j->idxM + a] = fcor[a] + fgrav[a];
+        if (!deriv) continue;
+        /* Km(rows(4:6),rows(1:3)) += brac(fgrav(4:6))      Body.m:119 */
+        double fb[3][3]; se3_brac3(fb, fgrav + 3);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Kb[(3 + a) * 6 + b] += fb[a][b];
+        /* Dm(rows,rows) += adt*M_i - [e1*Iw e2*Iw e3*Iw e1*mv e2*mv e3*mv ; e1*mv e2*mv e3*mv 0 0 0]   Body.m:121-129 */
+        double Iw[3] = { j->I_i[0] * j->phi[0], j->I_i[1] * j->phi[1], j->I_i[2] * j->phi[2] };
+        double mv[3] = { mass * j->phi[3], mass * j->phi[4], mass * j->phi[5] };
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) Db[a * 6 + b] += adm[b][a] * j->I_i[b];
+        for (int c = 0; c < 3; c++) {
+            double e[3] = { 0, 0, 0 }; e[c] = 1.0;
+            double eb[3][3]; se3_brac3(eb, e);
+            for (int a = 0; a < 3; a++) {
+                double eIw = 0, emv = 0;
+                for (int k = 0; k < 3; k++) { eIw += eb[a][k] * Iw[k]; emv += eb[a][k] * mv[k]; }
+                Db[a * 6 + c] -= eIw;            /* top-left:  e_c*Iw */
+                Db[a * 6 + 3 + c] -= emv;        /* top-right: e_c*mv */
+                Db[(3 + a) * 6 + c] -= emv;      /* bottom-left: e_c*mv */
+            }
+        }
+    }
+}
+
+/* Joint.computeForce (Joint.m:437-487).  Kr, Dr are diagonal for 1-DOF joints. */
+static void compute_joint_force(orc_scene* s) {
+    for (int i = 0; i < s->nr; i++) { s->fr[i] = 0; s->Kr[i] = 0; s->Dr[i] = 0; }
+    for (int i = 0; i < s->n; i++) {
+        onode* j = &s->nd[i];
+        if (!j->ndof) continue;
+        int r = j->idxR;
+        s->fr[r] += j->tau + j->stiffness * (j->qRest - j->q) - j->damping * j->qdot;
+        s->Kr[r] -= j->stiffness;
+        s->Dr[r] -= j->damping;
+        double hitL = (j->q < j->qLimL) ? 1.0 : 0.0;
+        double hitU = (j->q > j->qLimU) ? 1.0 : 0.0;
+        s->fr[r] += hitL * (j->qLimK * (j->qLimL - j->q) - j->qLimD * j->qdot);
+        s->fr[r] += hitU * (j->qLimK * (j->qLimU - j->q) - j->qLimD * j->qdot);
+        s->Kr[r] -= (hitL * hitL) * j->qLimK;
+        s->Kr[r] -= (hitU * hitU) * j->qLimK;
+        s->Dr[r] -= (hitL * hitL) * j->qLimD;
+        s->Dr[r] -= (hitU * hitU) * j->qLimD;
+    }
+}
+
+/* ------------------------------------------------ computeValues (driver) */
+
+/* y(nm) = Blk * x(nm) with Blk block-diagonal, blocks indexed by joint (rows idxM..idxM+5) */
+static void blkdiag_mulv(const orc_scene* s, const double* Blk, const double* x, double* y) {
+    for (int i = 0; i < s->n; i++) {
+        const double* B = Blk + 36 * i; int r0 = s->nd[i].idxM;
+        for (int a = 0; a < 6; a++) { double t = 0; for (int k = 0; k < 6; k++) t += B[a * 6 + k] * x[r0 + k]; y[r0 + a] = t; }
+    }
+}
+/* y(nr) = A' * x, A nm x nr col-major */
+static void matT_mulv(const orc_scene* s, const double* A, const double* x, double* y) {
+    for (int c = 0; c < s->nr; c++) {
+        const double* col = A + (size_t)c * s->nm; double t = 0;
+        for (int r = 0; r < s->nm; r++) { double v = col[r]; if (v != 0.0) t += v * x[r]; }
+        y[c] = t;
+    }
+}
+/* y(nm) = A * x, A nm x nr col-major */
+static void mat_mulv(const orc_scene* s, const double* A, const double* x, double* y) {
+    for (int r = 0; r < s->nm; r++) y[r] = 0;
+    for (int c = 0; c < s->nr; c++) {
+        const double* col = A + (size_t)c * s->nm; double xc = x[c];
+        if (xc == 0.0) continue;
+        for (int r = 0; r < s->nm; r++) y[r] += col[r] * xc;
+    }
+}
+/* C(nr x nr, col-major) = A' * (Blk * B), A,B nm x nr col-major */
+static void AtBlkB(const orc_scene* s, const double* A, const double* Blk, const double* B, double* C, double* tmpcol) {
+    for (int c = 0; c < s->nr; c++) {
+        blkdiag_mulv(s, Blk, B + (size_t)c * s->nm, tmpcol);
+        matT_mulv(s, A, tmpcol, C + (size_t)c * s->nr);
+    }
+}
+
+/* computeValues (driverRedMaxBDF1.m:190-243) */
+void orc_compute_values(orc_scene* s, double* M, double* f, double* dMdq, double* K, double* D) {
+    const int nr = s->nr, nm = s->nm;
+    const int deriv = (dMdq || K || D);
+    double* qdot = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* t_nm = (double*)calloc((size_t)nm, sizeof(double));
+    double* t_nm2 = (double*)calloc((size_t)nm, sizeof(double));
+    double* t_nr = (double*)calloc((size_t)nr + 1, sizeof(double));
+    orc_get_state(s, NULL, qdot);
+    compute_jacobian(s, deriv);
+    compute_mass_grav(s, deriv);
+    compute_joint_force(s);
+    /* M = J'*Mm*J   (:212) */
+    if (M) AtBlkB(s, s->J, s->Mm, s->J, M, t_nm);
+    /* fqvv = -J'*Mm*Jdot*qdot ; f = fr + J'*fm + fqvv   (:215-216) */
+    double* MmJdotqdot = (double*)calloc((size_t)nm, sizeof(double));
+    mat_mulv(s, s->Jdot, qdot, t_nm);
+    blkdiag_mulv(s, s->Mm, t_nm, MmJdotqdot);
+    if (f) {
+        matT_mulv(s, s->J, s->fm, t_nr);
+        double* t2 = (double*)calloc((size_t)nr + 1, sizeof(double));
+        matT_mulv(s, s->J, MmJdotqdot, t2);
+        for (int i = 0; i < nr; i++) f[i] = s->fr[i] + t_nr[i] + (-t2[i]);
+        free(t2);
+    }
+    if (deriv) {
+        double* tmp = (double*)calloc((size_t)nr * nr + 1, sizeof(double));
+        double* Kqvv = (double*)calloc((size_t)nr * nr + 1, sizeof(double));
+        double* Dqvv = (double*)calloc((size_t)nr * nr + 1, sizeof(double));
+        /* dMdq(:,:,i) = tmp' + tmp, tmp = J'*Mm*dJdq(:,:,i)   (:220-224) */
+        if (dMdq) for (int i = 0; i < nr; i++) {
+            AtBlkB(s, s->J, s->Mm, s->dJdq + (size_t)i * nm * nr, tmp, t_nm);
+            double* Di = dMdq + (size_t)i * nr * nr;
+            for (int a = 0; a < nr; a++) for (int b = 0; b < nr; b++) Di[(size_t)b * nr + a] = tmp[(size_t)a * nr + b] + tmp[(size_t)b * nr + a];
+        }
+        /* Dqvv = -J'*Mm*Jdot  (:227) */
+        AtBlkB(s, s->J, s->Mm, s->Jdot, Dqvv, t_nm);
+        for (int i = 0; i < nr * nr; i++) Dqvv[i] = -Dqvv[i];
+        for (int i = 0; i < nr; i++) {                 /* :229-234 */
+            const double* dJdqi = s->dJdq + (size_t)i * nm * nr;
+            const double* dJdotdqi = s->dJdotdq + (size_t)i * nm * nr;
+            /* Kqvv(:,i) = -dJdqi'*MmJdotqdot - J'*Mm*dJdotdqi*qdot */
+            matT_mulv(s, dJdqi, MmJdotqdot, t_nr);
+            mat_mulv(s, dJdotdqi, qdot, t_nm); blkdiag_mulv(s, s->Mm, t_nm, t_nm2);
+            double* t2 = (double*)calloc((size_t)nr + 1, sizeof(double));
+            matT_mulv(s, s->J, t_nm2, t2);
+            for (int a = 0; a < nr; a++) Kqvv[(size_t)i * nr + a] = -t_nr[a] - t2[a];
+            /* Dqvv(:,i) = Dqvv(:,i) - J'*Mm*dJdqi*qdot */
+            mat_mulv(s, dJdqi, qdot, t_nm); blkdiag_mulv(s, s->Mm, t_nm, t_nm2);
+            matT_mulv(s, s->J, t_nm2, t2);
+            for (int a = 0; a < nr; a++) Dqvv[(size_t)i * nr + a] -= t2[a];
+            free(t2);
+        }
+        /* K = Kr + J'*Km*J + Kqvv ; D = Dr + J'*Dm*J + Dqvv  (:236-237) */
+        if (K) {
+            AtBlkB(s, s->J, s->Km, s->J, K, t_nm);
+            for (int i = 0; i < nr * nr; i++) K[i] += Kqvv[i];
+            for (int i = 0; i < nr; i++) K[(size_t)i * nr + i] += s->Kr[i];
+            for (int i = 0; i < nr; i++) {             /* :238-241 */
+                const double* dJdqi = s->dJdq + (size_t)i * nm * nr;
+                matT_mulv(s, dJdqi, s->fm, t_nr);
+                mat_mulv(s, dJdqi, qdot, t_nm); blkdiag_mulv(s, s->Dm, t_nm, t_nm2);
+                double* t2 = (double*)calloc((size_t)nr + 1, sizeof(double));
+                matT_mulv(s, s->J, t_nm2, t2);
+                for (int a = 0; a < nr; a++) K[(size_t)i * nr + a] += t_nr[a] + t2[a];
+                free(t2);
+            }
+        }
+        if (D) {
+            AtBlkB(s, s->J, s->Dm, s->J, D, t_nm);
+            for (int i = 0; i < nr * nr; i++) D[i] += Dqvv[i];
+            for (int i = 0; i < nr; i++) D[(size_t)i * nr + i] += s->Dr[i];
+        }
+        free(tmp); free(Kqvv); free(Dqvv);
+    }
+    free(MmJdotqdot); free(qdot); free(t_nm); free(t_nm2); free(t_nr);
+}
+
+/* evalBDF1 (driverRedMaxBDF1.m:160-187) and its BDF2/SDIRK2 siblings (driverRedMaxBDF2.m:194-293)
+ * in the common form  qdot=(q-qA)/eta, dqtmp=q-qB, g=M*dqtmp-eta^2 f, H=M-eta*D-eta^2*K+dMdq*dqtmp. */
+void orc_eval_residual(orc_scene* s, const double* q, const double* qA, const double* qB, double eta, double* g, double* H) {
+    const int nr = s->nr;
+    size_t n2 = (size_t)nr * nr + 1;
+    double* qdot = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* dq = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* M = (double*)calloc(n2, sizeof(double));
+    double* f = (double*)calloc((size_t)nr + 1, sizeof(double));
+    for (int i = 0; i < nr; i++) { dq[i] = q[i] - qB[i]; qdot[i] = (q[i] - qA[i]) / eta; }
+    set_q(s, q, qdot);
+    scene_update(s);
+    const double e2 = eta * eta;
+    if (!H) {
+        orc_compute_values(s, M, f, NULL, NULL, NULL);
+        for (int a = 0; a < nr; a++) { double t = 0; for (int b = 0; b < nr; b++) t += M[(size_t)b * nr + a] * dq[b]; g[a] = t - e2 * f[a]; }
+    } else {
+        double* K = (double*)calloc(n2, sizeof(double));
+        double* D = (double*)calloc(n2, sizeof(double));
+        double* dMdq = (double*)calloc((size_t)nr * nr * nr + 1, sizeof(double));
+        orc_compute_values(s, M, f, dMdq, K, D);
+        for (int a = 0; a < nr; a++) { double t = 0; for (int b = 0; b < nr; b++) t += M[(size_t)b * nr + a] * dq[b]; g[a] = t - e2 * f[a]; }
+        for (size_t i = 0; i < (size_t)nr * nr; i++) H[i] = M[i] - eta * D[i] - e2 * K[i];
+        for (int i = 0; i < nr; i++) {
+            const double* Di = dMdq + (size_t)i * nr * nr;
+            for (int a = 0; a < nr; a++) { double t = 0; for (int b = 0; b < nr; b++) t += Di[(size_t)b * nr + a] * dq[b]; H[(size_t)i * nr + a] += t; }
+        }
+        free(K); free(D); free(dMdq);
+    }
+    free(qdot); free(dq); free(M); free(f);
+}
+
+/* ------------------------------------------------------------- newton */
+
+/* dx = -H\g : dense LU with partial pivoting (MATLAB mldivide -> LAPACK dgetrf/dgetrs;
+ * call site driverRedMaxBDF1.m:117).  H is col-major and is destroyed. Returns 0 if singular. */
+static int lu_solve_neg(int n, double* H, const double* g, double* dx) {
+    int* piv = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    double* b = (double*)malloc(sizeof(double) * (size_t)(n + 1));
+    for (int i = 0; i < n; i++) b[i] = -g[i];
+#define Hc(r, c) H[(size_t)(c) * n + (r)]
+    int ok = 1;
+    for (int k = 0; k < n; k++) {
+        int p = k; double mx = fabs(Hc(k, k));
+        for (int r = k + 1; r < n; r++) { double v = fabs(Hc(r, k)); if (v > mx) { mx = v; p = r; } }
+        piv[k] = p;
+        if (mx == 0.0) { ok = 0; continue; }
+        if (p != k) {
+            for (int c = 0; c < n; c++) { double t = Hc(k, c); Hc(k, c) = Hc(p, c); Hc(p, c) = t; }
+            double t = b[k]; b[k] = b[p]; b[p] = t;
+        }
+        double inv = 1.0 / Hc(k, k);
+        for (int r = k + 1; r < n; r++) Hc(r, k) *= inv;
+        for (int c = k + 1; c < n; c++) {
+            double hkc = Hc(k, c);
+            if (hkc != 0.0) for (int r = k + 1; r < n; r++) Hc(r, c) -= Hc(r, k) * hkc;
+        }
+    }
+    for (int k = 0; k < n; k++) for (int r = k + 1; r < n; r++) b[r] -= Hc(r, k) * b[k];    /* L y = b */
+    for (int k = n - 1; k >= 0; k--) { b[k] /= Hc(k, k); for (int r = 0; r < k; r++) b[r] -= Hc(r, k) * b[k]; }
+#undef Hc
+    for (int i = 0; i < n; i++) dx[i] = b[i];
+    free(piv); free(b);
+    return ok;
+}
+
+static double vnorm(int n, const double* x) { double t = 0; for (int i = 0; i < n; i++) t += x[i] * x[i]; return sqrt(t); }
+
+/* newton (driverRedMaxBDF1.m:94-157): x updated in place */
+static void newton(orc_scene* s, double* x, const double* qA, const double* qB, double eta, orc_stats* st) {
+    const int nr = s->nr;
+    const double tol = 1e-9, dxMax = 1e3;
+    const int iterMax = 10 * nr, iterLsMax = 20;
+    double* g = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* H = (double*)calloc((size_t)nr * nr + 1, sizeof(double));
+    double* dx = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* x0 = (double*)calloc((size_t)nr + 1, sizeof(double));
+    int iter = 1;
+    while (1) {
+        orc_eval_residual(s, x, qA, qB, eta, g, H);
+        if (st) { st->hessian_evals++; st->newton_iters++; }
+        lu_solve_neg(nr, H, g, dx);
+        if (vnorm(nr, dx) > dxMax) { if (st) st->diverged++; break; }
+        double alpha = 1.0;
+        double f0 = 0; for (int i = 0; i < nr; i++) f0 += g[i] * g[i]; f0 *= 0.5;
+        memcpy(x0, x, sizeof(double) * (size_t)nr);
+        int iterLs = 1;
+        while (1) {
+            for (int i = 0; i < nr; i++) x[i] = x0[i] + alpha * dx[i];
+            orc_eval_residual(s, x, qA, qB, eta, g, NULL);
+            if (st) st->residual_evals++;
+            double f = 0; for (int i = 0; i < nr; i++) f += g[i] * g[i]; f *= 0.5;
+            if (f < f0) break;
+            if (iterLs >= iterLsMax) break;
+            alpha = 0.5 * alpha;
+            iterLs++;
+        }
+        if (st) st->ls_halvings += iterLs - 1;
+        if (vnorm(nr, g) < tol) break;
+        if (iter >= iterMax) { if (st) st->not_converged++; break; }
+        iter++;
+    }
+    free(g); free(H); free(dx); free(x0);
+}
+
+/* simLoop (driverRedMaxBDF1.m:57-91) */
+void orc_step_bdf1(orc_scene* s, double h, int nsteps, orc_stats* st, double* Hist_T, double* Hist_V) {
+    const int nr = s->nr;
+    double* q0 = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* qd0 = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* q1 = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* qB = (double*)calloc((size_t)nr + 1, sizeof(double));
+    double* qd1 = (double*)calloc((size_t)nr + 1, sizeof(double));
+    if (st) memset(st, 0, sizeof(*st));
+    for (int k = 0; k < nsteps; k++) {
+        orc_get_state(s, q0, qd0);
+        for (int i = 0; i < s->n; i++) { s->nd[i].q0 = s->nd[i].q; s->nd[i].qdot0 = s->nd[i].qdot; }  /* setQ0 */
+        for (int i = 0; i < nr; i++) { q1[i] = q0[i] + h * qd0[i]; qB[i] = q0[i] + h * qd0[i]; }
+        newton(s, q1, q0, qB, h, st);
+        for (int i = 0; i < nr; i++) qd1[i] = (q1[i] - q0[i]) / h;
+        set_q(s, q1, qd1);
+        scene_update(s);
+        if (Hist_T || Hist_V) { double T, V; orc_energy(s, &T, &V); if (Hist_T) Hist_T[k] = T; if (Hist_V) Hist_V[k] = V; }
+    }
+    free(q0); free(qd0); free(q1); free(qB); free(qd1);
+}
+
+/* simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start (evalSDIRK2a :194-225, evalSDIRK2b :228-260)
+ * then BDF2 (evalBDF2 :263-293). Previous-step state is kept in nd[].q1/qdot1 (Joint.setQ1). */
+void orc_step_bdf2(orc_scene* s, double h, int step0, int nsteps, orc_stats* st, double* Hist_T, double* Hist_V) {
+    const int nr = s->nr;
+    size_t sz = (size_t)nr + 1;
+    double *q0 = calloc(sz, 8), *qd0 = calloc(sz, 8), *q1 = calloc(sz, 8), *qd1 = calloc(sz, 8);
+    double *x = calloc(sz, 8), *qA = calloc(sz, 8), *qB = calloc(sz, 8), *xd = calloc(sz, 8);
+    if (st) memset(st, 0, sizeof(*st));
+    for (int k = step0; k < step0 + nsteps; k++) {
+        if (k == 0) {
+            const double a = (2.0 - sqrt(2.0)) / 2.0;
+            orc_get_state(s, q0, qd0);
+            /* SDIRK2a */
+            for (int i = 0; i < nr; i++) { x[i] = q0[i] + a * h * qd0[i]; qA[i] = q0[i]; qB[i] = q0[i] + (a * h) * qd0[i]; }
+            newton(s, x, qA, qB, a * h, st);
+            double* qa = q1; double* qda = qd1;
+            for (int i = 0; i < nr; i++) { qa[i] = x[i]; qda[i] = (x[i] - q0[i]) / (a * h); }
+            /* SDIRK2b */
+            for (int i = 0; i < nr; i++) {
+                x[i] = qa[i] + (1 - a) * h * qda[i];
+                qA[i] = q0[i] + (1 - a) * h * qda[i];
+                qB[i] = q0[i] + (2 * a - 1) * h * qd0[i] + 2 * (1 - a) * h * qda[i];
+            }
+            newton(s, x, qA, qB, a * h, st);
+            for (int i = 0; i < nr; i++) xd[i] = (x[i] - q0[i] - (1 - a) * h * qda[i]) / (a * h);
+            set_q(s, x, xd);
+            for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) { s->nd[i].q1 = q0[s->nd[i].idxR]; s->nd[i].qdot1 = qd0[s->nd[i].idxR]; }  /* setQ1(q0,qdot0) */
+        } else {
+            for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) { q0[s->nd[i].idxR] = s->nd[i].q1; qd0[s->nd[i].idxR] = s->nd[i].qdot1; }
+            orc_get_state(s, q1, qd1);
+            for (int i = 0; i < s->n; i++) { s->nd[i].q1 = s->nd[i].q; s->nd[i].qdot1 = s->nd[i].qdot; }
+            for (int i = 0; i < nr; i++) {
+                x[i] = q1[i] + h * qd1[i];
+                qA[i] = (4.0 / 3.0) * q1[i] - (1.0 / 3.0) * q0[i];
+                qB[i] = (4.0 / 3.0) * q1[i] - (1.0 / 3.0) * q0[i] + (8.0 / 9.0) * h * qd1[i] - (2.0 / 9.0) * h * qd0[i];
+            }
+            newton(s, x, qA, qB, (2.0 / 3.0) * h, st);
+            for (int i = 0; i < nr; i++) xd[i] = (3.0 / (2.0 * h)) * (x[i] - (4.0 / 3.0) * q1[i] + (1.0 / 3.0) * q0[i]);
+            set_q(s, x, xd);
+        }
+        scene_update(s);
+        if (Hist_T || Hist_V) { double T, V; orc_energy(s, &T, &V); if (Hist_T) Hist_T[k - step0] = T; if (Hist_V) Hist_V[k - step0] = V; }
+    }
+    free(q0); free(qd0); free(q1); free(qd1); free(x); free(qA); free(qB); free(xd);
+}
+
+/* ---------------------------------------- matlab-simple euler (config 1) */
+
+/* matlab-simple Joint.computeJacobian (matlab-simple/+redmax/Joint.m:250-305):
+ * Jdot through world adjoints, Addot_ip = -Ad_iw*(Addot_wi*Ad_iw*Ad_wp - Addot_wp). */
+static void compute_jacobian_simple(orc_scene* s) {
+    const int nm = s->nm, nr = s->nr;
+    memset(s->J, 0, sizeof(double) * (size_t)nm * nr);
+    memset(s->Jdot, 0, sizeof(double) * (size_t)nm * nr);
+    for (int i = 0; i < s->n; i++) {
+        onode* ji = &s->nd[i];
+        const int rI = ji->idxM;
+        if (ji->ndof) {
+            double col[6]; blk_mul_col(col, ji->A0_ij, ji->S);
+            for (int r = 0; r < 6; r++) JX(s, rI + r, ji->idxR) = col[r];
+        }
+        if (ji->parent < 0) continue;
+        onode* jp = &s->nd[ji->parent];
+        const int rP = jp->idxM;
+        m6 T1, T2, Addot_ip;
+        m6_mul(T1, ji->Addot_wi, ji->Ad_iw); m6_mul(T2, T1, jp->Ad_wi);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) T2[a][b] -= jp->Addot_wi[a][b];
+        m6_mul(Addot_ip, ji->Ad_iw, T2);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) Addot_ip[a][b] = -Addot_ip[a][b];
+        for (int a = ji->parent; a >= 0; a = s->nd[a].parent) {
+            onode* ja = &s->nd[a];
+            if (!ja->ndof) continue;
+            const int cA = ja->idxR;
+            double JPA[6], JdPA[6], o1[6], o2[6], o3[6];
+            for (int r = 0; r < 6; r++) { JPA[r] = JX(s, rP + r, cA); JdPA[r] = JDX(s, rP + r, cA); }
+            blk_mul_col(o1, ji->Ad_ip, JPA);
+            blk_mul_col(o2, ji->Ad_ip, JdPA);
+            blk_mul_col(o3, Addot_ip, JPA);
+            for (int r = 0; r < 6; r++) { JX(s, rI + r, cA) = o1[r]; JDX(s, rI + r, cA) = o2[r] + o3[r]; }
+        }
+    }
+}
+
+/* euler (matlab-simple/testRedMax.m:67-109). Scenes without body damping: Dm = 0. */
+void orc_step_euler_simple(orc_scene* s, double h, int nsteps, double* Hist_T, double* Hist_V) {
+    const int nr = s->nr, nm = s->nm;
+    size_t sz = (size_t)nr + 1;
+    double *q0 = calloc(sz, 8), *qd0 = calloc(sz, 8), *qd1 = calloc(sz, 8), *q1 = calloc(sz, 8);
+    double *Mr = calloc((size_t)nr * nr + 1, 8), *Mt = calloc((size_t)nr * nr + 1, 8), *frt = calloc(sz, 8);
+    double *t_nm = calloc((size_t)nm, 8), *t_nm2 = calloc((size_t)nm, 8), *t_nr = calloc(sz, 8);
+    for (int k = 0; k < nsteps; k++) {
+        compute_mass_grav(s, 0);
+        compute_joint_force(s);   /* fr = tau - Kr*(q-qInit) - Dr*qdot ; Kr,Dr diagonal (Joint.m:212-247) */
+        compute_jacobian_simple(s);
+        orc_get_state(s, q0, qd0);
+        AtBlkB(s, s->J, s->Mm, s->J, Mr, t_nm);
+        for (int a = 0; a < nr; a++) for (int b = a + 1; b < nr; b++) {   /* Mr = 0.5*(Mr+Mr') */
+            double v = 0.5 * (Mr[(size_t)b * nr + a] + Mr[(size_t)a * nr + b]);
+            Mr[(size_t)b * nr + a] = v; Mr[(size_t)a * nr + b] = v;
+        }
+        /* frtilde = Mr*qdot0 + h*(J'*(fm - Mm*Jdot*qdot0) + fr) */
+        mat_mulv(s, s->Jdot, qd0, t_nm); blkdiag_mulv(s, s->Mm, t_nm, t_nm2);
+        for (int r = 0; r < nm; r++) t_nm2[r] = s->fm[r] - t_nm2[r];
+        matT_mulv(s, s->J, t_nm2, t_nr);
+        for (int a = 0; a < nr; a++) {
+            double t = 0; for (int b = 0; b < nr; b++) t += Mr[(size_t)b * nr + a] * qd0[b];
+            /* matlab-simple discards the damping FORCE ([~,Dr] = computeForceDamping, testRedMax.m:84):
+             * fr_simple = tau - Kr*(q-qInit) = fr + damping*qdot = fr - Dr*qdot */
+            frt[a] = t + h * (t_nr[a] + (s->fr[a] - s->Dr[a] * qd0[a]));
+        }
+        /* Mrtilde = Mr + J'*h*Dm*J + h*Dr - h*h*Kr ; matlab-simple sign convention: Dr=+damping, Kr=-stiffness;
+         * compute_joint_force stores Dr=-damping, Kr=-stiffness (matlab-diff convention) => h*Dr_simple = -h*Dr. */
+        memcpy(Mt, Mr, sizeof(double) * (size_t)nr * nr);
+        for (int a = 0; a < nr; a++) Mt[(size_t)a * nr + a] += -h * s->Dr[a] - h * h * s->Kr[a];
+        for (int a = 0; a < nr; a++) frt[a] = -frt[a];   /* lu_solve_neg solves Mt*x = -rhs */
+        lu_solve_neg(nr, Mt, frt, qd1);
+        for (int a = 0; a < nr; a++) q1[a] = q0[a] + h * qd1[a];
+        set_q(s, q1, qd1);
+        scene_update(s);
+        if (Hist_T || Hist_V) { double T, V; orc_energy(s, &T, &V); if (Hist_T) Hist_T[k] = T; if (Hist_V) Hist_V[k] = V; }
+    }
+    free(q0); free(qd0); free(qd1); free(q1); free(Mr); free(Mt); free(frt); free(t_nm); free(t_nm2); free(t_nr);
+}
+
+/* -------------------------------------------------- batch CPU baseline */
+
+long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads) {
+    long total = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel reduction(+ : total)
+    {
+        orc_scene* s = orc_create(d);
+        int nr = s->nr;
+        double* qrest = (double*)calloc((size_t)nr + 1, sizeof(double));
+        orc_get_state(s, qrest, NULL);       /* model constant: qRest = descriptor q */
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; b++) {
+            orc_stats st;
+            orc_set_state(s, q + (size_t)b * nr, qdot + (size_t)b * nr);
+            orc_set_qrest(s, qrest);
+            orc_step_bdf1(s, h, nsteps, &st, NULL, NULL);
+            orc_get_state(s, q + (size_t)b * nr, qdot + (size_t)b * nr);
+            total += st.newton_iters;
+        }
+        free(qrest);
+        orc_destroy(s);
+    }
+    return total;
+}

@@ -1,0 +1,302 @@
+"""Host-side mirror of the reference's ``+redmax`` class surface for the BDF1/BDF2 path.
+
+The reference builds a scene out of handle objects (matlab-diff/scenesRedMax.m):
+``BodyCuboid(density, sides)``, ``JointRevolute(parent, body, axis)``,
+``setJointTransform``, ``setBodyTransform``, ``q``, ``qdot`` ... and ``Scene.init()``
+links them and numbers the DOFs leaf-to-root (matlab-diff/+redmax/Scene.m:59-119).
+The same construction API is kept here so scene files read like the reference's; what
+changes is that ``Scene.init()`` flattens the tree into the POD model descriptor of
+``include/redmax_hip.h`` and every numerical method (update / computeJacobian /
+computeMassGrav / newton ...) is replaced by the HIP kernels behind the C ABI.
+
+Only what the path needs is mirrored: Body/BodyCuboid (Body.m, BodyCuboid.m),
+Joint + JointRevolute/JointPrismatic/JointFixed (Joint.m, JointRevolute.m,
+JointPrismatic.m, JointFixed.m) and Scene (Scene.m init/reset/saveHistory/plotEnergies).
+Drawing, FD self-tests and the other joint/force types are out of scope.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import se3
+
+JOINT_FIXED = 0
+JOINT_REVOLUTE = 1
+JOINT_PRISMATIC = 2
+
+
+class Body:
+    """Rigid body attached to a joint (matlab-diff/+redmax/Body.m:24-51)."""
+
+    _count = 1
+
+    def __init__(self, density):
+        self.name = "body%d" % Body._count
+        Body._count += 1
+        self.density = float(density)
+        self.damping = 0.0
+        self.I_i = np.ones(6)
+        self.E0_ji = np.eye(4)
+        self.joint = None
+        self.idxM = None
+
+    def setBodyTransform(self, E):
+        """Transform of this body wrt its joint (Body.m:46-51)."""
+        self.E0_ji = np.array(E, dtype=np.float64).reshape(4, 4)
+
+    def computeInertia(self):
+        self.computeInertia_()
+
+    def computeInertia_(self):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+
+class BodyCuboid(Body):
+    """matlab-diff/+redmax/BodyCuboid.m"""
+
+    def __init__(self, density, sides):
+        super().__init__(density)
+        self.sides = np.array(sides, dtype=np.float64).reshape(3)
+
+    def computeInertia_(self):
+        self.I_i = se3.inertiaCuboid(self.sides, self.density)  # BodyCuboid.m:17-20
+
+
+class Joint:
+    """Generic joint between a parent joint's body and ``body`` (Joint.m:56-92)."""
+
+    jtype = None
+
+    def __init__(self, parent, body, ndof):
+        pname = parent.body.name if (parent is not None and parent.body is not None) else "NULL"
+        self.name = "%s-%s" % (pname, body.name if body is not None else "NULL")
+        self.parent = parent
+        self.body = body
+        self.children = []
+        self.ndof = ndof
+        self.q = np.zeros(max(ndof, 1))      # q(1)=... on a fixed joint is legal in the reference
+        self.qdot = np.zeros(max(ndof, 1))
+        self.qLimL = -1e8                     # Joint.m:77-80
+        self.qLimU = 1e8
+        self.qLimK = 1e8
+        self.qLimD = 0.0
+        self.tau = 0.0
+        self.stiffness = 0.0
+        self.damping = 0.0
+        self.qRest = 0.0
+        self.E0_pj = None
+        self.axis = np.zeros(3)
+        self.idxR = None
+        body.joint = self
+        if parent is not None:
+            parent.children.append(self)
+
+    # --- setters, same names as the reference (Joint.m:95-131) ---
+    def setJointTransform(self, E):
+        self.E0_pj = np.array(E, dtype=np.float64).reshape(4, 4)
+
+    def setStiffness(self, stiffness):
+        self.stiffness = float(stiffness)
+
+    def setDamping(self, damping):
+        self.damping = float(damping)
+
+    def setLimitLower(self, limit):
+        self.qLimL = float(limit)
+
+    def setLimitUpper(self, limit):
+        self.qLimU = float(limit)
+
+    def setLimitStiffness(self, K):
+        self.qLimK = float(K)
+
+    def setLimitDamping(self, D):
+        self.qLimD = float(D)
+
+    def getTraversalOrder(self, order=None):
+        """Joint.m:134-146: parent before children, depth first."""
+        if order is None:
+            order = []
+        order.append(self)
+        for c in self.children:
+            c.getTraversalOrder(order)
+        return order
+
+
+class JointRevolute(Joint):
+    jtype = JOINT_REVOLUTE
+
+    def __init__(self, parent, body, axis):
+        super().__init__(parent, body, 1)
+        a = np.array(axis, dtype=np.float64).reshape(3)
+        self.axis = a / np.linalg.norm(a)  # JointRevolute.m:14
+
+
+class JointPrismatic(Joint):
+    jtype = JOINT_PRISMATIC
+
+    def __init__(self, parent, body, axis):
+        super().__init__(parent, body, 1)
+        a = np.array(axis, dtype=np.float64).reshape(3)
+        self.axis = a / np.linalg.norm(a)  # JointPrismatic.m:15
+
+
+class JointFixed(Joint):
+    jtype = JOINT_FIXED
+
+    def __init__(self, parent, body):
+        super().__init__(parent, body, 0)
+
+
+class Scene:
+    """Scene container (matlab-diff/+redmax/Scene.m).
+
+    ``init()`` reproduces the index layout parity depends on: joints must be listed
+    parent-before-child, reduced DOFs are numbered from the LAST listed joint to the
+    first (Scene.m:65-71), ``qRest`` is captured from the initial ``q`` (Joint.m:157).
+    """
+
+    def __init__(self):
+        Body._count = 1
+        self.name = ""
+        self.bodies = []
+        self.joints = []
+        self.forces = []
+        self.tEnd = 1.0
+        self.qInit = None
+        self.qdotInit = None
+        self.h = 1e-2
+        self.t = 0.0
+        self.k = 0
+        self.T0 = 0.0
+        self.V0 = 0.0
+        self.history = []
+        self.nsteps = 0
+        self.grav = np.array([0.0, 0.0, -980.0])
+        self.computeH = True
+        self.Hexpected = np.zeros(2)
+        self.nr = 0
+        self.nm = 0
+        self._desc = None
+
+    # -- Scene.init, Scene.m:59-119 --
+    def init(self):
+        joints = self.joints
+        n = len(joints)
+        order = joints[0].getTraversalOrder()
+        if len(order) != n or any(a is not b for a, b in zip(order, joints)):
+            # The reference's getTraversalOrder always returns 1:n, i.e. it silently assumes this.
+            raise ValueError("scene joints must be listed in depth-first, parent-before-child order")
+        if any(j.body is not b for j, b in zip(joints, self.bodies)):
+            raise ValueError("bodies must be listed in the same order as their joints")
+        if self.forces:
+            raise NotImplementedError("only ForceNull scenes are in scope (SURVEY.md §2 row 10)")
+        nr = 0
+        nm = 0
+        for j in reversed(joints):                   # leaf-to-root numbering
+            j.idxR = list(range(nr, nr + j.ndof))
+            nr += j.ndof
+            j.body.idxM = list(range(nm, nm + 6))
+            nm += 6
+            j.qRest = float(j.q[0]) if j.ndof else 0.0   # Joint.m:157
+        self.nr, self.nm = nr, nm
+        for j in joints:
+            if j.parent is not None and j.E0_pj is None:
+                raise ValueError("joint %s needs setJointTransform (Joint.m:513 uses E0_jp)" % j.name)
+        for b in self.bodies:
+            b.computeInertia()
+        self.qInit, self.qdotInit = self.getQ()
+        self.nsteps = int(math.ceil(self.tEnd / self.h))
+        self._desc = None
+        self.t = 0.0
+        self.k = 0
+        self.history = []
+
+    # -- gather / scatter in the reference's reduced ordering (Joint.getQ / setQ) --
+    def getQ(self):
+        q = np.zeros(self.nr)
+        qdot = np.zeros(self.nr)
+        for j in self.joints:
+            if j.ndof:
+                q[j.idxR[0]] = j.q[0]
+                qdot[j.idxR[0]] = j.qdot[0]
+        return q, qdot
+
+    def setQ(self, q, qdot=None):
+        for j in self.joints:
+            if j.ndof:
+                j.q[0] = q[j.idxR[0]]
+                if qdot is not None:
+                    j.qdot[0] = qdot[j.idxR[0]]
+
+    @staticmethod
+    def _cm(E):
+        return np.asarray(E, dtype=np.float64).reshape(4, 4).T.reshape(16)  # column-major, as MATLAB stores it
+
+    def desc(self):
+        """Flatten the tree into the arrays of ``rmx_model_desc`` (include/redmax_hip.h)."""
+        if self._desc is not None:
+            return self._desc
+        joints = self.joints
+        n = len(joints)
+        index = {id(j): i for i, j in enumerate(joints)}
+        d = {
+            "njoints": n,
+            "parent": np.array([index[id(j.parent)] if j.parent is not None else -1 for j in joints], dtype=np.int32),
+            "type": np.array([j.jtype for j in joints], dtype=np.int32),
+            "axis": np.ascontiguousarray(np.stack([j.axis for j in joints]), dtype=np.float64),
+            "E0_pj": np.ascontiguousarray(np.stack([self._cm(j.E0_pj if j.E0_pj is not None else np.eye(4)) for j in joints])),
+            "E0_ji": np.ascontiguousarray(np.stack([self._cm(j.body.E0_ji) for j in joints])),
+            "I_i": np.ascontiguousarray(np.stack([j.body.I_i for j in joints]), dtype=np.float64),
+            "q": np.array([j.q[0] if j.ndof else 0.0 for j in joints], dtype=np.float64),
+            "qdot": np.array([j.qdot[0] if j.ndof else 0.0 for j in joints], dtype=np.float64),
+            "qRest": np.array([j.qRest for j in joints], dtype=np.float64),
+            "tau": np.array([j.tau for j in joints], dtype=np.float64),
+            "stiffness": np.array([j.stiffness for j in joints], dtype=np.float64),
+            "damping": np.array([j.damping for j in joints], dtype=np.float64),
+            "qLimL": np.array([j.qLimL for j in joints], dtype=np.float64),
+            "qLimU": np.array([j.qLimU for j in joints], dtype=np.float64),
+            "qLimK": np.array([j.qLimK for j in joints], dtype=np.float64),
+            "qLimD": np.array([j.qLimD for j in joints], dtype=np.float64),
+            "grav": np.array(self.grav, dtype=np.float64).reshape(3),
+        }
+        self._desc = d
+        return d
+
+    # -- Scene.reset, Scene.m:122-131 (energies come from the device, see driver.py) --
+    def reset(self):
+        self.setQ(self.qInit, self.qdotInit)
+        self.t = 0.0
+        self.k = 0
+        self.history = []
+
+    # -- Scene.saveHistory, Scene.m:134-161 --
+    def saveHistory(self, q, qdot, T=None, V=None):
+        rec = {"q": np.array(q), "qdot": np.array(qdot), "t": self.t}
+        if self.computeH:
+            rec["T"] = T
+            rec["V"] = V
+        self.history.append(rec)
+
+    # -- Scene.plotEnergies, Scene.m:164-191 (the PASS/FAIL known-answer check, no plotting) --
+    def plotEnergies(self, itype, verbose=True):
+        """Returns (H_end, passed). ``itype`` is 1 (BDF1) or 2 (BDF2) as in the reference."""
+        T = np.array([self.T0] + [r["T"] for r in self.history])
+        V = np.array([self.V0] + [r["V"] for r in self.history])
+        V = V - V[0]
+        H = T + V
+        passed = None
+        if self.Hexpected[itype - 1] != 0:
+            dH = H[-1] - self.Hexpected[itype - 1]
+            passed = bool(abs(dH) <= 1e-2)
+            if verbose:
+                print("### PASS ###" if passed else "### FAIL: %.16e ###" % H[-1])
+        return float(H[-1]), passed
+
+    def countR(self):
+        return self.nr
+
+    def countM(self):
+        return self.nm

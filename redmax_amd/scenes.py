@@ -1,0 +1,217 @@
+"""Test scenes: the in-scope cases of matlab-diff/scenesRedMax.m plus the synthetic
+benchmark configurations of BASELINE.json / SURVEY.md §8(d).
+
+``scenesRedMax(sceneID)`` keeps the reference's entry-point name and scene numbering
+(scenesRedMax.m:1-13): 0 simple serial chain (:52-79), 1 different revolute axes (:80-100),
+2 branching (:101-130), 3 prismatic joint (:131-144), 14 joint limits (:371-401).  The
+golden energies ``Hexpected(BDF1/BDF2)`` are the reference's own known answers.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import se3
+from .redmax import BodyCuboid, JointFixed, JointPrismatic, JointRevolute, Scene
+
+BDF1 = 1
+BDF2 = 2
+
+
+def _T(p):
+    return se3.transform(p=p)
+
+
+def scenesRedMax(sceneID):
+    scene = Scene()
+    density = 1.0
+    if sceneID == 0:
+        scene.name = "Simple serial chain"
+        scene.Hexpected[BDF1 - 1] = -1.2705398823489915e05   # scenesRedMax.m:54
+        scene.Hexpected[BDF2 - 1] = 2.6058008179021417e03    # :55
+        sides = [10, 1, 1]
+        nbodies = 5
+        for i in range(1, nbodies + 1):
+            scene.bodies.append(BodyCuboid(density, sides))
+            if i == 1:
+                scene.joints.append(JointRevolute(None, scene.bodies[-1], [0, 1, 0]))
+                scene.joints[-1].setJointTransform(np.eye(4))
+            else:
+                if i % 2 == 1:
+                    scene.joints.append(JointRevolute(scene.joints[i - 2], scene.bodies[-1], [0, 1, 0]))
+                else:
+                    scene.joints.append(JointFixed(scene.joints[i - 2], scene.bodies[-1]))
+                scene.joints[-1].setJointTransform(_T([10, 0, 0]))
+            scene.bodies[-1].setBodyTransform(_T([5, 0, 0]))
+            scene.joints[-1].q[0] = math.pi / 4 if i % 2 == 1 else 0.0
+    elif sceneID == 1:
+        scene.name = "Different revolute axes"
+        scene.Hexpected[BDF1 - 1] = -3.8359074258588909e04   # :82
+        scene.Hexpected[BDF2 - 1] = -9.7138545812971279e02   # :83
+        sides = [10, 1, 1]
+        b = [BodyCuboid(density, sides) for _ in range(3)]
+        scene.bodies = b
+        j1 = JointRevolute(None, b[0], [0, 0, 1])
+        j2 = JointRevolute(j1, b[1], [0, 1, 0])
+        j3 = JointRevolute(j2, b[2], [0, 0, 1])
+        scene.joints = [j1, j2, j3]
+        for bb in b:
+            bb.setBodyTransform(_T([5, 0, 0]))
+        j1.setJointTransform(np.eye(4))
+        j2.setJointTransform(_T([10, 0, 0]))
+        j3.setJointTransform(_T([10, 0, 0]))
+        j1.q[0] = 0.0
+        j2.q[0] = math.pi / 2
+        j3.q[0] = math.pi / 2
+    elif sceneID == 2:
+        scene.name = "Branching"
+        scene.Hexpected[BDF1 - 1] = -2.2826101928480086e04   # :108
+        scene.Hexpected[BDF2 - 1] = -2.4159349151742754e02   # :109
+        b = [BodyCuboid(density, [1, 1, 10]), BodyCuboid(density, [1, 20, 1]),
+             BodyCuboid(density, [1, 1, 10]), BodyCuboid(density, [1, 1, 10])]
+        scene.bodies = b
+        j1 = JointRevolute(None, b[0], [1, 0, 0])
+        j2 = JointRevolute(j1, b[1], [0, 0, 1])
+        j3 = JointRevolute(j2, b[2], [1, 0, 0])
+        j4 = JointRevolute(j2, b[3], [0, 1, 0])
+        scene.joints = [j1, j2, j3, j4]
+        b[0].setBodyTransform(_T([0, 0, -5]))
+        b[1].setBodyTransform(_T([0, 0, 0]))
+        b[2].setBodyTransform(_T([0, 0, -5]))
+        b[3].setBodyTransform(_T([0, 0, -5]))
+        j1.setJointTransform(_T([0, 0, 15]))
+        j2.setJointTransform(_T([0, 0, -10]))
+        j3.setJointTransform(_T([0, -10, 0]))
+        j4.setJointTransform(_T([0, 10, 0]))
+        j3.q[0] = math.pi / 4
+        j4.q[0] = math.pi / 4
+    elif sceneID == 3:
+        scene.name = "Prismatic joint"
+        scene.Hexpected[BDF1 - 1] = -3.7579402399569808e04   # :133
+        scene.Hexpected[BDF2 - 1] = -6.1132876082600706e02   # :134
+        b1 = BodyCuboid(density, [20, 1, 1])
+        j1 = JointPrismatic(None, b1, [1, 0, 0])
+        j1.setJointTransform(np.eye(4))
+        b1.setBodyTransform(np.eye(4))
+        b2 = BodyCuboid(density, [1, 1, 10])
+        j2 = JointRevolute(j1, b2, [0, 1, 0])
+        j2.setJointTransform(_T([-10, 0, 0]))
+        b2.setBodyTransform(_T([0, 0, -5]))
+        j2.q[0] = math.pi / 2
+        scene.bodies = [b1, b2]
+        scene.joints = [j1, j2]
+    elif sceneID == 14:
+        scene.name = "Joint limits"
+        scene.Hexpected[BDF1 - 1] = -2.5928305306546572e04   # :373
+        scene.Hexpected[BDF2 - 1] = -1.8476279319765570e04   # :374
+        scene.h = 5e-3
+        sides = [10, 1, 1]
+        nbodies = 3
+        for i in range(1, nbodies + 1):
+            scene.bodies.append(BodyCuboid(density, sides))
+            if i == 1:
+                scene.joints.append(JointRevolute(None, scene.bodies[-1], [0, 1, 0]))
+                scene.joints[-1].setJointTransform(se3.transform(R=se3.aaToMat([0, 1, 0], math.pi / 2)))
+                scene.joints[-1].q[0] = 0.0
+            else:
+                scene.joints.append(JointRevolute(scene.joints[i - 2], scene.bodies[-1], [0, 1, 0]))
+                scene.joints[-1].setJointTransform(_T([10, 0, 0]))
+                scene.joints[-1].q[0] = -math.pi / 6
+            scene.bodies[-1].setBodyTransform(_T([5, 0, 0]))
+            j = scene.joints[-1]
+            j.setLimitLower(-math.pi / 2)
+            j.setLimitUpper(0.0)
+            j.setLimitStiffness(1e5)
+            j.setLimitDamping(1e2)
+            j.setDamping(1e2)
+    else:
+        raise ValueError("scene %r is out of scope (needs joint/force types outside SURVEY.md §8)" % (sceneID,))
+    return scene
+
+
+IN_SCOPE_SCENES = (0, 1, 2, 3, 14)
+
+
+def sceneChain(n=32, axis=(0, 1, 0), q0=0.0):
+    """Config 2 (north star): n-link serial revolute chain, the pattern of scenesRedMax.m:52-79 with
+    every joint revolute: cuboid(density 1, sides [10 1 1]), joint 1 at identity, joints 2..n at
+    [10 0 0], bodies at [5 0 0]."""
+    scene = Scene()
+    scene.name = "%d-link serial revolute chain" % n
+    for i in range(n):
+        scene.bodies.append(BodyCuboid(1.0, [10, 1, 1]))
+        parent = scene.joints[i - 1] if i else None
+        scene.joints.append(JointRevolute(parent, scene.bodies[-1], axis))
+        scene.joints[-1].setJointTransform(np.eye(4) if i == 0 else _T([10, 0, 0]))
+        scene.bodies[-1].setBodyTransform(_T([5, 0, 0]))
+        scene.joints[-1].q[0] = q0
+    return scene
+
+
+def sceneTree(n=64):
+    """Config 3: ~n-DOF branching tree following scene 2's pattern (scenesRedMax.m:101-130):
+    binary tree in depth-first order, 1-DOF joints alternating by depth parity between revolute
+    (axes cycling x,y,z) and prismatic (axis x), same [10 1 1] cuboids."""
+    scene = Scene()
+    scene.name = "%d-joint branching tree" % n
+    axes = ([1, 0, 0], [0, 1, 0], [0, 0, 1])
+    depth_limit = int(math.floor(math.log2(n + 1)))  # full binary levels, remainder hangs as a chain
+
+    state = {"count": 0, "rev": 0}
+
+    def add(parent, depth, offset):
+        if state["count"] >= n:
+            return None
+        body = BodyCuboid(1.0, [10, 1, 1])
+        if depth % 2 == 0:
+            ax = axes[state["rev"] % 3]
+            state["rev"] += 1
+            joint = JointRevolute(parent, body, ax)
+            joint.q[0] = 0.1
+        else:
+            joint = JointPrismatic(parent, body, [1, 0, 0])
+            joint.q[0] = 0.0
+            joint.setStiffness(1e4)   # keep the slider bounded
+        joint.setJointTransform(np.eye(4) if parent is None else _T(offset))
+        body.setBodyTransform(_T([5, 0, 0]))
+        scene.bodies.append(body)
+        scene.joints.append(joint)
+        state["count"] += 1
+        if depth + 1 < depth_limit:
+            add(joint, depth + 1, [10, -3, 0])
+            add(joint, depth + 1, [10, 3, 0])
+        return joint
+
+    add(None, 0, [0, 0, 0])
+    # hang whatever is left as a chain below the last joint so that exactly n joints exist
+    while state["count"] < n:
+        parent = scene.joints[-1]
+        body = BodyCuboid(1.0, [10, 1, 1])
+        joint = JointRevolute(parent, body, axes[state["rev"] % 3])
+        state["rev"] += 1
+        joint.setJointTransform(_T([10, 0, 0]))
+        joint.q[0] = 0.1
+        body.setBodyTransform(_T([5, 0, 0]))
+        scene.bodies.append(body)
+        scene.joints.append(joint)
+        state["count"] += 1
+    return scene
+
+
+def syntheticStates(nr, batch, first=0):
+    """Initial states of SURVEY.md §8(d): trajectory b has q~U(-pi/4,pi/4)^nr, qdot~U(-1,1)^nr from
+    numpy.random.default_rng(20240+b); trajectory 0 is the deterministic state q=0.1, qdot=0.
+    Seeds depend on the GLOBAL trajectory index so results are shard-invariant (§8(e))."""
+    q = np.empty((batch, nr))
+    qd = np.empty((batch, nr))
+    for i in range(batch):
+        b = first + i
+        if b == 0:
+            q[i] = 0.1
+            qd[i] = 0.0
+        else:
+            rng = np.random.default_rng(20240 + b)
+            q[i] = rng.uniform(-math.pi / 4, math.pi / 4, nr)
+            qd[i] = rng.uniform(-1.0, 1.0, nr)
+    return q, qd
