@@ -1,0 +1,163 @@
+/*
+ * redmax_hip.h -- C ABI of the MI355X-native batched RedMax BDF1/BDF2 forward-dynamics step.
+ *
+ * The reference (sueda/redmax) has no plugin / FFI / MEX boundary for this path: everything runs
+ * inside one MATLAB interpreter.  The seam this library replaces is the body of
+ *     simLoop(scene)                     matlab-diff/driverRedMaxBDF1.m:57-91
+ *       newton(@(q1)evalBDF1(q1,scene))  driverRedMaxBDF1.m:94-157, 160-187
+ *         computeValues(scene)           driverRedMaxBDF1.m:190-243
+ *           Joint.update / computeJacobian / computeForce   +redmax/Joint.m:382-613
+ *           Body.update / computeMassGrav                   +redmax/Body.m:70-135
+ *           se3.Ad / ad / inv / aaToMat                     se3.m:11-176
+ * re-expressed as a batch over independent trajectories of ONE scene.  Each entry point cites the
+ * reference code it stands in for.  A MATLAB MEX gateway or any other host binds
+ * these symbols; the in-repo host is the ctypes mirror in redmax_amd/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No exceptions cross the boundary.
+ *   - every function returns 0 on success, a negative RMX_E_* code otherwise; rmx_last_error()
+ *     gives the text.  Numerical failure (Newton diverged / not converged) is NOT an error: like
+ *     the reference (driverRedMaxBDF1.m:118-121,150-153: print and continue) it is reported per
+ *     trajectory in the stats arrays and stepping continues.
+ *   - all 4x4 transforms are COLUMN-MAJOR (what MATLAB's mxGetPr returns for a 4x4 double).
+ *   - reduced vectors use the reference's leaf-to-root DOF numbering (Scene.m:65-71): the LAST
+ *     listed joint owns index 0.  Batched arrays are [batch][nr], trajectory-major, fp64.
+ *   - matrices returned by rmx_eval are nr x nr COLUMN-MAJOR per trajectory ([batch][nr*nr]).
+ *   - host pointers are copied in/out and never retained; the library owns device memory.
+ *   - there is NO CPU fallback: without a usable HIP device every create call fails loudly.
+ */
+#ifndef REDMAX_HIP_H
+#define REDMAX_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMX_VERSION 100
+
+enum {
+    RMX_OK = 0,
+    RMX_E_INVALID = -1,     /* bad argument / unsupported scene                        */
+    RMX_E_NODEVICE = -2,    /* no HIP device (there is no CPU fallback)                */
+    RMX_E_HIP = -3,         /* HIP runtime error, see rmx_last_error()                 */
+    RMX_E_NOMEM = -4
+};
+
+enum { RMX_JOINT_FIXED = 0, RMX_JOINT_REVOLUTE = 1, RMX_JOINT_PRISMATIC = 2 };
+
+/* rmx_stats.status bits */
+/* RMX_ST_STALLED accompanies RMX_ST_MAXITER when the Newton iteration reached a floating-point fixed point
+ * (alpha*dx below one ulp of x): the reference repeats that identical iteration until iterMax and keeps x;
+ * the library returns the same x without spinning. */
+enum { RMX_ST_DIVERGED = 1, RMX_ST_MAXITER = 2, RMX_ST_NAN = 4, RMX_ST_STALLED = 8 };
+
+/* Scene listing, one entry per joint/body pair in the order the scene file lists them
+ * (parent before child; scenesRedMax.m).  Replaces the handle-object graph that Scene.init()
+ * links up (Scene.m:59-119).  Arrays are [njoints] unless noted. */
+typedef struct rmx_model_desc {
+    int njoints;
+    const int* parent;       /* parent joint index, -1 for the root          Joint.m:56-92       */
+    const int* type;         /* RMX_JOINT_*                                   JointRevolute/Prismatic/Fixed.m */
+    const double* axis;      /* [n][3] unit joint axis                        JointRevolute.m:14   */
+    const double* E0_pj;     /* [n][16] joint wrt parent joint at q=0         Joint.setJointTransform :95-99 */
+    const double* E0_ji;     /* [n][16] body wrt joint                        Body.setBodyTransform :46-51   */
+    const double* I_i;       /* [n][6] diagonal body inertia                  se3.inertiaCuboid :366-379     */
+    const double* qRest;     /* rest position of the joint spring (= initial q, Joint.m:157)     */
+    const double* tau;       /* joint torque                                  Joint.m:446          */
+    const double* stiffness; /* Joint.setStiffness                                                 */
+    const double* damping;   /* Joint.setDamping                                                   */
+    const double* qLimL;     /* joint limits                                  Joint.m:449-454      */
+    const double* qLimU;
+    const double* qLimK;
+    const double* qLimD;
+    double grav[3];          /* Scene.grav                                    Scene.m:48           */
+} rmx_model_desc;
+
+/* Newton constants of driverRedMaxBDF1.m:95-98; rmx_opts_default() fills the reference values. */
+typedef struct rmx_opts {
+    double h;              /* time step (Scene.h)                                  */
+    double tol;            /* 1e-9   ||g||_2 convergence threshold                 */
+    double dxMax;          /* 1e3    "Newton diverged" threshold on ||dx||_2       */
+    int iterMaxPerDof;     /* 10     iterMax = iterMaxPerDof * nr                  */
+    int iterLsMax;         /* 20     line-search halvings                          */
+} rmx_opts;
+
+typedef struct rmx_model rmx_model;
+typedef struct rmx_batch rmx_batch;
+
+const char* rmx_last_error(void);
+int rmx_version(void);
+int rmx_device_count(void);
+void rmx_opts_default(rmx_opts* o);
+
+/* Scene.init(): validates the listing, orders it depth-first, counts DOFs leaf-to-root and uploads
+ * the constant per-joint data.  (Scene.m:59-119, Joint.countDofs :149-158, Body.countDofs :54-60) */
+int rmx_model_create(const rmx_model_desc* desc, int device, rmx_model** out);
+void rmx_model_destroy(rmx_model* m);
+int rmx_model_nr(const rmx_model* m);      /* redmax.Scene.countR()  Scene.m:410-421 */
+int rmx_model_nm(const rmx_model* m);      /* redmax.Scene.countM()  Scene.m:398-409 */
+/* idx[n]: reduced index of each listed joint, -1 for a fixed joint (Joint.idxR) */
+int rmx_model_idxR(const rmx_model* m, int* idx);
+
+/* `batch` independent trajectories of the model, state resident in HBM on the model's device. */
+int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out);
+void rmx_batch_destroy(rmx_batch* b);
+int rmx_batch_size(const rmx_batch* b);
+
+/* Joint.setQ / Joint.getQ (Joint.m:173-292) for the whole batch: host arrays [batch][nr]. */
+int rmx_set_state(rmx_batch* b, const double* q, const double* qdot);
+int rmx_get_state(rmx_batch* b, double* q, double* qdot);
+/* Same, with DEVICE pointers (no host round trip; used to feed the final RCCL gather). */
+int rmx_set_state_device(rmx_batch* b, const double* d_q, const double* d_qdot);
+int rmx_get_state_device(rmx_batch* b, double* d_q, double* d_qdot);
+
+/* Parity hook = evalBDF1 / evalSDIRK2a / evalSDIRK2b / evalBDF2 (driverRedMaxBDF1.m:160-187,
+ * driverRedMaxBDF2.m:194-293) in their common form
+ *     qdot = (q - qA)/eta ;  dqtmp = q - qB ;  g = M dqtmp - eta^2 f ;  H = M - eta D - eta^2 K + dMdq dqtmp
+ * evaluated for every trajectory.  BDF1: eta = h, qA = q0, qB = q0 + h qdot0.
+ * q,qA,qB: host [batch][nr].  g: host [batch][nr].  H: host [batch][nr*nr] column-major or NULL
+ * (NULL selects the cheap residual-only path, nargout==1 in the reference).  Does not change state. */
+int rmx_eval(rmx_batch* b, const double* q, const double* qA, const double* qB, double eta,
+             double* g, double* H);
+
+/* Per-trajectory counters of one rmx_step_* call (host arrays [batch], any may be NULL). */
+typedef struct rmx_stats {
+    int* newton_iters;   /* Newton iterations summed over the steps                    */
+    int* ls_halvings;    /* line-search halvings summed over the steps                 */
+    int* status;         /* OR of RMX_ST_* over the steps                              */
+} rmx_stats;
+
+/* simLoop of driverRedMaxBDF1.m:57-91: nsteps fully-implicit BDF1 steps for every trajectory in ONE
+ * kernel launch (trajectories are independent, so the step loop runs on the device).
+ * hist_T/hist_V: optional host [nsteps][batch] kinetic / potential energy after each step
+ * (Scene.saveHistory, Scene.m:134-161; Joint/Body.computeEnergies).  May be NULL. */
+int rmx_step_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats,
+                  double* hist_T, double* hist_V);
+
+/* simLoop of driverRedMaxBDF2.m:57-125: the first call after set_state takes the SDIRK2 start step
+ * (two Newton solves, :64-88), later steps are BDF2 (:89-106).  The batch keeps (q,qdot) of step k-1. */
+int rmx_step_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats,
+                  double* hist_T, double* hist_V);
+
+/* Joint.computeEnergies + Body.computeEnergies at the current state (Joint.m:616-637, Body.m:167-173):
+ * host arrays [batch]. */
+int rmx_energy(rmx_batch* b, double* T, double* V);
+
+/* Timing hook for benchmarks: milliseconds spent in the kernels of the last rmx_step_* call, measured
+ * with hipEvents on the batch's own stream. */
+double rmx_last_step_ms(const rmx_batch* b);
+/* The HIP stream the batch's kernels are enqueued on (as void*), for callers that order other work
+ * (e.g. a torch.distributed gather) after it. */
+void* rmx_batch_stream(const rmx_batch* b);
+/* Asynchronous variant used by bench.py: enqueue the nsteps kernel and return without synchronising.
+ * rmx_sync() waits for the stream. */
+int rmx_step_bdf1_async(rmx_batch* b, const rmx_opts* opts, int nsteps);
+int rmx_sync(rmx_batch* b);
+/* The async variant accumulates the per-trajectory counters on the device: reset before, read after. */
+int rmx_stats_reset(rmx_batch* b);
+int rmx_stats_read(rmx_batch* b, rmx_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -71,6 +71,7 @@ def lib():
         L.orc_step_euler_simple.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp]
         L.orc_batch_step_bdf1.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int]
         L.orc_batch_step_bdf1.restype = C.c_long
+        L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -223,6 +224,11 @@ class Oracle:
         V = np.zeros(nsteps)
         self._L.orc_step_euler_simple(self._h, float(h), int(nsteps), _p(T), _p(V))
         return T, V
+
+
+def set_newton(tol=1e-9, dxMax=1e3, iterMaxPerDof=10, iterLsMax=20):
+    """Newton constants for every subsequent step call (defaults = driverRedMaxBDF1.m:95-98)."""
+    lib().orc_set_newton(float(tol), float(dxMax), int(iterMaxPerDof), int(iterLsMax))
 
 
 def batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0):

@@ -706,11 +706,20 @@ static int lu_solve_neg(int n, double* H, const double* g, double* dx) {
 
 static double vnorm(int n, const double* x) { double t = 0; for (int i = 0; i < n; i++) t += x[i] * x[i]; return sqrt(t); }
 
+/* Newton constants: the reference hard-codes tol=1e-9, dxMax=1e3, iterMax=10*nr, iterLsMax=20
+ * (driverRedMaxBDF1.m:95-98).  orc_set_newton lets tests/bench run the SAME algorithm with the SAME
+ * constants the HIP library was given (rmx_opts). */
+static double g_tol = 1e-9, g_dxMax = 1e3;
+static int g_iterMaxPerDof = 10, g_iterLsMax = 20;
+void orc_set_newton(double tol, double dxMax, int iterMaxPerDof, int iterLsMax) {
+    g_tol = tol; g_dxMax = dxMax; g_iterMaxPerDof = iterMaxPerDof; g_iterLsMax = iterLsMax;
+}
+
 /* newton (driverRedMaxBDF1.m:94-157): x updated in place */
 static void newton(orc_scene* s, double* x, const double* qA, const double* qB, double eta, orc_stats* st) {
     const int nr = s->nr;
-    const double tol = 1e-9, dxMax = 1e3;
-    const int iterMax = 10 * nr, iterLsMax = 20;
+    const double tol = g_tol, dxMax = g_dxMax;
+    const int iterMax = g_iterMaxPerDof * nr, iterLsMax = g_iterLsMax;
     double* g = (double*)calloc((size_t)nr + 1, sizeof(double));
     double* H = (double*)calloc((size_t)nr * nr + 1, sizeof(double));
     double* dx = (double*)calloc((size_t)nr + 1, sizeof(double));

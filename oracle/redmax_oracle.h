@@ -84,6 +84,10 @@ typedef struct orc_stats {
     int not_converged;    /* steps that hit iterMax                                   */
 } orc_stats;
 
+/* Newton constants used by every orc_step_* call (process-global).  Defaults = the reference's hard-coded
+ * values tol=1e-9, dxMax=1e3, iterMax=10*nr, iterLsMax=20 (driverRedMaxBDF1.m:95-98). */
+void orc_set_newton(double tol, double dxMax, int iterMaxPerDof, int iterLsMax);
+
 /* driverRedMaxBDF1.m simLoop:57-91 + newton:94-157.  Advances nsteps steps.
  * If Hist_T/Hist_V non-NULL they receive T,V after each step (Scene.saveHistory). */
 void orc_step_bdf1(orc_scene* s, double h, int nsteps, orc_stats* st, double* Hist_T, double* Hist_V);

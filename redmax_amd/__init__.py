@@ -1,0 +1,11 @@
+"""redmax_amd -- MI355X-native batched RedMax BDF1/BDF2 forward dynamics (host-side mirror).
+
+Scene construction keeps the reference's +redmax class surface (redmax.py, scenes.py); the numerics
+run in libredmax_hip.so (csrc/, C ABI in include/redmax_hip.h) on gfx950. No CPU fallback.
+"""
+from . import se3  # noqa: F401
+from .redmax import (Body, BodyCuboid, Joint, JointFixed, JointPrismatic, JointRevolute, Scene)  # noqa: F401
+from .scenes import IN_SCOPE_SCENES, sceneChain, scenesRedMax, sceneTree, syntheticStates  # noqa: F401
+from .batch import BatchSim  # noqa: F401
+from .driver import driverRedMaxBDF1, driverRedMaxBDF2, simLoop  # noqa: F401
+from ._abi import RedMaxHipError  # noqa: F401

@@ -1,0 +1,134 @@
+"""ctypes binding of the C ABI in include/redmax_hip.h (libredmax_hip.so, built in-tree).
+
+This is the only place the product touches native code.  There is deliberately no fallback:
+if the shared library is missing or no HIP device is visible, calls raise RedMaxHipError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libredmax_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# every symbol include/redmax_hip.h declares (tests/test_abi_symbols.py checks the .so exports them all)
+SYMBOLS = (
+    "rmx_last_error", "rmx_version", "rmx_device_count", "rmx_opts_default",
+    "rmx_model_create", "rmx_model_destroy", "rmx_model_nr", "rmx_model_nm", "rmx_model_idxR",
+    "rmx_batch_create", "rmx_batch_destroy", "rmx_batch_size",
+    "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
+    "rmx_eval", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_energy",
+    "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_sync",
+    "rmx_stats_reset", "rmx_stats_read",
+)
+
+
+class RedMaxHipError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("njoints", C.c_int),
+        ("parent", _ip), ("type", _ip),
+        ("axis", _dp), ("E0_pj", _dp), ("E0_ji", _dp), ("I_i", _dp),
+        ("qRest", _dp), ("tau", _dp), ("stiffness", _dp), ("damping", _dp),
+        ("qLimL", _dp), ("qLimU", _dp), ("qLimK", _dp), ("qLimD", _dp),
+        ("grav", C.c_double * 3),
+    ]
+
+
+class Opts(C.Structure):
+    _fields_ = [("h", C.c_double), ("tol", C.c_double), ("dxMax", C.c_double),
+                ("iterMaxPerDof", C.c_int), ("iterLsMax", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("newton_iters", _ip), ("ls_halvings", _ip), ("status", _ip)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libredmax_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RedMaxHipError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rmx_last_error.restype = C.c_char_p
+    L.rmx_version.restype = C.c_int
+    L.rmx_device_count.restype = C.c_int
+    L.rmx_opts_default.argtypes = [C.POINTER(Opts)]
+    L.rmx_model_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]
+    L.rmx_model_destroy.argtypes = [vp]
+    L.rmx_model_nr.argtypes = [vp]
+    L.rmx_model_nm.argtypes = [vp]
+    L.rmx_model_idxR.argtypes = [vp, _ip]
+    L.rmx_batch_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rmx_batch_destroy.argtypes = [vp]
+    L.rmx_batch_size.argtypes = [vp]
+    L.rmx_set_state.argtypes = [vp, _dp, _dp]
+    L.rmx_get_state.argtypes = [vp, _dp, _dp]
+    L.rmx_set_state_device.argtypes = [vp, vp, vp]
+    L.rmx_get_state_device.argtypes = [vp, vp, vp]
+    L.rmx_eval.argtypes = [vp, _dp, _dp, _dp, C.c_double, _dp, _dp]
+    L.rmx_step_bdf1.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(Stats), _dp, _dp]
+    L.rmx_step_bdf2.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(Stats), _dp, _dp]
+    L.rmx_energy.argtypes = [vp, _dp, _dp]
+    L.rmx_last_step_ms.argtypes = [vp]
+    L.rmx_last_step_ms.restype = C.c_double
+    L.rmx_batch_stream.argtypes = [vp]
+    L.rmx_batch_stream.restype = vp
+    L.rmx_step_bdf1_async.argtypes = [vp, C.POINTER(Opts), C.c_int]
+    L.rmx_sync.argtypes = [vp]
+    L.rmx_stats_reset.argtypes = [vp]
+    L.rmx_stats_read.argtypes = [vp, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rmx_last_error()
+        raise RedMaxHipError("%s failed (%d): %s" % (what or "redmax_hip call", rc, msg.decode() if msg else "?"))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def make_desc(d):
+    """dict from redmax.Scene.desc() -> (ModelDesc, keepalive)."""
+    keep = {}
+
+    def f64(k):
+        keep[k] = np.ascontiguousarray(d[k], dtype=np.float64)
+        return keep[k].ctypes.data_as(_dp)
+
+    def i32(k):
+        keep[k] = np.ascontiguousarray(d[k], dtype=np.int32)
+        return keep[k].ctypes.data_as(_ip)
+
+    s = ModelDesc()
+    s.njoints = int(d["njoints"])
+    s.parent, s.type = i32("parent"), i32("type")
+    for k in ("axis", "E0_pj", "E0_ji", "I_i", "qRest", "tau", "stiffness", "damping", "qLimL", "qLimU", "qLimK", "qLimD"):
+        setattr(s, k, f64(k))
+    for i in range(3):
+        s.grav[i] = float(d["grav"][i])
+    return s, keep

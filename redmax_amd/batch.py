@@ -1,0 +1,138 @@
+"""Batched rollouts of one scene on one MI355X: the host-side handle around the C ABI.
+
+``BatchSim`` is what replaces the body of ``simLoop`` (matlab-diff/driverRedMaxBDF1.m:57-91):
+the scene is flattened once (``Scene.desc()``), B independent (q, qdot) states live in HBM and
+``step_bdf1(nsteps)`` advances all of them in one kernel launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class BatchSim:
+    def __init__(self, scene_or_desc, batch=1, device=0):
+        d = scene_or_desc.desc() if hasattr(scene_or_desc, "desc") else scene_or_desc
+        self._L = _abi.lib()
+        self._desc, self._keep = _abi.make_desc(d)
+        self._model = C.c_void_p()
+        self._batch = C.c_void_p()
+        _abi.check(self._L.rmx_model_create(C.byref(self._desc), int(device), C.byref(self._model)), "rmx_model_create")
+        self.nr = self._L.rmx_model_nr(self._model)
+        self.nm = self._L.rmx_model_nm(self._model)
+        self.B = int(batch)
+        self.device = int(device)
+        _abi.check(self._L.rmx_batch_create(self._model, self.B, C.byref(self._batch)), "rmx_batch_create")
+        self.opts = _abi.Opts()
+        self._L.rmx_opts_default(C.byref(self.opts))
+
+    def close(self):
+        if getattr(self, "_batch", None):
+            self._L.rmx_batch_destroy(self._batch)
+            self._batch = None
+        if getattr(self, "_model", None):
+            self._L.rmx_model_destroy(self._model)
+            self._model = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Joint.setQ / getQ for the batch, reference (leaf-to-root) DOF order ----
+    def _arr(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != (self.B, self.nr):
+            a = np.ascontiguousarray(np.broadcast_to(a, (self.B, self.nr)))
+        return a
+
+    def idxR(self):
+        idx = np.zeros(self._desc.njoints, dtype=np.int32)
+        _abi.check(self._L.rmx_model_idxR(self._model, _abi.iptr(idx)), "rmx_model_idxR")
+        return idx
+
+    def set_state(self, q, qdot):
+        q, qdot = self._arr(q), self._arr(qdot)
+        _abi.check(self._L.rmx_set_state(self._batch, _abi.dptr(q), _abi.dptr(qdot)), "rmx_set_state")
+
+    def get_state(self):
+        q = np.empty((self.B, self.nr))
+        qd = np.empty((self.B, self.nr))
+        _abi.check(self._L.rmx_get_state(self._batch, _abi.dptr(q), _abi.dptr(qd)), "rmx_get_state")
+        return q, qd
+
+    def get_state_device(self, q_ptr, qdot_ptr):
+        """Copy the state into caller-owned DEVICE buffers (e.g. torch tensors' data_ptr())."""
+        _abi.check(self._L.rmx_get_state_device(self._batch, C.c_void_p(q_ptr), C.c_void_p(qdot_ptr)), "rmx_get_state_device")
+
+    def set_state_device(self, q_ptr, qdot_ptr):
+        _abi.check(self._L.rmx_set_state_device(self._batch, C.c_void_p(q_ptr), C.c_void_p(qdot_ptr)), "rmx_set_state_device")
+
+    # ---- evalBDF1 & friends: g (and H) for every trajectory ----
+    def eval_residual(self, q, qA, qB, eta, want_H=True):
+        q, qA, qB = self._arr(q), self._arr(qA), self._arr(qB)
+        g = np.empty((self.B, self.nr))
+        H = np.empty((self.B, self.nr * self.nr)) if want_H else None
+        _abi.check(self._L.rmx_eval(self._batch, _abi.dptr(q), _abi.dptr(qA), _abi.dptr(qB), float(eta), _abi.dptr(g), _abi.dptr(H)), "rmx_eval")
+        if want_H:
+            return g, H.reshape(self.B, self.nr, self.nr).transpose(0, 2, 1)   # column-major -> [b][row][col]
+        return g
+
+    def eval_bdf1(self, q1, q0, qdot0, h, want_H=True):
+        q0 = self._arr(q0)
+        return self.eval_residual(q1, q0, q0 + h * self._arr(qdot0), h, want_H)
+
+    # ---- stepping ----
+    def _step(self, fn, nsteps, h, stats, history):
+        if h is not None:
+            self.opts.h = float(h)
+        st = None
+        out = {}
+        if stats:
+            out["newton_iters"] = np.zeros(self.B, dtype=np.int32)
+            out["ls_halvings"] = np.zeros(self.B, dtype=np.int32)
+            out["status"] = np.zeros(self.B, dtype=np.int32)
+            st = _abi.Stats(_abi.iptr(out["newton_iters"]), _abi.iptr(out["ls_halvings"]), _abi.iptr(out["status"]))
+        T = V = None
+        if history:
+            T = np.empty((nsteps, self.B))
+            V = np.empty((nsteps, self.B))
+            out["T"], out["V"] = T, V
+        _abi.check(fn(self._batch, C.byref(self.opts), int(nsteps), C.byref(st) if st is not None else None,
+                      _abi.dptr(T), _abi.dptr(V)), "rmx_step")
+        out["ms"] = self._L.rmx_last_step_ms(self._batch)
+        return out
+
+    def step_bdf1(self, nsteps, h=None, stats=False, history=False):
+        return self._step(self._L.rmx_step_bdf1, nsteps, h, stats, history)
+
+    def step_bdf2(self, nsteps, h=None, stats=False, history=False):
+        return self._step(self._L.rmx_step_bdf2, nsteps, h, stats, history)
+
+    def step_bdf1_async(self, nsteps, h=None):
+        if h is not None:
+            self.opts.h = float(h)
+        _abi.check(self._L.rmx_step_bdf1_async(self._batch, C.byref(self.opts), int(nsteps)), "rmx_step_bdf1_async")
+
+    def sync(self):
+        _abi.check(self._L.rmx_sync(self._batch), "rmx_sync")
+        return self._L.rmx_last_step_ms(self._batch)
+
+    def stats_reset(self):
+        _abi.check(self._L.rmx_stats_reset(self._batch), "rmx_stats_reset")
+
+    def stats_read(self):
+        out = {k: np.zeros(self.B, dtype=np.int32) for k in ("newton_iters", "ls_halvings", "status")}
+        st = _abi.Stats(_abi.iptr(out["newton_iters"]), _abi.iptr(out["ls_halvings"]), _abi.iptr(out["status"]))
+        _abi.check(self._L.rmx_stats_read(self._batch, C.byref(st)), "rmx_stats_read")
+        return out
+
+    def energy(self):
+        T = np.empty(self.B)
+        V = np.empty(self.B)
+        _abi.check(self._L.rmx_energy(self._batch, _abi.dptr(T), _abi.dptr(V)), "rmx_energy")
+        return T, V

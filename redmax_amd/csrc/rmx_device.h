@@ -1,0 +1,577 @@
+// rmx_device.h -- device-side code of the batched RedMax implicit step for gfx950 (MI355X).
+//
+// One 64-lane wavefront owns one trajectory.  Within the wave, lane j owns joint/body j of the
+// kinematic tree (depth-first order), so every per-node quantity lives in registers and the tree
+// recursions of the reference (Joint.update / Joint.computeJacobian / Body.computeMassGrav,
+// matlab-diff/+redmax/Joint.m:382-613, Body.m:70-135) become
+//   * root->node path products/sums   : pointer jumping over ancestors with cross-lane permutes
+//   * node->leaves subtree sums       : transpose through LDS, one lane per component scans the nodes
+//   * the nr x nr Hessian             : lane = row, broadcast column vectors from LDS
+//   * the dense solve  dx = -H\g      : lane = row, row held in registers, pivot row via readlane
+// The algebra (world-frame recursive Newton-Euler with analytic derivatives, no J / dJdq tensors)
+// is derived in DESIGN.md and restated executable in tests/proto_worldframe.py.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rmx {
+
+constexpr int MAXN = 64;          // nodes per tree handled by one wavefront
+constexpr int NACC = 28;          // subtree-accumulated numbers per body (w6, m1, mc3, Ibar6, TL9, hf3)
+constexpr int ACC_STRIDE = 29;    // odd stride: conflict-free lane=node LDS writes
+constexpr int NCOL = 18;          // column-side Hessian vectors per node (yz6, m1 6, m2w3, sw3)
+constexpr int COL_STRIDE = 19;
+constexpr int MAXROUNDS = 6;      // log2(MAXN)
+
+// Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
+struct DevModel {
+    int n;            // nodes (joints == bodies)
+    int nr;           // reduced DOFs
+    int rounds;       // pointer-jumping rounds = ceil(log2(max depth + 1))
+    int is_chain;     // every subtree ends at n (serial chain): skip the range subtraction
+    const double* K;  // [36][MAXN]  T_j(q) = K0 + u K1 + w K2, rows: R(9) then p(3) for K0,K1,K2
+    const double* sb; // [6][MAXN]   joint screw in the body frame, A0_ij * S  (Joint.m:508)
+    const double* I4; // [4][MAXN]   I1,I2,I3,m  (se3.inertiaCuboid)
+    const double* prm;// [8][MAXN]   tau, stiffness, damping, qRest, qLimL, qLimU, qLimK, qLimD
+    const int* type;  // [MAXN]
+    const int* idx;   // [MAXN] reduced index (reference leaf-to-root numbering) or -1
+    const int* end;   // [MAXN] one past the last node of the subtree (depth-first order)
+    const int* anc;   // [MAXROUNDS][MAXN] ancestor 2^r levels up, or -1
+    double grav[3];
+};
+
+struct DevOpts {
+    double h, tol, dxMax;
+    int iterMax, iterLsMax;
+};
+
+// ----------------------------------------------------------------------------- small helpers
+
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double c[3]) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double dot3(const double a[3], const double b[3]) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+// y = R x, R row-major 3x3
+__device__ __forceinline__ void mat3v(const double R[9], const double x[3], double y[3]) {
+    y[0] = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+    y[1] = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+    y[2] = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+}
+// symmetric 3x3 stored xx,xy,xz,yy,yz,zz
+__device__ __forceinline__ void sym3v(const double S[6], const double x[3], double y[3]) {
+    y[0] = S[0] * x[0] + S[1] * x[1] + S[2] * x[2];
+    y[1] = S[1] * x[0] + S[3] * x[1] + S[4] * x[2];
+    y[2] = S[2] * x[0] + S[4] * x[1] + S[5] * x[2];
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+// Per-lane (per-node) results of one evaluation that the caller keeps.
+struct NodeOut {
+    double g;        // residual entry of this node's DOF (0 for a fixed joint)
+    double eT, eV;   // kinetic / potential energy contribution of this body + joint
+};
+
+// ----------------------------------------------------------------------------- the evaluation
+//
+// evalBDF1 / computeValues (driverRedMaxBDF1.m:160-243) for the generic implicit residual
+//     qdot = (x - qA)/eta ; v = x - qB ; g = M v - eta^2 f ; H = dg/dx
+// xq, xqd, xv: this lane's DOF position, velocity qdot and dqtmp entry v (node order; the caller forms
+// qdot and v from x, qA, qB).  Hrow[i] = H(row of this node, column of node i).
+template <int NP, bool WANT_H>
+__device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict__ sAcc, double* __restrict__ sCol,
+                                          const int lane, const double xq, const double xqd, const double xv,
+                                          const double eta, NodeOut& out, double (&Hrow)[NP]) {
+    const int n = M.n;
+    const bool act = lane < n;
+    const int jj = act ? lane : 0;
+    const int type = act ? M.type[jj] : 0;
+    const bool dof = type != 0;
+    const double e2 = eta * eta;
+
+    const double q = dof ? xq : 0.0;
+    const double qd = dof ? xqd : 0.0;
+    const double v = dof ? xv : 0.0;
+
+    // ---- joint transform T_j(q) = K0 + u K1 + w K2  (JointRevolute/Prismatic.update_, Joint.update :401-408,
+    //      Body.update :70-72, folded with the constant offsets E0_ij(parent) E0_pj and E0_ji)
+    double u = 0.0, w = 0.0;
+    if (type == 1) {
+        sincos(q, &u, &w);
+    } else if (type == 2) {
+        u = q;
+    }
+    double R[9], p[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[c] = M.K[c * MAXN + jj] + u * M.K[(12 + c) * MAXN + jj] + w * M.K[(24 + c) * MAXN + jj];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = M.K[(9 + c) * MAXN + jj] + u * M.K[(21 + c) * MAXN + jj] + w * M.K[(33 + c) * MAXN + jj];
+
+    // ---- world transforms E_w,j = E_w,parent T_j : pointer jumping (log2(depth) rounds)
+    for (int r = 0; r < M.rounds; ++r) {
+        const int a = act ? M.anc[r * MAXN + jj] : -1;
+        const int src = a >= 0 ? a : lane;
+        double Ra[9], pa[3];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Ra[c] = shfl_d(R[c], src);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pa[c] = shfl_d(p[c], src);
+        if (a >= 0) {
+            double Rn[9], pn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
+                pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = pn[c];
+        }
+    }
+
+    // ---- world-frame joint screw s_j = Ad(E_w,j) (A0_ij S)   (the column of J, Joint.m:508-522)
+    double sbw[3], sbv[3], sw[3], sv[3], t3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sbw[c] = act ? M.sb[c * MAXN + jj] : 0.0;
+        sbv[c] = act ? M.sb[(3 + c) * MAXN + jj] : 0.0;
+    }
+    mat3v(R, sbw, sw);
+    mat3v(R, sbv, sv);
+    cross3(p, sw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sv[c] += t3[c];
+
+    // ---- phi_j = sum_{a in anc*(j)} s_a qdot_a   ( = (J qdot)_j, Joint.update :411-419 )
+    double phw[3], phv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        phw[c] = sw[c] * qd;
+        phv[c] = sv[c] * qd;
+    }
+    for (int r = 0; r < M.rounds; ++r) {
+        const int a = act ? M.anc[r * MAXN + jj] : -1;
+        const int src = a >= 0 ? a : lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double tw = shfl_d(phw[c], src), tv = shfl_d(phv[c], src);
+            if (a >= 0) {
+                phw[c] += tw;
+                phv[c] += tv;
+            }
+        }
+    }
+    // ---- xi_j = ad(phi_j) s_j ; beta_j = sum_{a in anc*(j)} (s_a v_a + eta^2 xi_a qdot_a)  ( = (J v + eta^2 Jdot qdot)_j )
+    double xiw[3], xiv[3], bw[3], bv[3];
+    cross3(phw, sw, xiw);
+    cross3(phv, sw, xiv);
+    cross3(phw, sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xiv[c] += t3[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        bw[c] = sw[c] * v + e2 * qd * xiw[c];
+        bv[c] = sv[c] * v + e2 * qd * xiv[c];
+    }
+    for (int r = 0; r < M.rounds; ++r) {
+        const int a = act ? M.anc[r * MAXN + jj] : -1;
+        const int src = a >= 0 ? a : lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double tw = shfl_d(bw[c], src), tv = shfl_d(bv[c], src);
+            if (a >= 0) {
+                bw[c] += tw;
+                bv[c] += tv;
+            }
+        }
+    }
+
+    // ---- world-frame spatial inertia of body j (Body.computeMassGrav :99-101): m, mc, Ibar = R diag(I) R' + m [c][c]'
+    const double I1 = act ? M.I4[0 * MAXN + jj] : 0.0, I2 = act ? M.I4[1 * MAXN + jj] : 0.0;
+    const double I3 = act ? M.I4[2 * MAXN + jj] : 0.0, ms = act ? M.I4[3 * MAXN + jj] : 0.0;
+    double mc[3], Ib[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mc[c] = ms * p[c];
+    {
+        const double cc = dot3(p, p);
+        Ib[0] = I1 * R[0] * R[0] + I2 * R[1] * R[1] + I3 * R[2] * R[2] + ms * (cc - p[0] * p[0]);
+        Ib[1] = I1 * R[0] * R[3] + I2 * R[1] * R[4] + I3 * R[2] * R[5] - ms * p[0] * p[1];
+        Ib[2] = I1 * R[0] * R[6] + I2 * R[1] * R[7] + I3 * R[2] * R[8] - ms * p[0] * p[2];
+        Ib[3] = I1 * R[3] * R[3] + I2 * R[4] * R[4] + I3 * R[5] * R[5] + ms * (cc - p[1] * p[1]);
+        Ib[4] = I1 * R[3] * R[6] + I2 * R[4] * R[7] + I3 * R[5] * R[8] - ms * p[1] * p[2];
+        Ib[5] = I1 * R[6] * R[6] + I2 * R[7] * R[7] + I3 * R[8] * R[8] + ms * (cc - p[2] * p[2]);
+    }
+    // momentum h = I phi, I beta
+    double ht[3], hf[3], bt[3], bf[3];
+    sym3v(Ib, phw, ht);
+    cross3(mc, phv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ht[c] += t3[c];
+    cross3(mc, phw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) hf[c] = ms * phv[c] - t3[c];
+    sym3v(Ib, bw, bt);
+    cross3(mc, bv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bt[c] += t3[c];
+    cross3(mc, bw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bf[c] = ms * bv[c] - t3[c];
+    // Coriolis wrench ad(phi)' h (Body.m:102-103) and gravity wrench (Body.m:104-109), world frame
+    double fct[3], fcf[3], a3[3], b3[3];
+    cross3(phw, ht, a3);
+    cross3(phv, hf, b3);
+    cross3(phw, hf, fcf);
+    const double gv[3] = {M.grav[0], M.grav[1], M.grav[2]};
+    double fgt[3];
+    cross3(mc, gv, fgt);
+    double wt[3], wf[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        fct[c] = -a3[c] - b3[c];
+        wt[c] = bt[c] - e2 * (fct[c] + fgt[c]);
+        wf[c] = bf[c] - e2 * (-fcf[c] + ms * gv[c]);
+    }
+
+    // energies (Body.computeEnergies Body.m:167-173, Joint.computeEnergies Joint.m:616-637)
+    const double stiff = act ? M.prm[1 * MAXN + jj] : 0.0, damp = act ? M.prm[2 * MAXN + jj] : 0.0;
+    const double tau = act ? M.prm[0 * MAXN + jj] : 0.0, qRest = act ? M.prm[3 * MAXN + jj] : 0.0;
+    const double qLimL = act ? M.prm[4 * MAXN + jj] : 0.0, qLimU = act ? M.prm[5 * MAXN + jj] : 0.0;
+    const double qLimK = act ? M.prm[6 * MAXN + jj] : 0.0, qLimD = act ? M.prm[7 * MAXN + jj] : 0.0;
+    const double hitL = (dof && q < qLimL) ? 1.0 : 0.0, hitU = (dof && q > qLimU) ? 1.0 : 0.0;
+    {
+        double eT = 0.5 * (dot3(phw, ht) + dot3(phv, hf));
+        double eV = -dot3(gv, mc);
+        if (dof) {
+            const double dq = q - qRest;
+            const double dqL = hitL * (qLimL - q), dqU = hitU * (qLimU - q);
+            eV += 0.5 * stiff * (dq * dq) + 0.5 * qLimK * (dqL * dqL + dqU * dqU);
+        }
+        out.eT = act ? eT : 0.0;
+        out.eV = act ? eV : 0.0;
+    }
+
+    // ---- subtree sums through LDS: W (6) [+ m, mc, Ibar, TL, hf for the Hessian]
+    if (act) {
+        double* A = sAcc + lane * ACC_STRIDE;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            A[c] = wt[c];
+            A[3 + c] = wf[c];
+        }
+        if (WANT_H) {
+            A[6] = ms;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A[7 + c] = mc[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) A[10 + c] = Ib[c];
+            // TL = X + X' + [h_tau],  X = Ibar [phi_w] + [mc][phi_v]   (B = I ad(phi) + ad(phi)' I + N(h) = [[TL,0],[2[hf],0]])
+            const double Ibf[9] = {Ib[0], Ib[1], Ib[2], Ib[1], Ib[3], Ib[4], Ib[2], Ib[4], Ib[5]};
+            const double Om[9] = {0.0, -phw[2], phw[1], phw[2], 0.0, -phw[0], -phw[1], phw[0], 0.0};
+            const double Vx[9] = {0.0, -phv[2], phv[1], phv[2], 0.0, -phv[0], -phv[1], phv[0], 0.0};
+            const double Mc[9] = {0.0, -mc[2], mc[1], mc[2], 0.0, -mc[0], -mc[1], mc[0], 0.0};
+            const double Ht[9] = {0.0, -ht[2], ht[1], ht[2], 0.0, -ht[0], -ht[1], ht[0], 0.0};
+            double X[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) s += Ibf[3 * i + l] * Om[3 * l + k] + Mc[3 * i + l] * Vx[3 * l + k];
+                    X[3 * i + k] = s;
+                }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) A[16 + 3 * i + k] = X[3 * i + k] + X[3 * k + i] + Ht[3 * i + k];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A[25 + c] = hf[c];
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int NC = WANT_H ? NACC : 6;
+        if (lane < NC) {
+            double acc = 0.0;
+            for (int jn = n - 1; jn >= 0; --jn) {     // suffix sums over the depth-first order
+                acc += sAcc[jn * ACC_STRIDE + lane];
+                sAcc[jn * ACC_STRIDE + lane] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int NS = WANT_H ? NACC : 6;
+    double S[NS];
+    {
+        const double* A = sAcc + jj * ACC_STRIDE;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) S[c] = A[c];
+        if (!M.is_chain) {   // subtree(j) = suffix(j) - suffix(end_j); row n of sAcc is kept zero
+            const int en = act ? M.end[jj] : n;
+            const double* E = sAcc + en * ACC_STRIDE;
+#pragma unroll
+            for (int c = 0; c < NS; ++c) S[c] -= E[c];
+        }
+    }
+    const double* Wt = &S[0];
+    const double* Wf = &S[3];
+
+    // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
+    const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
+                      hitU * (qLimK * (qLimU - q) - qLimD * qd);
+    out.g = dof ? (dot3(sw, Wt) + dot3(sv, Wf) - e2 * fr) : 0.0;
+
+    if (WANT_H) {
+        __syncthreads();   // everyone has read sAcc (not strictly needed: sCol is a different region)
+        const double mS = S[6];
+        const double* mcS = &S[7];
+        const double* IbS = &S[10];
+        const double* TL = &S[16];
+        const double* hfS = &S[25];
+        // zeta = ad(beta) s + eta^2 ad(phi) xi ; m1 = s + 2 eta xi + zeta ; m2w = eta sw + eta^2 xiw
+        double zw[3], zv[3], m1w[3], m1v[3], m2w[3];
+        cross3(bw, sw, zw);
+        cross3(bv, sw, zv);
+        cross3(bw, sv, t3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) zv[c] += t3[c];
+        cross3(phw, xiw, a3);
+        cross3(phv, xiw, b3);
+        cross3(phw, xiv, t3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            zw[c] += e2 * a3[c];
+            zv[c] += e2 * (b3[c] + t3[c]);
+            m1w[c] = sw[c] + 2.0 * eta * xiw[c] + zw[c];
+            m1v[c] = sv[c] + 2.0 * eta * xiv[c] + zv[c];
+            m2w[c] = eta * sw[c] + e2 * xiw[c];
+        }
+        // y = Ic m1 - Bc m2 - eta^2 Kc s
+        double yt[3], yf[3];
+        sym3v(IbS, m1w, yt);
+        cross3(mcS, m1v, t3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) yt[c] += t3[c];
+        cross3(mcS, m1w, t3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) yf[c] = mS * m1v[c] - t3[c];
+        mat3v(TL, m2w, a3);                 // Bc m2 : top = TL m2w, bottom = 2 hf x m2w
+        cross3(hfS, m2w, b3);
+        double gxs[3], kt[3];
+        cross3(gv, sw, gxs);                // Kc s : top = mc x (g x sw), bottom = m g x sw
+        cross3(mcS, gxs, kt);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            yt[c] -= a3[c] + e2 * kt[c];
+            yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c];
+        }
+        // z = ad(s)' W
+        double zt[3], zf[3];
+        cross3(sw, Wt, a3);
+        cross3(sv, Wf, b3);
+        cross3(sw, Wf, zf);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            zt[c] = -a3[c] - b3[c];
+            zf[c] = -zf[c];
+        }
+        // diagonal: s.y - eta Dr - eta^2 Kr   (Joint.computeForce Joint.m:470-482)
+        const double Kr = -stiff - (hitL + hitU) * qLimK;
+        const double Dr = -damp - (hitL + hitU) * qLimD;
+        const double Hdiag = dof ? (dot3(sw, yt) + dot3(sv, yf) - eta * Dr - e2 * Kr) : 1.0;
+        // row-side vectors: r1 = Ic s, r2w = TL' sw - 2 hf x sv, r3w = eta^2 (g x (mc x sw) - m g x sv)
+        double r1t[3], r1f[3], r2w[3], r3w[3];
+        sym3v(IbS, sw, r1t);
+        cross3(mcS, sv, t3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r1t[c] += t3[c];
+        cross3(mcS, sw, t3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r1f[c] = mS * sv[c] - t3[c];
+        cross3(hfS, sv, b3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r2w[c] = TL[c] * sw[0] + TL[3 + c] * sw[1] + TL[6 + c] * sw[2] - 2.0 * b3[c];
+        cross3(gv, t3, a3);     // g x (mc x sw)
+        cross3(gv, sv, b3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r3w[c] = e2 * (a3[c] - mS * b3[c]);
+        // column-side vectors to LDS
+        if (act) {
+            double* Cn = sCol + lane * COL_STRIDE;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Cn[c] = yt[c] - zt[c];
+                Cn[3 + c] = yf[c] - zf[c];
+                Cn[6 + c] = m1w[c];
+                Cn[9 + c] = m1v[c];
+                Cn[12 + c] = m2w[c];
+                Cn[15 + c] = sw[c];
+            }
+        }
+        __syncthreads();
+        const int myend = act ? M.end[jj] : 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i >= n) {
+                Hrow[i] = (i == lane) ? 1.0 : 0.0;
+            } else {
+            const double* Ci = sCol + i * COL_STRIDE;
+            const int endi = M.end[i];
+            const double up = sw[0] * Ci[0] + sw[1] * Ci[1] + sw[2] * Ci[2] + sv[0] * Ci[3] + sv[1] * Ci[4] + sv[2] * Ci[5];
+            const double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
+                              (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
+            double hv = 0.0;
+            if (lane < i && i < myend) hv = up;            // this row's node is a strict ancestor of column node
+            else if (i < lane && lane < endi) hv = lo;     // strict descendant
+            else if (i == lane) hv = Hdiag;
+            Hrow[i] = hv;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------- dense solve
+//
+// dx = -H\g (driverRedMaxBDF1.m:117: MATLAB mldivide = LU with partial pivoting).  Lane = row; the row
+// lives in registers; rows are never moved (implicit permutation); the pivot row is broadcast with
+// v_readlane into scalar registers; the right-hand side is eliminated alongside.
+template <int NP>
+__device__ __forceinline__ double lu_solve_neg(const int n, const int lane, double (&Hrow)[NP], const double g) {
+    double b = -g;
+    int pivstep = (lane < n) ? -1 : (NP + 1);   // -1: not yet used as a pivot row
+    double rinv_own = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if (k < n) {   // wave-uniform guard (no break: the loop must unroll fully so Hrow stays in registers)
+            // pivot search: max |H(a,k)| over unused rows; 26-bit key (exponent + 14 mantissa bits) + lane id
+            unsigned key = 0u;
+            if (pivstep < 0) key = ((unsigned)(__double2hiint(Hrow[k]) & 0x7fffffff) & ~63u) + 64u + (unsigned)lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)key, o, 64);
+                key = other > key ? other : key;
+            }
+            const int pl = __builtin_amdgcn_readfirstlane((int)(key & 63u));
+            const double piv = readlane_d(Hrow[k], pl);
+            const double rinv = 1.0 / piv;
+            const bool elim = pivstep < 0 && lane != pl;
+            if (lane == pl) {
+                pivstep = k;
+                rinv_own = rinv;
+            }
+            const double l = elim ? Hrow[k] * rinv : 0.0;
+#pragma unroll
+            for (int c = k + 1; c < NP; ++c) {   // columns >= n hold zeros on every row < n: harmless
+                const double pr = readlane_d(Hrow[c], pl);
+                Hrow[c] -= l * pr;               // l == 0 on rows that are not being eliminated
+            }
+            const double pb = readlane_d(b, pl);
+            b -= l * pb;
+        }
+    }
+    // back substitution on the implicitly permuted upper triangle
+    double dx = 0.0;
+#pragma unroll
+    for (int k = NP - 1; k >= 0; --k) {
+        if (k < n) {
+            const unsigned long long mk = __ballot(pivstep == k);
+            const int pl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mk) - 1);
+            const double xk = readlane_d(b * rinv_own, pl);
+            if (lane == k) dx = xk;
+            if (pivstep < k) b -= Hrow[k] * xk;
+        }
+    }
+    return dx;
+}
+
+// ----------------------------------------------------------------------------- Newton
+//
+// newton (driverRedMaxBDF1.m:94-157): damped Newton, backtracking on 0.5|g|^2 with strict decrease,
+// at most iterLsMax halvings (the last trial is kept), stop on |g|<tol, iter>=iterMax or |dx|>dxMax.
+template <int NP>
+__device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
+                                              double x, const double qA, const double qB, const double eta, NodeOut& last,
+                                              int& iters, int& halvings, int& status) {
+    double Hrow[NP];
+    int iter = 1;
+    while (true) {
+        NodeOut e;
+        eval_node<NP, true>(M, sAcc, sCol, lane, x, (x - qA) / eta, x - qB, eta, e, Hrow);
+        const NodeOut e0 = e;
+        last = e;
+        ++iters;
+        const double dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        const double dxn2 = wave_sum(dx * dx);
+        if (!(dxn2 == dxn2)) {   // NaN: give up on this trajectory instead of spinning to iterMax
+            status |= 4;
+            break;
+        }
+        if (sqrt(dxn2) > o.dxMax) {
+            status |= 1;         // "Newton diverged" (:118-121): x is left at the last iterate
+            break;
+        }
+        double alpha = 1.0;
+        const double g0n2 = wave_sum(e.g * e.g);
+        const double f0 = 0.5 * g0n2;
+        const double x0 = x;
+        int iterLs = 1;
+        double gn2 = g0n2;
+        bool stalled = false;
+        while (true) {
+            x = x0 + alpha * dx;
+            if (__all(x == x0)) {
+                // alpha*dx is below one ulp of x in every DOF: this and every further halving re-evaluates g at x0
+                // bit-for-bit, so f == f0 is never a strict decrease, the reference runs out its iterLsMax trials and
+                // keeps x0 (:132-138).  Same outcome, without the evaluations.
+                stalled = true;
+                iterLs = o.iterLsMax;
+                e = e0;              // the evaluation at x0
+                break;
+            }
+            double dummy[NP];
+            eval_node<NP, false>(M, sAcc, sCol, lane, x, (x - qA) / eta, x - qB, eta, e, dummy);
+            gn2 = wave_sum(e.g * e.g);
+            if (0.5 * gn2 < f0) break;
+            if (iterLs >= o.iterLsMax) break;
+            alpha *= 0.5;
+            ++iterLs;
+        }
+        last = e;
+        halvings += iterLs - 1;
+        if (stalled) {
+            // g is g(x0) again.  If it is not below tol the next Newton iteration is this one repeated exactly, and so
+            // on until iter >= iterMax ("Newton did not converge", :150-153) with x unchanged: report that now.
+            if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+            break;
+        }
+        if (sqrt(gn2) < o.tol) break;
+        if (iter >= o.iterMax) {
+            status |= 2;         // "Newton did not converge" (:150-153)
+            break;
+        }
+        ++iter;
+    }
+    return x;
+}
+
+}  // namespace rmx

@@ -1,0 +1,55 @@
+"""Entry points with the reference's names and signatures.
+
+``driverRedMaxBDF1(sceneID, batch)`` / ``driverRedMaxBDF2(sceneID, batch)`` mirror
+matlab-diff/driverRedMaxBDF1.m:1-54 and driverRedMaxBDF2.m: build the scene, ``init()``, run
+``simLoop`` and check the final energy against ``Hexpected`` (Scene.plotEnergies, Scene.m:164-178).
+``simLoop`` is ONE call into the HIP library (all steps run on the device); ``batch`` keeps the
+reference's meaning (non-interactive: no drawing, no FD self-tests - which is all this build does).
+"""
+from __future__ import annotations
+
+from .batch import BatchSim
+from .scenes import scenesRedMax
+
+
+def simLoop(scene, itype=1, device=0):
+    """driverRedMaxBDF1.m:57-91 / driverRedMaxBDF2.m:57-125 for a single trajectory."""
+    sim = BatchSim(scene, batch=1, device=device)
+    q0, qd0 = scene.getQ()
+    sim.set_state(q0[None, :], qd0[None, :])
+    T0, V0 = sim.energy()                      # Scene.reset: T0, V0 at the initial state (Scene.m:126-127)
+    scene.T0, scene.V0 = float(T0[0]), float(V0[0])
+    step = sim.step_bdf1 if itype == 1 else sim.step_bdf2
+    out = step(scene.nsteps, h=scene.h, stats=True, history=True)
+    q, qd = sim.get_state()
+    scene.setQ(q[0], qd[0])
+    scene.history = []
+    for k in range(scene.nsteps):              # per-step q/qdot stay on the device; energies are recorded per step
+        scene.t = (k + 1) * scene.h
+        scene.k = k + 1
+        scene.history.append({"t": scene.t, "T": float(out["T"][k, 0]), "V": float(out["V"][k, 0])})
+    scene.history[-1]["q"], scene.history[-1]["qdot"] = q[0].copy(), qd[0].copy()
+    scene.solverInfo = {"newton_iters": int(out["newton_iters"][0]), "ls_halvings": int(out["ls_halvings"][0]),
+                        "status": int(out["status"][0]), "kernel_ms": out["ms"]}
+    sim.close()
+    return scene
+
+
+def _driver(sceneID, batch, itype, device, verbose):
+    scene = scenesRedMax(sceneID)
+    scene.init()
+    if not batch:
+        raise NotImplementedError("interactive mode (Scene.test / Scene.draw) is out of scope; call with batch=True")
+    if verbose:
+        print("(%d) '%s': tEnd=%.1f, nsteps=%d, nr=%d, nm=%d" % (sceneID, scene.name, scene.tEnd, scene.nsteps, scene.countR(), scene.countM()))
+    simLoop(scene, itype, device)
+    H, passed = scene.plotEnergies(itype, verbose=verbose)
+    return scene, H, passed
+
+
+def driverRedMaxBDF1(sceneID=0, batch=True, device=0, verbose=True):
+    return _driver(sceneID, batch, 1, device, verbose)
+
+
+def driverRedMaxBDF2(sceneID=0, batch=True, device=0, verbose=True):
+    return _driver(sceneID, batch, 2, device, verbose)

@@ -1,0 +1,245 @@
+"""numpy prototype of the algorithm the HIP kernels implement (development aid + executable
+derivation; NOT the oracle and NOT the product).
+
+World-frame recursive Newton-Euler residual with analytic derivatives for the implicit step
+    qdot = (q - qA)/eta,  v = q - qB,
+    g = M(q) v - eta^2 f(q,qdot),   H = dg/dq = M - eta D - eta^2 K + dM/dq . v
+which is algebraically identical to evalBDF1/computeValues (driverRedMaxBDF1.m:160-243) but never
+forms J, Jdot or the dJ/dq tensors.  All spatial quantities are expressed in the WORLD frame so
+the tree recursions collapse to path sums (root->node) and subtree sums (node->leaves):
+
+    s_a        world screw axis of joint a            = Ad(E_w,Ba) A0_BaJa S_a   (column of J, any row)
+    phi_b      = sum_{a in anc*(b)} s_a qdot_a                                     (J qdot)_b
+    xi_a       = ad(phi_a) s_a
+    beta_b     = sum_{a in anc*(b)} (s_a v_a + eta^2 xi_a qdot_a)                   (J v + eta^2 Jdot qdot)_b
+    w_b        = I_b beta_b - eta^2 (ad(phi_b)' I_b phi_b + fgrav_b)                net body wrench * eta^2
+    W_a, Ic_a, Bc_a = subtree sums of w_b, I_b, B_b,  B_b = I_b ad(phi_b) + ad(phi_b)' I_b + N(I_b phi_b)
+    g_a        = s_a . W_a - eta^2 fr_a
+    H(a,i)     = s_a . (y_i - [a != i] z_i)                       a ancestor-or-self of i
+               = r1_a . m1_i - r2_a . m2_i - eta^2 r3_a . s_i     a strict descendant of i
+               = 0                                                otherwise
+    with zeta_i = ad(beta_i) s_i + eta^2 ad(phi_i) xi_i,  m1_i = s_i + 2 eta xi_i + zeta_i,
+         m2_i = eta s_i + eta^2 xi_i,  y_i = Ic_i m1_i - Bc_i m2_i - eta^2 Kc_i s_i,  z_i = ad(s_i)' W_i,
+         r1_a = Ic_a s_a,  r2_a = Bc_a' s_a,  r3_a = Kc_a' s_a,  Kc = [[ [mc][g], 0 ], [ m [g], 0 ]].
+tests/test_proto_worldframe.py checks this against the oracle's literal tensor path.
+"""
+import numpy as np
+
+from redmax_amd import se3
+
+
+def _cm(E16):
+    return np.asarray(E16, dtype=np.float64).reshape(4, 4).T
+
+
+def _ad(phi):
+    return se3.ad(phi)
+
+
+def _brac(x):
+    return se3.brac(x)
+
+
+def build_model(d):
+    n = d["njoints"]
+    parent = [int(p) for p in d["parent"]]
+    typ = [int(t) for t in d["type"]]
+    m = {"n": n, "parent": parent, "type": typ, "grav": np.asarray(d["grav"], float)}
+    L, Rt, sb, axes = [], [], [], []
+    for j in range(n):
+        E0_pj = _cm(d["E0_pj"][j])
+        E0_ji = _cm(d["E0_ji"][j])
+        if parent[j] >= 0:
+            E0_ji_p = _cm(d["E0_ji"][parent[j]])
+            L.append(se3.inv(E0_ji_p) @ E0_pj)   # parent body -> this joint's base frame
+        else:
+            L.append(E0_pj)
+        Rt.append(E0_ji)
+        a = np.asarray(d["axis"][j], float)
+        S = np.zeros(6)
+        if typ[j] == 1:
+            S[:3] = a
+        elif typ[j] == 2:
+            S[3:] = a
+        sb.append(se3.Ad(se3.inv(E0_ji)) @ S)    # A0_ij * S: joint screw in the body frame (constant)
+        axes.append(a)
+    # reduced index: leaf-to-root (Scene.m:65-71)
+    idx = [-1] * n
+    nr = 0
+    for j in reversed(range(n)):
+        if typ[j] != 0:
+            idx[j] = nr
+            nr += 1
+    m.update(L=L, Rt=Rt, sb=sb, axis=axes, idx=idx, nr=nr, I=np.asarray(d["I_i"], float))
+    for k in ("tau", "stiffness", "damping", "qRest", "qLimL", "qLimU", "qLimK", "qLimD"):
+        m[k] = np.asarray(d[k], float)
+    # ancestor-or-self relation
+    anc = np.zeros((n, n), bool)   # anc[a,b]: a in anc*(b)
+    for b in range(n):
+        a = b
+        while a >= 0:
+            anc[a, b] = True
+            a = parent[a]
+    m["anc"] = anc
+    return m
+
+
+def eval_world(m, q, qA, qB, eta, want_H=True):
+    n, par, typ, idx, nr = m["n"], m["parent"], m["type"], m["idx"], m["nr"]
+    grav = m["grav"]
+    qj = np.zeros(n)
+    qdj = np.zeros(n)
+    vj = np.zeros(n)
+    for j in range(n):
+        if idx[j] >= 0:
+            k = idx[j]
+            qj[j] = q[k]
+            qdj[j] = (q[k] - qA[k]) / eta
+            vj[j] = q[k] - qB[k]
+    e2 = eta * eta
+    # --- world transforms (serial root->leaf product) ---
+    Ew = [None] * n
+    for j in range(n):
+        Q = np.eye(4)
+        if typ[j] == 1:
+            Q[:3, :3] = se3.aaToMat(m["axis"][j], qj[j])
+        elif typ[j] == 2:
+            Q[:3, 3] = m["axis"][j] * qj[j]
+        T = m["L"][j] @ Q @ m["Rt"][j]
+        Ew[j] = T if par[j] < 0 else Ew[par[j]] @ T
+    # --- per node world-frame screw; path sums ---
+    s = [se3.Ad(Ew[j]) @ m["sb"][j] for j in range(n)]
+    phi = [None] * n
+    xi = [None] * n
+    beta = [None] * n
+    for j in range(n):
+        pphi = np.zeros(6) if par[j] < 0 else phi[par[j]]
+        phi[j] = pphi + s[j] * qdj[j]
+        xi[j] = _ad(phi[j]) @ s[j]
+        pbeta = np.zeros(6) if par[j] < 0 else beta[par[j]]
+        beta[j] = pbeta + s[j] * vj[j] + e2 * xi[j] * qdj[j]
+    # --- per body world-frame inertia, wrench, B ---
+    Iw, w, Bm, mc, mass = [], [], [], [], []
+    for j in range(n):
+        R = Ew[j][:3, :3]
+        c = Ew[j][:3, 3]
+        I3 = m["I"][j][:3]
+        ms = m["I"][j][3]
+        cb = _brac(c)
+        Ibar = R @ np.diag(I3) @ R.T + ms * cb @ cb.T
+        I6 = np.zeros((6, 6))
+        I6[:3, :3] = Ibar
+        I6[:3, 3:] = ms * cb
+        I6[3:, :3] = ms * cb.T
+        I6[3:, 3:] = ms * np.eye(3)
+        hmom = I6 @ phi[j]
+        adp = _ad(phi[j])
+        fcor = adp.T @ hmom
+        fgrav = np.concatenate([np.cross(c, ms * grav), ms * grav])
+        w.append(I6 @ beta[j] - e2 * (fcor + fgrav))
+        N = np.zeros((6, 6))
+        N[:3, :3] = _brac(hmom[:3])
+        N[:3, 3:] = _brac(hmom[3:])
+        N[3:, :3] = _brac(hmom[3:])
+        Bm.append(I6 @ adp + adp.T @ I6 + N)
+        Iw.append(I6)
+        mc.append(ms * c)
+        mass.append(ms)
+    # --- subtree sums (reverse order: children before parents) ---
+    W = [x.copy() for x in w]
+    Ic = [x.copy() for x in Iw]
+    Bc = [x.copy() for x in Bm]
+    mcc = [x.copy() for x in mc]
+    mss = list(mass)
+    for j in reversed(range(n)):
+        p = par[j]
+        if p >= 0:
+            W[p] += W[j]
+            Ic[p] += Ic[j]
+            Bc[p] += Bc[j]
+            mcc[p] += mcc[j]
+            mss[p] += mss[j]
+    # --- residual ---
+    g = np.zeros(nr)
+    Hd = np.zeros(nr)
+    for j in range(n):
+        if idx[j] < 0:
+            continue
+        hitL = 1.0 if qj[j] < m["qLimL"][j] else 0.0
+        hitU = 1.0 if qj[j] > m["qLimU"][j] else 0.0
+        fr = m["tau"][j] + m["stiffness"][j] * (m["qRest"][j] - qj[j]) - m["damping"][j] * qdj[j]
+        fr += hitL * (m["qLimK"][j] * (m["qLimL"][j] - qj[j]) - m["qLimD"][j] * qdj[j])
+        fr += hitU * (m["qLimK"][j] * (m["qLimU"][j] - qj[j]) - m["qLimD"][j] * qdj[j])
+        g[idx[j]] = s[j] @ W[j] - e2 * fr
+        Kr = -m["stiffness"][j] - (hitL + hitU) * m["qLimK"][j]
+        Dr = -m["damping"][j] - (hitL + hitU) * m["qLimD"][j]
+        Hd[idx[j]] = -eta * Dr - e2 * Kr
+    if not want_H:
+        return g
+    # --- Hessian ---
+    gb = _brac(grav)
+    y, z, m1, m2, r1, r2, r3 = ([None] * n for _ in range(7))
+    for i in range(n):
+        if idx[i] < 0:
+            continue
+        zeta = _ad(beta[i]) @ s[i] + e2 * _ad(phi[i]) @ xi[i]
+        m1[i] = s[i] + 2 * eta * xi[i] + zeta
+        m2[i] = eta * s[i] + e2 * xi[i]
+        Kc = np.zeros((6, 6))
+        Kc[:3, :3] = _brac(mcc[i]) @ gb
+        Kc[3:, :3] = mss[i] * gb
+        y[i] = Ic[i] @ m1[i] - Bc[i] @ m2[i] - e2 * Kc @ s[i]
+        z[i] = _ad(s[i]).T @ W[i]
+        r1[i] = Ic[i] @ s[i]
+        r2[i] = Bc[i].T @ s[i]
+        r3[i] = Kc.T @ s[i]
+    H = np.zeros((nr, nr))
+    anc = m["anc"]
+    for a in range(n):
+        if idx[a] < 0:
+            continue
+        for i in range(n):
+            if idx[i] < 0:
+                continue
+            if anc[a, i]:
+                val = s[a] @ y[i]
+                if a != i:
+                    val -= s[a] @ z[i]
+            elif anc[i, a]:
+                val = r1[a] @ m1[i] - r2[a] @ m2[i] - e2 * (r3[a] @ s[i])
+            else:
+                val = 0.0
+            H[idx[a], idx[i]] = val
+    H[np.arange(nr), np.arange(nr)] += Hd
+    return g, H
+
+
+def energy_world(m, q, qdot):
+    """T, V exactly as Joint.computeEnergies / Body.computeEnergies (Joint.m:616-637, Body.m:167-173)."""
+    n, par, typ, idx = m["n"], m["parent"], m["type"], m["idx"]
+    Ew = [None] * n
+    phi = [None] * n
+    T = 0.0
+    V = 0.0
+    for j in range(n):
+        qj = q[idx[j]] if idx[j] >= 0 else 0.0
+        qd = qdot[idx[j]] if idx[j] >= 0 else 0.0
+        Q = np.eye(4)
+        if typ[j] == 1:
+            Q[:3, :3] = se3.aaToMat(m["axis"][j], qj)
+        elif typ[j] == 2:
+            Q[:3, 3] = m["axis"][j] * qj
+        Tm = m["L"][j] @ Q @ m["Rt"][j]
+        Ew[j] = Tm if par[j] < 0 else Ew[par[j]] @ Tm
+        sw = se3.Ad(Ew[j]) @ m["sb"][j]
+        phi[j] = (np.zeros(6) if par[j] < 0 else phi[par[j]]) + sw * qd
+        phib = se3.Ad(se3.inv(Ew[j])) @ phi[j]
+        T += 0.5 * phib @ (m["I"][j] * phib)
+        V -= m["I"][j][5] * (m["grav"] @ Ew[j][:3, 3])
+        if idx[j] >= 0:
+            dq = qj - m["qRest"][j]
+            V += 0.5 * m["stiffness"][j] * dq * dq
+            dqL = (m["qLimL"][j] - qj) if qj < m["qLimL"][j] else 0.0
+            dqU = (m["qLimU"][j] - qj) if qj > m["qLimU"][j] else 0.0
+            V += 0.5 * m["qLimK"][j] * (dqL * dqL + dqU * dqU)
+    return T, V

@@ -1,0 +1,245 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) vs the CPU oracle on identical inputs.
+
+Tolerances (fp64, stated per SURVEY.md §8(d)):
+  single evaluation  : |dg|/|g| <= 1e-11, |dH|_F/|H|_F <= 1e-11
+  single BDF1 step   : |dq| <= 1e-11 |q| + 1e-10, |dqdot| <= 1e-9 |qdot| + 1e-8 (qdot is a difference quotient / h).
+                       The absolute floors are the Newton stopping tolerance seen through H^-1: both solvers stop at
+                       |g| < 1e-9 (driverRedMaxBDF1.m:95,146), which pins q only to ~|H^-1| 1e-9 ~ 1e-11..1e-10.
+  k-step rollout     : |dq|/|q| <= 1e-8 per trajectory
+  energy KATs        : the reference's own goldens, 1e-9 relative (reference criterion: 1e-2 absolute)
+"""
+import math
+
+import numpy as np
+import pytest
+
+from redmax_amd.scenes import IN_SCOPE_SCENES, sceneChain, scenesRedMax, sceneTree, syntheticStates
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _close(a, b, rtol, atol):
+    return np.linalg.norm(a - b) <= rtol * np.linalg.norm(b) + atol
+
+
+def _scene(name):
+    if name == "chain32":
+        return sceneChain(32)
+    if name == "chain8skew":
+        return sceneChain(8, axis=(0.3, 1.0, 0.2))
+    if name == "tree15":
+        return sceneTree(15)
+    if name == "tree64":
+        return sceneTree(64)
+    return scenesRedMax(int(name))
+
+
+@pytest.mark.parametrize("name", ["0", "1", "2", "3", "14", "chain8skew", "chain32", "tree15", "tree64"])
+def test_eval_matches_oracle(oracle_lib, name):
+    """rmx_eval (g, H) vs evalBDF1 of the oracle (driverRedMaxBDF1.m:160-187) at random states."""
+    from redmax_amd import BatchSim
+    sc = _scene(name)
+    sc.init()
+    B = 3
+    rng = np.random.default_rng(7)
+    nr = sc.nr
+    h = sc.h
+    q0 = rng.uniform(-0.7, 0.7, (B, nr))
+    qd0 = rng.uniform(-1, 1, (B, nr))
+    q1 = q0 + h * qd0 + rng.uniform(-1e-2, 1e-2, (B, nr))
+    if name == "14":
+        q1 = rng.uniform(-2.0, 0.5, (B, nr))       # exercise both joint limits
+    sim = BatchSim(sc, batch=B)
+    g, H = sim.eval_bdf1(q1, q0, qd0, h)
+    g_only = sim.eval_bdf1(q1, q0, qd0, h, want_H=False)
+    o = oracle_lib.Oracle(sc.desc())
+    for b in range(B):
+        go, Ho = o.eval_bdf1(q1[b], q0[b], qd0[b], h)
+        assert _rel(g[b], go) <= 1e-11, (name, b, _rel(g[b], go))
+        assert _rel(H[b], Ho) <= 1e-11, (name, b, _rel(H[b], Ho))
+        assert _rel(g_only[b], go) <= 1e-11
+
+
+@pytest.mark.parametrize("name", ["0", "1", "2", "3", "14", "chain32", "tree15"])
+def test_single_step_matches_oracle(oracle_lib, name):
+    from redmax_amd import BatchSim
+    sc = _scene(name)
+    sc.init()
+    B = 4
+    nr = sc.nr
+    q, qd = syntheticStates(nr, B)
+    q0s, qd0s = sc.getQ()
+    q[0], qd[0] = q0s, qd0s                                   # trajectory 0 = the scene's own initial state
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(1, h=sc.h, stats=True)
+    qg, qdg = sim.get_state()
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        st = o.step_bdf1(sc.h, 1)
+        qo, qdo = o.get_state()
+        assert _close(qg[b], qo, 1e-11, 1e-10), (name, b, _rel(qg[b], qo))
+        assert _close(qdg[b], qdo, 1e-9, 1e-8), (name, b, _rel(qdg[b], qdo))
+        if name != "chain32":       # chain32: tol sits at the fp64 noise floor of g, counts are roundoff-dependent
+            assert out["newton_iters"][b] == st.newton_iters, (name, b)
+            assert out["ls_halvings"][b] == st.ls_halvings
+    assert not (out["status"] & 5).any()
+
+
+@pytest.mark.parametrize("sid", IN_SCOPE_SCENES)
+def test_bdf1_energy_kat_on_gpu(sid):
+    """The reference's own known answers, through driverRedMaxBDF1 (the drop-in entry point)."""
+    from redmax_amd import driverRedMaxBDF1
+    scene, H, passed = driverRedMaxBDF1(sid, True, verbose=False)
+    assert passed is True
+    assert abs(H - scene.Hexpected[0]) <= 1e-9 * abs(scene.Hexpected[0]), (sid, H)
+    assert scene.solverInfo["status"] == 0
+
+
+@pytest.mark.parametrize("sid", IN_SCOPE_SCENES)
+def test_bdf2_energy_kat_on_gpu(sid):
+    from redmax_amd import driverRedMaxBDF2
+    scene, H, passed = driverRedMaxBDF2(sid, True, verbose=False)
+    assert passed is True
+    assert abs(H - scene.Hexpected[1]) <= 1e-9 * abs(scene.Hexpected[1]), (sid, H)
+
+
+def test_chain32_rollout_matches_oracle(oracle_lib):
+    """Config 2 at a size the oracle finishes in seconds: 6 trajectories x 10 steps."""
+    from redmax_amd import BatchSim
+    sc = sceneChain(32)
+    sc.init()
+    B, K = 6, 10
+    q, qd = syntheticStates(32, B)
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(K, h=1e-2, stats=True)
+    qg, qdg = sim.get_state()
+    iters_o = []
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        st = o.step_bdf1(1e-2, K)
+        qo, qdo = o.get_state()
+        iters_o.append(st.newton_iters)
+        assert _rel(qg[b], qo) <= 1e-8, (b, _rel(qg[b], qo))
+        assert _rel(qdg[b], qdo) <= 1e-6, (b, _rel(qdg[b], qdo))
+    assert not (out["status"] & 5).any()          # no "Newton diverged", no NaN
+    # Iteration counts are NOT asserted equal here: for this chain the reference's tol=1e-9 sits at the fp64
+    # noise floor of g (|g| ~ 1e4 initially, eps-level scatter ~1e-9 near the root), so whether an iterate
+    # passes |g|<tol is decided by roundoff and differs between any two implementations (DESIGN.md "Workload").
+    print("newton iters gpu", list(out["newton_iters"]), "oracle", iters_o)
+
+
+def test_chain32_bench_tol_matches_reference_constants(oracle_lib):
+    """bench.py runs config 2 with tol=1e-8 (above the noise floor).  The result must still be the reference's:
+    GPU(tol=1e-8) vs the oracle run with the reference's own constants (tol=1e-9), 10 steps, <= 1e-8."""
+    from redmax_amd import BatchSim
+    sc = sceneChain(32)
+    sc.init()
+    B, K = 4, 10
+    q, qd = syntheticStates(32, B)
+    sim = BatchSim(sc, batch=B)
+    sim.opts.tol = 1e-8
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(K, h=1e-2, stats=True)
+    qg, qdg = sim.get_state()
+    assert (out["status"] == 0).all()
+    oracle_lib.set_newton()                        # reference constants
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        o.step_bdf1(1e-2, K)
+        qo, qdo = o.get_state()
+        assert _rel(qg[b], qo) <= 1e-8, (b, _rel(qg[b], qo))
+        assert _rel(qdg[b], qdo) <= 1e-6, (b, _rel(qdg[b], qdo))
+
+
+def test_full_size_batch_properties():
+    """BASELINE.json config 2 at FULL size (B=1024, 32-DOF chain) through size-independent properties:
+    shard invariance (a trajectory's result does not depend on its batch neighbours), determinism,
+    all trajectories converge, energy history consistent with rmx_energy."""
+    from redmax_amd import BatchSim
+    sc = sceneChain(32)
+    sc.init()
+    B, K = 1024, 5
+    q, qd = syntheticStates(32, B)
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    sim.opts.tol = 1e-8                            # the bench setting: every trajectory-step converges
+    out = sim.step_bdf1(K, h=1e-2, stats=True, history=True)
+    qa, qda = sim.get_state()
+    assert (out["status"] == 0).all()
+    assert np.isfinite(qa).all() and np.isfinite(qda).all()
+    T, V = sim.energy()
+    assert np.allclose(T, out["T"][-1], rtol=1e-12, atol=1e-9)
+    assert np.allclose(V, out["V"][-1], rtol=1e-12, atol=1e-9)
+    # shard invariance: rows 256..383 recomputed alone give bit-identical results
+    sub = BatchSim(sc, batch=128)
+    sub.opts.tol = 1e-8
+    sub.set_state(q[256:384], qd[256:384])
+    sub.step_bdf1(K, h=1e-2)
+    qs, qds = sub.get_state()
+    assert np.array_equal(qs, qa[256:384]) and np.array_equal(qds, qda[256:384])
+    # determinism
+    sim.set_state(q, qd)
+    sim.step_bdf1(K, h=1e-2)
+    qb, qdb = sim.get_state()
+    assert np.array_equal(qa, qb) and np.array_equal(qda, qdb)
+
+
+def test_tree64_rollout_matches_oracle(oracle_lib):
+    """Config 3's tree (64 joints, revolute/prismatic mix) at oracle-feasible size."""
+    from redmax_amd import BatchSim
+    sc = sceneTree(64)
+    sc.init()
+    B, K = 2, 3
+    q0, qd0 = sc.getQ()
+    rng = np.random.default_rng(3)
+    q = q0[None, :] + 0.05 * rng.standard_normal((B, sc.nr))
+    qd = 0.5 * rng.standard_normal((B, sc.nr))
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(K, h=1e-2, stats=True)
+    qg, qdg = sim.get_state()
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        o.step_bdf1(1e-2, K)
+        qo, qdo = o.get_state()
+        assert _rel(qg[b], qo) <= 1e-8, (b, _rel(qg[b], qo))
+    assert (out["status"] == 0).all()
+
+
+def test_energy_matches_oracle(oracle_lib):
+    from redmax_amd import BatchSim
+    for sid in (2, 14):
+        sc = scenesRedMax(sid)
+        sc.init()
+        rng = np.random.default_rng(5)
+        q = rng.uniform(-1.8, 0.4, (3, sc.nr))
+        qd = rng.uniform(-2, 2, (3, sc.nr))
+        sim = BatchSim(sc, batch=3)
+        sim.set_state(q, qd)
+        T, V = sim.energy()
+        o = oracle_lib.Oracle(sc.desc())
+        for b in range(3):
+            o.set_state(q[b], qd[b])
+            To, Vo = o.energy()
+            assert abs(T[b] - To) <= 1e-12 * max(abs(To), 1.0)
+            assert abs(V[b] - Vo) <= 1e-12 * max(abs(Vo), 1.0)
+
+
+def test_library_is_loaded_in_tree():
+    """The HIP extension must be the in-tree .so (not a fallback)."""
+    import os
+    from redmax_amd import _abi
+    _abi.lib()
+    with open("/proc/self/maps") as f:
+        maps = f.read()
+    assert os.path.realpath(_abi.LIB_PATH) in maps or _abi.LIB_PATH in maps

@@ -1,0 +1,84 @@
+"""Host-side logic: the +redmax scene mirror (index layout, ordering checks, descriptor) and se3 helpers."""
+import math
+
+import numpy as np
+import pytest
+
+from redmax_amd import se3
+from redmax_amd.redmax import BodyCuboid, JointFixed, JointRevolute, Scene
+from redmax_amd.scenes import sceneChain, scenesRedMax, sceneTree, syntheticStates
+
+
+def test_se3_identities():
+    rng = np.random.default_rng(0)
+    R = se3.aaToMat(rng.normal(size=3), 0.9)
+    E = se3.transform(R=R, p=rng.normal(size=3))
+    assert np.allclose(se3.inv(E) @ E, np.eye(4), atol=1e-14)
+    assert np.allclose(se3.Ad(se3.inv(E)) @ se3.Ad(E), np.eye(6), atol=1e-13)
+    a, b = rng.normal(size=6), rng.normal(size=6)
+    assert np.allclose(se3.ad(a) @ b, -se3.ad(b) @ a, atol=1e-14)           # Lie bracket antisymmetry
+    assert np.allclose(se3.Ad(E) @ se3.ad(a) @ se3.Ad(se3.inv(E)), se3.ad(se3.Ad(E) @ a), atol=1e-12)
+
+
+def test_aaToMat_axis_aligned_has_exact_zeros():
+    """se3.m:124-156: axis-aligned rotations carry exact zeros/ones."""
+    R = se3.aaToMat([0, 1, 0], 0.3)
+    assert R[0, 1] == 0.0 and R[1, 0] == 0.0 and R[1, 1] == 1.0 and R[0, 0] == math.cos(0.3) and R[0, 2] == math.sin(0.3)
+    Rn = se3.aaToMat([0, 0, -2.0], 0.3)
+    assert np.allclose(Rn, se3.aaToMat([0, 0, 1], -0.3))
+
+
+def test_inertia_cuboid():
+    m = se3.inertiaCuboid([10, 1, 1], 1.0)
+    assert np.allclose(m, [10 / 12 * 2, 10 / 12 * 101, 10 / 12 * 101, 10, 10, 10])
+
+
+def test_scene_index_layout_leaf_to_root():
+    sc = scenesRedMax(0)
+    sc.init()
+    assert (sc.nr, sc.nm) == (3, 30)
+    assert [j.idxR for j in sc.joints] == [[2], [], [1], [], [0]]
+    assert sc.joints[0].body.idxM == list(range(24, 30)) and sc.joints[-1].body.idxM == list(range(0, 6))
+    d = sc.desc()
+    assert list(d["parent"]) == [-1, 0, 1, 2, 3] and list(d["type"]) == [1, 0, 1, 0, 1]
+    assert d["E0_pj"].shape == (5, 16) and d["E0_pj"][1][12] == 10.0       # column-major: translation x at [12]
+    assert sc.nsteps == 100
+
+
+def test_scene_rejects_bad_ordering():
+    sc = Scene()
+    b = [BodyCuboid(1.0, [1, 1, 1]) for _ in range(3)]
+    j0 = JointRevolute(None, b[0], [0, 1, 0])
+    j1 = JointRevolute(j0, b[1], [0, 1, 0])
+    j2 = JointFixed(j0, b[2])
+    for j in (j0, j1, j2):
+        j.setJointTransform(np.eye(4))
+    sc.bodies = [b[0], b[2], b[1]]
+    sc.joints = [j0, j2, j1]            # not depth-first order of the tree (children of j0 are j1 then j2)
+    with pytest.raises(ValueError):
+        sc.init()
+
+
+def test_qrest_is_initial_q():
+    sc = scenesRedMax(14)
+    sc.init()
+    assert [j.qRest for j in sc.joints] == [0.0, -math.pi / 6, -math.pi / 6]
+
+
+def test_synthetic_states_are_shard_invariant():
+    qa, qda = syntheticStates(32, 8, first=0)
+    qb, qdb = syntheticStates(32, 4, first=4)
+    assert np.array_equal(qa[4:], qb) and np.array_equal(qda[4:], qdb)
+    assert np.all(qa[0] == 0.1) and np.all(qda[0] == 0.0)
+    assert np.abs(qa[1:]).max() <= 0.1
+
+
+def test_benchmark_scenes_shapes():
+    c = sceneChain(32)
+    c.init()
+    assert (c.nr, c.nm) == (32, 192)
+    t = sceneTree(64)
+    t.init()
+    assert len(t.joints) == 64 and t.nr == 64
+    types = {j.jtype for j in t.joints}
+    assert types == {1, 2}

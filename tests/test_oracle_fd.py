@@ -1,0 +1,82 @@
+"""Finite-difference self-tests of the oracle's analytic derivatives, mirroring Scene.test
+(matlab-diff/+redmax/Scene.m:224-378; pass criterion 1e-6 relative, Scene.printError :424-450)."""
+import numpy as np
+import pytest
+
+from redmax_amd.scenes import sceneChain, scenesRedMax
+
+SQE = np.sqrt(np.finfo(float).eps)
+
+
+def _err(v0, v1):
+    e = np.linalg.norm(v1 - v0)
+    n0, n1 = np.linalg.norm(v0), np.linalg.norm(v1)
+    if n0 > 1e-4 and n1 > 1e-4:
+        e /= min(n0, n1)
+    return e
+
+
+@pytest.mark.parametrize("sid", [0, 1, 2, 3, "chain6"])
+def test_scene_test_fd_identities(oracle_lib, sid):
+    sc = sceneChain(6, axis=(0.2, 1.0, 0.1)) if sid == "chain6" else scenesRedMax(sid)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    rng = np.random.default_rng(2)
+    nr = o.nr
+    q = rng.uniform(-0.8, 0.8, nr)
+    qd = rng.uniform(-1, 1, nr)
+    o.set_state(q, qd)
+    J, Jdot, dJdq, dJdotdq = o.jacobian(deriv=True)
+    M, f, dMdq, K, D = o.compute_values()
+    # Jdot  (Scene.m:275-283)
+    o.set_state(q + SQE * qd, qd)
+    J_, _ = o.jacobian()
+    assert _err((J_ - J) / SQE, Jdot) < 1e-6
+    K_ = np.zeros((nr, nr))
+    D_ = np.zeros((nr, nr))
+    for i in range(nr):
+        q_ = q.copy()
+        q_[i] += SQE
+        o.set_state(q_, qd)
+        J_, Jdot_ = o.jacobian()
+        assert _err((J_ - J) / SQE, dJdq[:, :, i]) < 1e-6            # dJ/dq   (:286-299)
+        assert _err((Jdot_ - Jdot) / SQE, dJdotdq[:, :, i]) < 2e-6   # dJdot/dq
+        M_, f_ = o.compute_values(deriv=False)
+        assert _err((M_ - M) / SQE, dMdq[:, :, i]) < 1e-6            # dM/dq   (:302-313)
+        # K, D (:343-376).  f is O(1e5..1e6) here, so the reference's one-sided sqrt(eps) difference carries
+        # ~eps|f|/sqrt(eps) ~ 1e-2 of roundoff; central differences with a larger step test the same identity cleanly.
+        hk, hd = 1e-5, 1e-4
+        fp = []
+        for sgn in (+1, -1):
+            q_ = q.copy()
+            q_[i] += sgn * hk
+            o.set_state(q_, qd)
+            fp.append(o.compute_values(deriv=False)[1])
+        K_[:, i] = (fp[0] - fp[1]) / (2 * hk)
+        fp = []
+        for sgn in (+1, -1):
+            qd_ = qd.copy()
+            qd_[i] += sgn * hd
+            o.set_state(q, qd_)
+            fp.append(o.compute_values(deriv=False)[1])
+        D_[:, i] = (fp[0] - fp[1]) / (2 * hd)
+    assert _err(K_, K) < 1e-6
+    assert _err(D_, D) < 1e-6
+
+
+def test_newton_hessian_is_jacobian_of_g(oracle_lib):
+    """testGrad of newton (driverRedMaxBDF1.m:104-115): H = dg/dq1."""
+    sc = scenesRedMax(2)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    rng = np.random.default_rng(4)
+    nr, h = o.nr, sc.h
+    q0, qd0 = rng.uniform(-0.5, 0.5, nr), rng.uniform(-1, 1, nr)
+    q1 = q0 + h * qd0
+    g, H = o.eval_bdf1(q1, q0, qd0, h)
+    H_ = np.zeros_like(H)
+    for i in range(nr):
+        x = q1.copy()
+        x[i] += SQE
+        H_[:, i] = (o.eval_bdf1(x, q0, qd0, h, want_H=False) - g) / SQE
+    assert _err(H_, H) < 1e-6
