@@ -154,6 +154,10 @@ void* rmx_batch_stream(const rmx_batch* b);
 int rmx_step_bdf1_async(rmx_batch* b, const rmx_opts* opts, int nsteps);
 int rmx_sync(rmx_batch* b);
 /* The async variant accumulates the per-trajectory counters on the device: reset before, read after. */
+/* Profiling hook: mean shader-clock cycles per wavefront of {residual evaluation, residual+Hessian evaluation,
+ * LU solve, the two norm reductions} of one Newton iteration at the current state (reps repetitions per trajectory)
+ * in cycles16[0..3]; cycles16[4..15] split the residual+Hessian evaluation into its 12 stages (rmx_device.h RMX_STAMP). */
+int rmx_profile_phases(rmx_batch* b, int reps, double h, double* cycles16);
 int rmx_stats_reset(rmx_batch* b);
 int rmx_stats_read(rmx_batch* b, rmx_stats* stats);
 

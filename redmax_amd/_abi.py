@@ -24,7 +24,7 @@ SYMBOLS = (
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
     "rmx_eval", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_energy",
     "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_sync",
-    "rmx_stats_reset", "rmx_stats_read",
+    "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases",
 )
 
 
@@ -93,6 +93,7 @@ def lib():
     L.rmx_step_bdf1_async.argtypes = [vp, C.POINTER(Opts), C.c_int]
     L.rmx_sync.argtypes = [vp]
     L.rmx_stats_reset.argtypes = [vp]
+    L.rmx_profile_phases.argtypes = [vp, C.c_int, C.c_double, _dp]
     L.rmx_stats_read.argtypes = [vp, C.POINTER(Stats)]
     _lib = L
     return L

@@ -122,6 +122,15 @@ class BatchSim:
         _abi.check(self._L.rmx_sync(self._batch), "rmx_sync")
         return self._L.rmx_last_step_ms(self._batch)
 
+    def profile_phases(self, reps=20, h=1e-2):
+        """Mean cycles per wavefront of (g-eval, g+H-eval, LU solve, 2 reductions) at the current state."""
+        c = np.zeros(16)
+        _abi.check(self._L.rmx_profile_phases(self._batch, int(reps), float(h), _abi.dptr(c)), "rmx_profile_phases")
+        d = dict(zip(("eval_g", "eval_gH", "lu", "reductions"), c[:4]))
+        d["gH_stamps"] = dict(zip(("joint_T", "jump_E", "screw_phi", "xi_beta", "inertia_w", "lds_write", "suffix_scan",
+                                   "subtree_read", "residual", "H_vectors", "col_write", "H_columns"), c[4:]))
+        return d
+
     def stats_reset(self):
         _abi.check(self._L.rmx_stats_reset(self._batch), "rmx_stats_reset")
 

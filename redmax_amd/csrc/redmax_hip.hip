@@ -196,6 +196,45 @@ __global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, co
     }
 }
 
+// Profiling hook: shader-clock cycles (s_memtime) of the phases of one Newton iteration, measured in place with the
+// production device functions at the production occupancy (one wavefront per trajectory).
+template <int NP>
+__global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int reps, const double* __restrict__ q,
+                                                   const double* __restrict__ qd, const double h, unsigned long long* __restrict__ out) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    const double q0 = id >= 0 ? q[off] : 0.0, qd0 = id >= 0 ? qd[off] : 0.0;
+    double x = q0 + h * qd0;
+    unsigned long long tg = 0, tH = 0, tLU = 0, tred = 0;
+    unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double sink = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        NodeOut e;
+        double Hrow[NP];
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        eval_node<NP, false>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow);
+        sink += e.g;
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        eval_node<NP, true, true>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow, stamps);
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        const double dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        const double s1 = wave_sum(dx * dx) + wave_sum(e.g * e.g);
+        unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        sink += s1;
+        x += 1e-3 * dx;   // keep the iterations data dependent
+        tg += t1 - t0; tH += t2 - t1; tLU += t3 - t2; tred += t4 - t3;
+    }
+    if (lane == 0) {
+        out[16 * traj + 0] = tg; out[16 * traj + 1] = tH; out[16 * traj + 2] = tLU; out[16 * traj + 3] = tred;
+        for (int k = 0; k < 12; ++k) out[16 * traj + 4 + k] = stamps[k];
+    }
+    if (sink == 1.2345e301) out[0] = 0;   // keep the results live
+}
+
 // ============================================================================ host side
 
 static thread_local std::string g_err;
@@ -357,6 +396,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     // ---- constants per node
     std::vector<double> K(36 * MAXN, 0.0), sb(6 * MAXN, 0.0), I4(4 * MAXN, 0.0), prm(8 * MAXN, 0.0);
     std::vector<int> type(MAXN, 0), idx(MAXN, -1), endd(MAXN, 0), anc(MAXROUNDS * MAXN, -1);
+    std::vector<unsigned long long> rel(2 * MAXN, 0ull);
     for (int k = 0; k < n; ++k) {
         const int L = order[k];
         type[k] = d->type[L];
@@ -366,7 +406,11 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
         // ancestor 2^r levels up
         {
             std::vector<int> chain;   // chain[t] = ancestor t+1 levels up
-            for (int t = par[k]; t >= 0; t = par[t]) chain.push_back(t);
+            for (int t = par[k]; t >= 0; t = par[t]) {
+                chain.push_back(t);
+                rel[k] |= 1ull << t;            // t is a strict ancestor of k
+                rel[MAXN + t] |= 1ull << k;     // k is a strict descendant of t
+            }
             for (int r = 0; r < MAXROUNDS; ++r) {
                 int lv = 1 << r;
                 anc[r * MAXN + k] = (lv <= (int)chain.size()) ? chain[lv - 1] : -1;
@@ -476,7 +520,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     if (hipSetDevice(device) != hipSuccess) { delete m; return fail(RMX_E_HIP, "hipSetDevice failed"); }
     const size_t nd = K.size() + sb.size() + I4.size() + prm.size();
     const size_t ni = type.size() + idx.size() + endd.size() + anc.size();
-    const size_t bytes = nd * sizeof(double) + ni * sizeof(int);
+    const size_t bytes = nd * sizeof(double) + rel.size() * sizeof(unsigned long long) + ni * sizeof(int);
     hipError_t e = hipMalloc(&m->dbuf, bytes);
     if (e != hipSuccess) { delete m; return fail(RMX_E_NOMEM, std::string("hipMalloc(model): ") + hipGetErrorString(e)); }
     std::vector<char> host(bytes);
@@ -491,6 +535,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     m->dm.sb = (const double*)put(sb.data(), sb.size() * sizeof(double));
     m->dm.I4 = (const double*)put(I4.data(), I4.size() * sizeof(double));
     m->dm.prm = (const double*)put(prm.data(), prm.size() * sizeof(double));
+    m->dm.rel = (const unsigned long long*)put(rel.data(), rel.size() * sizeof(unsigned long long));
     m->dm.type = (const int*)put(type.data(), type.size() * sizeof(int));
     m->dm.idx = (const int*)put(idx.data(), idx.size() * sizeof(int));
     m->dm.end = (const int*)put(endd.data(), endd.size() * sizeof(int));
@@ -747,6 +792,32 @@ extern "C" int rmx_sync(rmx_batch* b) {
     HIPCHK(hipStreamSynchronize(b->stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
+    return RMX_OK;
+}
+
+template <int NP>
+static void launch_phase(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d) {
+    const dim3 grid(b->B), block(64);
+    k_phase_time<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, reps, b->q, b->qd, h, d);
+}
+extern "C" int rmx_profile_phases(rmx_batch* b, int reps, double h, double* cycles4) {
+    if (!b || !cycles4 || reps < 1) return fail(RMX_E_INVALID, "bad argument");
+    rmx_model* m = b->m;
+    HIPCHK(hipSetDevice(m->device));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(unsigned long long) * 16 * b->B));
+    DISPATCH_NP(m->NP, launch_phase, m, b, reps, h, d);
+    std::vector<unsigned long long> hbuf(16 * (size_t)b->B);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hbuf.data(), d, sizeof(unsigned long long) * hbuf.size(), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_profile_phases: ") + hipGetErrorString(e));
+    for (int k = 0; k < 16; ++k) {   // [0..3] phase totals, [4..15] stamps inside the (g,H) evaluation
+        double sum = 0;
+        for (int t = 0; t < b->B; ++t) sum += (double)hbuf[16 * (size_t)t + k];
+        cycles4[k] = sum / ((double)b->B * reps);
+    }
     return RMX_OK;
 }
 

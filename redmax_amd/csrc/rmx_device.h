@@ -36,6 +36,7 @@ struct DevModel {
     const int* idx;   // [MAXN] reduced index (reference leaf-to-root numbering) or -1
     const int* end;   // [MAXN] one past the last node of the subtree (depth-first order)
     const int* anc;   // [MAXROUNDS][MAXN] ancestor 2^r levels up, or -1
+    const unsigned long long* rel;  // [2][MAXN] bit i of rel[j]: node i is a strict ancestor of j; of rel[MAXN+j]: strict descendant
     double grav[3];
 };
 
@@ -69,17 +70,62 @@ __device__ __forceinline__ void sym3v(const double S[6], const double x[3], doub
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 __device__ __forceinline__ double readlane_d(double v, int l) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, l);
     hi = __builtin_amdgcn_readlane(hi, l);
     return __hiloint2double(hi, lo);
+}
+
+// DPP lane permutations inside a 16-lane row (no LDS traffic, a few cycles each)
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i within each 8 lanes
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i within the row
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+
+// Sum over the 64 lanes, identical (bitwise) in every lane: butterfly inside each 16-lane row with DPP, then the
+// four row sums are combined through scalar registers in a fixed order.
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HALF_MIRROR>(v);
+    v += dpp_d<DPP_MIRROR>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    unsigned t;
+    t = (unsigned)dpp_i<DPP_XOR1>((int)v); v = t > v ? t : v;
+    t = (unsigned)dpp_i<DPP_XOR2>((int)v); v = t > v ? t : v;
+    t = (unsigned)dpp_i<DPP_HALF_MIRROR>((int)v); v = t > v ? t : v;
+    t = (unsigned)dpp_i<DPP_MIRROR>((int)v); v = t > v ? t : v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// same, when only lanes 0..31 can hold candidates (NP <= 32): two rows
+__device__ __forceinline__ unsigned wave_umax32(unsigned v) {
+    unsigned t;
+    t = (unsigned)dpp_i<DPP_XOR1>((int)v); v = t > v ? t : v;
+    t = (unsigned)dpp_i<DPP_XOR2>((int)v); v = t > v ? t : v;
+    t = (unsigned)dpp_i<DPP_HALF_MIRROR>((int)v); v = t > v ? t : v;
+    t = (unsigned)dpp_i<DPP_MIRROR>((int)v); v = t > v ? t : v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    return a > b ? a : b;
+}
+// 1/x to full double precision: hardware estimate + two Newton steps (error <= 1 ulp; LAPACK's dgetf2 also scales
+// the pivot column by the reciprocal)
+__device__ __forceinline__ double recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
 }
 
 // Per-lane (per-node) results of one evaluation that the caller keeps.
@@ -94,10 +140,18 @@ struct NodeOut {
 //     qdot = (x - qA)/eta ; v = x - qB ; g = M v - eta^2 f ; H = dg/dx
 // xq, xqd, xv: this lane's DOF position, velocity qdot and dqtmp entry v (node order; the caller forms
 // qdot and v from x, qA, qB).  Hrow[i] = H(row of this node, column of node i).
-template <int NP, bool WANT_H>
+#define RMX_STAMP(k)                                                  \
+    if (TIMED) {                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        stamps[k] += now_ - last_;                                    \
+        last_ = now_;                                                 \
+    }
+template <int NP, bool WANT_H, bool TIMED = false>
 __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict__ sAcc, double* __restrict__ sCol,
                                           const int lane, const double xq, const double xqd, const double xv,
-                                          const double eta, NodeOut& out, double (&Hrow)[NP]) {
+                                          const double eta, NodeOut& out, double (&Hrow)[NP],
+                                          unsigned long long* stamps = nullptr) {
+    unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     const int n = M.n;
     const bool act = lane < n;
     const int jj = act ? lane : 0;
@@ -123,6 +177,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = M.K[(9 + c) * MAXN + jj] + u * M.K[(21 + c) * MAXN + jj] + w * M.K[(33 + c) * MAXN + jj];
 
+    RMX_STAMP(0)
     // ---- world transforms E_w,j = E_w,parent T_j : pointer jumping (log2(depth) rounds)
     for (int r = 0; r < M.rounds; ++r) {
         const int a = act ? M.anc[r * MAXN + jj] : -1;
@@ -147,6 +202,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
         }
     }
 
+    RMX_STAMP(1)
     // ---- world-frame joint screw s_j = Ad(E_w,j) (A0_ij S)   (the column of J, Joint.m:508-522)
     double sbw[3], sbv[3], sw[3], sv[3], t3[3];
 #pragma unroll
@@ -179,6 +235,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
             }
         }
     }
+    RMX_STAMP(2)
     // ---- xi_j = ad(phi_j) s_j ; beta_j = sum_{a in anc*(j)} (s_a v_a + eta^2 xi_a qdot_a)  ( = (J v + eta^2 Jdot qdot)_j )
     double xiw[3], xiv[3], bw[3], bv[3];
     cross3(phw, sw, xiw);
@@ -204,6 +261,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
         }
     }
 
+    RMX_STAMP(3)
     // ---- world-frame spatial inertia of body j (Body.computeMassGrav :99-101): m, mc, Ibar = R diag(I) R' + m [c][c]'
     const double I1 = act ? M.I4[0 * MAXN + jj] : 0.0, I2 = act ? M.I4[1 * MAXN + jj] : 0.0;
     const double I3 = act ? M.I4[2 * MAXN + jj] : 0.0, ms = act ? M.I4[3 * MAXN + jj] : 0.0;
@@ -269,6 +327,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
         out.eV = act ? eV : 0.0;
     }
 
+    RMX_STAMP(4)
     // ---- subtree sums through LDS: W (6) [+ m, mc, Ibar, TL, hf for the Hessian]
     if (act) {
         double* A = sAcc + lane * ACC_STRIDE;
@@ -307,17 +366,26 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
             for (int c = 0; c < 3; ++c) A[25 + c] = hf[c];
         }
     }
+    RMX_STAMP(5)
     __syncthreads();
     {
         constexpr int NC = WANT_H ? NACC : 6;
-        if (lane < NC) {
+        if (lane < NC) {   // suffix sums over the depth-first order: all loads in flight first, then a register scan
+            double a[NP];
+#pragma unroll
+            for (int jn = 0; jn < NP; ++jn) a[jn] = (jn < n) ? sAcc[jn * ACC_STRIDE + lane] : 0.0;
             double acc = 0.0;
-            for (int jn = n - 1; jn >= 0; --jn) {     // suffix sums over the depth-first order
-                acc += sAcc[jn * ACC_STRIDE + lane];
-                sAcc[jn * ACC_STRIDE + lane] = acc;
+#pragma unroll
+            for (int jn = NP - 1; jn >= 0; --jn) {
+                acc += a[jn];
+                a[jn] = acc;
             }
+#pragma unroll
+            for (int jn = 0; jn < NP; ++jn)
+                if (jn < n) sAcc[jn * ACC_STRIDE + lane] = a[jn];
         }
     }
+    RMX_STAMP(6)
     __syncthreads();
     constexpr int NS = WANT_H ? NACC : 6;
     double S[NS];
@@ -335,13 +403,14 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
     const double* Wt = &S[0];
     const double* Wf = &S[3];
 
+    RMX_STAMP(7)
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
     const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
                       hitU * (qLimK * (qLimU - q) - qLimD * qd);
     out.g = dof ? (dot3(sw, Wt) + dot3(sv, Wf) - e2 * fr) : 0.0;
 
+    RMX_STAMP(8)
     if (WANT_H) {
-        __syncthreads();   // everyone has read sAcc (not strictly needed: sCol is a different region)
         const double mS = S[6];
         const double* mcS = &S[7];
         const double* IbS = &S[10];
@@ -414,39 +483,36 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
         cross3(gv, sv, b3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) r3w[c] = e2 * (a3[c] - mS * b3[c]);
-        // column-side vectors to LDS
-        if (act) {
-            double* Cn = sCol + lane * COL_STRIDE;
+        RMX_STAMP(9)
+        // column-side vectors stay in this lane's registers (zero on idle lanes); column i is broadcast out of lane i with
+        // v_readlane into scalar registers, which the FMAs consume directly: no LDS round trip, no latency per column.
+        double cv[NCOL];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                Cn[c] = yt[c] - zt[c];
-                Cn[3 + c] = yf[c] - zf[c];
-                Cn[6 + c] = m1w[c];
-                Cn[9 + c] = m1v[c];
-                Cn[12 + c] = m2w[c];
-                Cn[15 + c] = sw[c];
-            }
+        for (int c = 0; c < 3; ++c) {
+            cv[c] = act ? yt[c] - zt[c] : 0.0;
+            cv[3 + c] = act ? yf[c] - zf[c] : 0.0;
+            cv[6 + c] = act ? m1w[c] : 0.0;
+            cv[9 + c] = act ? m1v[c] : 0.0;
+            cv[12 + c] = act ? m2w[c] : 0.0;
+            cv[15 + c] = act ? sw[c] : 0.0;
         }
-        __syncthreads();
-        const int myend = act ? M.end[jj] : 0;
+        RMX_STAMP(10)
+        const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (i >= n) {
-                Hrow[i] = (i == lane) ? 1.0 : 0.0;
-            } else {
-            const double* Ci = sCol + i * COL_STRIDE;
-            const int endi = M.end[i];
+            double Ci[NCOL];
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) Ci[c] = readlane_d(cv[c], i);
             const double up = sw[0] * Ci[0] + sw[1] * Ci[1] + sw[2] * Ci[2] + sv[0] * Ci[3] + sv[1] * Ci[4] + sv[2] * Ci[5];
             const double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
                               (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
-            double hv = 0.0;
-            if (lane < i && i < myend) hv = up;            // this row's node is a strict ancestor of column node
-            else if (i < lane && lane < endi) hv = lo;     // strict descendant
-            else if (i == lane) hv = Hdiag;
-            Hrow[i] = hv;
-            }
+            // branch-free select: relation bits -> 0/1 weights (columns of idle lanes are all-zero vectors)
+            const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
+            const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
+            const double hv = mu * up + ml * lo;
+            Hrow[i] = (i == lane) ? Hdiag : hv;
         }
-        __syncthreads();
+        RMX_STAMP(11)
     }
 }
 
@@ -457,49 +523,41 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
 // v_readlane into scalar registers; the right-hand side is eliminated alongside.
 template <int NP>
 __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, double (&Hrow)[NP], const double g) {
+    // Rows/columns >= n are the identity (eval_node pads them), so all NP steps run unguarded: straight-line code lets
+    // the scheduler overlap the pivot search of step k+1 with the trailing updates of step k.
+    (void)n;
     double b = -g;
-    int pivstep = (lane < n) ? -1 : (NP + 1);   // -1: not yet used as a pivot row
+    int pivstep = (lane < NP) ? -1 : (NP + 1);   // -1: not yet used as a pivot row
     double rinv_own = 0.0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        if (k < n) {   // wave-uniform guard (no break: the loop must unroll fully so Hrow stays in registers)
-            // pivot search: max |H(a,k)| over unused rows; 26-bit key (exponent + 14 mantissa bits) + lane id
-            unsigned key = 0u;
-            if (pivstep < 0) key = ((unsigned)(__double2hiint(Hrow[k]) & 0x7fffffff) & ~63u) + 64u + (unsigned)lane;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned other = (unsigned)__shfl_xor((int)key, o, 64);
-                key = other > key ? other : key;
-            }
-            const int pl = __builtin_amdgcn_readfirstlane((int)(key & 63u));
-            const double piv = readlane_d(Hrow[k], pl);
-            const double rinv = 1.0 / piv;
-            const bool elim = pivstep < 0 && lane != pl;
-            if (lane == pl) {
-                pivstep = k;
-                rinv_own = rinv;
-            }
-            const double l = elim ? Hrow[k] * rinv : 0.0;
-#pragma unroll
-            for (int c = k + 1; c < NP; ++c) {   // columns >= n hold zeros on every row < n: harmless
-                const double pr = readlane_d(Hrow[c], pl);
-                Hrow[c] -= l * pr;               // l == 0 on rows that are not being eliminated
-            }
-            const double pb = readlane_d(b, pl);
-            b -= l * pb;
+        // every lane inverts its own candidate while the search runs (off the critical path)
+        const double rinv_mine = recip(Hrow[k]);
+        // pivot search: max |H(a,k)| over unused rows; 26-bit key (exponent + 14 mantissa bits) + lane id
+        unsigned key = 0u;
+        if (pivstep < 0) key = ((unsigned)(__double2hiint(Hrow[k]) & 0x7fffffff) & ~63u) + 64u + (unsigned)lane;
+        key = (NP <= 32) ? wave_umax32(key) : wave_umax(key);
+        const int pl = (int)(key & 63u);
+        const double rinv = readlane_d(rinv_mine, pl);
+        const bool elim = pivstep < 0 && lane != pl;
+        if (lane == pl) {
+            pivstep = k;
+            rinv_own = rinv;
         }
+        const double l = elim ? Hrow[k] * rinv : 0.0;
+#pragma unroll
+        for (int c = k + 1; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], pl);   // l == 0 on rows not being eliminated
+        b -= l * readlane_d(b, pl);
     }
     // back substitution on the implicitly permuted upper triangle
     double dx = 0.0;
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
-        if (k < n) {
-            const unsigned long long mk = __ballot(pivstep == k);
-            const int pl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mk) - 1);
-            const double xk = readlane_d(b * rinv_own, pl);
-            if (lane == k) dx = xk;
-            if (pivstep < k) b -= Hrow[k] * xk;
-        }
+        const unsigned long long mk = __ballot(pivstep == k);
+        const int pl = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mk) - 1);
+        const double xk = readlane_d(b * rinv_own, pl);
+        if (lane == k) dx = xk;
+        if (pivstep < k) b -= Hrow[k] * xk;
     }
     return dx;
 }

@@ -1,0 +1,114 @@
+// Micro-benchmarks of the cross-lane primitives the step kernel leans on, one wavefront per SIMD (1024 blocks of 64).
+// Build+run on the GPU box: hipcc --offload-arch=gfx950 -O3 tools/ubench.hip -o /tmp/ubench && /tmp/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k(double* out, unsigned long long* cyc, int reps, int dynlane) {
+    const int lane = threadIdx.x;
+    double a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 1.0 + 1e-3 * (lane + i);
+    double l = 1e-6 * lane;
+    __shared__ double sm[64 * 17];
+    int pl = dynlane;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < reps; ++r) {
+        if (MODE == 0) {   // 16 independent fp64 FMAs
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = fma(a[i], 0.999, l);
+        } else if (MODE == 1) {   // 16 dependent fp64 FMAs
+#pragma unroll
+            for (int i = 0; i < 16; ++i) l = fma(l, 0.999, a[i]);
+        } else if (MODE == 2) {   // 16 x (readlane_d dynamic + FMA) : the LU inner pattern
+            pl = __builtin_amdgcn_readfirstlane((pl + 7) & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] -= l * readlane_d(a[i], pl);
+        } else if (MODE == 3) {   // 16 x (readlane_d immediate + FMA)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] -= l * readlane_d(a[i], 5);
+        } else if (MODE == 4) {   // 16 x __shfl (ds_bpermute) of doubles, independent
+            const int src = (lane + 1 + r) & 63;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] += __shfl(a[i], src, 64);
+        } else if (MODE == 5) {   // 16 dependent DPP adds (int)
+            int v = lane + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v += dpp_i<0xB1>(v);
+            l += v;
+        } else if (MODE == 6) {   // LDS: 16 writes (stride 17) then 16 reads transposed
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm[lane * 17 + i] = a[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] += sm[((lane + i) & 63) * 17 + i];
+            __syncthreads();
+        } else if (MODE == 7) {   // dependent chain: ds_bpermute -> add, 16 deep
+#pragma unroll
+            for (int i = 0; i < 16; ++i) l += __shfl(l, (lane + 1) & 63, 64);
+        } else if (MODE == 8) {   // v_rcp_f64 + 2 Newton steps, 4 independent
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double x = a[i], rr = __builtin_amdgcn_rcp(x);
+                rr = fma(fma(-x, rr, 1.0), rr, rr);
+                rr = fma(fma(-x, rr, 1.0), rr, rr);
+                a[i] = rr + 1.0;
+            }
+        } else if (MODE == 9) {   // sincos fp64
+            double s_, c_;
+            sincos(a[0], &s_, &c_);
+            a[0] = s_ + c_ * 0.5 + 1.0;
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = l;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i];
+    out[blockIdx.x * 64 + lane] = s;
+    if (lane == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* name, int per, int nblk) {
+    double* out; unsigned long long* cyc;
+    hipMalloc(&out, sizeof(double) * 64 * nblk); hipMalloc(&cyc, sizeof(unsigned long long) * nblk);
+    const int reps = 200;
+    k<MODE><<<nblk, 64>>>(out, cyc, reps, 3);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k<MODE><<<nblk, 64>>>(out, cyc, reps, 3);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(nblk);
+    hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * nblk, hipMemcpyDeviceToHost);
+    double m = 0; for (auto v : h) m += v; m /= nblk;
+    printf("%-44s blocks %5d: %8.1f memtime-ticks/rep  (%6.2f per item)  wall %.3f ms => %.1f ns/rep\n", name, nblk, m / reps, m / reps / per, ms, ms * 1e6 / reps);
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    for (int nblk : {1024, 4096}) {
+        run<0>("16 indep v_fma_f64", 16, nblk);
+        run<1>("16 dependent v_fma_f64", 16, nblk);
+        run<2>("16 x (readlane_d dyn + fma)", 16, nblk);
+        run<3>("16 x (readlane_d imm + fma)", 16, nblk);
+        run<4>("16 indep __shfl double (2 bpermute)", 16, nblk);
+        run<5>("16 dependent dpp add (int)", 16, nblk);
+        run<6>("LDS 16 wr + sync + 16 rd + sync", 32, nblk);
+        run<7>("16 dependent __shfl double + add", 16, nblk);
+        run<8>("4 x recip (rcp + 2 newton)", 4, nblk);
+        run<9>("sincos fp64", 1, nblk);
+    }
+    return 0;
+}
