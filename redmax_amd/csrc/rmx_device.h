@@ -119,6 +119,13 @@ __device__ __forceinline__ unsigned wave_umax32(unsigned v) {
     const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
     return a > b ? a : b;
 }
+// row_shr:K inside each 16-lane row; lanes without a source (lane&15 < K) receive 0
+template <int K>
+__device__ __forceinline__ double dpp_shr0(double v) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + K, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + K, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 // 1/x to full double precision: hardware estimate + two Newton steps (error <= 1 ulp; LAPACK's dgetf2 also scales
 // the pivot column by the reciprocal)
 __device__ __forceinline__ double recip(double x) {
@@ -138,19 +145,118 @@ struct NodeOut {
 //
 // evalBDF1 / computeValues (driverRedMaxBDF1.m:160-243) for the generic implicit residual
 //     qdot = (x - qA)/eta ; v = x - qB ; g = M v - eta^2 f ; H = dg/dx
-// xq, xqd, xv: this lane's DOF position, velocity qdot and dqtmp entry v (node order; the caller forms
-// qdot and v from x, qA, qB).  Hrow[i] = H(row of this node, column of node i).
+// split in two stages that share the per-node state in registers:
+//   eval_front : kinematics, path sums, body wrenches, subtree sums, residual g   (the reference's nargout==1 path)
+//   eval_hess  : the Hessian row of this node from the retained state              (the extra work of nargout==2)
+// The reference evaluates g at the accepted line-search point and then g AND H again at the same point at the top of the
+// next Newton iteration (driverRedMaxBDF1.m:103,125); here the second evaluation reuses the first one's state.
 #define RMX_STAMP(k)                                                  \
     if (TIMED) {                                                      \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
         stamps[k] += now_ - last_;                                    \
         last_ = now_;                                                 \
     }
-template <int NP, bool WANT_H, bool TIMED = false>
-__device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict__ sAcc, double* __restrict__ sCol,
-                                          const int lane, const double xq, const double xqd, const double xv,
-                                          const double eta, NodeOut& out, double (&Hrow)[NP],
-                                          unsigned long long* stamps = nullptr) {
+
+// What eval_hess needs from eval_front (all per lane = per node, world frame)
+struct FrontState {
+    double sw[3], sv[3];      // joint screw
+    double phw[3], phv[3];    // phi  = (J qdot)_j
+    double xiw[3], xiv[3];    // xi   = ad(phi) s
+    double bw[3], bv[3];      // beta = (J v + eta^2 Jdot qdot)_j
+    double S[NACC];           // subtree sums: W(6), m, mc(3), Ibar(6), TL(9), hf(3)
+    double eta, kd, dd;       // step; -Kr and -Dr of this joint (stiffness/damping incl. active limits)
+    bool act, dof;
+};
+
+// Inclusive root->node "path" composition for a serial chain (parent(j) = j-1): Hillis-Steele scan with DPP row shifts
+// inside each 16-lane row, then the row prefixes are chained through scalar broadcasts.  NROWS = rows in use.
+template <int NP>
+__device__ __forceinline__ void chain_scan_sum6(const int lane, double (&a)[3], double (&b)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a[c] += dpp_shr0<1>(a[c]); b[c] += dpp_shr0<1>(b[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a[c] += dpp_shr0<2>(a[c]); b[c] += dpp_shr0<2>(b[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a[c] += dpp_shr0<4>(a[c]); b[c] += dpp_shr0<4>(b[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a[c] += dpp_shr0<8>(a[c]); b[c] += dpp_shr0<8>(b[c]);
+    }
+    constexpr int NROWS = (NP + 15) / 16;
+#pragma unroll
+    for (int r = 1; r < NROWS; ++r) {   // row r adds the (already complete) total of lane 16r-1
+        const bool in = (lane >> 4) == r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double ta = readlane_d(a[c], 16 * r - 1), tb = readlane_d(b[c], 16 * r - 1);
+            a[c] += in ? ta : 0.0;
+            b[c] += in ? tb : 0.0;
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void chain_compose_step(const int lane, double (&R)[9], double (&p)[3]) {
+    double Ra[9], pa[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ra[c] = dpp_shr0<K>(R[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pa[c] = dpp_shr0<K>(p[c]);
+    if ((lane & 15) >= K) {
+        double Rn[9], pn[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
+            pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = pn[c];
+    }
+}
+template <int NP>
+__device__ __forceinline__ void chain_scan_transform(const int lane, double (&R)[9], double (&p)[3]) {
+    chain_compose_step<1>(lane, R, p);
+    chain_compose_step<2>(lane, R, p);
+    chain_compose_step<4>(lane, R, p);
+    chain_compose_step<8>(lane, R, p);
+    constexpr int NROWS = (NP + 15) / 16;
+#pragma unroll
+    for (int r = 1; r < NROWS; ++r) {
+        double Ra[9], pa[3];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Ra[c] = readlane_d(R[c], 16 * r - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pa[c] = readlane_d(p[c], 16 * r - 1);
+        if ((lane >> 4) == r) {
+            double Rn[9], pn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
+                pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = pn[c];
+        }
+    }
+}
+
+// FULL: accumulate the Hessian's subtree sums as well (28 numbers per body instead of 6)
+template <int NP, bool FULL, bool TIMED = false>
+__device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
+                                           const double xqd, const double xv, const double eta, NodeOut& out, FrontState& fs,
+                                           unsigned long long* stamps = nullptr) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     const int n = M.n;
     const bool act = lane < n;
@@ -176,35 +282,47 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
     for (int c = 0; c < 9; ++c) R[c] = M.K[c * MAXN + jj] + u * M.K[(12 + c) * MAXN + jj] + w * M.K[(24 + c) * MAXN + jj];
 #pragma unroll
     for (int c = 0; c < 3; ++c) p[c] = M.K[(9 + c) * MAXN + jj] + u * M.K[(21 + c) * MAXN + jj] + w * M.K[(33 + c) * MAXN + jj];
+    if (!act) {   // idle lanes carry the identity so that they are neutral in the chain scans
+#pragma unroll
+        for (int c = 0; c < 9; ++c) R[c] = (c % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = 0.0;
+    }
 
     RMX_STAMP(0)
-    // ---- world transforms E_w,j = E_w,parent T_j : pointer jumping (log2(depth) rounds)
-    for (int r = 0; r < M.rounds; ++r) {
-        const int a = act ? M.anc[r * MAXN + jj] : -1;
-        const int src = a >= 0 ? a : lane;
-        double Ra[9], pa[3];
+    // ---- world transforms E_w,j = E_w,parent T_j
+    if (M.is_chain) {
+        chain_scan_transform<NP>(lane, R, p);
+    } else {   // general tree: pointer jumping over ancestors (log2(depth) rounds of cross-lane permutes)
+        for (int r = 0; r < M.rounds; ++r) {
+            const int a = act ? M.anc[r * MAXN + jj] : -1;
+            const int src = a >= 0 ? a : lane;
+            double Ra[9], pa[3];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) Ra[c] = shfl_d(R[c], src);
+            for (int c = 0; c < 9; ++c) Ra[c] = shfl_d(R[c], src);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pa[c] = shfl_d(p[c], src);
-        if (a >= 0) {
-            double Rn[9], pn[3];
+            for (int c = 0; c < 3; ++c) pa[c] = shfl_d(p[c], src);
+            if (a >= 0) {
+                double Rn[9], pn[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+                for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
-                pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
+                    for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
+                    pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[c] = pn[c];
             }
-#pragma unroll
-            for (int c = 0; c < 9; ++c) R[c] = Rn[c];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) p[c] = pn[c];
         }
     }
 
     RMX_STAMP(1)
     // ---- world-frame joint screw s_j = Ad(E_w,j) (A0_ij S)   (the column of J, Joint.m:508-522)
-    double sbw[3], sbv[3], sw[3], sv[3], t3[3];
+    double sbw[3], sbv[3], t3[3];
+    double (&sw)[3] = fs.sw;
+    double (&sv)[3] = fs.sv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         sbw[c] = act ? M.sb[c * MAXN + jj] : 0.0;
@@ -217,27 +335,35 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
     for (int c = 0; c < 3; ++c) sv[c] += t3[c];
 
     // ---- phi_j = sum_{a in anc*(j)} s_a qdot_a   ( = (J qdot)_j, Joint.update :411-419 )
-    double phw[3], phv[3];
+    double (&phw)[3] = fs.phw;
+    double (&phv)[3] = fs.phv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         phw[c] = sw[c] * qd;
         phv[c] = sv[c] * qd;
     }
-    for (int r = 0; r < M.rounds; ++r) {
-        const int a = act ? M.anc[r * MAXN + jj] : -1;
-        const int src = a >= 0 ? a : lane;
+    if (M.is_chain) {
+        chain_scan_sum6<NP>(lane, phw, phv);
+    } else {
+        for (int r = 0; r < M.rounds; ++r) {
+            const int a = act ? M.anc[r * MAXN + jj] : -1;
+            const int src = a >= 0 ? a : lane;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double tw = shfl_d(phw[c], src), tv = shfl_d(phv[c], src);
-            if (a >= 0) {
-                phw[c] += tw;
-                phv[c] += tv;
+            for (int c = 0; c < 3; ++c) {
+                const double tw = shfl_d(phw[c], src), tv = shfl_d(phv[c], src);
+                if (a >= 0) {
+                    phw[c] += tw;
+                    phv[c] += tv;
+                }
             }
         }
     }
     RMX_STAMP(2)
     // ---- xi_j = ad(phi_j) s_j ; beta_j = sum_{a in anc*(j)} (s_a v_a + eta^2 xi_a qdot_a)  ( = (J v + eta^2 Jdot qdot)_j )
-    double xiw[3], xiv[3], bw[3], bv[3];
+    double (&xiw)[3] = fs.xiw;
+    double (&xiv)[3] = fs.xiv;
+    double (&bw)[3] = fs.bw;
+    double (&bv)[3] = fs.bv;
     cross3(phw, sw, xiw);
     cross3(phv, sw, xiv);
     cross3(phw, sv, t3);
@@ -248,15 +374,19 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
         bw[c] = sw[c] * v + e2 * qd * xiw[c];
         bv[c] = sv[c] * v + e2 * qd * xiv[c];
     }
-    for (int r = 0; r < M.rounds; ++r) {
-        const int a = act ? M.anc[r * MAXN + jj] : -1;
-        const int src = a >= 0 ? a : lane;
+    if (M.is_chain) {
+        chain_scan_sum6<NP>(lane, bw, bv);
+    } else {
+        for (int r = 0; r < M.rounds; ++r) {
+            const int a = act ? M.anc[r * MAXN + jj] : -1;
+            const int src = a >= 0 ? a : lane;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double tw = shfl_d(bw[c], src), tv = shfl_d(bv[c], src);
-            if (a >= 0) {
-                bw[c] += tw;
-                bv[c] += tv;
+            for (int c = 0; c < 3; ++c) {
+                const double tw = shfl_d(bw[c], src), tv = shfl_d(bv[c], src);
+                if (a >= 0) {
+                    bw[c] += tw;
+                    bv[c] += tv;
+                }
             }
         }
     }
@@ -336,7 +466,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
             A[c] = wt[c];
             A[3 + c] = wf[c];
         }
-        if (WANT_H) {
+        if (FULL) {
             A[6] = ms;
 #pragma unroll
             for (int c = 0; c < 3; ++c) A[7 + c] = mc[c];
@@ -369,7 +499,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
     RMX_STAMP(5)
     __syncthreads();
     {
-        constexpr int NC = WANT_H ? NACC : 6;
+        constexpr int NC = FULL ? NACC : 6;
         if (lane < NC) {   // suffix sums over the depth-first order: all loads in flight first, then a register scan
             double a[NP];
 #pragma unroll
@@ -387,8 +517,8 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
     }
     RMX_STAMP(6)
     __syncthreads();
-    constexpr int NS = WANT_H ? NACC : 6;
-    double S[NS];
+    constexpr int NS = FULL ? NACC : 6;
+    double (&S)[NACC] = fs.S;
     {
         const double* A = sAcc + jj * ACC_STRIDE;
 #pragma unroll
@@ -400,120 +530,152 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
             for (int c = 0; c < NS; ++c) S[c] -= E[c];
         }
     }
-    const double* Wt = &S[0];
-    const double* Wf = &S[3];
-
+    __syncthreads();   // sAcc is rewritten by the next evaluation
     RMX_STAMP(7)
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
     const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
                       hitU * (qLimK * (qLimU - q) - qLimD * qd);
-    out.g = dof ? (dot3(sw, Wt) + dot3(sv, Wf) - e2 * fr) : 0.0;
-
+    out.g = dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
+    fs.eta = eta;
+    fs.kd = stiff + (hitL + hitU) * qLimK;    // -Kr  (Joint.computeForce Joint.m:470-482)
+    fs.dd = damp + (hitL + hitU) * qLimD;     // -Dr
+    fs.act = act;
+    fs.dof = dof;
     RMX_STAMP(8)
-    if (WANT_H) {
-        const double mS = S[6];
-        const double* mcS = &S[7];
-        const double* IbS = &S[10];
-        const double* TL = &S[16];
-        const double* hfS = &S[25];
-        // zeta = ad(beta) s + eta^2 ad(phi) xi ; m1 = s + 2 eta xi + zeta ; m2w = eta sw + eta^2 xiw
-        double zw[3], zv[3], m1w[3], m1v[3], m2w[3];
-        cross3(bw, sw, zw);
-        cross3(bv, sw, zv);
-        cross3(bw, sv, t3);
+}
+
+// Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle lanes are the identity.
+template <int NP, bool TIMED = false>
+__device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
+                                          unsigned long long* stamps = nullptr) {
+    unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
+    const double eta = fs.eta, e2 = eta * eta;
+    const bool act = fs.act, dof = fs.dof;
+    const int jj = act ? lane : 0;
+    const double (&sw)[3] = fs.sw;
+    const double (&sv)[3] = fs.sv;
+    const double (&phw)[3] = fs.phw;
+    const double (&phv)[3] = fs.phv;
+    const double (&xiw)[3] = fs.xiw;
+    const double (&xiv)[3] = fs.xiv;
+    const double (&bw)[3] = fs.bw;
+    const double (&bv)[3] = fs.bv;
+    const double* Wt = &fs.S[0];
+    const double* Wf = &fs.S[3];
+    const double mS = fs.S[6];
+    const double* mcS = &fs.S[7];
+    const double* IbS = &fs.S[10];
+    const double* TL = &fs.S[16];
+    const double* hfS = &fs.S[25];
+    const double gv[3] = {M.grav[0], M.grav[1], M.grav[2]};
+    double t3[3], a3[3], b3[3];
+    // zeta = ad(beta) s + eta^2 ad(phi) xi ; m1 = s + 2 eta xi + zeta ; m2w = eta sw + eta^2 xiw
+    double zw[3], zv[3], m1w[3], m1v[3], m2w[3];
+    cross3(bw, sw, zw);
+    cross3(bv, sw, zv);
+    cross3(bw, sv, t3);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) zv[c] += t3[c];
-        cross3(phw, xiw, a3);
-        cross3(phv, xiw, b3);
-        cross3(phw, xiv, t3);
+    for (int c = 0; c < 3; ++c) zv[c] += t3[c];
+    cross3(phw, xiw, a3);
+    cross3(phv, xiw, b3);
+    cross3(phw, xiv, t3);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            zw[c] += e2 * a3[c];
-            zv[c] += e2 * (b3[c] + t3[c]);
-            m1w[c] = sw[c] + 2.0 * eta * xiw[c] + zw[c];
-            m1v[c] = sv[c] + 2.0 * eta * xiv[c] + zv[c];
-            m2w[c] = eta * sw[c] + e2 * xiw[c];
-        }
-        // y = Ic m1 - Bc m2 - eta^2 Kc s
-        double yt[3], yf[3];
-        sym3v(IbS, m1w, yt);
-        cross3(mcS, m1v, t3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) yt[c] += t3[c];
-        cross3(mcS, m1w, t3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) yf[c] = mS * m1v[c] - t3[c];
-        mat3v(TL, m2w, a3);                 // Bc m2 : top = TL m2w, bottom = 2 hf x m2w
-        cross3(hfS, m2w, b3);
-        double gxs[3], kt[3];
-        cross3(gv, sw, gxs);                // Kc s : top = mc x (g x sw), bottom = m g x sw
-        cross3(mcS, gxs, kt);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            yt[c] -= a3[c] + e2 * kt[c];
-            yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c];
-        }
-        // z = ad(s)' W
-        double zt[3], zf[3];
-        cross3(sw, Wt, a3);
-        cross3(sv, Wf, b3);
-        cross3(sw, Wf, zf);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            zt[c] = -a3[c] - b3[c];
-            zf[c] = -zf[c];
-        }
-        // diagonal: s.y - eta Dr - eta^2 Kr   (Joint.computeForce Joint.m:470-482)
-        const double Kr = -stiff - (hitL + hitU) * qLimK;
-        const double Dr = -damp - (hitL + hitU) * qLimD;
-        const double Hdiag = dof ? (dot3(sw, yt) + dot3(sv, yf) - eta * Dr - e2 * Kr) : 1.0;
-        // row-side vectors: r1 = Ic s, r2w = TL' sw - 2 hf x sv, r3w = eta^2 (g x (mc x sw) - m g x sv)
-        double r1t[3], r1f[3], r2w[3], r3w[3];
-        sym3v(IbS, sw, r1t);
-        cross3(mcS, sv, t3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) r1t[c] += t3[c];
-        cross3(mcS, sw, t3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) r1f[c] = mS * sv[c] - t3[c];
-        cross3(hfS, sv, b3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) r2w[c] = TL[c] * sw[0] + TL[3 + c] * sw[1] + TL[6 + c] * sw[2] - 2.0 * b3[c];
-        cross3(gv, t3, a3);     // g x (mc x sw)
-        cross3(gv, sv, b3);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) r3w[c] = e2 * (a3[c] - mS * b3[c]);
-        RMX_STAMP(9)
-        // column-side vectors stay in this lane's registers (zero on idle lanes); column i is broadcast out of lane i with
-        // v_readlane into scalar registers, which the FMAs consume directly: no LDS round trip, no latency per column.
-        double cv[NCOL];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            cv[c] = act ? yt[c] - zt[c] : 0.0;
-            cv[3 + c] = act ? yf[c] - zf[c] : 0.0;
-            cv[6 + c] = act ? m1w[c] : 0.0;
-            cv[9 + c] = act ? m1v[c] : 0.0;
-            cv[12 + c] = act ? m2w[c] : 0.0;
-            cv[15 + c] = act ? sw[c] : 0.0;
-        }
-        RMX_STAMP(10)
-        const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            double Ci[NCOL];
-#pragma unroll
-            for (int c = 0; c < NCOL; ++c) Ci[c] = readlane_d(cv[c], i);
-            const double up = sw[0] * Ci[0] + sw[1] * Ci[1] + sw[2] * Ci[2] + sv[0] * Ci[3] + sv[1] * Ci[4] + sv[2] * Ci[5];
-            const double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
-                              (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
-            // branch-free select: relation bits -> 0/1 weights (columns of idle lanes are all-zero vectors)
-            const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
-            const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
-            const double hv = mu * up + ml * lo;
-            Hrow[i] = (i == lane) ? Hdiag : hv;
-        }
-        RMX_STAMP(11)
+    for (int c = 0; c < 3; ++c) {
+        zw[c] += e2 * a3[c];
+        zv[c] += e2 * (b3[c] + t3[c]);
+        m1w[c] = sw[c] + 2.0 * eta * xiw[c] + zw[c];
+        m1v[c] = sv[c] + 2.0 * eta * xiv[c] + zv[c];
+        m2w[c] = eta * sw[c] + e2 * xiw[c];
     }
+    // y = Ic m1 - Bc m2 - eta^2 Kc s
+    double yt[3], yf[3];
+    sym3v(IbS, m1w, yt);
+    cross3(mcS, m1v, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yt[c] += t3[c];
+    cross3(mcS, m1w, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yf[c] = mS * m1v[c] - t3[c];
+    mat3v(TL, m2w, a3);                 // Bc m2 : top = TL m2w, bottom = 2 hf x m2w
+    cross3(hfS, m2w, b3);
+    double gxs[3], kt[3];
+    cross3(gv, sw, gxs);                // Kc s : top = mc x (g x sw), bottom = m g x sw
+    cross3(mcS, gxs, kt);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        yt[c] -= a3[c] + e2 * kt[c];
+        yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c];
+    }
+    // z = ad(s)' W
+    double zt[3], zf[3];
+    cross3(sw, Wt, a3);
+    cross3(sv, Wf, b3);
+    cross3(sw, Wf, zf);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        zt[c] = -a3[c] - b3[c];
+        zf[c] = -zf[c];
+    }
+    // diagonal: s.y - eta Dr - eta^2 Kr   (Joint.computeForce Joint.m:470-482)
+    const double Hdiag = dof ? (dot3(sw, yt) + dot3(sv, yf) + eta * fs.dd + e2 * fs.kd) : 1.0;
+    // row-side vectors: r1 = Ic s, r2w = TL' sw - 2 hf x sv, r3w = eta^2 (g x (mc x sw) - m g x sv)
+    double r1t[3], r1f[3], r2w[3], r3w[3];
+    sym3v(IbS, sw, r1t);
+    cross3(mcS, sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1t[c] += t3[c];
+    cross3(mcS, sw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1f[c] = mS * sv[c] - t3[c];
+    cross3(hfS, sv, b3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r2w[c] = TL[c] * sw[0] + TL[3 + c] * sw[1] + TL[6 + c] * sw[2] - 2.0 * b3[c];
+    cross3(gv, t3, a3);     // g x (mc x sw)
+    cross3(gv, sv, b3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r3w[c] = e2 * (a3[c] - mS * b3[c]);
+    RMX_STAMP(9)
+    // column-side vectors stay in this lane's registers (zero on idle lanes); column i is broadcast out of lane i with
+    // v_readlane into scalar registers, which the FMAs consume directly: no LDS round trip, no latency per column.
+    double cv[NCOL];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        cv[c] = act ? yt[c] - zt[c] : 0.0;
+        cv[3 + c] = act ? yf[c] - zf[c] : 0.0;
+        cv[6 + c] = act ? m1w[c] : 0.0;
+        cv[9 + c] = act ? m1v[c] : 0.0;
+        cv[12 + c] = act ? m2w[c] : 0.0;
+        cv[15 + c] = act ? sw[c] : 0.0;
+    }
+    RMX_STAMP(10)
+    const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        double Ci[NCOL];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) Ci[c] = readlane_d(cv[c], i);
+        const double up = sw[0] * Ci[0] + sw[1] * Ci[1] + sw[2] * Ci[2] + sv[0] * Ci[3] + sv[1] * Ci[4] + sv[2] * Ci[5];
+        const double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
+                          (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
+        // branch-free select: relation bits -> 0/1 weights (columns of idle lanes are all-zero vectors)
+        const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
+        const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
+        const double hv = mu * up + ml * lo;
+        Hrow[i] = (i == lane) ? Hdiag : hv;
+    }
+    RMX_STAMP(11)
+}
+
+// One-shot evaluation (parity hook / energy kernels)
+template <int NP, bool WANT_H, bool TIMED = false>
+__device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict__ sAcc, double* __restrict__ sCol,
+                                          const int lane, const double xq, const double xqd, const double xv,
+                                          const double eta, NodeOut& out, double (&Hrow)[NP],
+                                          unsigned long long* stamps = nullptr) {
+    (void)sCol;
+    FrontState fs;
+    eval_front<NP, WANT_H, TIMED>(M, sAcc, lane, xq, xqd, xv, eta, out, fs, stamps);
+    if (WANT_H) eval_hess<NP, TIMED>(M, lane, fs, Hrow, stamps);
 }
 
 // ----------------------------------------------------------------------------- dense solve
@@ -566,15 +728,20 @@ __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, doub
 //
 // newton (driverRedMaxBDF1.m:94-157): damped Newton, backtracking on 0.5|g|^2 with strict decrease,
 // at most iterLsMax halvings (the last trial is kept), stop on |g|<tol, iter>=iterMax or |dx|>dxMax.
+// The (g,H) evaluation at the top of iteration k+1 is the Hessian stage applied to the state of the line-search
+// evaluation that accepted x_{k+1} (same x, same arithmetic, so the same g the reference recomputes).
 template <int NP>
 __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
                                               int& iters, int& halvings, int& status) {
+    (void)sCol;
     double Hrow[NP];
+    FrontState fs;
+    NodeOut e;
+    eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     int iter = 1;
     while (true) {
-        NodeOut e;
-        eval_node<NP, true>(M, sAcc, sCol, lane, x, (x - qA) / eta, x - qB, eta, e, Hrow);
+        eval_hess<NP>(M, lane, fs, Hrow);
         const NodeOut e0 = e;
         last = e;
         ++iters;
@@ -606,8 +773,7 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
                 e = e0;              // the evaluation at x0
                 break;
             }
-            double dummy[NP];
-            eval_node<NP, false>(M, sAcc, sCol, lane, x, (x - qA) / eta, x - qB, eta, e, dummy);
+            eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
             gn2 = wave_sum(e.g * e.g);
             if (0.5 * gn2 < f0) break;
             if (iterLs >= o.iterLsMax) break;
