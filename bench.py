@@ -113,7 +113,8 @@ def main():
     st = sim.stats_read()
     iters = int(st["newton_iters"].sum())
     halv = int(st["ls_halvings"].sum())
-    bad = int((st["status"] != 0).sum())
+    bad = int(((st["status"] & 15) != 0).sum())
+    pivoted = int(((st["status"] & 16) != 0).sum())
     qf, qdf = sim.get_state()
     finite = bool(np.isfinite(qf).all() and np.isfinite(qdf).all())
 
@@ -146,7 +147,8 @@ def main():
                        "batch_per_gpu": B, "links": n, "h": h, "newton_tol": args.tol, "reference_newton_tol": 1e-9,
                        "init": "q,qdot~U(-0.1,0.1), rng(20240+global_index); traj 0: q=0.1,qdot=0",
                        "parallelism": "batch-sharded x%d, one RCCL all-gather of final (q,qdot)" % world,
-                       "steps_per_launch": K, "not_converged_trajectories": bad, "all_finite": finite},
+                       "steps_per_launch": K, "not_converged_trajectories": bad, "trajectories_with_pivoted_fallback": pivoted,
+                       "all_finite": finite},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -49,7 +49,9 @@ enum { RMX_JOINT_FIXED = 0, RMX_JOINT_REVOLUTE = 1, RMX_JOINT_PRISMATIC = 2 };
 /* RMX_ST_STALLED accompanies RMX_ST_MAXITER when the Newton iteration reached a floating-point fixed point
  * (alpha*dx below one ulp of x): the reference repeats that identical iteration until iterMax and keeps x;
  * the library returns the same x without spinning. */
-enum { RMX_ST_DIVERGED = 1, RMX_ST_MAXITER = 2, RMX_ST_NAN = 4, RMX_ST_STALLED = 8 };
+/* RMX_ST_PIVOTED is informational: at least one linear solve tripped the diagonal-pivot growth guard and was redone
+ * with full partial pivoting (see rmx_device.h lu_solve_neg_diag). */
+enum { RMX_ST_DIVERGED = 1, RMX_ST_MAXITER = 2, RMX_ST_NAN = 4, RMX_ST_STALLED = 8, RMX_ST_PIVOTED = 16 };
 
 /* Scene listing, one entry per joint/body pair in the order the scene file lists them
  * (parent before child; scenesRedMax.m).  Replaces the handle-object graph that Scene.init()
@@ -80,6 +82,10 @@ typedef struct rmx_opts {
     double dxMax;          /* 1e3    "Newton diverged" threshold on ||dx||_2       */
     int iterMaxPerDof;     /* 10     iterMax = iterMaxPerDof * nr                  */
     int iterLsMax;         /* 20     line-search halvings                          */
+    int lu_mode;           /* dx = -H\g (driverRedMaxBDF1.m:117, LU with partial pivoting in MATLAB):
+                              0 (default) eliminate on the diagonal under a growth guard (|multiplier| <= 8, i.e. threshold
+                                pivoting with tau = 1/8) and redo the solve with full partial pivoting when the guard trips;
+                              1 always full partial pivoting (the literal reference behaviour, ~2x slower solve)  */
 } rmx_opts;
 
 typedef struct rmx_model rmx_model;

@@ -283,6 +283,7 @@ extern "C" void rmx_opts_default(rmx_opts* o) {
     o->dxMax = 1e3;         // :96
     o->iterMaxPerDof = 10;  // :97
     o->iterLsMax = 20;      // :98
+    o->lu_mode = 0;
 }
 
 namespace {
@@ -689,6 +690,7 @@ static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
     d.dxMax = o->dxMax;
     d.iterMax = o->iterMaxPerDof * b->m->nr;    // iterMax = 10*length(xInit) (:97)
     d.iterLsMax = o->iterLsMax;
+    d.lu_mode = o->lu_mode;
     return RMX_OK;
 }
 

@@ -43,6 +43,7 @@ struct DevModel {
 struct DevOpts {
     double h, tol, dxMax;
     int iterMax, iterLsMax;
+    int lu_mode;      // 0: diagonal pivots under a growth guard, partial pivoting on demand; 1: always partial pivoting
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -683,6 +684,36 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
 // dx = -H\g (driverRedMaxBDF1.m:117: MATLAB mldivide = LU with partial pivoting).  Lane = row; the row
 // lives in registers; rows are never moved (implicit permutation); the pivot row is broadcast with
 // v_readlane into scalar registers; the right-hand side is eliminated alongside.
+// Fast path: eliminate on the diagonal (no search, static lanes) under a growth guard.  Every multiplier must satisfy
+// |l| <= LU_GROWTH_MAX, i.e. the diagonal passes threshold pivoting with tau = 1/LU_GROWTH_MAX (the criterion sparse direct
+// solvers use); H = M - eta D - eta^2 K + dMdq.v is a modest perturbation of the SPD mass matrix, so this nearly always
+// holds.  If any multiplier violates it (or is NaN) `ok` comes back false and the caller redoes the solve with full
+// partial pivoting (lu_solve_neg) on a re-assembled H: pivoting semantics are kept, its cost is paid only when needed.
+constexpr double LU_GROWTH_MAX = 8.0;
+template <int NP>
+__device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, bool& ok) {
+    double b = -g;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const double rinv = recip(readlane_d(Hrow[k], k));
+        const double l = (lane > k) ? Hrow[k] * rinv : 0.0;
+        bad = bad || !(fabs(l) <= LU_GROWTH_MAX);
+#pragma unroll
+        for (int c = k + 1; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], k);
+        b -= l * readlane_d(b, k);
+    }
+    double dx = 0.0;
+#pragma unroll
+    for (int k = NP - 1; k >= 0; --k) {
+        const double xk = readlane_d(b, k) * recip(readlane_d(Hrow[k], k));
+        if (lane == k) dx = xk;
+        if (lane < k) b -= Hrow[k] * xk;
+    }
+    ok = !__any(bad);
+    return dx;
+}
+
 template <int NP>
 __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, double (&Hrow)[NP], const double g) {
     // Rows/columns >= n are the identity (eval_node pads them), so all NP steps run unguarded: straight-line code lets
@@ -745,7 +776,16 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
         const NodeOut e0 = e;
         last = e;
         ++iters;
-        const double dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        bool lu_ok = false;
+        double dx = 0.0;
+        if (o.lu_mode == 0) dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, lu_ok);
+        if (!lu_ok) {            // growth guard tripped (or lu_mode 1): (re-)assemble H and solve with partial pivoting
+            if (o.lu_mode == 0) {
+                eval_hess<NP>(M, lane, fs, Hrow);   // H was destroyed in place
+                status |= 16;
+            }
+            dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        }
         const double dxn2 = wave_sum(dx * dx);
         if (!(dxn2 == dxn2)) {   // NaN: give up on this trajectory instead of spinning to iterMax
             status |= 4;

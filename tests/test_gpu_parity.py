@@ -98,7 +98,7 @@ def test_bdf1_energy_kat_on_gpu(sid):
     scene, H, passed = driverRedMaxBDF1(sid, True, verbose=False)
     assert passed is True
     assert abs(H - scene.Hexpected[0]) <= 1e-9 * abs(scene.Hexpected[0]), (sid, H)
-    assert scene.solverInfo["status"] == 0
+    assert scene.solverInfo["status"] & 15 == 0
 
 
 @pytest.mark.parametrize("sid", IN_SCOPE_SCENES)
@@ -149,7 +149,7 @@ def test_chain32_bench_tol_matches_reference_constants(oracle_lib):
     sim.set_state(q, qd)
     out = sim.step_bdf1(K, h=1e-2, stats=True)
     qg, qdg = sim.get_state()
-    assert (out["status"] == 0).all()
+    assert (out["status"] & 15 == 0).all()
     oracle_lib.set_newton()                        # reference constants
     for b in range(B):
         o = oracle_lib.Oracle(sc.desc())
@@ -174,7 +174,7 @@ def test_full_size_batch_properties():
     sim.opts.tol = 1e-8                            # the bench setting: every trajectory-step converges
     out = sim.step_bdf1(K, h=1e-2, stats=True, history=True)
     qa, qda = sim.get_state()
-    assert (out["status"] == 0).all()
+    assert (out["status"] & 15 == 0).all()
     assert np.isfinite(qa).all() and np.isfinite(qda).all()
     T, V = sim.energy()
     assert np.allclose(T, out["T"][-1], rtol=1e-12, atol=1e-9)
@@ -213,7 +213,7 @@ def test_tree64_rollout_matches_oracle(oracle_lib):
         o.step_bdf1(1e-2, K)
         qo, qdo = o.get_state()
         assert _rel(qg[b], qo) <= 1e-8, (b, _rel(qg[b], qo))
-    assert (out["status"] == 0).all()
+    assert (out["status"] & 15 == 0).all()
 
 
 def test_energy_matches_oracle(oracle_lib):
@@ -243,3 +243,29 @@ def test_library_is_loaded_in_tree():
     with open("/proc/self/maps") as f:
         maps = f.read()
     assert os.path.realpath(_abi.LIB_PATH) in maps or _abi.LIB_PATH in maps
+
+
+@pytest.mark.parametrize("name", ["2", "14", "chain32", "tree15"])
+def test_lu_modes_agree(name):
+    """lu_mode 0 (diagonal pivots under the growth guard) and lu_mode 1 (always partial pivoting, the literal
+    `-H\\g` of driverRedMaxBDF1.m:117) give the same rollout to roundoff."""
+    from redmax_amd import BatchSim
+    sc = _scene(name)
+    sc.init()
+    B, K = 8, 10
+    q, qd = syntheticStates(sc.nr, B)
+    q0s, qd0s = sc.getQ()
+    q[0], qd[0] = q0s, qd0s
+    res = []
+    for mode in (0, 1):
+        sim = BatchSim(sc, batch=B)
+        sim.opts.lu_mode = mode
+        sim.opts.tol = 1e-8 if name == "chain32" else 1e-9
+        sim.set_state(q, qd)
+        out = sim.step_bdf1(K, h=sc.h, stats=True)
+        assert not (out["status"] & 5).any()
+        if mode == 1:
+            assert not (out["status"] & 16).any()
+        res.append(sim.get_state())
+    for b in range(B):
+        assert _close(res[0][0][b], res[1][0][b], 1e-10, 1e-10), (name, b, _rel(res[0][0][b], res[1][0][b]))
