@@ -127,6 +127,13 @@ __device__ __forceinline__ double dpp_shr0(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + K, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// row_shl:K inside each 16-lane row (lane l receives lane l+K); lanes without a source receive 0
+template <int K>
+__device__ __forceinline__ double dpp_shl0(double v) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + K, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + K, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 // 1/x to full double precision: hardware estimate + two Newton steps (error <= 1 ulp; LAPACK's dgetf2 also scales
 // the pivot column by the reciprocal)
 __device__ __forceinline__ double recip(double x) {
@@ -249,6 +256,30 @@ __device__ __forceinline__ void chain_scan_transform(const int lane, double (&R)
             for (int c = 0; c < 9; ++c) R[c] = Rn[c];
 #pragma unroll
             for (int c = 0; c < 3; ++c) p[c] = pn[c];
+        }
+    }
+}
+
+// Subtree sums for a serial chain = suffix sums over the lanes: DPP row_shl scan inside each row, then the complete total of
+// the next row's first lane is handed down through scalar registers (highest row first).  No LDS, no barriers.
+template <int NP, int NS>
+__device__ __forceinline__ void chain_suffix_sum(const int lane, double (&S)[NACC]) {
+#pragma unroll
+    for (int c = 0; c < NS; ++c) S[c] += dpp_shl0<1>(S[c]);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) S[c] += dpp_shl0<2>(S[c]);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) S[c] += dpp_shl0<4>(S[c]);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) S[c] += dpp_shl0<8>(S[c]);
+    constexpr int NROWS = (NP + 15) / 16;
+#pragma unroll
+    for (int r = NROWS - 2; r >= 0; --r) {
+        const bool in = (lane >> 4) == r;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const double t = readlane_d(S[c], 16 * (r + 1));
+            S[c] += in ? t : 0.0;
         }
     }
 }
@@ -459,49 +490,59 @@ __device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict
     }
 
     RMX_STAMP(4)
-    // ---- subtree sums through LDS: W (6) [+ m, mc, Ibar, TL, hf for the Hessian]
-    if (act) {
-        double* A = sAcc + lane * ACC_STRIDE;
+    // ---- subtree sums: W (6) [+ m, mc, Ibar, TL, hf for the Hessian].  Idle lanes hold zeros (zero mass).
+    constexpr int NS = FULL ? NACC : 6;
+    double (&S)[NACC] = fs.S;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            A[c] = wt[c];
-            A[3 + c] = wf[c];
-        }
-        if (FULL) {
-            A[6] = ms;
+    for (int c = 0; c < 3; ++c) {
+        S[c] = wt[c];
+        S[3 + c] = wf[c];
+    }
+    if (FULL) {
+        S[6] = ms;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) A[7 + c] = mc[c];
+        for (int c = 0; c < 3; ++c) S[7 + c] = mc[c];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) A[10 + c] = Ib[c];
-            // TL = X + X' + [h_tau],  X = Ibar [phi_w] + [mc][phi_v]   (B = I ad(phi) + ad(phi)' I + N(h) = [[TL,0],[2[hf],0]])
-            const double Ibf[9] = {Ib[0], Ib[1], Ib[2], Ib[1], Ib[3], Ib[4], Ib[2], Ib[4], Ib[5]};
-            const double Om[9] = {0.0, -phw[2], phw[1], phw[2], 0.0, -phw[0], -phw[1], phw[0], 0.0};
-            const double Vx[9] = {0.0, -phv[2], phv[1], phv[2], 0.0, -phv[0], -phv[1], phv[0], 0.0};
-            const double Mc[9] = {0.0, -mc[2], mc[1], mc[2], 0.0, -mc[0], -mc[1], mc[0], 0.0};
-            const double Ht[9] = {0.0, -ht[2], ht[1], ht[2], 0.0, -ht[0], -ht[1], ht[0], 0.0};
-            double X[9];
+        for (int c = 0; c < 6; ++c) S[10 + c] = Ib[c];
+        // TL = X + X' + [h_tau],  X = Ibar [phi_w] + [mc][phi_v]   (B = I ad(phi) + ad(phi)' I + N(h) = [[TL,0],[2[hf],0]])
+        const double Ibf[9] = {Ib[0], Ib[1], Ib[2], Ib[1], Ib[3], Ib[4], Ib[2], Ib[4], Ib[5]};
+        const double Om[9] = {0.0, -phw[2], phw[1], phw[2], 0.0, -phw[0], -phw[1], phw[0], 0.0};
+        const double Vx[9] = {0.0, -phv[2], phv[1], phv[2], 0.0, -phv[0], -phv[1], phv[0], 0.0};
+        const double Mc[9] = {0.0, -mc[2], mc[1], mc[2], 0.0, -mc[0], -mc[1], mc[0], 0.0};
+        const double Ht[9] = {0.0, -ht[2], ht[1], ht[2], 0.0, -ht[0], -ht[1], ht[0], 0.0};
+        double X[9];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    double s = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double t = 0.0;
 #pragma unroll
-                    for (int l = 0; l < 3; ++l) s += Ibf[3 * i + l] * Om[3 * l + k] + Mc[3 * i + l] * Vx[3 * l + k];
-                    X[3 * i + k] = s;
-                }
+                for (int l = 0; l < 3; ++l) t += Ibf[3 * i + l] * Om[3 * l + k] + Mc[3 * i + l] * Vx[3 * l + k];
+                X[3 * i + k] = t;
+            }
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) A[16 + 3 * i + k] = X[3 * i + k] + X[3 * k + i] + Ht[3 * i + k];
+            for (int k = 0; k < 3; ++k) S[16 + 3 * i + k] = X[3 * i + k] + X[3 * k + i] + Ht[3 * i + k];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) A[25 + c] = hf[c];
-        }
+        for (int c = 0; c < 3; ++c) S[25 + c] = hf[c];
     }
     RMX_STAMP(5)
-    __syncthreads();
-    {
-        constexpr int NC = FULL ? NACC : 6;
-        if (lane < NC) {   // suffix sums over the depth-first order: all loads in flight first, then a register scan
+    if (M.is_chain && !FULL) {
+        // measured: the register (DPP) scan wins for the 6-number residual-only accumulation (10.5k vs 12.3k cycles per
+        // evaluation) but loses for the full 28-number one (24.7k vs 23.9k), which stays on the LDS transpose below
+        chain_suffix_sum<NP, NS>(lane, S);
+        RMX_STAMP(6)
+    } else {
+        // general tree: transpose through LDS (stride 29: conflict-free), one lane per component scans the nodes in
+        // depth-first order in registers; subtree(j) = suffix(j) - suffix(end_j), row n of sAcc is kept zero
+        if (act) {
+            double* A = sAcc + lane * ACC_STRIDE;
+#pragma unroll
+            for (int c = 0; c < NS; ++c) A[c] = S[c];
+        }
+        __syncthreads();
+        if (lane < NS) {
             double a[NP];
 #pragma unroll
             for (int jn = 0; jn < NP; ++jn) a[jn] = (jn < n) ? sAcc[jn * ACC_STRIDE + lane] : 0.0;
@@ -515,23 +556,21 @@ __device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict
             for (int jn = 0; jn < NP; ++jn)
                 if (jn < n) sAcc[jn * ACC_STRIDE + lane] = a[jn];
         }
-    }
-    RMX_STAMP(6)
-    __syncthreads();
-    constexpr int NS = FULL ? NACC : 6;
-    double (&S)[NACC] = fs.S;
-    {
-        const double* A = sAcc + jj * ACC_STRIDE;
+        RMX_STAMP(6)
+        __syncthreads();
+        {
+            const double* A = sAcc + jj * ACC_STRIDE;
 #pragma unroll
-        for (int c = 0; c < NS; ++c) S[c] = A[c];
-        if (!M.is_chain) {   // subtree(j) = suffix(j) - suffix(end_j); row n of sAcc is kept zero
-            const int en = act ? M.end[jj] : n;
-            const double* E = sAcc + en * ACC_STRIDE;
+            for (int c = 0; c < NS; ++c) S[c] = A[c];
+            if (!M.is_chain) {
+                const int en = act ? M.end[jj] : n;
+                const double* E = sAcc + en * ACC_STRIDE;
 #pragma unroll
-            for (int c = 0; c < NS; ++c) S[c] -= E[c];
+                for (int c = 0; c < NS; ++c) S[c] -= E[c];
+            }
         }
+        __syncthreads();   // sAcc is rewritten by the next evaluation
     }
-    __syncthreads();   // sAcc is rewritten by the next evaluation
     RMX_STAMP(7)
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
     const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
@@ -694,9 +733,11 @@ template <int NP>
 __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, bool& ok) {
     double b = -g;
     bool bad = false;
+    double rinv_own = 0.0;    // 1/U(lane,lane), kept for the back substitution
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const double rinv = recip(readlane_d(Hrow[k], k));
+        rinv_own = (lane == k) ? rinv : rinv_own;
         const double l = (lane > k) ? Hrow[k] * rinv : 0.0;
         bad = bad || !(fabs(l) <= LU_GROWTH_MAX);
 #pragma unroll
@@ -706,7 +747,7 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     double dx = 0.0;
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
-        const double xk = readlane_d(b, k) * recip(readlane_d(Hrow[k], k));
+        const double xk = readlane_d(b * rinv_own, k);
         if (lane == k) dx = xk;
         if (lane < k) b -= Hrow[k] * xk;
     }
@@ -781,7 +822,11 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
         if (o.lu_mode == 0) dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, lu_ok);
         if (!lu_ok) {            // growth guard tripped (or lu_mode 1): (re-)assemble H and solve with partial pivoting
             if (o.lu_mode == 0) {
-                eval_hess<NP>(M, lane, fs, Hrow);   // H was destroyed in place
+                // H was destroyed in place.  The front is re-evaluated too (same x, same arithmetic) so that its state does
+                // not have to stay live in registers across the fast-path LU for the sake of this rare branch.
+                NodeOut e2;
+                eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
+                eval_hess<NP>(M, lane, fs, Hrow);
                 status |= 16;
             }
             dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
