@@ -31,6 +31,7 @@ import numpy as np
 F_G = 363712        # one residual evaluation
 F_H = 1418432       # one residual + Hessian evaluation
 F_LU = 23893        # one 32x32 LU solve
+HBM_TRAFFIC_BYTES = int((1498.6875 + 608.0) * 1024)   # measured with PMC counters, see roofline.traffic_note
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the
                           # microarch guide lists no fp64 row, so the datasheet value is used and stated)
 
@@ -44,8 +45,8 @@ def main():
     ap.add_argument("--links", type=int, default=32)
     ap.add_argument("--tol", type=float, default=1e-8, help="Newton |g| tolerance (reference hard-codes 1e-9, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-traj", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-traj", type=int, default=0, help="rollouts in the CPU sample (default: 4 per host core, <= batch)")
+    ap.add_argument("--cpu-steps", type=int, default=40)
     args = ap.parse_args()
 
     import torch
@@ -130,7 +131,10 @@ def main():
         if flops is not None and kernel_ms > 0:
             ach = flops / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP64_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP64_PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_BYTES if (B == 1024 and K == 100 and n == 32) else None,
+                    "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01b_pmc_*.csv): 1498.7 KB + 608 KB per "
+                                    "launch of 100 steps x 1024 rollouts, reported uncorrected (8-byte-per-lane accesses: the guide's x2 FETCH "
+                                    "correction is calibrated for 16 B/lane streams only); algorithmic = 1 MiB (q,qdot in + out)",
                     "kernel": "k_step_bdf1<32>", "kernel_ms": round(kernel_ms, 4),
                     "newton_iters_per_step": round(iters / (B * K), 3), "ls_halvings_per_step": round(halv / (B * K), 4),
                     "note": "fp64 path: FP64 vector == FP64 matrix peak on MI355X (78.6 TF, datasheet); algorithmic flops = SURVEY.md "
@@ -165,8 +169,10 @@ def cpu_baseline(scene, args, h):
     Newton constants as the GPU run.  Also returns max_b |q_gpu - q_oracle| / |q_oracle| on that sample."""
     from oracle import oracle as orc
     from redmax_amd import BatchSim, syntheticStates
-    nb, ks = args.cpu_traj, args.cpu_steps
     cores = os.cpu_count() or 1
+    nb = args.cpu_traj if args.cpu_traj > 0 else min(4 * cores, args.batch)
+    ks = args.cpu_steps
+    cores = min(cores, nb)                  # threads actually used (OpenMP over rollouts)
     q, qd = syntheticStates(scene.nr, nb)
     qc, qdc = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
     orc.set_newton(tol=args.tol)
