@@ -170,12 +170,17 @@ def cpu_baseline(scene, args, h):
     from oracle import oracle as orc
     from redmax_amd import BatchSim, syntheticStates
     cores = os.cpu_count() or 1
-    nb = args.cpu_traj if args.cpu_traj > 0 else min(4 * cores, args.batch)
-    ks = args.cpu_steps
+    nb = args.cpu_traj if args.cpu_traj > 0 else min(cores, args.batch)     # one rollout per host thread
     cores = min(cores, nb)                  # threads actually used (OpenMP over rollouts)
     q, qd = syntheticStates(scene.nr, nb)
-    qc, qdc = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
     orc.set_newton(tol=args.tol)
+    # size the sample to ~15 s of wall time: time 2 steps first, then pick the step count (bounded by --cpu-steps)
+    qc, qdc = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
+    t0 = time.perf_counter()
+    orc.batch_step_bdf1(scene.desc(), qc, qdc, h, 2, nthreads=cores)
+    per_step = (time.perf_counter() - t0) / 2
+    ks = int(max(4, min(args.cpu_steps, 15.0 / max(per_step, 1e-6))))
+    qc, qdc = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
     t0 = time.perf_counter()
     orc.batch_step_bdf1(scene.desc(), qc, qdc, h, ks, nthreads=cores)
     dt = time.perf_counter() - t0

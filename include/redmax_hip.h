@@ -145,6 +145,11 @@ int rmx_step_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* sta
 int rmx_step_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats,
                   double* hist_T, double* hist_V);
 
+/* euler() of matlab-simple/testRedMax.m:67-109 (BASELINE.json configs[0]): nsteps linearly-implicit Euler steps,
+ *   Mr = J'MmJ ; (Mr + h Dr - h^2 Kr) qdot1 = Mr qdot0 + h (J'(fm - Mm Jdot qdot0) + fr) ; q1 = q0 + h qdot1.
+ * hist_T/hist_V as in rmx_step_bdf1. */
+int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hist_T, double* hist_V);
+
 /* Joint.computeEnergies + Body.computeEnergies at the current state (Joint.m:616-637, Body.m:167-173):
  * host arrays [batch]. */
 int rmx_energy(rmx_batch* b, double* T, double* V);

@@ -7,5 +7,5 @@ from . import se3  # noqa: F401
 from .redmax import (Body, BodyCuboid, Joint, JointFixed, JointPrismatic, JointRevolute, Scene)  # noqa: F401
 from .scenes import IN_SCOPE_SCENES, sceneChain, scenesRedMax, sceneTree, syntheticStates  # noqa: F401
 from .batch import BatchSim  # noqa: F401
-from .driver import driverRedMaxBDF1, driverRedMaxBDF2, simLoop  # noqa: F401
+from .driver import driverRedMaxBDF1, driverRedMaxBDF2, simLoop, testRedMax  # noqa: F401
 from ._abi import RedMaxHipError  # noqa: F401

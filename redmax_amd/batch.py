@@ -113,6 +113,18 @@ class BatchSim:
     def step_bdf2(self, nsteps, h=None, stats=False, history=False):
         return self._step(self._L.rmx_step_bdf2, nsteps, h, stats, history)
 
+    def step_euler(self, nsteps, h, history=False):
+        """euler() of matlab-simple/testRedMax.m:67-109 (linearly-implicit Euler, config 1)."""
+        out = {}
+        T = V = None
+        if history:
+            T = np.empty((nsteps, self.B))
+            V = np.empty((nsteps, self.B))
+            out["T"], out["V"] = T, V
+        _abi.check(self._L.rmx_step_euler(self._batch, float(h), int(nsteps), _abi.dptr(T), _abi.dptr(V)), "rmx_step_euler")
+        out["ms"] = self._L.rmx_last_step_ms(self._batch)
+        return out
+
     def step_bdf1_async(self, nsteps, h=None):
         if h is not None:
             self.opts.h = float(h)

@@ -148,6 +148,47 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
     }
 }
 
+// euler (matlab-simple/testRedMax.m:67-109), BASELINE.json configs[0]: linearly-implicit Euler,
+//   Mr = J'MmJ ; (Mr + h Dr - h^2 Kr) qdot1 = Mr qdot0 + h (J'(fm - Mm Jdot qdot0) + fr) ; q1 = q0 + h qdot1
+// with the same front as the implicit integrators: the right-hand side is g(v = qdot0, e2 = -h) plus h*damping*qdot0
+// (matlab-simple drops the joint damping FORCE, testRedMax.m:84), the matrix is eval_mass + the joint diagonals.
+template <int NP>
+__global__ void __launch_bounds__(64) k_step_euler(const DevModel M, const double h, const StepArgs a) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    for (int s = 0; s < a.nsteps; ++s) {
+        FrontState fs;
+        NodeOut e;
+        double Mrow[NP];
+        eval_front_e2<NP, true>(M, sAcc, lane, q, qd, qd, 0.0, -h, e, fs);
+        eval_mass<NP>(M, lane, fs, Mrow);
+        const double rhs = e.g + h * fs.dd * qd;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (i == lane && fs.dof) Mrow[i] += h * fs.dd + h * h * fs.kd;
+        const double qd1 = lu_solve_neg<NP>(M.n, lane, Mrow, -rhs);
+        q = q + h * qd1;
+        qd = qd1;
+        if (a.histT) {
+            eval_front<NP, false>(M, sAcc, lane, q, qd, 0.0, 1.0, e, fs);
+            const double T = wave_sum(e.eT), V = wave_sum(e.eV);
+            if (lane == 0) {
+                a.histT[(size_t)s * a.B + traj] = T;
+                a.histV[(size_t)s * a.B + traj] = V;
+            }
+        }
+    }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+    }
+}
+
 // Parity hook: one residual (+Hessian) evaluation per trajectory, results to HBM.
 template <int NP, bool WANT_H>
 __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, const double* __restrict__ q,
@@ -647,6 +688,11 @@ static void launch_step_np(const rmx_model* m, const rmx_batch* b, int integ, co
     else k_step_bdf2<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
 }
 template <int NP>
+static void launch_euler(const rmx_model* m, const rmx_batch* b, double h, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    k_step_euler<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, h, a);
+}
+template <int NP>
 static void launch_energy(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);
     k_energy<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
@@ -763,6 +809,42 @@ extern "C" int rmx_step_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx
 }
 extern "C" int rmx_step_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats, double* hist_T, double* hist_V) {
     return step_sync(b, opts, nsteps, stats, hist_T, hist_V, INTEG_BDF2);
+}
+
+extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, double* hV) {
+    if (!b) return fail(RMX_E_INVALID, "null batch");
+    if (nsteps < 0 || !(h > 0)) return fail(RMX_E_INVALID, "bad nsteps / h");
+    if ((hT == nullptr) != (hV == nullptr)) return fail(RMX_E_INVALID, "hist_T and hist_V must be given together");
+    rmx_model* m = b->m;
+    HIPCHK(hipSetDevice(m->device));
+    if (nsteps == 0 || m->nr == 0) return RMX_OK;
+    double *dT = nullptr, *dV = nullptr;
+    const size_t nh = (size_t)nsteps * b->B;
+    if (hT) {
+        HIPCHK(hipMalloc((void**)&dT, nh * sizeof(double)));
+        hipError_t e = hipMalloc((void**)&dV, nh * sizeof(double));
+        if (e != hipSuccess) { (void)hipFree(dT); return fail(RMX_E_NOMEM, "hipMalloc(hist)"); }
+    }
+    StepArgs a{};
+    a.B = b->B; a.nsteps = nsteps; a.q = b->q; a.qd = b->qd; a.histT = dT; a.histV = dV;
+    hipError_t e = hipEventRecord(b->ev0, b->stream);
+    DISPATCH_NP(m->NP, launch_euler, m, b, h, a);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->started, 0, sizeof(int), b->stream);
+    if (e == hipSuccess && hT) {
+        e = hipMemcpyAsync(hT, dT, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hV, dV, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
+    }
+    if (dT) (void)hipFree(dT);
+    if (dV) (void)hipFree(dV);
+    if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_step_euler: ") + hipGetErrorString(e));
+    return RMX_OK;
 }
 
 extern "C" int rmx_step_bdf1_async(rmx_batch* b, const rmx_opts* opts, int nsteps) {

@@ -284,18 +284,19 @@ __device__ __forceinline__ void chain_suffix_sum(const int lane, double (&S)[NAC
     }
 }
 
-// FULL: accumulate the Hessian's subtree sums as well (28 numbers per body instead of 6)
+// FULL: accumulate the Hessian's subtree sums as well (28 numbers per body instead of 6).
+// e2 is the coefficient of f in g = M v - e2 f: eta^2 for the implicit integrators; the linearly-implicit Euler step of
+// matlab-simple uses e2 = -h with v = qdot0 so that g = M qdot0 + h f is its right-hand side.
 template <int NP, bool FULL, bool TIMED = false>
-__device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
-                                           const double xqd, const double xv, const double eta, NodeOut& out, FrontState& fs,
-                                           unsigned long long* stamps = nullptr) {
+__device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
+                                              const double xqd, const double xv, const double eta, const double e2, NodeOut& out,
+                                              FrontState& fs, unsigned long long* stamps = nullptr) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     const int n = M.n;
     const bool act = lane < n;
     const int jj = act ? lane : 0;
     const int type = act ? M.type[jj] : 0;
     const bool dof = type != 0;
-    const double e2 = eta * eta;
 
     const double q = dof ? xq : 0.0;
     const double qd = dof ? xqd : 0.0;
@@ -582,6 +583,53 @@ __device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict
     fs.act = act;
     fs.dof = dof;
     RMX_STAMP(8)
+}
+
+template <int NP, bool FULL, bool TIMED = false>
+__device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
+                                           const double xqd, const double xv, const double eta, NodeOut& out, FrontState& fs,
+                                           unsigned long long* stamps = nullptr) {
+    eval_front_e2<NP, FULL, TIMED>(M, sAcc, lane, xq, xqd, xv, eta, eta * eta, out, fs, stamps);
+}
+
+// Reduced mass matrix row M(a,:) = (J' Mm J)(a,:) of this node from the subtree inertias (computeValues :212;
+// matlab-simple euler :86-87): M(a,i) = (Ic_a s_a).s_i if i is an ancestor-or-self of a, s_a.(Ic_i s_i) if a descendant.
+template <int NP>
+__device__ __forceinline__ void eval_mass(const DevModel& M, const int lane, const FrontState& fs, double (&Mrow)[NP]) {
+    const bool act = fs.act;
+    const int jj = act ? lane : 0;
+    const double mS = fs.S[6];
+    const double* mcS = &fs.S[7];
+    const double* IbS = &fs.S[10];
+    double r1[6], t3[3];
+    sym3v(IbS, fs.sw, r1);
+    cross3(mcS, fs.sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1[c] += t3[c];
+    cross3(mcS, fs.sw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1[3 + c] = mS * fs.sv[c] - t3[c];
+    double cv[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        cv[c] = act ? fs.sw[c] : 0.0;
+        cv[3 + c] = act ? fs.sv[c] : 0.0;
+        cv[6 + c] = act ? r1[c] : 0.0;
+        cv[9 + c] = act ? r1[3 + c] : 0.0;
+    }
+    const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
+    const double mdiag = fs.dof ? (fs.sw[0] * r1[0] + fs.sw[1] * r1[1] + fs.sw[2] * r1[2] + fs.sv[0] * r1[3] + fs.sv[1] * r1[4] + fs.sv[2] * r1[5]) : 1.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        double Ci[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) Ci[c] = readlane_d(cv[c], i);
+        const double lo = r1[0] * Ci[0] + r1[1] * Ci[1] + r1[2] * Ci[2] + r1[3] * Ci[3] + r1[4] * Ci[4] + r1[5] * Ci[5];
+        const double up = fs.sw[0] * Ci[6] + fs.sw[1] * Ci[7] + fs.sw[2] * Ci[8] + fs.sv[0] * Ci[9] + fs.sv[1] * Ci[10] + fs.sv[2] * Ci[11];
+        const double mu = (double)(unsigned)((desc_m >> i) & 1ull);
+        const double ml = (double)(unsigned)((anc_m >> i) & 1ull);
+        Mrow[i] = (i == lane) ? mdiag : (mu * up + ml * lo);
+    }
 }
 
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle lanes are the identity.

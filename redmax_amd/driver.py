@@ -53,3 +53,28 @@ def driverRedMaxBDF1(sceneID=0, batch=True, device=0, verbose=True):
 
 def driverRedMaxBDF2(sceneID=0, batch=True, device=0, verbose=True):
     return _driver(sceneID, batch, 2, device, verbose)
+
+
+def testRedMax(sceneID=0, device=0, verbose=True):
+    """matlab-simple/testRedMax.m:1-41 (BASELINE.json configs[0]): scene, init, euler() over tspan=[0 2] with
+    hEuler=1e-2 (matlab-simple/+redmax/Scene.m:22-23), then the energy check of matlab/testRedMax.m:164-177 against
+    Hexpected(REDMAX_EULER) (matlab/testRedMaxScenes.m:39,67,93 - same scenes, h, tspan and gravity)."""
+    Hexpected = {0: -5930.8171118834870867, 1: -9423.2594023734018265, 2: -1123.9825362491046690}
+    scene = scenesRedMax(sceneID)
+    scene.init()
+    h, nsteps = 1e-2, 200
+    sim = BatchSim(scene, batch=1, device=device)
+    q0, qd0 = scene.getQ()
+    sim.set_state(q0[None, :], qd0[None, :])
+    _, V0 = sim.energy()
+    out = sim.step_euler(nsteps, h, history=True)
+    q, qd = sim.get_state()
+    scene.setQ(q[0], qd[0])
+    H = float(out["T"][-1, 0] + out["V"][-1, 0] - V0[0])
+    passed = None
+    if sceneID in Hexpected:
+        passed = bool(abs(H - Hexpected[sceneID]) <= 1e-2)
+        if verbose:
+            print("### PASS ###" if passed else "### FAIL: %.16f ###" % H)
+    sim.close()
+    return scene, H, passed

@@ -269,3 +269,21 @@ def test_lu_modes_agree(name):
         res.append(sim.get_state())
     for b in range(B):
         assert _close(res[0][0][b], res[1][0][b], 1e-10, 1e-10), (name, b, _rel(res[0][0][b], res[1][0][b]))
+
+
+@pytest.mark.parametrize("sid,Hexp", [(0, -5930.8171118834870867), (1, -9423.2594023734018265), (2, -1123.9825362491046690)])
+def test_config1_euler_on_gpu(oracle_lib, sid, Hexp):
+    """BASELINE.json configs[0]: matlab-simple testRedMax (linearly-implicit Euler, 200 steps of h=1e-2) through the
+    drop-in entry point, against the reference's golden energy (matlab/testRedMaxScenes.m:39,67,93) and the oracle."""
+    from redmax_amd import testRedMax
+    scene, H, passed = testRedMax(sid, verbose=False)
+    assert passed is True
+    assert abs(H - Hexp) <= 1e-8 * abs(Hexp), (sid, H)
+    sc = scenesRedMax(sid)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc(), normalize_axis=0)
+    o.step_euler_simple(1e-2, 200)
+    qo, qdo = o.get_state()
+    qg, qdg = scene.getQ()
+    assert _rel(qg, qo) <= 1e-9, _rel(qg, qo)
+    assert _rel(qdg, qdo) <= 1e-8, _rel(qdg, qdo)
