@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -55,11 +56,12 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
     double q = id >= 0 ? a.q[off] : 0.0;
     double qd = id >= 0 ? a.qd[off] : 0.0;
     int iters = 0, halv = 0, status = 0;
+    PivotPolicy piv;
     for (int s = 0; s < a.nsteps; ++s) {
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
         NodeOut last;
-        const double x = newton_node<NP>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status);
+        const double x = newton_node<NP>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
         qd = (x - q0) / o.h;                       // (:72)
         q = x;
         if (a.histT) {                             // Scene.saveHistory (Scene.m:134-161)
@@ -96,6 +98,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
     const bool started = (*a.started) != 0;
     const double h = o.h;
     int iters = 0, halv = 0, status = 0;
+    PivotPolicy piv;
     for (int s = 0; s < a.nsteps; ++s) {
         NodeOut last;
         if (s == 0 && !started) {
@@ -103,13 +106,13 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             const double q0 = q, qd0 = qd;
             // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
             const double xa0 = q0 + al * h * qd0;
-            const double qa = newton_node<NP>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status);
+            const double qa = newton_node<NP>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv);
             const double qda = (qa - q0) / (al * h);
             // SDIRK2b (evalSDIRK2b :228-260)
             const double x10 = qa + (1.0 - al) * h * qda;
             const double qA = q0 + (1.0 - al) * h * qda;
             const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-            const double q1 = newton_node<NP>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status);
+            const double q1 = newton_node<NP>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv);
             qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
             q = q1;
             qp = q0;
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             const double x0 = q1 + h * qd1;
             const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
             const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-            const double q2 = newton_node<NP>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status);
+            const double q2 = newton_node<NP>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv);
             qp = q1;
             qdp = qd1;
             qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);

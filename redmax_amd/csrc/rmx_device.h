@@ -846,14 +846,37 @@ __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, doub
 
 // ----------------------------------------------------------------------------- Newton
 //
+// Per-trajectory state of the linear-solve policy (lu_mode 0).  The Newton loop exists in two instantiations: the fast one
+// (diagonal pivots under the growth guard, a tripped solve is redone with partial pivoting) and a pivot-only one.  The
+// choice is made per STEP, outside the loop: putting the choice inside the loop cost 40 % on the 32-chain (9.9 -> 13.9 ms
+// per 100 steps) through worse register allocation of the hot loop, whatever the policy did.  A trajectory whose solves
+// tripped the guard PIV_STREAK times in a row (scenes whose diagonal ordering never passes, e.g. trees with prismatic
+// joints) runs its next `len` steps pivot-only, doubling up to PIV_HOLD_MAX while the retries keep failing; isolated
+// trips (the 32-chain) just pay for the redone solve.
+constexpr int PIV_STREAK = 3, PIV_HOLD_MIN = 8, PIV_HOLD_MAX = 128;
+struct PivotPolicy {
+    int hold = 0;     // steps left that use the pivot-only Newton
+    int len = 0;      // current hold length (0: not backing off)
+    int streak = 0;   // consecutive tripped solves
+};
+__device__ __forceinline__ void pivot_policy_update(PivotPolicy& piv) {   // after a step of the fast Newton
+    if (piv.streak >= PIV_STREAK) {
+        piv.len = piv.len == 0 ? PIV_HOLD_MIN : (piv.len < PIV_HOLD_MAX ? 2 * piv.len : piv.len);
+        piv.hold = piv.len;
+        piv.streak = 0;
+    } else if (piv.streak == 0) {
+        piv.len = 0;
+    }
+}
+//
 // newton (driverRedMaxBDF1.m:94-157): damped Newton, backtracking on 0.5|g|^2 with strict decrease,
 // at most iterLsMax halvings (the last trial is kept), stop on |g|<tol, iter>=iterMax or |dx|>dxMax.
 // The (g,H) evaluation at the top of iteration k+1 is the Hessian stage applied to the state of the line-search
 // evaluation that accepted x_{k+1} (same x, same arithmetic, so the same g the reference recomputes).
-template <int NP>
-__device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
+template <int NP, bool PIVOT_ONLY>
+__device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
-                                              int& iters, int& halvings, int& status) {
+                                              int& iters, int& halvings, int& status, PivotPolicy& piv) {
     (void)sCol;
     double Hrow[NP];
     FrontState fs;
@@ -865,19 +888,24 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
         const NodeOut e0 = e;
         last = e;
         ++iters;
-        bool lu_ok = false;
-        double dx = 0.0;
-        if (o.lu_mode == 0) dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, lu_ok);
-        if (!lu_ok) {            // growth guard tripped (or lu_mode 1): (re-)assemble H and solve with partial pivoting
-            if (o.lu_mode == 0) {
+        double dx;
+        if (PIVOT_ONLY) {
+            dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        } else {
+            bool lu_ok;
+            dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, lu_ok);
+            if (lu_ok) {
+                piv.streak = 0;
+            } else {             // growth guard tripped: redo this solve with partial pivoting
+                ++piv.streak;
+                status |= 16;
                 // H was destroyed in place.  The front is re-evaluated too (same x, same arithmetic) so that its state does
                 // not have to stay live in registers across the fast-path LU for the sake of this rare branch.
                 NodeOut e2;
                 eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
                 eval_hess<NP>(M, lane, fs, Hrow);
-                status |= 16;
+                dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
             }
-            dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
         }
         const double dxn2 = wave_sum(dx * dx);
         if (!(dxn2 == dxn2)) {   // NaN: give up on this trajectory instead of spinning to iterMax
@@ -929,6 +957,19 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
         ++iter;
     }
     return x;
+}
+
+template <int NP>
+__device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
+                                              double x, const double qA, const double qB, const double eta, NodeOut& last,
+                                              int& iters, int& halvings, int& status, PivotPolicy& piv) {
+    if (o.lu_mode != 0 || piv.hold > 0) {     // wave-uniform
+        if (piv.hold > 0) --piv.hold;
+        return newton_impl<NP, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    }
+    const double r = newton_impl<NP, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    pivot_policy_update(piv);
+    return r;
 }
 
 }  // namespace rmx
