@@ -145,6 +145,25 @@ int rmx_step_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* sta
 int rmx_step_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats,
                   double* hist_T, double* hist_V);
 
+/* TaskBDF1PointPos (matlab-diff/+redmax/TaskBDF1PointPos.m): bring a point of a body to a world target at one step;
+ * the parameters are constant joint torques tau = pscale * p. */
+typedef struct rmx_task_pointpos {
+    int body;              /* listing index of the body             setBody                       */
+    double xlocal[3];      /* point in body coordinates             setPoint                      */
+    double xtarget[3];     /* world target                          setTarget                     */
+    int step;              /* 1-based step at which the point is measured (setTime: step = round(t/h)) */
+    double pscale;         /* torque scale                          setScale                      */
+    double wreg, wpos;     /* regulariser / position weights        setWeights                    */
+} rmx_task_pointpos;
+
+/* taskObjective of driverRedMaxAdjointBDF1.m:39-62, batched (BASELINE.json configs[3]): starting from the batch's current
+ * state, forward simLoop (:65-102) with the line-search-free newton (:105-146; opts->iterMaxPerDof should be 5 as at :108)
+ * under the torques tau = pscale*p, storing H, M, D of the last evaluated iterate of every step in HBM, then the backward
+ * sweep TaskBDF1.calcFinal (TaskBDF1.m:45-81).  p: host [batch][nr]; P: host [batch]; dPdp: host [batch][nr].
+ * The batch state is left at the end of the forward rollout. */
+int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
+                     double* P, double* dPdp, rmx_stats* stats);
+
 /* euler() of matlab-simple/testRedMax.m:67-109 (BASELINE.json configs[0]): nsteps linearly-implicit Euler steps,
  *   Mr = J'MmJ ; (Mr + h Dr - h^2 Kr) qdot1 = Mr qdot0 + h (J'(fm - Mm Jdot qdot0) + fr) ; q1 = q0 + h qdot1.
  * hist_T/hist_V as in rmx_step_bdf1. */

@@ -35,6 +35,11 @@ class Stats(C.Structure):
                 ("hessian_evals", C.c_int), ("diverged", C.c_int), ("not_converged", C.c_int)]
 
 
+class TaskPointPos(C.Structure):
+    _fields_ = [("body", C.c_int), ("xlocal", C.c_double * 3), ("xtarget", C.c_double * 3), ("t", C.c_double),
+                ("pscale", C.c_double), ("wreg", C.c_double), ("wpos", C.c_double)]
+
+
 def build(force=False):
     src = os.path.join(_HERE, "redmax_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -72,6 +77,8 @@ def lib():
         L.orc_batch_step_bdf1.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int]
         L.orc_batch_step_bdf1.restype = C.c_long
         L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
+        L.orc_adjoint_bdf1.restype = C.c_double
         _lib = L
     return _lib
 
@@ -218,6 +225,21 @@ class Oracle:
             return st, T, V
         self._L.orc_step_bdf2(self._h, float(h), int(step0), int(nsteps), C.byref(st), None, None)
         return st
+
+    def adjoint_bdf1(self, h, nsteps, task, p):
+        """taskObjective (driverRedMaxAdjointBDF1.m:39-62). task: dict(body, xlocal, xtarget, t, pscale, wreg, wpos).
+        Returns (P, dPdp, stats)."""
+        tk = TaskPointPos()
+        tk.body = int(task["body"])
+        for i in range(3):
+            tk.xlocal[i] = float(task["xlocal"][i])
+            tk.xtarget[i] = float(task["xtarget"][i])
+        tk.t, tk.pscale, tk.wreg, tk.wpos = (float(task[k]) for k in ("t", "pscale", "wreg", "wpos"))
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        dPdp = np.zeros(self.nr)
+        st = Stats()
+        P = self._L.orc_adjoint_bdf1(self._h, float(h), int(nsteps), C.byref(tk), _p(p), _p(dPdp), C.byref(st))
+        return float(P), dPdp, st
 
     def step_euler_simple(self, h, nsteps):
         T = np.zeros(nsteps)

@@ -898,6 +898,156 @@ void orc_step_euler_simple(orc_scene* s, double h, int nsteps, double* Hist_T, d
     free(q0); free(qd0); free(qd1); free(q1); free(Mr); free(Mt); free(frt); free(t_nm); free(t_nm2); free(t_nr);
 }
 
+/* ------------------------------------ adjoint BDF1 (config 4) */
+
+/* [L,U,p] = lu(H,'vector') (driverRedMaxAdjointBDF1.m:127): in-place LU with partial pivoting and explicit row swaps,
+ * H(p,:) = L*U, unit-lower L below the diagonal, U on and above.  H col-major n x n. */
+static void lu_factor(int n, double* H, int* perm) {
+#define Hc(r, c) H[(size_t)(c) * n + (r)]
+    for (int i = 0; i < n; i++) perm[i] = i;
+    for (int k = 0; k < n; k++) {
+        int p = k; double mx = fabs(Hc(k, k));
+        for (int r = k + 1; r < n; r++) { double v = fabs(Hc(r, k)); if (v > mx) { mx = v; p = r; } }
+        if (p != k) {
+            for (int c = 0; c < n; c++) { double t = Hc(k, c); Hc(k, c) = Hc(p, c); Hc(p, c) = t; }
+            int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+        }
+        if (Hc(k, k) == 0.0) continue;
+        double inv = 1.0 / Hc(k, k);
+        for (int r = k + 1; r < n; r++) Hc(r, k) *= inv;
+        for (int c = k + 1; c < n; c++) {
+            double hkc = Hc(k, c);
+            if (hkc != 0.0) for (int r = k + 1; r < n; r++) Hc(r, c) -= Hc(r, k) * hkc;
+        }
+    }
+}
+/* dx = -(Hu\(Hl\g(Hp)))  (:128) */
+static void lu_apply_neg(int n, const double* LU, const int* perm, const double* g, double* dx) {
+#define Lc(r, c) LU[(size_t)(c) * n + (r)]
+    for (int i = 0; i < n; i++) dx[i] = g[perm[i]];
+    for (int k = 0; k < n; k++) for (int r = k + 1; r < n; r++) dx[r] -= Lc(r, k) * dx[k];
+    for (int k = n - 1; k >= 0; k--) { dx[k] /= Lc(k, k); for (int r = 0; r < k; r++) dx[r] -= Lc(r, k) * dx[k]; }
+    for (int i = 0; i < n; i++) dx[i] = -dx[i];
+}
+/* zkk0(Hp) = Hl'\(Hu'\yk)   (TaskBDF1.m:76) */
+static void lu_apply_transposed(int n, const double* LU, const int* perm, const double* y, double* z) {
+    double* w = (double*)malloc(sizeof(double) * (size_t)(n + 1));
+    for (int i = 0; i < n; i++) w[i] = y[i];
+    for (int k = 0; k < n; k++) { w[k] /= Lc(k, k); for (int c = k + 1; c < n; c++) w[c] -= Lc(k, c) * w[k]; }     /* U' w = y */
+    for (int k = n - 1; k >= 0; k--) for (int c = 0; c < k; c++) w[c] -= Lc(k, c) * w[k];                          /* L' u = w */
+    for (int i = 0; i < n; i++) z[perm[i]] = w[i];
+    free(w);
+#undef Lc
+#undef Hc
+}
+
+/* taskObjective (driverRedMaxAdjointBDF1.m:39-62) for TaskBDF1PointPos: scene.reset(), forward simLoop (:65-102) with the
+ * line-search-free newton (:105-146; note x = x+dx BEFORE the |g|<tol test, so the stored factors/M/D/J belong to the last
+ * EVALUATED iterate), TaskBDF1PointPos.applyStep/calcStep (TaskBDF1PointPos.m:58-107) and the backward sweep
+ * TaskBDF1.calcFinal (TaskBDF1.m:45-81).  p: nr parameters (reduced order).  Returns P, fills dPdp (nr). */
+double orc_adjoint_bdf1(orc_scene* s, double h, int nsteps, const orc_task_pointpos* task, const double* p, double* dPdp, orc_stats* st) {
+    const int nr = s->nr, nm = s->nm;
+    const size_t n2 = (size_t)nr * nr;
+    double* LUh = (double*)calloc(n2 * (size_t)nsteps + 1, sizeof(double));
+    double* Mh = (double*)calloc(n2 * (size_t)nsteps + 1, sizeof(double));
+    double* Dh = (double*)calloc(n2 * (size_t)nsteps + 1, sizeof(double));
+    int* Ph = (int*)calloc((size_t)nr * nsteps + 1, sizeof(int));
+    double* dPdq = (double*)calloc((size_t)nr * nsteps + 1, sizeof(double));
+    double *q0 = calloc((size_t)nr + 1, 8), *qd0 = calloc((size_t)nr + 1, 8), *x = calloc((size_t)nr + 1, 8), *qB = calloc((size_t)nr + 1, 8);
+    double *g = calloc((size_t)nr + 1, 8), *dx = calloc((size_t)nr + 1, 8), *qd1 = calloc((size_t)nr + 1, 8);
+    double *H = calloc(n2 + 1, 8), *M = calloc(n2 + 1, 8), *f = calloc((size_t)nr + 1, 8), *K = calloc(n2 + 1, 8), *D = calloc(n2 + 1, 8);
+    double *dMdq = calloc(n2 * nr + 1, 8), *Jk = calloc((size_t)nm * nr + 1, 8);
+    const double tol = 1e-9, dxMax = 1e3;           /* :106-107 */
+    const int iterMax = 5 * nr;                      /* :108 */
+    if (st) memset(st, 0, sizeof(*st));
+    orc_reset(s);                                    /* scene.reset() :40 */
+    double P = 0.0, t = 0.0;                         /* task.init(): P = 0 */
+    for (int k = 1; k <= nsteps; k++) {
+        /* task.applyStep(): joint.tau = pscale*p(idxR)   TaskBDF1PointPos.m:58-64 */
+        for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) s->nd[i].tau = task->pscale * p[s->nd[i].idxR];
+        orc_get_state(s, q0, qd0);
+        for (int i = 0; i < nr; i++) { x[i] = q0[i] + h * qd0[i]; qB[i] = q0[i] + h * qd0[i]; }
+        double* LUk = LUh + n2 * (size_t)(k - 1); int* Pk = Ph + (size_t)nr * (k - 1);
+        int iter = 1;
+        while (1) {
+            /* [g,H,M,f,K,D,J] = evalBDF1(x) :160-176 */
+            for (int i = 0; i < nr; i++) qd1[i] = (x[i] - q0[i]) / h;
+            set_q(s, x, qd1); scene_update(s);
+            orc_compute_values(s, M, f, dMdq, K, D);
+            memcpy(Jk, s->J, sizeof(double) * (size_t)nm * nr);
+            for (int a = 0; a < nr; a++) { double tt = 0; for (int b = 0; b < nr; b++) tt += M[(size_t)b * nr + a] * (x[b] - qB[b]); g[a] = tt - h * h * f[a]; }
+            for (size_t i = 0; i < n2; i++) H[i] = M[i] - h * D[i] - h * h * K[i];
+            for (int i = 0; i < nr; i++) {
+                const double* Di = dMdq + (size_t)i * n2;
+                for (int a = 0; a < nr; a++) { double tt = 0; for (int b = 0; b < nr; b++) tt += Di[(size_t)b * nr + a] * (x[b] - qB[b]); H[(size_t)i * nr + a] += tt; }
+            }
+            if (st) { st->newton_iters++; st->hessian_evals++; }
+            memcpy(LUk, H, sizeof(double) * n2);
+            lu_factor(nr, LUk, Pk);                   /* :127 */
+            lu_apply_neg(nr, LUk, Pk, g, dx);         /* :128 */
+            if (vnorm(nr, dx) > dxMax) { if (st) st->diverged++; break; }
+            for (int i = 0; i < nr; i++) x[i] += dx[i];   /* :134 (before the convergence test) */
+            if (vnorm(nr, g) < tol) break;
+            if (iter >= iterMax) { if (st) st->not_converged++; break; }
+            iter++;
+        }
+        for (int i = 0; i < nr; i++) qd1[i] = (x[i] - q0[i]) / h;
+        set_q(s, x, qd1); scene_update(s);
+        t += h;
+        /* saveHistory(Hl,Hu,Hp,M,f,K,D,J) Scene.m:139-153 */
+        memcpy(Mh + n2 * (size_t)(k - 1), M, sizeof(double) * n2);
+        memcpy(Dh + n2 * (size_t)(k - 1), D, sizeof(double) * n2);
+        /* task.calcStep()  TaskBDF1PointPos.m:67-107 */
+        if (fabs(task->t - t) < 1e-6) {
+            const onode* b = &s->nd[task->body];
+            double xw[3], dxw[3];
+            for (int a = 0; a < 3; a++) {
+                xw[a] = b->E_wi[a][0] * task->xlocal[0] + b->E_wi[a][1] * task->xlocal[1] + b->E_wi[a][2] * task->xlocal[2] + b->E_wi[a][3];
+                dxw[a] = xw[a] - task->xtarget[a];
+            }
+            P += task->wpos * 0.5 * (dxw[0] * dxw[0] + dxw[1] * dxw[1] + dxw[2] * dxw[2]);
+            /* dxdqm(:,idxM) = R*Gamma(xlocal), Gamma = [brac(xlocal)', I]; dPdq = J'*dxdqm'*dx*wp */
+            double G[3][6], xb[3][3], RG[3][6];
+            se3_brac3(xb, task->xlocal);
+            for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) { G[a][c] = xb[c][a]; G[a][3 + c] = (a == c); }
+            for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) { double tt = 0; for (int e = 0; e < 3; e++) tt += b->E_wi[a][e] * G[e][c]; RG[a][c] = tt; }
+            double wm[6];
+            for (int c = 0; c < 6; c++) wm[c] = (RG[0][c] * dxw[0] + RG[1][c] * dxw[1] + RG[2][c] * dxw[2]) * task->wpos;
+            for (int a = 0; a < nr; a++) {
+                double tt = 0;
+                for (int c = 0; c < 6; c++) tt += Jk[(size_t)a * nm + b->idxM + c] * wm[c];
+                dPdq[(size_t)nr * (k - 1) + a] = tt;
+            }
+        }
+    }
+    /* TaskBDF1.calcFinal  TaskBDF1.m:45-81 */
+    double wreg2 = 0; for (int i = 0; i < nr; i++) wreg2 += p[i] * p[i];
+    P += task->wreg * 0.5 * wreg2;
+    double* z = (double*)calloc((size_t)nr * (nsteps + 2) + 1, sizeof(double));
+    double* yk = (double*)calloc((size_t)nr + 1, sizeof(double));
+    for (int k = nsteps; k >= 1; k--) {
+        for (int a = 0; a < nr; a++) yk[a] = dPdq[(size_t)nr * (k - 1) + a];
+        if (k < nsteps) {      /* block = -2*M + h*D of step k+1; yk -= block'*z(k+1) */
+            const double* M1 = Mh + n2 * (size_t)k; const double* D1 = Dh + n2 * (size_t)k; const double* z1 = z + (size_t)nr * k;
+            for (int a = 0; a < nr; a++) { double tt = 0; for (int j = 0; j < nr; j++) tt += (-2.0 * M1[(size_t)a * nr + j] + h * D1[(size_t)a * nr + j]) * z1[j]; yk[a] -= tt; }
+        }
+        if (k < nsteps - 1) {  /* block = M of step k+2 */
+            const double* M2 = Mh + n2 * (size_t)(k + 1); const double* z2 = z + (size_t)nr * (k + 1);
+            for (int a = 0; a < nr; a++) { double tt = 0; for (int j = 0; j < nr; j++) tt += M2[(size_t)a * nr + j] * z2[j]; yk[a] -= tt; }
+        }
+        lu_apply_transposed(nr, LUh + n2 * (size_t)(k - 1), Ph + (size_t)nr * (k - 1), yk, z + (size_t)nr * (k - 1));
+    }
+    /* dPdp = wreg*p' - z'*dgdp, dgdp(kk,:) = -h^2*pscale*I  (TaskBDF1PointPos.m:104-105) */
+    for (int a = 0; a < nr; a++) {
+        double zs = 0; for (int k = 0; k < nsteps; k++) zs += z[(size_t)nr * k + a];
+        dPdp[a] = task->wreg * p[a] + h * h * task->pscale * zs;
+    }
+    for (int i = 0; i < s->n; i++) s->nd[i].tau = 0.0;
+    free(LUh); free(Mh); free(Dh); free(Ph); free(dPdq); free(q0); free(qd0); free(x); free(qB); free(g); free(dx); free(qd1);
+    free(H); free(M); free(f); free(K); free(D); free(dMdq); free(Jk); free(z); free(yk);
+    return P;
+}
+
 /* -------------------------------------------------- batch CPU baseline */
 
 long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads) {

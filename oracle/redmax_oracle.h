@@ -99,6 +99,22 @@ void orc_step_bdf2(orc_scene* s, double h, int step0, int nsteps, orc_stats* st,
 /* matlab-simple/testRedMax.m euler:67-109 (linearly-implicit Euler, config 1). */
 void orc_step_euler_simple(orc_scene* s, double h, int nsteps, double* Hist_T, double* Hist_V);
 
+/* TaskBDF1PointPos (matlab-diff/+redmax/TaskBDF1PointPos.m): move a point of a body to a target at time t; the
+ * parameters are constant joint torques tau = pscale*p. */
+typedef struct orc_task_pointpos {
+    int body;                 /* listing index of the body                         setBody   */
+    double xlocal[3];         /* point in body coordinates                         setPoint  */
+    double xtarget[3];        /* world target                                      setTarget */
+    double t;                 /* measurement time                                  setTime   */
+    double pscale;            /* torque scale                                      setScale  */
+    double wreg, wpos;        /* regulariser / position weights                    setWeights */
+} orc_task_pointpos;
+
+/* taskObjective of driverRedMaxAdjointBDF1.m:39-62: reset, forward sim storing LU factors/M/D/J per step, backward sweep
+ * TaskBDF1.calcFinal.  Returns P, fills dPdp[nr].  Pinned only by the finite-difference identity (testGrad :46-61): the
+ * reference holds no golden numbers for this path ("parity unpinned" beyond FD). */
+double orc_adjoint_bdf1(orc_scene* s, double h, int nsteps, const orc_task_pointpos* task, const double* p, double* dPdp, orc_stats* st);
+
 /* Batch helper for the timed CPU baseline: B independent trajectories of the same scene,
  * OpenMP over trajectories (nthreads), q/qdot [B][nr] in/out. Returns total Newton iterations. */
 long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads);

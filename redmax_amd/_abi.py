@@ -22,7 +22,7 @@ SYMBOLS = (
     "rmx_model_create", "rmx_model_destroy", "rmx_model_nr", "rmx_model_nm", "rmx_model_idxR",
     "rmx_batch_create", "rmx_batch_destroy", "rmx_batch_size",
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
-    "rmx_eval", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_euler", "rmx_energy",
+    "rmx_eval", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_energy",
     "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_sync",
     "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases",
 )
@@ -46,6 +46,11 @@ class ModelDesc(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("h", C.c_double), ("tol", C.c_double), ("dxMax", C.c_double),
                 ("iterMaxPerDof", C.c_int), ("iterLsMax", C.c_int), ("lu_mode", C.c_int)]
+
+
+class TaskPointPos(C.Structure):
+    _fields_ = [("body", C.c_int), ("xlocal", C.c_double * 3), ("xtarget", C.c_double * 3), ("step", C.c_int),
+                ("pscale", C.c_double), ("wreg", C.c_double), ("wpos", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -86,6 +91,7 @@ def lib():
     L.rmx_step_bdf1.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(Stats), _dp, _dp]
     L.rmx_step_bdf2.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(Stats), _dp, _dp]
     L.rmx_step_euler.argtypes = [vp, C.c_double, C.c_int, _dp, _dp]
+    L.rmx_adjoint_bdf1.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(TaskPointPos), _dp, _dp, _dp, C.POINTER(Stats)]
     L.rmx_energy.argtypes = [vp, _dp, _dp]
     L.rmx_last_step_ms.argtypes = [vp]
     L.rmx_last_step_ms.restype = C.c_double

@@ -125,6 +125,35 @@ class BatchSim:
         out["ms"] = self._L.rmx_last_step_ms(self._batch)
         return out
 
+    def adjoint_bdf1(self, nsteps, h, task, p, stats=False):
+        """taskObjective (driverRedMaxAdjointBDF1.m:39-62) for every trajectory: forward rollout from the current state
+        under torques pscale*p, then the backward sweep.  task: dict(body, xlocal, xtarget, t | step, pscale, wreg, wpos);
+        p: [B][nr].  Returns (P[B], dPdp[B][nr], info)."""
+        tk = _abi.TaskPointPos()
+        tk.body = int(task["body"])
+        for i in range(3):
+            tk.xlocal[i] = float(task["xlocal"][i])
+            tk.xtarget[i] = float(task["xtarget"][i])
+        tk.step = int(task["step"]) if "step" in task else int(round(float(task["t"]) / float(h)))
+        tk.pscale, tk.wreg, tk.wpos = float(task["pscale"]), float(task["wreg"]), float(task["wpos"])
+        opts = _abi.Opts()
+        C.memmove(C.byref(opts), C.byref(self.opts), C.sizeof(opts))
+        opts.h = float(h)
+        opts.iterMaxPerDof = 5                      # driverRedMaxAdjointBDF1.m:108
+        p = self._arr(p)
+        P = np.empty(self.B)
+        dPdp = np.empty((self.B, self.nr))
+        info = {}
+        st = None
+        if stats:
+            info["newton_iters"] = np.zeros(self.B, dtype=np.int32)
+            info["status"] = np.zeros(self.B, dtype=np.int32)
+            st = _abi.Stats(_abi.iptr(info["newton_iters"]), None, _abi.iptr(info["status"]))
+        _abi.check(self._L.rmx_adjoint_bdf1(self._batch, C.byref(opts), int(nsteps), C.byref(tk), _abi.dptr(p), _abi.dptr(P),
+                                            _abi.dptr(dPdp), C.byref(st) if st is not None else None), "rmx_adjoint_bdf1")
+        info["ms"] = self._L.rmx_last_step_ms(self._batch)
+        return P, dPdp, info
+
     def step_bdf1_async(self, nsteps, h=None):
         if h is not None:
             self.opts.h = float(h)

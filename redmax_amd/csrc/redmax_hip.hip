@@ -192,6 +192,175 @@ __global__ void __launch_bounds__(64) k_step_euler(const DevModel M, const doubl
     }
 }
 
+// ---------------------------------------------------------------- adjoint BDF1 (BASELINE.json configs[3])
+//
+// taskObjective of driverRedMaxAdjointBDF1.m:39-62 for TaskBDF1PointPos, batched: parameters p[B][nr] are constant joint
+// torques tau = pscale*p (TaskBDF1PointPos.applyStep :58-64).  Forward = simLoop :65-102 with the line-search-free newton
+// :105-146; per step the H, M, D of the LAST EVALUATED iterate are kept in HBM ([B][nsteps][n*n], column-major over nodes),
+// which is what Scene.saveHistory stores (the reference keeps lu(H), the backward kernel re-factors H').  Backward =
+// TaskBDF1.calcFinal :45-81.
+struct AdjArgs {
+    int B, nsteps, task_step, task_node;
+    double xl[3], xt[3], pscale, wreg, wpos;
+    double *q, *qd;
+    const double* p;
+    double *Hs, *Ms, *Ds;     // [B][nsteps][n*n]
+    double* dPdq;             // [B][n]   dP/dq of the task step
+    double* P;                // [B]
+    double* dPdp;             // [B][nr]
+    int *it, *status;
+};
+
+template <int NP>
+__global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
+    const int id = (lane < n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    const double pj = id >= 0 ? a.p[off] : 0.0;
+    const double h = o.h;
+    FrontState fs;
+    fs.tau_add = a.pscale * pj;
+    // does the task body hang below (or at) this lane's joint?  (rows of J(idxM_body, :) that are non-zero)
+    const bool on_path = lane < n && (lane == a.task_node || ((M.rel[MAXN + lane] >> a.task_node) & 1ull));
+    int iters = 0, status = 0;
+    double Ptask = 0.0;
+    const size_t nn = (size_t)n * n;
+    for (int s = 1; s <= a.nsteps; ++s) {
+        const double q0 = q, qd0 = qd;
+        const double xB = q0 + h * qd0;
+        double x = xB;
+        double* Hk = a.Hs + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        double* Mk = a.Ms + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        double* Dk = a.Ds + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        double Jw[3] = {0.0, 0.0, 0.0}, Jv[3] = {0.0, 0.0, 0.0};   // J(idxM_body, this joint) of the last evaluated iterate
+        int iter = 1;
+        while (true) {
+            NodeOut e;
+            double Hrow[NP];
+            eval_front<NP, true>(M, sAcc, lane, x, (x - q0) / h, x - xB, h, e, fs);
+            eval_hess<NP>(M, lane, fs, Hrow);
+            {
+                double Mrow[NP], Drow[NP];
+                eval_MD<NP>(M, lane, fs, Mrow, Drow);
+                if (lane < n) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        if (i < n) {
+                            Hk[(size_t)i * n + lane] = Hrow[i];
+                            Mk[(size_t)i * n + lane] = Mrow[i];
+                            Dk[(size_t)i * n + lane] = Drow[i];
+                        }
+                }
+            }
+            if (s == a.task_step) {   // J(body rows, joint) = Ad(E_body^-1) s_joint : body-frame twist of the task body per unit qdot
+                double Rb[9], pb[3], t3[3], d3[3];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) Rb[c] = readlane_d(fs.Rw[c], a.task_node);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pb[c] = readlane_d(fs.pw[c], a.task_node);
+                cross3(pb, fs.sw, t3);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d3[c] = fs.sv[c] - t3[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {   // R' (.)
+                    Jw[c] = on_path ? (Rb[c] * fs.sw[0] + Rb[3 + c] * fs.sw[1] + Rb[6 + c] * fs.sw[2]) : 0.0;
+                    Jv[c] = on_path ? (Rb[c] * d3[0] + Rb[3 + c] * d3[1] + Rb[6 + c] * d3[2]) : 0.0;
+                }
+            }
+            ++iters;
+            const double dx = lu_solve_neg<NP>(n, lane, Hrow, e.g);      // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128
+            const double dxn2 = wave_sum(dx * dx);
+            if (!(dxn2 == dxn2)) { status |= 4; break; }
+            if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }            // :129-132
+            x = x + dx;                                                   // :134, before the convergence test
+            if (sqrt(wave_sum(e.g * e.g)) < o.tol) break;                 // :135-138
+            if (iter >= o.iterMax) { status |= 2; break; }                // :139-142
+            ++iter;
+        }
+        qd = (x - q0) / h;
+        q = x;
+        if (s == a.task_step) {    // TaskBDF1PointPos.calcStep :67-107 at the final state of this step
+            NodeOut e;
+            eval_front<NP, false>(M, sAcc, lane, q, qd, 0.0, 1.0, e, fs);
+            double Rb[9], pb[3], dxw[3], vl[3], t3[3];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Rb[c] = readlane_d(fs.Rw[c], a.task_node);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pb[c] = readlane_d(fs.pw[c], a.task_node);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dxw[c] = Rb[3 * c] * a.xl[0] + Rb[3 * c + 1] * a.xl[1] + Rb[3 * c + 2] * a.xl[2] + pb[c] - a.xt[c];
+            Ptask += a.wpos * 0.5 * dot3(dxw, dxw);
+            // dPdq = J' * (R*Gamma(xlocal))' * dx * wp ,  Gamma = [brac(xlocal)', I]  =>  R (v + w x xlocal) . dx * wp
+            const double xl[3] = {a.xl[0], a.xl[1], a.xl[2]};
+            cross3(Jw, xl, t3);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vl[c] = Jv[c] + t3[c];
+            double g3[3];
+            mat3v(Rb, vl, g3);
+            if (lane < n) a.dPdq[(size_t)traj * n + lane] = a.wpos * dot3(g3, dxw);
+        }
+    }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+    }
+    const double preg = wave_sum(pj * pj);
+    if (lane == 0) {
+        a.P[traj] = Ptask + a.wreg * 0.5 * preg;      // TaskBDF1.calcFinal :49
+        if (a.it) {
+            a.it[traj] = iters;
+            a.status[traj] = status;
+        }
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+    const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
+    const int id = (lane < n) ? M.idx[lane] : -1;
+    const size_t nn = (size_t)n * n;
+    const double h = o.h;
+    const int col = lane < n ? lane : 0;
+    double z1 = 0.0, z2 = 0.0, zs = 0.0;
+    for (int k = a.nsteps; k >= 1; --k) {
+        double y = (k == a.task_step && lane < n) ? a.dPdq[(size_t)traj * n + lane] : 0.0;
+        if (k < a.nsteps) {       // yk -= (-2 M_{k+1} + h D_{k+1})' z_{k+1}     TaskBDF1.m:58-64
+            const double* Mc = a.Ms + ((size_t)traj * a.nsteps + k) * nn + (size_t)col * n;
+            const double* Dc = a.Ds + ((size_t)traj * a.nsteps + k) * nn + (size_t)col * n;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double blk = (j < n && lane < n) ? (-2.0 * Mc[j] + h * Dc[j]) : 0.0;
+                y -= blk * readlane_d(z1, j);
+            }
+        }
+        if (k < a.nsteps - 1) {   // yk -= M_{k+2}' z_{k+2}                      :65-70
+            const double* Mc = a.Ms + ((size_t)traj * a.nsteps + k + 1) * nn + (size_t)col * n;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double blk = (j < n && lane < n) ? Mc[j] : 0.0;
+                y -= blk * readlane_d(z2, j);
+            }
+        }
+        // z_k = H_k'^-1 y_k  (zkk0(Hp) = Hl'\(Hu'\yk) :76): this lane's "row" of H' is column `lane` of H
+        double Hrow[NP];
+        const double* Hc = a.Hs + ((size_t)traj * a.nsteps + (k - 1)) * nn + (size_t)col * n;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? Hc[i] : ((i == lane) ? 1.0 : 0.0);
+        const double z = lu_solve_neg<NP>(n, lane, Hrow, -y);
+        zs += z;
+        z2 = z1;
+        z1 = z;
+    }
+    if (id >= 0) {   // dPdp = wreg*p' - z'*dgdp, dgdp(kk,:) = -h^2*pscale*I      :79, TaskBDF1PointPos.m:104-105
+        const size_t off = (size_t)traj * M.nr + id;
+        a.dPdp[off] = a.wreg * a.p[off] + h * h * a.pscale * zs;
+    }
+}
+
 // Parity hook: one residual (+Hessian) evaluation per trajectory, results to HBM.
 template <int NP, bool WANT_H>
 __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, const double* __restrict__ q,
@@ -296,6 +465,7 @@ struct rmx_model {
     int device = 0;
     int n = 0, nr = 0, nm = 0, NP = 0;
     std::vector<int> idx_listing;   // reduced index per LISTED joint (-1 fixed)
+    std::vector<int> node_of_listing;   // depth-first node index of each LISTED joint/body
     void* dbuf = nullptr;           // one device allocation holding all constant arrays
     DevModel dm{};
     size_t smem_bytes = 0;
@@ -560,6 +730,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     m->nr = nr;
     m->nm = 6 * n;
     m->idx_listing = idxL;
+    m->node_of_listing = pos;
     m->NP = n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64;
     m->smem_bytes = sizeof(double) * ((size_t)(n + 1) * ACC_STRIDE + (size_t)n * COL_STRIDE);
     if (hipSetDevice(device) != hipSuccess) { delete m; return fail(RMX_E_HIP, "hipSetDevice failed"); }
@@ -847,6 +1018,65 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
     if (dT) (void)hipFree(dT);
     if (dV) (void)hipFree(dV);
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_step_euler: ") + hipGetErrorString(e));
+    return RMX_OK;
+}
+
+template <int NP>
+static void launch_adjoint(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a) {
+    const dim3 grid(b->B), block(64);
+    k_adjoint_fwd<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    k_adjoint_bwd<NP><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+}
+
+extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
+                                double* P, double* dPdp, rmx_stats* stats) {
+    if (!b || !task || !p || !P || !dPdp) return fail(RMX_E_INVALID, "null argument");
+    rmx_model* m = b->m;
+    if (nsteps < 1) return fail(RMX_E_INVALID, "nsteps < 1");
+    if (task->body < 0 || task->body >= m->n) return fail(RMX_E_INVALID, "task body out of range");
+    if (task->step < 1 || task->step > nsteps) return fail(RMX_E_INVALID, "task step must be in [1, nsteps]");
+    HIPCHK(hipSetDevice(m->device));
+    DevOpts o;
+    int rc = make_opts(b, opts, o);
+    if (rc) return rc;
+    const size_t nn = (size_t)m->n * m->n, nv = (size_t)b->B * m->nr;
+    const size_t hist = (size_t)b->B * nsteps * nn * sizeof(double);
+    if (3 * hist > ((size_t)200 << 30)) return fail(RMX_E_NOMEM, "adjoint history (H, M, D per step) would exceed 200 GiB");
+    AdjArgs a{};
+    a.B = b->B; a.nsteps = nsteps; a.task_step = task->step; a.task_node = m->node_of_listing[task->body];
+    for (int c = 0; c < 3; ++c) { a.xl[c] = task->xlocal[c]; a.xt[c] = task->xtarget[c]; }
+    a.pscale = task->pscale; a.wreg = task->wreg; a.wpos = task->wpos;
+    a.q = b->q; a.qd = b->qd; a.p = b->tmpA;
+    a.it = stats ? b->it : nullptr; a.status = b->status;
+    void* bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t sizes[6] = {hist, hist, hist, (size_t)b->B * m->n * sizeof(double), (size_t)b->B * sizeof(double), nv * sizeof(double)};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipMalloc(&bufs[i], sizes[i] ? sizes[i] : 8);
+    if (e == hipSuccess) e = hipMemsetAsync(bufs[3], 0, sizes[3], b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->tmpA, p, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) {
+        a.Hs = (double*)bufs[0]; a.Ms = (double*)bufs[1]; a.Ds = (double*)bufs[2];
+        a.dPdq = (double*)bufs[3]; a.P = (double*)bufs[4]; a.dPdp = (double*)bufs[5];
+        e = hipEventRecord(b->ev0, b->stream);
+        DISPATCH_NP(m->NP, launch_adjoint, m, b, o, a);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(b->started, 0, sizeof(int), b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(P, a.P, sizes[4], hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dPdp, a.dPdp, sizes[5], hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess && stats) {
+            if (stats->newton_iters) e = hipMemcpyAsync(stats->newton_iters, b->it, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
+            if (e == hipSuccess && stats->status) e = hipMemcpyAsync(stats->status, b->status, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
+        }
+    }
+    for (void* ptr : bufs)
+        if (ptr) (void)hipFree(ptr);
+    if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_adjoint_bdf1: ") + hipGetErrorString(e));
     return RMX_OK;
 }
 

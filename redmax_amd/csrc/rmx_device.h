@@ -173,6 +173,8 @@ struct FrontState {
     double bw[3], bv[3];      // beta = (J v + eta^2 Jdot qdot)_j
     double S[NACC];           // subtree sums: W(6), m, mc(3), Ibar(6), TL(9), hf(3)
     double eta, kd, dd;       // step; -Kr and -Dr of this joint (stiffness/damping incl. active limits)
+    double Rw[9], pw[3];      // world transform of this body (only kept alive where a caller reads it)
+    double tau_add = 0.0;     // extra joint torque set by the caller (adjoint task parameters, TaskBDF1PointPos.applyStep)
     bool act, dof;
 };
 
@@ -574,9 +576,13 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     }
     RMX_STAMP(7)
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
-    const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
+    const double fr = (tau + fs.tau_add) + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
                       hitU * (qLimK * (qLimU - q) - qLimD * qd);
     out.g = dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) fs.Rw[c] = R[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) fs.pw[c] = p[c];
     fs.eta = eta;
     fs.kd = stiff + (hitL + hitU) * qLimK;    // -Kr  (Joint.computeForce Joint.m:470-482)
     fs.dd = damp + (hitL + hitU) * qLimD;     // -Dr
@@ -629,6 +635,79 @@ __device__ __forceinline__ void eval_mass(const DevModel& M, const int lane, con
         const double mu = (double)(unsigned)((desc_m >> i) & 1ull);
         const double ml = (double)(unsigned)((anc_m >> i) & 1ull);
         Mrow[i] = (i == lane) ? mdiag : (mu * up + ml * lo);
+    }
+}
+
+// M and D = df/dqdot rows of this node (computeValues :212, :227-237), what the adjoint backward sweep needs per step
+// (TaskBDF1.m:58-70):  D(a,i) = s_a.(Bc_i s_i - 2 Ic_i xi_i)  a ancestor-or-self of i ;
+//                              = (Bc_a' s_a).s_i - 2 (Ic_a s_a).xi_i  a strict descendant ;  + Dr on the diagonal.
+// Idle rows/columns: identity in M, zero in D.
+template <int NP>
+__device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const FrontState& fs, double (&Mrow)[NP], double (&Drow)[NP]) {
+    const bool act = fs.act;
+    const int jj = act ? lane : 0;
+    const double mS = fs.S[6];
+    const double* mcS = &fs.S[7];
+    const double* IbS = &fs.S[10];
+    const double* TL = &fs.S[16];
+    const double* hfS = &fs.S[25];
+    double r1[6], ix[6], yD[6], r2w[3], t3[3], b3[3];
+    sym3v(IbS, fs.sw, r1);                    // r1 = Ic s
+    cross3(mcS, fs.sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1[c] += t3[c];
+    cross3(mcS, fs.sw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1[3 + c] = mS * fs.sv[c] - t3[c];
+    sym3v(IbS, fs.xiw, ix);                   // ix = Ic xi
+    cross3(mcS, fs.xiv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ix[c] += t3[c];
+    cross3(mcS, fs.xiw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ix[3 + c] = mS * fs.xiv[c] - t3[c];
+    mat3v(TL, fs.sw, yD);                     // Bc s = [TL sw ; 2 hf x sw]
+    cross3(hfS, fs.sw, b3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        yD[c] -= 2.0 * ix[c];
+        yD[3 + c] = 2.0 * b3[c] - 2.0 * ix[3 + c];
+    }
+    cross3(hfS, fs.sv, b3);                   // r2w = (Bc' s)_w = TL' sw - 2 hf x sv
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r2w[c] = TL[c] * fs.sw[0] + TL[3 + c] * fs.sw[1] + TL[6 + c] * fs.sw[2] - 2.0 * b3[c];
+    double cv[24];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        cv[c] = act ? fs.sw[c] : 0.0;
+        cv[3 + c] = act ? fs.sv[c] : 0.0;
+        cv[6 + c] = act ? fs.xiw[c] : 0.0;
+        cv[9 + c] = act ? fs.xiv[c] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        cv[12 + c] = act ? r1[c] : 0.0;
+        cv[18 + c] = act ? yD[c] : 0.0;
+    }
+    const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
+    const double sr1 = fs.sw[0] * r1[0] + fs.sw[1] * r1[1] + fs.sw[2] * r1[2] + fs.sv[0] * r1[3] + fs.sv[1] * r1[4] + fs.sv[2] * r1[5];
+    const double syD = fs.sw[0] * yD[0] + fs.sw[1] * yD[1] + fs.sw[2] * yD[2] + fs.sv[0] * yD[3] + fs.sv[1] * yD[4] + fs.sv[2] * yD[5];
+    const double mdiag = fs.dof ? sr1 : 1.0;
+    const double ddiag = fs.dof ? (syD - fs.dd) : 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        double Ci[24];
+#pragma unroll
+        for (int c = 0; c < 24; ++c) Ci[c] = readlane_d(cv[c], i);
+        const double m_lo = r1[0] * Ci[0] + r1[1] * Ci[1] + r1[2] * Ci[2] + r1[3] * Ci[3] + r1[4] * Ci[4] + r1[5] * Ci[5];
+        const double m_up = fs.sw[0] * Ci[12] + fs.sw[1] * Ci[13] + fs.sw[2] * Ci[14] + fs.sv[0] * Ci[15] + fs.sv[1] * Ci[16] + fs.sv[2] * Ci[17];
+        const double d_lo = r2w[0] * Ci[0] + r2w[1] * Ci[1] + r2w[2] * Ci[2] -
+                            2.0 * (r1[0] * Ci[6] + r1[1] * Ci[7] + r1[2] * Ci[8] + r1[3] * Ci[9] + r1[4] * Ci[10] + r1[5] * Ci[11]);
+        const double d_up = fs.sw[0] * Ci[18] + fs.sw[1] * Ci[19] + fs.sw[2] * Ci[20] + fs.sv[0] * Ci[21] + fs.sv[1] * Ci[22] + fs.sv[2] * Ci[23];
+        const double mu = (double)(unsigned)((desc_m >> i) & 1ull);
+        const double ml = (double)(unsigned)((anc_m >> i) & 1ull);
+        Mrow[i] = (i == lane) ? mdiag : (mu * m_up + ml * m_lo);
+        Drow[i] = (i == lane) ? ddiag : (mu * d_up + ml * d_lo);
     }
 }
 

@@ -125,12 +125,37 @@ def scenesRedMax(sceneID):
             j.setLimitStiffness(1e5)
             j.setLimitDamping(1e2)
             j.setDamping(1e2)
+    elif sceneID == 100:
+        return sceneAdjointChain(2)                            # scenesRedMax.m:402-436 ('Adjoint BDF1')
     else:
         raise ValueError("scene %r is out of scope (needs joint/force types outside SURVEY.md §8)" % (sceneID,))
     return scene
 
 
 IN_SCOPE_SCENES = (0, 1, 2, 3, 14)
+
+
+def sceneAdjointChain(n=2):
+    """Scene 100 'Adjoint BDF1' (scenesRedMax.m:402-436) generalised to n links (BASELINE.json configs[3] uses n=16):
+    revolute y-axis chain of [10 1 1] cuboids, q = pi/2 at the root and pi/4 elsewhere, qdot = 1, joint stiffness and
+    damping 1e4, and a TaskBDF1PointPos on the last body (point [5 0 0], target [10 0 -10], pscale 1e5, weights 1e-2/1e2,
+    measured at tEnd)."""
+    scene = Scene()
+    scene.name = "Adjoint BDF1" if n == 2 else "Adjoint BDF1, %d links" % n
+    for i in range(n):
+        scene.bodies.append(BodyCuboid(1.0, [10, 1, 1]))
+        parent = scene.joints[i - 1] if i else None
+        j = JointRevolute(parent, scene.bodies[-1], [0, 1, 0])
+        j.setJointTransform(np.eye(4) if i == 0 else _T([10, 0, 0]))
+        j.q[0] = math.pi / 2 if i == 0 else math.pi / 4
+        j.qdot[0] = 1.0
+        j.setStiffness(1e4)
+        j.setDamping(1e4)
+        scene.joints.append(j)
+        scene.bodies[-1].setBodyTransform(_T([5, 0, 0]))
+    scene.task = {"body": n - 1, "xlocal": [5.0, 0.0, 0.0], "xtarget": [10.0, 0.0, -10.0], "t": scene.tEnd,
+                  "pscale": 1e5, "wreg": 1e-2, "wpos": 1e2}
+    return scene
 
 
 def sceneChain(n=32, axis=(0, 1, 0), q0=0.0):

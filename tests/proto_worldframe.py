@@ -243,3 +243,68 @@ def energy_world(m, q, qdot):
             dqU = (m["qLimU"][j] - qj) if qj > m["qLimU"][j] else 0.0
             V += 0.5 * m["qLimK"][j] * (dqL * dqL + dqU * dqU)
     return T, V
+
+
+def eval_MD_world(m, q, qdot):
+    """M = J'MmJ and D = df/dqdot (computeValues, driverRedMaxBDF1.m:212,227-237) in the world-frame formulation:
+        M(a,i) = s_a.(Ic_i s_i)           a ancestor-or-self of i ;  (Ic_a s_a).s_i otherwise (symmetric)
+        D(a,i) = s_a.(Bc_i s_i - 2 Ic_i xi_i)          a ancestor-or-self of i
+               = (Bc_a' s_a).s_i - 2 (Ic_a s_a).xi_i   a strict descendant of i ;   + Dr on the diagonal
+    (used by the adjoint backward sweep, TaskBDF1.m:58-70)."""
+    n, par, typ, idx, nr = m["n"], m["parent"], m["type"], m["idx"], m["nr"]
+    Ew = [None] * n
+    s, phi, xi = [None] * n, [None] * n, [None] * n
+    Ic, Bc = [None] * n, [None] * n
+    qdj = np.zeros(n)
+    for j in range(n):
+        qj = q[idx[j]] if idx[j] >= 0 else 0.0
+        qdj[j] = qdot[idx[j]] if idx[j] >= 0 else 0.0
+        Q = np.eye(4)
+        if typ[j] == 1:
+            Q[:3, :3] = se3.aaToMat(m["axis"][j], qj)
+        elif typ[j] == 2:
+            Q[:3, 3] = m["axis"][j] * qj
+        T = m["L"][j] @ Q @ m["Rt"][j]
+        Ew[j] = T if par[j] < 0 else Ew[par[j]] @ T
+        s[j] = se3.Ad(Ew[j]) @ m["sb"][j]
+        phi[j] = (np.zeros(6) if par[j] < 0 else phi[par[j]]) + s[j] * qdj[j]
+        xi[j] = _ad(phi[j]) @ s[j]
+        R, c = Ew[j][:3, :3], Ew[j][:3, 3]
+        ms = m["I"][j][3]
+        cb = _brac(c)
+        I6 = np.zeros((6, 6))
+        I6[:3, :3] = R @ np.diag(m["I"][j][:3]) @ R.T + ms * cb @ cb.T
+        I6[:3, 3:] = ms * cb
+        I6[3:, :3] = ms * cb.T
+        I6[3:, 3:] = ms * np.eye(3)
+        hm = I6 @ phi[j]
+        adp = _ad(phi[j])
+        N = np.zeros((6, 6))
+        N[:3, :3] = _brac(hm[:3])
+        N[:3, 3:] = _brac(hm[3:])
+        N[3:, :3] = _brac(hm[3:])
+        Ic[j] = I6
+        Bc[j] = I6 @ adp + adp.T @ I6 + N
+    for j in reversed(range(n)):
+        if par[j] >= 0:
+            Ic[par[j]] = Ic[par[j]] + Ic[j]
+            Bc[par[j]] = Bc[par[j]] + Bc[j]
+    M = np.zeros((nr, nr))
+    D = np.zeros((nr, nr))
+    anc = m["anc"]
+    for a in range(n):
+        if idx[a] < 0:
+            continue
+        for i in range(n):
+            if idx[i] < 0:
+                continue
+            if anc[a, i]:
+                M[idx[a], idx[i]] = s[a] @ (Ic[i] @ s[i])
+                D[idx[a], idx[i]] = s[a] @ (Bc[i] @ s[i] - 2 * Ic[i] @ xi[i])
+            elif anc[i, a]:
+                M[idx[a], idx[i]] = (Ic[a] @ s[a]) @ s[i]
+                D[idx[a], idx[i]] = (Bc[a].T @ s[a]) @ s[i] - 2 * (Ic[a] @ s[a]) @ xi[i]
+        qj = q[idx[a]]
+        hit = (1.0 if qj < m["qLimL"][a] else 0.0) + (1.0 if qj > m["qLimU"][a] else 0.0)
+        D[idx[a], idx[a]] += -m["damping"][a] - hit * m["qLimD"][a]
+    return M, D

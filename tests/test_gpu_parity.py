@@ -287,3 +287,33 @@ def test_config1_euler_on_gpu(oracle_lib, sid, Hexp):
     qg, qdg = scene.getQ()
     assert _rel(qg, qo) <= 1e-9, _rel(qg, qo)
     assert _rel(qdg, qdo) <= 1e-8, _rel(qdg, qdo)
+
+
+@pytest.mark.parametrize("n", [2, 5, 16])
+def test_adjoint_bdf1_matches_oracle(oracle_lib, n):
+    """BASELINE.json configs[3] / SURVEY §8(f)-2: forward + backward adjoint sweep (P and dP/dp) vs the oracle's literal
+    restatement of driverRedMaxAdjointBDF1 / TaskBDF1.calcFinal, which itself is pinned by the FD identity
+    (tests/test_oracle_adjoint.py); the reference has no golden numbers for this path."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneAdjointChain
+    sc = sceneAdjointChain(n)
+    sc.init()
+    B, nsteps = 4, (20 if n < 16 else 10)
+    rng = np.random.default_rng(9)
+    p = 0.1 * rng.standard_normal((B, sc.nr))
+    p[0] = 0.0
+    task = dict(sc.task, t=nsteps * sc.h)
+    sim = BatchSim(sc, batch=B)
+    q0, qd0 = sc.getQ()
+    sim.set_state(q0[None, :], qd0[None, :])
+    P, dPdp, info = sim.adjoint_bdf1(nsteps, sc.h, task, p, stats=True)
+    assert (info["status"] == 0).all()
+    qg, _ = sim.get_state()
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        Po, dPo, st = o.adjoint_bdf1(sc.h, nsteps, task, p[b])
+        qo, _ = o.get_state()
+        assert _rel(qg[b], qo) <= 1e-9, (n, b, _rel(qg[b], qo))
+        assert abs(P[b] - Po) <= 1e-9 * abs(Po), (n, b, P[b], Po)
+        assert _rel(dPdp[b], dPo) <= 1e-7, (n, b, _rel(dPdp[b], dPo))
+        assert info["newton_iters"][b] == st.newton_iters
