@@ -5,7 +5,9 @@ run in libredmax_hip.so (csrc/, C ABI in include/redmax_hip.h) on gfx950. No CPU
 """
 from . import se3  # noqa: F401
 from .redmax import (Body, BodyCuboid, Joint, JointFixed, JointPrismatic, JointRevolute, Scene)  # noqa: F401
-from .scenes import IN_SCOPE_SCENES, sceneChain, scenesRedMax, sceneTree, syntheticStates  # noqa: F401
+from .scenes import (IN_SCOPE_SCENES, sceneAdjointChain, sceneChain, scenesRedMax, sceneTree,  # noqa: F401
+                     syntheticStates)
 from .batch import BatchSim  # noqa: F401
-from .driver import driverRedMaxBDF1, driverRedMaxBDF2, simLoop, testRedMax  # noqa: F401
+from .driver import (driverRedMaxAdjointBDF1, driverRedMaxBDF1, driverRedMaxBDF2, simLoop, taskObjective,  # noqa: F401
+                     testRedMax)
 from ._abi import RedMaxHipError  # noqa: F401

@@ -78,3 +78,40 @@ def testRedMax(sceneID=0, device=0, verbose=True):
             print("### PASS ###" if passed else "### FAIL: %.16f ###" % H)
     sim.close()
     return scene, H, passed
+
+
+def taskObjective(p, scene, sim=None, device=0):
+    """taskObjective of driverRedMaxAdjointBDF1.m:39-62: scene.reset(), forward simLoop under the task parameters,
+    task.calcFinal() -> (P, dPdp).  `p` may be [nr] (one rollout) or [B][nr] (a batch of parameter vectors, each its own
+    rollout).  Forward and backward sweeps are two kernel launches inside rmx_adjoint_bdf1."""
+    import numpy as np
+    p = np.atleast_2d(np.asarray(p, dtype=np.float64))
+    own = sim is None
+    if own:
+        sim = BatchSim(scene, batch=p.shape[0], device=device)
+    q0, qd0 = scene.qInit, scene.qdotInit                       # Scene.reset (Scene.m:122-131)
+    sim.set_state(np.broadcast_to(q0, (sim.B, scene.nr)), np.broadcast_to(qd0, (sim.B, scene.nr)))
+    P, dPdp, info = sim.adjoint_bdf1(scene.nsteps, scene.h, scene.task, p, stats=True)
+    if own:
+        sim.close()
+    return P, dPdp, info
+
+
+def driverRedMaxAdjointBDF1(nlinks=2, device=0, verbose=True, maxiter=50):
+    """driverRedMaxAdjointBDF1.m:1-36 with scene 100 (or its n-link generalisation): minimise the task objective over the
+    joint torques.  MATLAB's fminunc (quasi-Newton, gradient supplied) is replaced by scipy's BFGS with the same
+    objective/gradient callback."""
+    import numpy as np
+    from scipy.optimize import minimize
+    from .scenes import sceneAdjointChain
+    scene = sceneAdjointChain(nlinks)
+    scene.init()
+    sim = BatchSim(scene, batch=1, device=device)
+
+    def fun(p):
+        P, dPdp, _ = taskObjective(p, scene, sim=sim)
+        return float(P[0]), dPdp[0]
+
+    res = minimize(fun, np.zeros(scene.nr), jac=True, method="BFGS", options={"maxiter": maxiter, "disp": verbose})
+    sim.close()
+    return scene, res
