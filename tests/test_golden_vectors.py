@@ -1,0 +1,93 @@
+"""tests/golden/oracle_vectors.npz (made by tests/golden/make_golden.py from the KAT-pinned oracle):
+ * CPU: the oracle still reproduces its own frozen vectors (guards against silent drift);
+ * GPU: the HIP path matches them with NO oracle library involved (data-only check)."""
+import os
+
+import numpy as np
+import pytest
+
+from redmax_amd.scenes import sceneChain, scenesRedMax, sceneTree, syntheticStates
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("sid", [0, 1, 2, 3, 14])
+def test_oracle_reproduces_frozen_trajectories(oracle_lib, sid):
+    sc = scenesRedMax(sid)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    done = 0
+    for k in (1, 10, sc.nsteps):
+        o.step_bdf1(sc.h, k - done)
+        done = k
+        q, qd = o.get_state()
+        assert _rel(q, G["scene%d_bdf1_step%d_q" % (sid, k)]) <= 1e-12
+        assert _rel(qd, G["scene%d_bdf1_step%d_qdot" % (sid, k)]) <= 1e-10
+
+
+def test_oracle_reproduces_frozen_chain32_eval(oracle_lib):
+    sc = sceneChain(32)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    q1, q0, qd0 = G["chain32_eval_inputs"]
+    g, H = o.eval_bdf1(q1, q0, qd0, 1e-2)
+    assert _rel(g, G["chain32_eval_g"]) <= 1e-13 and _rel(H, G["chain32_eval_H"]) <= 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sid", [0, 1, 2, 3, 14])
+def test_gpu_matches_frozen_trajectories(sid):
+    from redmax_amd import BatchSim
+    sc = scenesRedMax(sid)
+    sc.init()
+    sim = BatchSim(sc, batch=1)
+    q0, qd0 = sc.getQ()
+    sim.set_state(q0[None], qd0[None])
+    done = 0
+    for k in (1, 10, sc.nsteps):
+        out = sim.step_bdf1(k - done, h=sc.h, history=True)
+        done = k
+        q, qd = sim.get_state()
+        assert _rel(q[0], G["scene%d_bdf1_step%d_q" % (sid, k)]) <= 1e-9, (sid, k)
+        assert _rel(qd[0], G["scene%d_bdf1_step%d_qdot" % (sid, k)]) <= 1e-7, (sid, k)
+        T, V, V0 = G["scene%d_bdf1_step%d_TV" % (sid, k)]
+        assert abs(out["T"][-1, 0] - T) <= 1e-8 * max(abs(T), 1.0)
+        assert abs(out["V"][-1, 0] - V) <= 1e-8 * max(abs(V), 1.0)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_frozen_chain32_vectors():
+    from redmax_amd import BatchSim
+    sc = sceneChain(32)
+    sc.init()
+    sim = BatchSim(sc, batch=1)
+    q1, q0, qd0 = G["chain32_eval_inputs"]
+    g, H = sim.eval_bdf1(q1[None], q0[None], qd0[None], 1e-2)
+    assert _rel(g[0], G["chain32_eval_g"]) <= 1e-11 and _rel(H[0], G["chain32_eval_H"]) <= 1e-11
+    q, qd = syntheticStates(32, 4)
+    sim4 = BatchSim(sc, batch=4)
+    sim4.set_state(q, qd)
+    sim4.step_bdf1(1, h=1e-2)
+    q1s, _ = sim4.get_state()
+    sim4.step_bdf1(9, h=1e-2)
+    q10s, _ = sim4.get_state()
+    for b in range(4):
+        assert np.linalg.norm(q1s[b] - G["chain32_traj%d_step1_q" % b]) <= 1e-11 * np.linalg.norm(q1s[b]) + 1e-10
+        assert _rel(q10s[b], G["chain32_traj%d_step10_q" % b]) <= 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_matches_frozen_tree15():
+    from redmax_amd import BatchSim
+    sc = sceneTree(15)
+    sc.init()
+    sim = BatchSim(sc, batch=1)
+    q0, qd0 = sc.getQ()
+    sim.set_state(q0[None], qd0[None])
+    sim.step_bdf1(10, h=sc.h)
+    q, qd = sim.get_state()
+    assert _rel(q[0], G["tree15_bdf1_step10_q"]) <= 1e-9
