@@ -40,8 +40,29 @@ template <int NP>
 __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, double*& sCol) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     sAcc = smem;
-    sCol = smem + (M.n + 1) * ACC_STRIDE;
+    sCol = smem + (M.n + 1) * ACC_STRIDE;     // per-node constants, [NCONST][NP] (see eval_front_e2)
     if (threadIdx.x < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + threadIdx.x] = 0.0;   // zero row n (end-of-tree suffix)
+    if (threadIdx.x < NP) {
+        const int j = threadIdx.x;
+        const bool in = j < M.n;
+        double* c = sCol;
+        for (int r = 0; r < 36; ++r) c[r * NP + j] = in ? M.K[r * MAXN + j] : 0.0;
+        c += 36 * NP;
+        for (int r = 0; r < 6; ++r) c[r * NP + j] = in ? M.sb[r * MAXN + j] : 0.0;
+        c += 6 * NP;
+        for (int r = 0; r < 4; ++r) c[r * NP + j] = in ? M.I4[r * MAXN + j] : 0.0;
+        c += 4 * NP;
+        for (int r = 0; r < 8; ++r) c[r * NP + j] = in ? M.prm[r * MAXN + j] : 0.0;
+        c += 8 * NP;
+        c[j] = in ? (double)M.type[j] : 0.0;
+        c += NP;
+        c[j] = in ? __longlong_as_double((long long)M.rel[j]) : 0.0;
+        c[NP + j] = in ? __longlong_as_double((long long)M.rel[MAXN + j]) : 0.0;
+        c += 2 * NP;
+        for (int r = 0; r < MAXROUNDS; ++r) c[r * NP + j] = in ? (double)M.anc[r * MAXN + j] : -1.0;
+        c += MAXROUNDS * NP;
+        c[j] = in ? (double)M.end[j] : (double)M.n;
+    }
     __syncthreads();
 }
 
@@ -732,7 +753,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     m->idx_listing = idxL;
     m->node_of_listing = pos;
     m->NP = n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64;
-    m->smem_bytes = sizeof(double) * ((size_t)(n + 1) * ACC_STRIDE + (size_t)n * COL_STRIDE);
+    m->smem_bytes = sizeof(double) * ((size_t)(n + 1) * ACC_STRIDE + (size_t)NCONST * m->NP);
     if (hipSetDevice(device) != hipSuccess) { delete m; return fail(RMX_E_HIP, "hipSetDevice failed"); }
     const size_t nd = K.size() + sb.size() + I4.size() + prm.size();
     const size_t ni = type.size() + idx.size() + endd.size() + anc.size();

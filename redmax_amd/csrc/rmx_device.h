@@ -21,6 +21,7 @@ constexpr int ACC_STRIDE = 29;    // odd stride: conflict-free lane=node LDS wri
 constexpr int NCOL = 18;          // column-side Hessian vectors per node (yz6, m1 6, m2w3, sw3)
 constexpr int COL_STRIDE = 19;
 constexpr int MAXROUNDS = 6;      // log2(MAXN)
+constexpr int NCONST = 64;        // per-node constants staged in LDS: K(36) sb(6) I4(4) prm(8) type(1) rel(2) anc(6) end(1)
 
 // Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
 struct DevModel {
@@ -175,6 +176,7 @@ struct FrontState {
     double eta, kd, dd;       // step; -Kr and -Dr of this joint (stiffness/damping incl. active limits)
     double Rw[9], pw[3];      // world transform of this body (only kept alive where a caller reads it)
     double tau_add = 0.0;     // extra joint torque set by the caller (adjoint task parameters, TaskBDF1PointPos.applyStep)
+    unsigned long long anc_m, desc_m;   // bit i: node i is a strict ancestor / descendant of this node
     bool act, dof;
 };
 
@@ -297,8 +299,20 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     const int n = M.n;
     const bool act = lane < n;
     const int jj = act ? lane : 0;
-    const int type = act ? M.type[jj] : 0;
+    // per-node constants staged in LDS by smem_setup (stride NP): reading them from L2 at every evaluation left the single
+    // resident wave parked at s_waitcnt (SQ_WAIT_ANY 31 % of wave cycles)
+    const double* cK = sAcc + (n + 1) * ACC_STRIDE;
+    const double* cSb = cK + 36 * NP;
+    const double* cI4 = cSb + 6 * NP;
+    const double* cPrm = cI4 + 4 * NP;
+    const double* cTyp = cPrm + 8 * NP;     // joint type, stored as a double
+    const double* cRel = cTyp + NP;         // 2 rows: ancestor / descendant bit masks (bit patterns)
+    const double* cAnc = cRel + 2 * NP;     // MAXROUNDS rows: ancestor 2^r levels up (as doubles), trees only
+    const double* cEnd = cAnc + MAXROUNDS * NP;
+    const int type = act ? (int)cTyp[jj] : 0;
     const bool dof = type != 0;
+    fs.anc_m = act ? (unsigned long long)__double_as_longlong(cRel[jj]) : 0ull;
+    fs.desc_m = act ? (unsigned long long)__double_as_longlong(cRel[NP + jj]) : 0ull;
 
     const double q = dof ? xq : 0.0;
     const double qd = dof ? xqd : 0.0;
@@ -314,9 +328,9 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     }
     double R[9], p[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) R[c] = M.K[c * MAXN + jj] + u * M.K[(12 + c) * MAXN + jj] + w * M.K[(24 + c) * MAXN + jj];
+    for (int c = 0; c < 9; ++c) R[c] = cK[c * NP + jj] + u * cK[(12 + c) * NP + jj] + w * cK[(24 + c) * NP + jj];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) p[c] = M.K[(9 + c) * MAXN + jj] + u * M.K[(21 + c) * MAXN + jj] + w * M.K[(33 + c) * MAXN + jj];
+    for (int c = 0; c < 3; ++c) p[c] = cK[(9 + c) * NP + jj] + u * cK[(21 + c) * NP + jj] + w * cK[(33 + c) * NP + jj];
     if (!act) {   // idle lanes carry the identity so that they are neutral in the chain scans
 #pragma unroll
         for (int c = 0; c < 9; ++c) R[c] = (c % 4 == 0) ? 1.0 : 0.0;
@@ -330,7 +344,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         chain_scan_transform<NP>(lane, R, p);
     } else {   // general tree: pointer jumping over ancestors (log2(depth) rounds of cross-lane permutes)
         for (int r = 0; r < M.rounds; ++r) {
-            const int a = act ? M.anc[r * MAXN + jj] : -1;
+            const int a = act ? (int)cAnc[r * NP + jj] : -1;
             const int src = a >= 0 ? a : lane;
             double Ra[9], pa[3];
 #pragma unroll
@@ -360,8 +374,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     double (&sv)[3] = fs.sv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        sbw[c] = act ? M.sb[c * MAXN + jj] : 0.0;
-        sbv[c] = act ? M.sb[(3 + c) * MAXN + jj] : 0.0;
+        sbw[c] = act ? cSb[c * NP + jj] : 0.0;
+        sbv[c] = act ? cSb[(3 + c) * NP + jj] : 0.0;
     }
     mat3v(R, sbw, sw);
     mat3v(R, sbv, sv);
@@ -381,7 +395,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         chain_scan_sum6<NP>(lane, phw, phv);
     } else {
         for (int r = 0; r < M.rounds; ++r) {
-            const int a = act ? M.anc[r * MAXN + jj] : -1;
+            const int a = act ? (int)cAnc[r * NP + jj] : -1;
             const int src = a >= 0 ? a : lane;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -413,7 +427,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         chain_scan_sum6<NP>(lane, bw, bv);
     } else {
         for (int r = 0; r < M.rounds; ++r) {
-            const int a = act ? M.anc[r * MAXN + jj] : -1;
+            const int a = act ? (int)cAnc[r * NP + jj] : -1;
             const int src = a >= 0 ? a : lane;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -428,8 +442,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
 
     RMX_STAMP(3)
     // ---- world-frame spatial inertia of body j (Body.computeMassGrav :99-101): m, mc, Ibar = R diag(I) R' + m [c][c]'
-    const double I1 = act ? M.I4[0 * MAXN + jj] : 0.0, I2 = act ? M.I4[1 * MAXN + jj] : 0.0;
-    const double I3 = act ? M.I4[2 * MAXN + jj] : 0.0, ms = act ? M.I4[3 * MAXN + jj] : 0.0;
+    const double I1 = act ? cI4[0 * NP + jj] : 0.0, I2 = act ? cI4[1 * NP + jj] : 0.0;
+    const double I3 = act ? cI4[2 * NP + jj] : 0.0, ms = act ? cI4[3 * NP + jj] : 0.0;
     double mc[3], Ib[6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) mc[c] = ms * p[c];
@@ -475,10 +489,10 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     }
 
     // energies (Body.computeEnergies Body.m:167-173, Joint.computeEnergies Joint.m:616-637)
-    const double stiff = act ? M.prm[1 * MAXN + jj] : 0.0, damp = act ? M.prm[2 * MAXN + jj] : 0.0;
-    const double tau = act ? M.prm[0 * MAXN + jj] : 0.0, qRest = act ? M.prm[3 * MAXN + jj] : 0.0;
-    const double qLimL = act ? M.prm[4 * MAXN + jj] : 0.0, qLimU = act ? M.prm[5 * MAXN + jj] : 0.0;
-    const double qLimK = act ? M.prm[6 * MAXN + jj] : 0.0, qLimD = act ? M.prm[7 * MAXN + jj] : 0.0;
+    const double stiff = act ? cPrm[1 * NP + jj] : 0.0, damp = act ? cPrm[2 * NP + jj] : 0.0;
+    const double tau = act ? cPrm[0 * NP + jj] : 0.0, qRest = act ? cPrm[3 * NP + jj] : 0.0;
+    const double qLimL = act ? cPrm[4 * NP + jj] : 0.0, qLimU = act ? cPrm[5 * NP + jj] : 0.0;
+    const double qLimK = act ? cPrm[6 * NP + jj] : 0.0, qLimD = act ? cPrm[7 * NP + jj] : 0.0;
     const double hitL = (dof && q < qLimL) ? 1.0 : 0.0, hitU = (dof && q > qLimU) ? 1.0 : 0.0;
     {
         double eT = 0.5 * (dot3(phw, ht) + dot3(phv, hf));
@@ -566,7 +580,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
 #pragma unroll
             for (int c = 0; c < NS; ++c) S[c] = A[c];
             if (!M.is_chain) {
-                const int en = act ? M.end[jj] : n;
+                const int en = act ? (int)cEnd[jj] : n;
                 const double* E = sAcc + en * ACC_STRIDE;
 #pragma unroll
                 for (int c = 0; c < NS; ++c) S[c] -= E[c];
@@ -623,7 +637,7 @@ __device__ __forceinline__ void eval_mass(const DevModel& M, const int lane, con
         cv[6 + c] = act ? r1[c] : 0.0;
         cv[9 + c] = act ? r1[3 + c] : 0.0;
     }
-    const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
+    const unsigned long long anc_m = fs.anc_m, desc_m = fs.desc_m;
     const double mdiag = fs.dof ? (fs.sw[0] * r1[0] + fs.sw[1] * r1[1] + fs.sw[2] * r1[2] + fs.sv[0] * r1[3] + fs.sv[1] * r1[4] + fs.sv[2] * r1[5]) : 1.0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -689,7 +703,7 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
         cv[12 + c] = act ? r1[c] : 0.0;
         cv[18 + c] = act ? yD[c] : 0.0;
     }
-    const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
+    const unsigned long long anc_m = fs.anc_m, desc_m = fs.desc_m;
     const double sr1 = fs.sw[0] * r1[0] + fs.sw[1] * r1[1] + fs.sw[2] * r1[2] + fs.sv[0] * r1[3] + fs.sv[1] * r1[4] + fs.sv[2] * r1[5];
     const double syD = fs.sw[0] * yD[0] + fs.sw[1] * yD[1] + fs.sw[2] * yD[2] + fs.sv[0] * yD[3] + fs.sv[1] * yD[4] + fs.sv[2] * yD[5];
     const double mdiag = fs.dof ? sr1 : 1.0;
@@ -815,7 +829,7 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
         cv[15 + c] = act ? sw[c] : 0.0;
     }
     RMX_STAMP(10)
-    const unsigned long long anc_m = act ? M.rel[jj] : 0ull, desc_m = act ? M.rel[MAXN + jj] : 0ull;
+    const unsigned long long anc_m = fs.anc_m, desc_m = fs.desc_m;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         double Ci[NCOL];
