@@ -77,6 +77,7 @@ def lib():
         L.orc_batch_step_bdf1.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int]
         L.orc_batch_step_bdf1.restype = C.c_long
         L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
         L.orc_adjoint_bdf1.restype = C.c_double
         _lib = L
@@ -121,6 +122,13 @@ class Oracle:
         self.nm = self._L.orc_nm(self._h)
         if "qRest" in desc_dict:
             self.set_qrest_joint_order(desc_dict["qRest"])
+        if desc_dict.get("contact") is not None and np.any(desc_dict["contact"]):
+            g = desc_dict["ground"]
+            self._cflags = np.ascontiguousarray(desc_dict["contact"], dtype=np.int32)
+            self._csides = np.ascontiguousarray(desc_dict["sides"], dtype=np.float64)
+            self._cE = np.ascontiguousarray(np.asarray(g["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
+            self._L.orc_set_ground_contact(self._h, self._cflags.ctypes.data_as(_ip), _p(self._csides), _p(self._cE),
+                                           float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"]))
 
     def __del__(self):
         try:

@@ -172,6 +172,10 @@ struct orc_scene {
     double *Mm, *Km, *Dm;                /* n blocks of 36 (row-major 6x6), in idxM/6 order */
     double *fm;                          /* nm */
     double *fr, *Kr, *Dr;                /* nr, nr (diagonals)      */
+    /* ForceGroundCuboid (one per flagged body, shared parameters) */
+    int* contact;                        /* [n] flag */
+    double* sides;                       /* [n][3]   */
+    m4 groundE; double kn, kt, mu, kd;
 };
 
 #define JX(s, r, c) ((s)->J[(size_t)(c) * (s)->nm + (r)])
@@ -255,6 +259,8 @@ static void scene_update(orc_scene* s) {
     }
 }
 
+static double ground_contact_energy(const orc_scene* s);
+
 /* Joint.computeEnergies (Joint.m:616-637) + Body.computeEnergies (Body.m:167-173) */
 void orc_energy(const orc_scene* s, double* T, double* V) {
     double t = 0, v = 0;
@@ -272,7 +278,7 @@ void orc_energy(const orc_scene* s, double* T, double* V) {
             v += 0.5 * j->qLimK * (dqL * dqL + dqU * dqU);
         }
     }
-    *T = t; *V = v;
+    *T = t; *V = v + ground_contact_energy(s);   /* forces{1}.computeEnergy(V)  Scene.m:127,156 */
 }
 
 void orc_get_state(const orc_scene* s, double* q, double* qdot) {
@@ -371,6 +377,7 @@ void orc_destroy(orc_scene* s) {
     free(s->nd); free(s->qInit); free(s->qdotInit);
     free(s->J); free(s->Jdot); free(s->dJdq); free(s->dJdotdq);
     free(s->Mm); free(s->Km); free(s->Dm); free(s->fm); free(s->fr); free(s->Kr); free(s->Dr);
+    free(s->contact); free(s->sides);
     free(s);
 }
 
@@ -505,6 +512,176 @@ static void compute_mass_grav(orc_scene* s, int deriv) {
     }
 }
 
+/* ForceGroundCuboid.computeValues_ (ForceGroundCuboid.m:54-153): Geilinger-style penalty contact of the 8 cuboid corners with
+ * the ground plane (frame E, Z up): normal spring-damper, static/dynamic friction; adds to fm and, if deriv, to the body's
+ * 6x6 blocks of Km and Dm.  3x3 / 3x6 helpers are written out; G = Gamma(xl) = [brac(xl)', I] (se3.m:38-41). */
+static void m33_mul(double C[3][3], const double A[3][3], const double B[3][3]) {
+    double T[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double t = 0; for (int k = 0; k < 3; k++) t += A[i][k] * B[k][j]; T[i][j] = t; }
+    memcpy(C, T, sizeof(T));
+}
+static void m33_mulv(double y[3], const double A[3][3], const double x[3]) {
+    double t[3];
+    for (int i = 0; i < 3; i++) t[i] = A[i][0] * x[0] + A[i][1] * x[1] + A[i][2] * x[2];
+    memcpy(y, t, sizeof(t));
+}
+/* Blk(6x6) += sign * G' * X(3x6) */
+static void add_Gt_X(double* Blk, double sign, const double G[3][6], const double X[3][6]) {
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+        double t = 0; for (int k = 0; k < 3; k++) t += G[k][a] * X[k][b];
+        Blk[a * 6 + b] += sign * t;
+    }
+}
+static void compute_ground_contact(orc_scene* s, int deriv) {
+    if (!s->contact) return;
+    double xg[3], ng[3], N[3][3], T[3][3];
+    for (int a = 0; a < 3; a++) { xg[a] = s->groundE[a][3]; ng[a] = s->groundE[a][2]; }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { N[a][b] = ng[a] * ng[b]; T[a][b] = (a == b) - N[a][b]; }
+    double eb[3][3][3];
+    for (int c = 0; c < 3; c++) { double e[3] = { 0, 0, 0 }; e[c] = 1.0; se3_brac3(eb[c], e); }
+    for (int ib = 0; ib < s->n; ib++) {
+        if (!s->contact[ib]) continue;
+        onode* j = &s->nd[ib];
+        double* fm = s->fm + j->idxM; double* Kb = s->Km + 36 * ib; double* Db = s->Dm + 36 * ib;
+        double R[3][3], Rt[3][3], p[3], RNR[3][3], RtN[3][3], B[3][3], RtT[3][3], pxgtmp[3][3], tv[3];
+        for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) { R[a][b] = j->E_wi[a][b]; Rt[b][a] = R[a][b]; } p[a] = j->E_wi[a][3]; }
+        m33_mul(RtN, Rt, N); m33_mul(RNR, RtN, R);             /* RNR = R'*N*R */
+        m33_mul(RtT, Rt, T); m33_mul(B, RtT, R);               /* B = R'*T*R   */
+        double pm[3] = { p[0] - xg[0], p[1] - xg[1], p[2] - xg[2] };
+        m33_mulv(tv, RtN, pm); se3_brac3(pxgtmp, tv);          /* pxgtmp = brac(R'*N*(p - xg)) */
+        const double* phi = j->phi;
+        for (int ic = 0; ic < 8; ic++) {
+            double xli[3] = { ((ic & 4) ? 0.5 : -0.5) * s->sides[3 * ib], ((ic & 2) ? 0.5 : -0.5) * s->sides[3 * ib + 1],
+                              ((ic & 1) ? 0.5 : -0.5) * s->sides[3 * ib + 2] };
+            double xwi[3]; m33_mulv(xwi, R, xli); for (int a = 0; a < 3; a++) xwi[a] += p[a];
+            double d = 0; for (int a = 0; a < 3; a++) d += ng[a] * (xwi[a] - xg[a]);
+            if (d > 0) continue;                                /* no collision */
+            double xlb[3][3]; se3_brac3(xlb, xli);
+            double G[3][6];
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { G[a][b] = xlb[b][a]; G[a][3 + b] = (a == b); }
+            double Gphi[3]; for (int a = 0; a < 3; a++) { double t = 0; for (int b = 0; b < 6; b++) t += G[a][b] * phi[b]; Gphi[a] = t; }
+            double vwi[3]; m33_mulv(vwi, R, Gphi);
+            /* fc = -kn*ng*d - kd*N*vwi ; fm += G'*R'*fc */
+            double Nv[3]; m33_mulv(Nv, N, vwi);
+            double fc[3], Rtf[3];
+            for (int a = 0; a < 3; a++) fc[a] = -s->kn * ng[a] * d - s->kd * Nv[a];
+            m33_mulv(Rtf, Rt, fc);
+            for (int a = 0; a < 6; a++) { double t = 0; for (int k = 0; k < 3; k++) t += G[k][a] * Rtf[k]; fm[a] += t; }
+            if (deriv) {
+                double RNRxl[3], RNRGphi[3], Gpb[3][3], X[3][6], t33[3][3];
+                m33_mulv(RNRxl, RNR, xli); m33_mulv(RNRGphi, RNR, Gphi); se3_brac3(Gpb, Gphi);
+                /* tmp1 = -[e1b*RNRxl,e2b*RNRxl,e3b*RNRxl] - RNR*xlbrac + pxgtmp ; Km -= kn*G'*[tmp1 RNR] */
+                m33_mul(t33, RNR, xlb);
+                for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) {
+                    double ec = eb[c][a][0] * RNRxl[0] + eb[c][a][1] * RNRxl[1] + eb[c][a][2] * RNRxl[2];
+                    X[a][c] = -ec - t33[a][c] + pxgtmp[a][c];
+                    X[a][3 + c] = RNR[a][c];
+                }
+                add_Gt_X(Kb, -s->kn, G, X);
+                /* tmp2 = -[e1b*RNRGphi,...] - RNR*Gphibrac ; Km -= kd*G'*[tmp2 0] */
+                m33_mul(t33, RNR, Gpb);
+                for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) {
+                    double ec = eb[c][a][0] * RNRGphi[0] + eb[c][a][1] * RNRGphi[1] + eb[c][a][2] * RNRGphi[2];
+                    X[a][c] = -ec - t33[a][c];
+                    X[a][3 + c] = 0.0;
+                }
+                add_Gt_X(Kb, -s->kd, G, X);
+                /* Dm -= kd*G'*RNR*G */
+                for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 3; k++) t += RNR[a][k] * G[k][c]; X[a][c] = t; }
+                add_Gt_X(Db, -s->kd, G, X);
+            }
+            if (s->mu == 0) continue;
+            /* friction: a = T*xwdot, xwdot = R*G*phi */
+            double av[3]; m33_mulv(av, T, vwi);
+            double anorm = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+            if (s->mu * fabs(s->kn * d) > s->kt * anorm) {      /* static friction: fs = -kt*a */
+                double fs[3] = { -s->kt * av[0], -s->kt * av[1], -s->kt * av[2] };
+                m33_mulv(Rtf, Rt, fs);
+                for (int a = 0; a < 6; a++) { double t = 0; for (int k = 0; k < 3; k++) t += G[k][a] * Rtf[k]; fm[a] += t; }
+                if (deriv) {
+                    double X[3][6];
+                    /* D = -kt*G'*R'*T*R*G = -kt*G'*B*G */
+                    for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 3; k++) t += B[a][k] * G[k][c]; X[a][c] = t; }
+                    add_Gt_X(Db, -s->kt, G, X);
+                    /* K = -kt*G'*[(B*e1b-e1b*B)*Gphi, (B*e2b-e2b*B)*Gphi, (B*e3b-e3b*B)*Gphi, Z] */
+                    for (int c = 0; c < 3; c++) {
+                        double Be[3][3], eB[3][3], col[3];
+                        m33_mul(Be, B, eb[c]); m33_mul(eB, eb[c], B);
+                        for (int a = 0; a < 3; a++) for (int k = 0; k < 3; k++) Be[a][k] -= eB[a][k];
+                        m33_mulv(col, Be, Gphi);
+                        for (int a = 0; a < 3; a++) { X[a][c] = col[a]; X[a][3 + c] = 0.0; }
+                    }
+                    add_Gt_X(Kb, -s->kt, G, X);
+                }
+            } else {                                            /* dynamic friction: fd = -mu*kn*d*t */
+                const double mukn = s->mu * s->kn;
+                double tt[3] = { av[0] / anorm, av[1] / anorm, av[2] / anorm };
+                double fd[3] = { -mukn * d * tt[0], -mukn * d * tt[1], -mukn * d * tt[2] };
+                m33_mulv(Rtf, Rt, fd);
+                for (int a = 0; a < 6; a++) { double t = 0; for (int k = 0; k < 3; k++) t += G[k][a] * Rtf[k]; fm[a] += t; }
+                if (deriv) {
+                    /* A = (a'*a*I - a*a')/norm(a)^3 */
+                    double A[3][3], aa = av[0] * av[0] + av[1] * av[1] + av[2] * av[2], n3 = anorm * anorm * anorm;
+                    for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) A[a][c] = (aa * (a == c) - av[a] * av[c]) / n3;
+                    double AT[3][3], RtAT[3][3], RtATR[3][3], X[3][6];
+                    m33_mul(AT, A, T); m33_mul(RtAT, Rt, AT); m33_mul(RtATR, RtAT, R);
+                    /* D = -mukn*G'*R'*d*A*T*R*G */
+                    for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 3; k++) t += RtATR[a][k] * G[k][c]; X[a][c] = d * t; }
+                    add_Gt_X(Db, -mukn, G, X);
+                    /* K1 = -d*[e1b*R't, e2b*R't, e3b*R't, Z]; K2 = R'*t*ng'*R*G; K3 = -d*R'*A*T*R*[brac(G*phi), Z]; K = -mukn*G'*(K1+K2+K3) */
+                    double Rtt[3], ngR[3], Gpb[3][3], K3[3][3];
+                    m33_mulv(Rtt, Rt, tt);
+                    for (int c = 0; c < 3; c++) ngR[c] = ng[0] * R[0][c] + ng[1] * R[1][c] + ng[2] * R[2][c];
+                    se3_brac3(Gpb, Gphi); m33_mul(K3, RtATR, Gpb);
+                    double ngRG[6];
+                    for (int c = 0; c < 6; c++) ngRG[c] = ngR[0] * G[0][c] + ngR[1] * G[1][c] + ngR[2] * G[2][c];
+                    for (int a = 0; a < 3; a++) {
+                        for (int c = 0; c < 3; c++) {
+                            double ec = eb[c][a][0] * Rtt[0] + eb[c][a][1] * Rtt[1] + eb[c][a][2] * Rtt[2];
+                            X[a][c] = -d * ec + Rtt[a] * ngRG[c] - d * K3[a][c];
+                            X[a][3 + c] = Rtt[a] * ngRG[3 + c];
+                        }
+                    }
+                    add_Gt_X(Kb, -mukn, G, X);
+                }
+            }
+        }
+    }
+}
+/* ForceGroundCuboid.computeEnergy_ (ForceGroundCuboid.m:156-183) */
+static double ground_contact_energy(const orc_scene* s) {
+    if (!s->contact) return 0.0;
+    double v = 0;
+    for (int ib = 0; ib < s->n; ib++) {
+        if (!s->contact[ib]) continue;
+        const onode* j = &s->nd[ib];
+        for (int ic = 0; ic < 8; ic++) {
+            double xli[3] = { ((ic & 4) ? 0.5 : -0.5) * s->sides[3 * ib], ((ic & 2) ? 0.5 : -0.5) * s->sides[3 * ib + 1],
+                              ((ic & 1) ? 0.5 : -0.5) * s->sides[3 * ib + 2] };
+            double d = 0;
+            for (int a = 0; a < 3; a++) {
+                double xw = j->E_wi[a][0] * xli[0] + j->E_wi[a][1] * xli[1] + j->E_wi[a][2] * xli[2] + j->E_wi[a][3];
+                d += s->groundE[a][2] * (xw - s->groundE[a][3]);
+            }
+            if (d > 0) continue;
+            v += 0.5 * s->kn * (d * d);
+        }
+    }
+    return v;
+}
+/* Attach ForceGroundCuboid to the flagged bodies (scenesRedMax.m:307-311 style: setTransform, setStiffness, setDamping,
+ * setFriction).  E16 column-major. */
+void orc_set_ground_contact(orc_scene* s, const int* flags, const double* sides, const double* E16, double kn, double kt, double mu, double kd) {
+    free(s->contact); free(s->sides);
+    s->contact = (int*)malloc(sizeof(int) * (size_t)s->n);
+    s->sides = (double*)malloc(sizeof(double) * 3 * (size_t)s->n);
+    memcpy(s->contact, flags, sizeof(int) * (size_t)s->n);
+    memcpy(s->sides, sides, sizeof(double) * 3 * (size_t)s->n);
+    cm16_to_m4(s->groundE, E16);
+    s->kn = kn; s->kt = kt; s->mu = mu; s->kd = kd;
+    orc_reset(s);
+}
+
 /* Joint.computeForce (Joint.m:437-487).  Kr, Dr are diagonal for 1-DOF joints. */
 static void compute_joint_force(orc_scene* s) {
     for (int i = 0; i < s->nr; i++) { s->fr[i] = 0; s->Kr[i] = 0; s->Dr[i] = 0; }
@@ -571,6 +748,7 @@ void orc_compute_values(orc_scene* s, double* M, double* f, double* dMdq, double
     orc_get_state(s, NULL, qdot);
     compute_jacobian(s, deriv);
     compute_mass_grav(s, deriv);
+    compute_ground_contact(s, deriv);      /* froot.computeValues (driverRedMaxBDF1.m:203,209) */
     compute_joint_force(s);
     /* M = J'*Mm*J   (:212) */
     if (M) AtBlkB(s, s->J, s->Mm, s->J, M, t_nm);

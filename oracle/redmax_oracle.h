@@ -61,6 +61,12 @@ void orc_set_state(orc_scene* s, const double* q, const double* qdot); /* Joint.
 void orc_set_qrest(orc_scene* s, const double* qrest);  /* override qRest (reduced order) */
 void orc_energy(const orc_scene* s, double* T, double* V);          /* Joint.computeEnergies */
 
+/* ForceGroundCuboid (matlab-diff/+redmax/ForceGroundCuboid.m): penalty ground contact with friction on the 8 corners of the
+ * flagged cuboids.  flags[n], sides[n][3], ground frame E (column-major 4x4, Z up), setStiffness(kn,kt), setFriction(mu),
+ * setDamping(kd).  Pinned by Hexpected of scene 11 (scenesRedMax.m:292-293) with JointFree2D emulated by a
+ * prismatic-x / prismatic-y / revolute-z chain of massless links (same reduced coordinates, JointFree2D.m:20-33). */
+void orc_set_ground_contact(orc_scene* s, const int* flags, const double* sides, const double* E16, double kn, double kt, double mu, double kd);
+
 /* Joint.computeJacobian at the current state; any pointer may be NULL.
  * J,Jdot: nm x nr column-major; dJdq,dJdotdq: nm x nr x nr (MATLAB layout). */
 void orc_jacobian(orc_scene* s, double* J, double* Jdot, double* dJdq, double* dJdotdq);

@@ -4,8 +4,8 @@ Scene construction keeps the reference's +redmax class surface (redmax.py, scene
 run in libredmax_hip.so (csrc/, C ABI in include/redmax_hip.h) on gfx950. No CPU fallback.
 """
 from . import se3  # noqa: F401
-from .redmax import (Body, BodyCuboid, Joint, JointFixed, JointPrismatic, JointRevolute, Scene)  # noqa: F401
-from .scenes import (IN_SCOPE_SCENES, sceneAdjointChain, sceneChain, scenesRedMax, sceneTree,  # noqa: F401
+from .redmax import (Body, BodyCuboid, ForceGroundCuboid, Joint, JointFixed, JointPrismatic, JointRevolute, Scene)  # noqa: F401
+from .scenes import (IN_SCOPE_SCENES, sceneAdjointChain, sceneChain, sceneChainGround, scenesRedMax, sceneTree,  # noqa: F401
                      syntheticStates)
 from .batch import BatchSim  # noqa: F401
 from .driver import (driverRedMaxAdjointBDF1, driverRedMaxBDF1, driverRedMaxBDF2, simLoop, taskObjective,  # noqa: F401

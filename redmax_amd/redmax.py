@@ -150,6 +150,32 @@ class JointFixed(Joint):
         super().__init__(parent, body, 0)
 
 
+class ForceGroundCuboid:
+    """Penalty ground contact with friction on the 8 corners of a cuboid (matlab-diff/+redmax/ForceGroundCuboid.m:1-47).
+    Same setters as the reference; the numerics live in the HIP kernels."""
+
+    def __init__(self, cuboid):
+        self.name = cuboid.name + "-GROUND"
+        self.cuboid = cuboid
+        self.E = np.eye(4)
+        self.kn, self.kt, self.mu, self.kd = 1.0, 0.0, 0.0, 0.0
+
+    def setTransform(self, E):
+        self.E = np.array(E, dtype=np.float64).reshape(4, 4)
+
+    def setStiffness(self, kn, kt):
+        self.kn, self.kt = float(kn), float(kt)
+
+    def setDamping(self, kd):
+        self.kd = float(kd)
+
+    def setFriction(self, mu):
+        self.mu = float(mu)
+
+    def params(self):
+        return (self.kn, self.kt, self.mu, self.kd) + tuple(self.E.reshape(-1))
+
+
 class Scene:
     """Scene container (matlab-diff/+redmax/Scene.m).
 
@@ -191,8 +217,13 @@ class Scene:
             raise ValueError("scene joints must be listed in depth-first, parent-before-child order")
         if any(j.body is not b for j, b in zip(joints, self.bodies)):
             raise ValueError("bodies must be listed in the same order as their joints")
-        if self.forces:
-            raise NotImplementedError("only ForceNull scenes are in scope (SURVEY.md §2 row 10)")
+        for f in self.forces:
+            if not isinstance(f, ForceGroundCuboid):
+                raise NotImplementedError("only ForceNull and ForceGroundCuboid are in scope (SURVEY.md §2 row 10)")
+            if not isinstance(f.cuboid, BodyCuboid) or f.cuboid not in self.bodies:
+                raise ValueError("ForceGroundCuboid needs a BodyCuboid of this scene")
+        if len({f.params() for f in self.forces}) > 1:
+            raise NotImplementedError("all ForceGroundCuboid instances of a scene must share one ground frame and one parameter set")
         nr = 0
         nm = 0
         for j in reversed(joints):                   # leaf-to-root numbering
@@ -262,6 +293,12 @@ class Scene:
             "qLimD": np.array([j.qLimD for j in joints], dtype=np.float64),
             "grav": np.array(self.grav, dtype=np.float64).reshape(3),
         }
+        if self.forces:
+            f0 = self.forces[0]
+            touched = {id(f.cuboid) for f in self.forces}
+            d["contact"] = np.array([1 if id(j.body) in touched else 0 for j in joints], dtype=np.int32)
+            d["sides"] = np.ascontiguousarray(np.stack([getattr(j.body, "sides", np.zeros(3)) for j in joints]), dtype=np.float64)
+            d["ground"] = {"E": f0.E.copy(), "kn": f0.kn, "kt": f0.kt, "mu": f0.mu, "kd": f0.kd}
         self._desc = d
         return d
 

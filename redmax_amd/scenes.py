@@ -13,7 +13,7 @@ import math
 import numpy as np
 
 from . import se3
-from .redmax import BodyCuboid, JointFixed, JointPrismatic, JointRevolute, Scene
+from .redmax import BodyCuboid, ForceGroundCuboid, JointFixed, JointPrismatic, JointRevolute, Scene
 
 BDF1 = 1
 BDF2 = 2
@@ -125,6 +125,38 @@ def scenesRedMax(sceneID):
             j.setLimitStiffness(1e5)
             j.setLimitDamping(1e2)
             j.setDamping(1e2)
+    elif sceneID == 11:
+        # scenesRedMax.m:290-311 'Free2D with ground'.  JointFree2D (JointFree2D.m:20-33: Q = [Rz(q3) [q1;q2;0]], S = body-frame
+        # twist per (xdot, ydot, thetadot)) is out of scope as a joint type; it is reproduced EXACTLY by a serial chain
+        # prismatic-x / prismatic-y / revolute-z whose two intermediate links are massless (density 0): same transform, same
+        # generalised coordinates and velocities, same M, f.  The reduced index order differs (leaf-to-root per joint) but
+        # energies do not depend on it, so the reference's Hexpected pins ForceGroundCuboid.
+        scene.name = "Free2D with ground"
+        scene.Hexpected[BDF1 - 1] = -4.4208045000000002e03    # :292 (the reference notes BDF1 "doesn't work" for this scene)
+        scene.Hexpected[BDF2 - 1] = -2.7811251900394832e03    # :293
+        scene.h = 5e-4
+        scene.tEnd = 0.6
+        scene.grav = np.array([0.0, -980.0, 0.0])
+        bx = BodyCuboid(0.0, [1, 1, 1])
+        by = BodyCuboid(0.0, [1, 1, 1])
+        b = BodyCuboid(density, [3, 1, 1])
+        jx = JointPrismatic(None, bx, [1, 0, 0])
+        jy = JointPrismatic(jx, by, [0, 1, 0])
+        jr = JointRevolute(jy, b, [0, 0, 1])
+        for j in (jx, jy, jr):
+            j.setJointTransform(np.eye(4))
+        for bb in (bx, by, b):
+            bb.setBodyTransform(np.eye(4))
+        jx.q[0], jy.q[0], jr.q[0] = -1.0, 2.0, 0.0
+        jx.qdot[0], jy.qdot[0], jr.qdot[0] = 5.0, 70.0, 2.0
+        scene.bodies = [bx, by, b]
+        scene.joints = [jx, jy, jr]
+        f = ForceGroundCuboid(b)
+        f.setTransform(se3.transform(R=se3.aaToMat([1, 0, 0], -math.pi / 2)))
+        f.setStiffness(1e5, 1e2)
+        f.setDamping(3e1)
+        f.setFriction(0.5)
+        scene.forces = [f]
     elif sceneID == 100:
         return sceneAdjointChain(2)                            # scenesRedMax.m:402-436 ('Adjoint BDF1')
     else:
@@ -171,6 +203,24 @@ def sceneChain(n=32, axis=(0, 1, 0), q0=0.0):
         scene.joints[-1].setJointTransform(np.eye(4) if i == 0 else _T([10, 0, 0]))
         scene.bodies[-1].setBodyTransform(_T([5, 0, 0]))
         scene.joints[-1].q[0] = q0
+    return scene
+
+
+def sceneChainGround(n=32, ground_z=-2.0, q0=0.0):
+    """Config 5: the n-link revolute chain of config 2 over a frictional ground plane (ForceGroundCuboid on every body,
+    the stiffness / damping / friction values of scenesRedMax.m:305-309), BDF2 at scene 11's step h = 5e-4
+    (scenesRedMax.m:295).  The ground frame is z-up at height ground_z, so the chain swings down into it."""
+    scene = sceneChain(n, q0=q0)
+    scene.name = "%d-link chain over frictional ground" % n
+    scene.h = 5e-4
+    scene.tEnd = 0.1
+    for b in scene.bodies:
+        f = ForceGroundCuboid(b)
+        f.setTransform(_T([0, 0, ground_z]))
+        f.setStiffness(1e5, 1e2)
+        f.setDamping(3e1)
+        f.setFriction(0.5)
+        scene.forces.append(f)
     return scene
 
 

@@ -81,7 +81,122 @@ def build_model(d):
             anc[a, b] = True
             a = parent[a]
     m["anc"] = anc
+    m["contact"] = d.get("contact")
+    m["sides"] = d.get("sides")
+    m["ground"] = d.get("ground")
     return m
+
+
+def contact_blocks_body(m, j, E, phi_body):
+    """ForceGroundCuboid.computeValues_ (ForceGroundCuboid.m:54-153) for body j: body-frame wrench fm (6) and the 6x6
+    blocks Km, Dm, plus the contact energy (:156-183)."""
+    g = m["ground"]
+    kn, kt, mu, kd = g["kn"], g["kt"], g["mu"], g["kd"]
+    Eg = np.asarray(g["E"], float)
+    xg, ng = Eg[:3, 3], Eg[:3, 2]
+    N = np.outer(ng, ng)
+    T = np.eye(3) - N
+    R, p = E[:3, :3], E[:3, 3]
+    eb = [_brac(e) for e in np.eye(3)]
+    RNR = R.T @ N @ R
+    pxg = _brac(R.T @ N @ (p - xg))
+    fm = np.zeros(6)
+    Km = np.zeros((6, 6))
+    Dm = np.zeros((6, 6))
+    V = 0.0
+    Z = np.zeros((3, 3))
+    sides = np.asarray(m["sides"][j], float)
+    for ic in range(8):
+        xl = 0.5 * sides * np.array([1 if ic & 4 else -1, 1 if ic & 2 else -1, 1 if ic & 1 else -1])
+        xw = R @ xl + p
+        dpen = ng @ (xw - xg)
+        if dpen > 0:
+            continue
+        V += 0.5 * kn * dpen * dpen
+        G = np.hstack([_brac(xl).T, np.eye(3)])
+        Gphi = G @ phi_body
+        vw = R @ Gphi
+        fc = -kn * ng * dpen - kd * N @ vw
+        fm += G.T @ R.T @ fc
+        RNRxl, RNRGphi = RNR @ xl, RNR @ Gphi
+        tmp1 = -np.column_stack([e @ RNRxl for e in eb]) - RNR @ _brac(xl) + pxg
+        tmp2 = -np.column_stack([e @ RNRGphi for e in eb]) - RNR @ _brac(Gphi)
+        Km += -kn * G.T @ np.hstack([tmp1, RNR]) - kd * G.T @ np.hstack([tmp2, Z])
+        Dm += -kd * G.T @ RNR @ G
+        if mu == 0:
+            continue
+        a = T @ vw
+        an = np.linalg.norm(a)
+        if mu * abs(kn * dpen) > kt * an:
+            fm += G.T @ R.T @ (-kt * a)
+            B = R.T @ T @ R
+            Dm += -kt * G.T @ B @ G
+            Km += -kt * G.T @ np.hstack([np.column_stack([(B @ e - e @ B) @ Gphi for e in eb]), Z])
+        else:
+            mukn = mu * kn
+            t = a / an
+            fm += G.T @ R.T @ (-mukn * dpen * t)
+            A = (a @ a * np.eye(3) - np.outer(a, a)) / an ** 3
+            Dm += -mukn * G.T @ R.T @ (dpen * A) @ T @ R @ G
+            K1 = -dpen * np.hstack([np.column_stack([e @ R.T @ t for e in eb]), Z])
+            K2 = np.outer(R.T @ t, ng) @ R @ G
+            K3 = -dpen * R.T @ A @ T @ R @ np.hstack([_brac(Gphi), Z])
+            Km += -mukn * G.T @ (K1 + K2 + K3)
+    return fm, Km, Dm, V
+
+
+def contact_world(m, j, E, phi_w):
+    """The same contact wrench and K/D blocks written directly in the WORLD frame (what the HIP kernel computes).  With the
+    corner x = R xl + p, its velocity vw = v_O + w x x, d = n.(x - xg) <= 0 and Gw = [-[x], I] (world twist -> corner
+    velocity), conjugating ForceGroundCuboid.m:76-150 by R / Ad gives per penetrating corner
+        F  += Gw' f,   f = -kn n d - kd N vw  [- kt T vw  |  - mu kn d t]
+        Kw += Gw' X,   X = -kn [d[n] - N[x], N] - kd [[N vw] - N[vw], 0]
+                           [- kt [[T vw] - T[vw], 0]  |  - mu kn ([d[t] - d A T [vw], 0] + t n' Gw)]
+        Dw += Gw' Y Gw,  Y = -kd N  [- kt T  |  - mu kn d A T]
+    so no 6x6 congruence is needed.  Returns (F, Kw, Dw, V)."""
+    g = m["ground"]
+    kn, kt, mu, kd = g["kn"], g["kt"], g["mu"], g["kd"]
+    Eg = np.asarray(g["E"], float)
+    xg, ng = Eg[:3, 3], Eg[:3, 2]
+    N = np.outer(ng, ng)
+    T = np.eye(3) - N
+    R, p = E[:3, :3], E[:3, 3]
+    om, vO = phi_w[:3], phi_w[3:]
+    Z = np.zeros((3, 3))
+    F = np.zeros(6)
+    Kw = np.zeros((6, 6))
+    Dw = np.zeros((6, 6))
+    V = 0.0
+    sides = np.asarray(m["sides"][j], float)
+    for ic in range(8):
+        xl = 0.5 * sides * np.array([1 if ic & 4 else -1, 1 if ic & 2 else -1, 1 if ic & 1 else -1])
+        x = R @ xl + p
+        d = ng @ (x - xg)
+        if d > 0:
+            continue
+        V += 0.5 * kn * d * d
+        vw = vO + np.cross(om, x)
+        Gw = np.hstack([-_brac(x), np.eye(3)])
+        f = -kn * ng * d - kd * N @ vw
+        Y = -kd * N
+        X = -kn * np.hstack([d * _brac(ng) - N @ _brac(x), N]) - kd * np.hstack([_brac(N @ vw) - N @ _brac(vw), Z])
+        if mu != 0:
+            a = T @ vw
+            an = np.linalg.norm(a)
+            if mu * abs(kn * d) > kt * an:
+                f = f - kt * a
+                Y = Y - kt * T
+                X = X - kt * np.hstack([_brac(a) - T @ _brac(vw), Z])
+            else:
+                t = a / an
+                A = (a @ a * np.eye(3) - np.outer(a, a)) / an ** 3
+                f = f - mu * kn * d * t
+                Y = Y - mu * kn * d * A @ T
+                X = X - mu * kn * (np.hstack([d * _brac(t) - d * A @ T @ _brac(vw), Z]) + np.outer(t, ng) @ Gw)
+        F += Gw.T @ f
+        Kw += Gw.T @ X
+        Dw += Gw.T @ Y @ Gw
+    return F, Kw, Dw, V
 
 
 def eval_world(m, q, qA, qB, eta, want_H=True):
@@ -119,7 +234,7 @@ def eval_world(m, q, qA, qB, eta, want_H=True):
         pbeta = np.zeros(6) if par[j] < 0 else beta[par[j]]
         beta[j] = pbeta + s[j] * vj[j] + e2 * xi[j] * qdj[j]
     # --- per body world-frame inertia, wrench, B ---
-    Iw, w, Bm, mc, mass = [], [], [], [], []
+    Iw, w, Bm, mc, mass, Kx = [], [], [], [], [], []
     for j in range(n):
         R = Ew[j][:3, :3]
         c = Ew[j][:3, 3]
@@ -136,12 +251,18 @@ def eval_world(m, q, qA, qB, eta, want_H=True):
         adp = _ad(phi[j])
         fcor = adp.T @ hmom
         fgrav = np.concatenate([np.cross(c, ms * grav), ms * grav])
-        w.append(I6 @ beta[j] - e2 * (fcor + fgrav))
+        fcon = np.zeros(6)
+        Kw = np.zeros((6, 6))
+        Dw = np.zeros((6, 6))
+        if m.get("contact") is not None and m["contact"][j]:
+            fcon, Kw, Dw, _ = contact_world(m, j, Ew[j], phi[j])
+        Kx.append(Kw)
+        w.append(I6 @ beta[j] - e2 * (fcor + fgrav + fcon))
         N = np.zeros((6, 6))
         N[:3, :3] = _brac(hmom[:3])
         N[:3, 3:] = _brac(hmom[3:])
         N[3:, :3] = _brac(hmom[3:])
-        Bm.append(I6 @ adp + adp.T @ I6 + N)
+        Bm.append(I6 @ adp + adp.T @ I6 + N + Dw)
         Iw.append(I6)
         mc.append(ms * c)
         mass.append(ms)
@@ -151,6 +272,7 @@ def eval_world(m, q, qA, qB, eta, want_H=True):
     Bc = [x.copy() for x in Bm]
     mcc = [x.copy() for x in mc]
     mss = list(mass)
+    Kxc = [x.copy() for x in Kx]
     for j in reversed(range(n)):
         p = par[j]
         if p >= 0:
@@ -159,6 +281,7 @@ def eval_world(m, q, qA, qB, eta, want_H=True):
             Bc[p] += Bc[j]
             mcc[p] += mcc[j]
             mss[p] += mss[j]
+            Kxc[p] += Kxc[j]
     # --- residual ---
     g = np.zeros(nr)
     Hd = np.zeros(nr)
@@ -188,6 +311,7 @@ def eval_world(m, q, qA, qB, eta, want_H=True):
         Kc = np.zeros((6, 6))
         Kc[:3, :3] = _brac(mcc[i]) @ gb
         Kc[3:, :3] = mss[i] * gb
+        Kc += Kxc[i]
         y[i] = Ic[i] @ m1[i] - Bc[i] @ m2[i] - e2 * Kc @ s[i]
         z[i] = _ad(s[i]).T @ W[i]
         r1[i] = Ic[i] @ s[i]
@@ -236,6 +360,8 @@ def energy_world(m, q, qdot):
         phib = se3.Ad(se3.inv(Ew[j])) @ phi[j]
         T += 0.5 * phib @ (m["I"][j] * phib)
         V -= m["I"][j][5] * (m["grav"] @ Ew[j][:3, 3])
+        if m.get("contact") is not None and m["contact"][j]:
+            V += contact_world(m, j, Ew[j], phi[j])[3]      # ForceGroundCuboid.m:156-183
         if idx[j] >= 0:
             dq = qj - m["qRest"][j]
             V += 0.5 * m["stiffness"][j] * dq * dq

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from redmax_amd.scenes import sceneChain, scenesRedMax
+from redmax_amd.scenes import sceneChain, sceneChainGround, scenesRedMax
 
 SQE = np.sqrt(np.finfo(float).eps)
 
@@ -79,4 +79,43 @@ def test_newton_hessian_is_jacobian_of_g(oracle_lib):
         x = q1.copy()
         x[i] += SQE
         H_[:, i] = (o.eval_bdf1(x, q0, qd0, h, want_H=False) - g) / SQE
+    assert _err(H_, H) < 1e-6
+
+
+def test_ground_contact_fd(oracle_lib):
+    """ForceGroundCuboid's K and D against central differences of f (Scene.test K/D checks, Scene.m:343-376) on a chain
+    whose corners penetrate the ground, plus H = dg/dq1 of the BDF1 residual through contact."""
+    sc = sceneChainGround(4, ground_z=-1.0)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    rng = np.random.default_rng(8)
+    nr, h = o.nr, sc.h
+    q = rng.uniform(0.1, 0.4, nr)
+    qd = rng.uniform(-3, 3, nr)
+    o.set_state(q, qd)
+    M, f, dMdq, K, D = o.compute_values()
+    _, V = o.energy()
+    assert V > 0
+    K_, D_ = np.zeros((nr, nr)), np.zeros((nr, nr))
+    for i in range(nr):
+        for A_, x, step in ((K_, 0, 1e-6), (D_, 1, 1e-5)):
+            fp = []
+            for sgn in (+1, -1):
+                q_, qd_ = q.copy(), qd.copy()
+                (q_ if x == 0 else qd_)[i] += sgn * step
+                o.set_state(q_, qd_)
+                fp.append(o.compute_values(deriv=False)[1])
+            A_[:, i] = (fp[0] - fp[1]) / (2 * step)
+    assert _err(K_, K) < 1e-6
+    assert _err(D_, D) < 1e-6
+    q1 = q + h * qd
+    g, H = o.eval_bdf1(q1, q, qd, h)
+    H_ = np.zeros_like(H)
+    for i in range(nr):
+        gp = []
+        for sgn in (+1, -1):
+            x = q1.copy()
+            x[i] += sgn * 1e-7
+            gp.append(o.eval_bdf1(x, q, qd, h, want_H=False))
+        H_[:, i] = (gp[0] - gp[1]) / 2e-7
     assert _err(H_, H) < 1e-6
