@@ -105,6 +105,22 @@ int rmx_model_nm(const rmx_model* m);      /* redmax.Scene.countM()  Scene.m:398
 /* idx[n]: reduced index of each listed joint, -1 for a fixed joint (Joint.idxR) */
 int rmx_model_idxR(const rmx_model* m, int* idx);
 
+/* ForceGroundCuboid (matlab-diff/+redmax/ForceGroundCuboid.m:18-48, 54-183): penalty ground contact with Coulomb friction
+ * on the 8 corners of the flagged cuboid bodies -- normal spring kn and damper kd, tangential stick spring kt, friction mu
+ * (static/dynamic branch per corner, :112-150), energy 0.5 kn d^2 (:176).  Replaces, for one ground frame per scene,
+ *     f = redmax.ForceGroundCuboid(body); f.setTransform(E); f.setStiffness(kn,kt); f.setDamping(kd); f.setFriction(mu);
+ * (scenesRedMax.m:303-309).  Arrays follow the scene listing like rmx_model_desc.  Call before stepping; BDF1/BDF2/eval/energy
+ * honour it, rmx_step_euler and rmx_adjoint_bdf1 refuse such a model.  All flags zero removes the contact. */
+typedef struct rmx_ground_contact {
+    const int* flags;        /* [n] 1: this body carries a ForceGroundCuboid                       */
+    const double* sides;     /* [n][3] cuboid side lengths (BodyCuboid.sides)  ForceGroundCuboid.m:71-75 */
+    double E[16];            /* ground frame, column-major 4x4; its Z axis is the plane normal    :30-32, 56-57 */
+    double kn, kt;           /* setStiffness(kn, kt)   :35-38 */
+    double mu;               /* setFriction(mu)        :46-48 */
+    double kd;               /* setDamping(kd)         :41-43 */
+} rmx_ground_contact;
+int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc);
+
 /* `batch` independent trajectories of the model, state resident in HBM on the model's device. */
 int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out);
 void rmx_batch_destroy(rmx_batch* b);

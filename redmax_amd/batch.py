@@ -23,6 +23,15 @@ class BatchSim:
         _abi.check(self._L.rmx_model_create(C.byref(self._desc), int(device), C.byref(self._model)), "rmx_model_create")
         self.nr = self._L.rmx_model_nr(self._model)
         self.nm = self._L.rmx_model_nm(self._model)
+        if d.get("contact") is not None and np.any(d["contact"]):     # scene.forces: ForceGroundCuboid
+            g = d["ground"]
+            gc = _abi.GroundContact()
+            self._keep["contact"] = np.ascontiguousarray(d["contact"], dtype=np.int32)
+            self._keep["sides"] = np.ascontiguousarray(d["sides"], dtype=np.float64)
+            gc.flags, gc.sides = _abi.iptr(self._keep["contact"]), _abi.dptr(self._keep["sides"])
+            gc.E[:] = list(np.asarray(g["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
+            gc.kn, gc.kt, gc.mu, gc.kd = float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"])
+            _abi.check(self._L.rmx_model_set_ground_contact(self._model, C.byref(gc)), "rmx_model_set_ground_contact")
         self.B = int(batch)
         self.device = int(device)
         _abi.check(self._L.rmx_batch_create(self._model, self.B, C.byref(self._batch)), "rmx_batch_create")

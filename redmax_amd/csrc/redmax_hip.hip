@@ -62,12 +62,14 @@ __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, dou
         for (int r = 0; r < MAXROUNDS; ++r) c[r * NP + j] = in ? (double)M.anc[r * MAXN + j] : -1.0;
         c += MAXROUNDS * NP;
         c[j] = in ? (double)M.end[j] : (double)M.n;
+        c += NP;
+        for (int r = 0; r < 4; ++r) c[r * NP + j] = (in && M.con) ? M.con[r * MAXN + j] : 0.0;
     }
     __syncthreads();
 }
 
 // simLoop (driverRedMaxBDF1.m:57-91): all steps of one trajectory inside one wavefront.
-template <int NP>
+template <int NP, bool CT>
 __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpts o, const StepArgs a) {
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
         NodeOut last;
-        const double x = newton_node<NP>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
+        const double x = newton_node<NP, CT>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
         qd = (x - q0) / o.h;                       // (:72)
         q = x;
         if (a.histT) {                             // Scene.saveHistory (Scene.m:134-161)
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
 }
 
 // simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.
-template <int NP>
+template <int NP, bool CT>
 __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpts o, const StepArgs a) {
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
@@ -127,13 +129,13 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             const double q0 = q, qd0 = qd;
             // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
             const double xa0 = q0 + al * h * qd0;
-            const double qa = newton_node<NP>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv);
+            const double qa = newton_node<NP, CT>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv);
             const double qda = (qa - q0) / (al * h);
             // SDIRK2b (evalSDIRK2b :228-260)
             const double x10 = qa + (1.0 - al) * h * qda;
             const double qA = q0 + (1.0 - al) * h * qda;
             const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-            const double q1 = newton_node<NP>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv);
+            const double q1 = newton_node<NP, CT>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv);
             qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
             q = q1;
             qp = q0;
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             const double x0 = q1 + h * qd1;
             const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
             const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-            const double q2 = newton_node<NP>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv);
+            const double q2 = newton_node<NP, CT>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv);
             qp = q1;
             qdp = qd1;
             qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
@@ -383,7 +385,7 @@ __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevO
 }
 
 // Parity hook: one residual (+Hessian) evaluation per trajectory, results to HBM.
-template <int NP, bool WANT_H>
+template <int NP, bool WANT_H, bool CT>
 __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, const double* __restrict__ q,
                                              const double* __restrict__ qA, const double* __restrict__ qB, const double eta,
                                              double* __restrict__ g, double* __restrict__ H) {
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, cons
     const double xb = id >= 0 ? qB[off] : 0.0;
     NodeOut e;
     double Hrow[NP];
-    eval_node<NP, WANT_H>(M, sAcc, sCol, lane, x, (x - xa) / eta, x - xb, eta, e, Hrow);
+    eval_node<NP, WANT_H, false, CT>(M, sAcc, sCol, lane, x, (x - xa) / eta, x - xb, eta, e, Hrow);
     if (id >= 0) g[off] = e.g;
     if (WANT_H) {
         double* Ht = H + (size_t)traj * M.nr * M.nr;
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, cons
 }
 
 // Joint.computeEnergies / Body.computeEnergies at the stored state.
-template <int NP>
+template <int NP, bool CT>
 __global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, const double* __restrict__ q,
                                                const double* __restrict__ qd, double* __restrict__ T, double* __restrict__ V) {
     double *sAcc, *sCol;
@@ -422,7 +424,7 @@ __global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, co
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     NodeOut e;
     double Hrow[NP];
-    eval_node<NP, false>(M, sAcc, sCol, lane, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, e, Hrow);
+    eval_node<NP, false, false, CT>(M, sAcc, sCol, lane, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, e, Hrow);
     const double t = wave_sum(e.eT), v = wave_sum(e.eV);
     if (lane == 0) {
         T[traj] = t;
@@ -488,6 +490,7 @@ struct rmx_model {
     std::vector<int> idx_listing;   // reduced index per LISTED joint (-1 fixed)
     std::vector<int> node_of_listing;   // depth-first node index of each LISTED joint/body
     void* dbuf = nullptr;           // one device allocation holding all constant arrays
+    void* dcon = nullptr;           // contact flags + cuboid sides (rmx_model_set_ground_contact)
     DevModel dm{};
     size_t smem_bytes = 0;
 };
@@ -788,7 +791,36 @@ extern "C" void rmx_model_destroy(rmx_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->dbuf) (void)hipFree(m->dbuf);
+    if (m->dcon) (void)hipFree(m->dcon);
     delete m;
+}
+
+// scene.forces{end+1} = ForceGroundCuboid(body); setTransform / setStiffness / setDamping / setFriction
+// (scenesRedMax.m:303-309, ForceGroundCuboid.m:18-48) for every flagged body, one ground frame per scene.
+extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc) {
+    if (!m || !gc || !gc->flags || !gc->sides) return fail(RMX_E_INVALID, "null argument");
+    if (!(gc->kn >= 0) || !(gc->kt >= 0) || !(gc->mu >= 0) || !(gc->kd >= 0)) return fail(RMX_E_INVALID, "contact constants must be >= 0");
+    HIPCHK(hipSetDevice(m->device));
+    std::vector<double> con(4 * MAXN, 0.0);
+    bool any = false;
+    for (int L = 0; L < m->n; ++L) {
+        const int k = m->node_of_listing[L];
+        con[k] = gc->flags[L] ? 1.0 : 0.0;
+        any = any || gc->flags[L];
+        for (int c = 0; c < 3; ++c) con[(1 + c) * MAXN + k] = gc->sides[3 * L + c];
+    }
+    if (m->dcon) { (void)hipFree(m->dcon); m->dcon = nullptr; m->dm.con = nullptr; }
+    if (!any) return RMX_OK;
+    HIPCHK(hipMalloc(&m->dcon, con.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(m->dcon, con.data(), con.size() * sizeof(double), hipMemcpyHostToDevice));
+    m->dm.con = (const double*)m->dcon;
+    const M4 E = from_cm(gc->E);
+    for (int c = 0; c < 3; ++c) {
+        m->dm.gn[c] = E.a[c][2];      // ng = E(1:3,3)   ForceGroundCuboid.m:70
+        m->dm.gx[c] = E.a[c][3];      // xg = E(1:3,4)   :69
+    }
+    m->dm.kn = gc->kn; m->dm.kt = gc->kt; m->dm.mu = gc->mu; m->dm.kdc = gc->kd;
+    return RMX_OK;
 }
 extern "C" int rmx_model_nr(const rmx_model* m) { return m ? m->nr : RMX_E_INVALID; }
 extern "C" int rmx_model_nm(const rmx_model* m) { return m ? m->nm : RMX_E_INVALID; }
@@ -873,14 +905,20 @@ extern "C" int rmx_get_state_device(rmx_batch* b, double* q, double* qdot) { ret
 template <int NP>
 static void launch_eval(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
     const dim3 grid(b->B), block(64);
-    if (wantH) k_eval<NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
-    else k_eval<NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    const bool ct = m->dm.con != nullptr;   // scenes with ForceGroundCuboid run the contact instantiations
+    if (wantH && ct) k_eval<NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    else if (wantH) k_eval<NP, true, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    else if (ct) k_eval<NP, false, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    else k_eval<NP, false, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
 }
 template <int NP>
 static void launch_step_np(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
-    if (integ == INTEG_BDF1) k_step_bdf1<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
-    else k_step_bdf2<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    const bool ct = m->dm.con != nullptr;
+    if (integ == INTEG_BDF1 && ct) k_step_bdf1<NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else if (integ == INTEG_BDF1) k_step_bdf1<NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else if (ct) k_step_bdf2<NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else k_step_bdf2<NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
 }
 template <int NP>
 static void launch_euler(const rmx_model* m, const rmx_batch* b, double h, const StepArgs& a) {
@@ -890,7 +928,8 @@ static void launch_euler(const rmx_model* m, const rmx_batch* b, double h, const
 template <int NP>
 static void launch_energy(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);
-    k_energy<NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
+    if (m->dm.con) k_energy<NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
+    else k_energy<NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
 }
 
 extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const double* qB, double eta, double* g, double* H) {
@@ -1008,6 +1047,7 @@ extern "C" int rmx_step_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx
 
 extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, double* hV) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
+    if (b->m->dm.con) return fail(RMX_E_INVALID, "rmx_step_euler: matlab-simple has no ForceGroundCuboid; use rmx_step_bdf1/bdf2");
     if (nsteps < 0 || !(h > 0)) return fail(RMX_E_INVALID, "bad nsteps / h");
     if ((hT == nullptr) != (hV == nullptr)) return fail(RMX_E_INVALID, "hist_T and hist_V must be given together");
     rmx_model* m = b->m;
@@ -1054,6 +1094,7 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
     if (!b || !task || !p || !P || !dPdp) return fail(RMX_E_INVALID, "null argument");
     rmx_model* m = b->m;
     if (nsteps < 1) return fail(RMX_E_INVALID, "nsteps < 1");
+    if (m->dm.con) return fail(RMX_E_INVALID, "rmx_adjoint_bdf1: ground contact is outside the adjoint path (SURVEY.md 8(f))");
     if (task->body < 0 || task->body >= m->n) return fail(RMX_E_INVALID, "task body out of range");
     if (task->step < 1 || task->step > nsteps) return fail(RMX_E_INVALID, "task step must be in [1, nsteps]");
     HIPCHK(hipSetDevice(m->device));

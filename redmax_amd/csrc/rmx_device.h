@@ -21,7 +21,8 @@ constexpr int ACC_STRIDE = 29;    // odd stride: conflict-free lane=node LDS wri
 constexpr int NCOL = 18;          // column-side Hessian vectors per node (yz6, m1 6, m2w3, sw3)
 constexpr int COL_STRIDE = 19;
 constexpr int MAXROUNDS = 6;      // log2(MAXN)
-constexpr int NCONST = 64;        // per-node constants staged in LDS: K(36) sb(6) I4(4) prm(8) type(1) rel(2) anc(6) end(1)
+constexpr int NCONST = 68;        // per-node constants staged in LDS: K(36) sb(6) I4(4) prm(8) type(1) rel(2) anc(6) end(1) contact(1) sides(3)
+constexpr int NCOLX = 24;         // with ground contact the column side also needs m2v(3) and sv(3)
 
 // Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
 struct DevModel {
@@ -39,6 +40,10 @@ struct DevModel {
     const int* anc;   // [MAXROUNDS][MAXN] ancestor 2^r levels up, or -1
     const unsigned long long* rel;  // [2][MAXN] bit i of rel[j]: node i is a strict ancestor of j; of rel[MAXN+j]: strict descendant
     double grav[3];
+    // ForceGroundCuboid: one ground plane per scene, per-body flags (null con: no contact forces in the scene)
+    const double* con;   // [4][MAXN]  contact flag, cuboid sides(3)
+    double gn[3], gx[3]; // plane normal (Z axis of the ground frame) and origin   ForceGroundCuboid.m:56-57
+    double kn, kt, mu, kdc;   // setStiffness(kn, kt), setFriction(mu), setDamping(kd)
 };
 
 struct DevOpts {
@@ -175,6 +180,7 @@ struct FrontState {
     double S[NACC];           // subtree sums: W(6), m, mc(3), Ibar(6), TL(9), hf(3)
     double eta, kd, dd;       // step; -Kr and -Dr of this joint (stiffness/damping incl. active limits)
     double Rw[9], pw[3];      // world transform of this body (only kept alive where a caller reads it)
+    double cxy[6], cxr2[6], cxr3[6];   // ground contact: Dxc m2 + eta^2 Kxc s ; Dxc' s ; eta^2 Kxc' s  (subtree contact blocks)
     double tau_add = 0.0;     // extra joint torque set by the caller (adjoint task parameters, TaskBDF1PointPos.applyStep)
     unsigned long long anc_m, desc_m;   // bit i: node i is a strict ancestor / descendant of this node
     bool act, dof;
@@ -288,10 +294,212 @@ __device__ __forceinline__ void chain_suffix_sum(const int lane, double (&S)[NAC
     }
 }
 
+// ----------------------------------------------------------------------------- ground contact
+//
+// ForceGroundCuboid.computeValues_ / computeEnergy_ (matlab-diff/+redmax/ForceGroundCuboid.m:54-183): penalty contact of the
+// 8 corners of a cuboid with the plane (xg, n): normal spring-damper, static / dynamic friction branch per corner.  The
+// reference builds body-frame blocks fm, Km, Dm and pulls them through J; conjugating its formulas by R / Ad (DESIGN.md,
+// tests/proto_worldframe.py contact_world) gives, per penetrating corner x = R xl + p with velocity vw = v_O + w x x,
+// d = n.(x - xg) <= 0 and Gw = [-[x], I]:
+//     F  += Gw' f       f = -kn d n - kd N vw   [ - kt T vw  |  - mu kn d t ]
+//     Kw += Gw' [XL XR] XL = -kn (d[n] - N[x]) - kd ([N vw] - N[vw])  [ - kt ([a] - T[vw]) | - mu kn (d[t] - d AT [vw] - t (n x x)') ]
+//                       XR = -kn N                                    [                    | - mu kn t n' ]
+//     Dw += Gw' Y Gw    Y  = -kd N   [ - kt T  |  - mu kn d AT ]      a = T vw, t = a/|a|, AT = (|a|^2 I - a a')/|a|^3 - N/|a|
+// as world-frame tensors, so nothing is rotated back and forth.  DERIV=false: wrench and energy only (line-search points).
+__device__ __forceinline__ void skew3(const double a[3], double S[9]) {
+    S[0] = 0.0;   S[1] = -a[2]; S[2] = a[1];
+    S[3] = a[2];  S[4] = 0.0;   S[5] = -a[0];
+    S[6] = -a[1]; S[7] = a[0];  S[8] = 0.0;
+}
+// out(6x6 row-major) += Gw' [CL CR] = [[x] C; C] for the 3x6 block C = [CL CR]
+__device__ __forceinline__ void acc_GwT(const double x[3], const double CL[9], const double CR[9], double (&out)[36]) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double* Cm = c < 3 ? CL : CR;
+        const int cc = c < 3 ? c : c - 3;
+        const double col[3] = {Cm[cc], Cm[3 + cc], Cm[6 + cc]};
+        double xc[3];
+        cross3(x, col, xc);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            out[6 * r + c] += xc[r];
+            out[6 * (3 + r) + c] += col[r];
+        }
+    }
+}
+
+template <bool DERIV>
+__device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, const double sd[3], const double R[9],
+                                             const double p[3], const double phw[3], const double phv[3], double (&F)[6],
+                                             double (&Kw)[36], double (&Dw)[36], double& V) {
+    const double n[3] = {M.gn[0], M.gn[1], M.gn[2]};
+    const double kn = M.kn, kt = M.kt, mu = M.mu, kdc = M.kdc;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) F[c] = 0.0;
+    if (DERIV) {
+#pragma unroll
+        for (int c = 0; c < 36; ++c) {
+            Kw[c] = 0.0;
+            Dw[c] = 0.0;
+        }
+    }
+    V = 0.0;
+    bool touched = false;
+    for (int ic = 0; ic < 8; ++ic) {
+        // the 8 corners (+-sides/2, ForceGroundCuboid.m:71-83); their order is irrelevant to the sums
+        const double xl[3] = {(ic & 4 ? 0.5 : -0.5) * sd[0], (ic & 2 ? 0.5 : -0.5) * sd[1], (ic & 1 ? 0.5 : -0.5) * sd[2]};
+        double x[3];
+        mat3v(R, xl, x);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] += p[c];
+        const double d = n[0] * (x[0] - M.gx[0]) + n[1] * (x[1] - M.gx[1]) + n[2] * (x[2] - M.gx[2]);
+        const bool pen = con && !(d > 0.0);          // only penetrating corners act (:84-88)
+        if (!__any(pen)) continue;                   // wave-uniform skip
+        touched = true;
+        if (pen) {
+            V += 0.5 * kn * d * d;                   // (:176)
+            double vw[3], t3[3];
+            cross3(phw, x, t3);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vw[c] = phv[c] + t3[c];
+            const double nv = dot3(n, vw);
+            double a[3], f[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a[c] = vw[c] - n[c] * nv;            // T vw
+                f[c] = -kn * d * n[c] - kdc * nv * n[c];
+            }
+            const double an = sqrt(dot3(a, a));
+            const bool fric = mu != 0.0;
+            const bool stat = fric && (mu * fabs(kn * d) > kt * an);   // (:112)
+            const double mukn = mu * kn;
+            double tt[3] = {0.0, 0.0, 0.0};
+            if (fric) {
+                if (stat) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) f[c] -= kt * a[c];
+                } else {
+                    const double ia = 1.0 / an;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        tt[c] = a[c] * ia;
+                        f[c] -= mukn * d * tt[c];
+                    }
+                }
+            }
+            cross3(x, f, t3);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                F[c] += t3[c];
+                F[3 + c] += f[c];
+            }
+            if (DERIV) {
+                double nx[3], nxv[3];
+                cross3(n, x, nx);
+                cross3(n, vw, nxv);
+                double XL[9], XR[9], Y[9], Sk[9];
+                // normal spring + damper
+                const double Nv[3] = {n[0] * nv, n[1] * nv, n[2] * nv};
+                double Sn[9], SNv[9];
+                skew3(n, Sn);
+                skew3(Nv, SNv);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double nn = n[i] * n[k];
+                        XL[3 * i + k] = -kn * (d * Sn[3 * i + k] - n[i] * nx[k]) - kdc * (SNv[3 * i + k] - n[i] * nxv[k]);
+                        XR[3 * i + k] = -kn * nn;
+                        Y[3 * i + k] = -kdc * nn;
+                    }
+                if (fric) {
+                    double Sv[9];
+                    skew3(vw, Sv);
+                    if (stat) {
+                        skew3(a, Sk);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const double Tik = (i == k ? 1.0 : 0.0) - n[i] * n[k];
+                                Y[3 * i + k] -= kt * Tik;
+                                XL[3 * i + k] -= kt * (Sk[3 * i + k] - (Sv[3 * i + k] - n[i] * nxv[k]));
+                            }
+                    } else {
+                        const double ia = 1.0 / an, ia3 = ia * ia * ia, a2 = an * an;
+                        double AT[9], ATS[9];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                AT[3 * i + k] = ((i == k ? a2 : 0.0) - a[i] * a[k]) * ia3 - n[i] * n[k] * ia;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                ATS[3 * i + k] = AT[3 * i] * Sv[k] + AT[3 * i + 1] * Sv[3 + k] + AT[3 * i + 2] * Sv[6 + k];
+                        skew3(tt, Sk);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                Y[3 * i + k] -= mukn * d * AT[3 * i + k];
+                                XL[3 * i + k] -= mukn * (d * Sk[3 * i + k] - d * ATS[3 * i + k] - tt[i] * nx[k]);
+                                XR[3 * i + k] -= mukn * tt[i] * n[k];
+                            }
+                    }
+                }
+                acc_GwT(x, XL, XR, Kw);
+                // Y Gw = [-Y[x], Y]
+                double Sx[9], YL[9];
+                skew3(x, Sx);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        YL[3 * i + k] = -(Y[3 * i] * Sx[k] + Y[3 * i + 1] * Sx[3 + k] + Y[3 * i + 2] * Sx[6 + k]);
+                acc_GwT(x, YL, Y, Dw);
+            }
+        }
+    }
+    return touched;
+}
+
+// Subtree sums of NC <= 28 per-node numbers through the LDS transpose (the scan of eval_front_e2 as a function: contact's 72
+// extra accumulations go through it in chunks).  Row n of sAcc is zero; ends with a barrier so sAcc can be rewritten.
+template <int NP, int NC>
+__device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __restrict__ sAcc, const double* cEnd, const int lane,
+                                                const bool act, const int jj, double* v) {
+    static_assert(NC <= NACC, "chunk wider than the accumulation row");
+    const int n = M.n;
+    if (act) {
+        double* A = sAcc + lane * ACC_STRIDE;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) A[c] = v[c];
+    }
+    __syncthreads();
+    if (lane < NC) {
+        double acc = 0.0;
+        for (int jn = n - 1; jn >= 0; --jn) {
+            acc += sAcc[jn * ACC_STRIDE + lane];
+            sAcc[jn * ACC_STRIDE + lane] = acc;
+        }
+    }
+    __syncthreads();
+    {
+        const double* A = sAcc + jj * ACC_STRIDE;
+        const int en = (act && !M.is_chain) ? (int)cEnd[jj] : n;
+        const double* E = sAcc + en * ACC_STRIDE;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = A[c] - E[c];
+    }
+    __syncthreads();
+}
+
 // FULL: accumulate the Hessian's subtree sums as well (28 numbers per body instead of 6).
 // e2 is the coefficient of f in g = M v - e2 f: eta^2 for the implicit integrators; the linearly-implicit Euler step of
 // matlab-simple uses e2 = -h with v = qdot0 so that g = M qdot0 + h f is its right-hand side.
-template <int NP, bool FULL, bool TIMED = false>
+template <int NP, bool FULL, bool TIMED = false, bool CT = false>
 __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
                                               const double xqd, const double xv, const double eta, const double e2, NodeOut& out,
                                               FrontState& fs, unsigned long long* stamps = nullptr) {
@@ -309,6 +517,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     const double* cRel = cTyp + NP;         // 2 rows: ancestor / descendant bit masks (bit patterns)
     const double* cAnc = cRel + 2 * NP;     // MAXROUNDS rows: ancestor 2^r levels up (as doubles), trees only
     const double* cEnd = cAnc + MAXROUNDS * NP;
+    const double* cCon = cEnd + NP;         // 4 rows: contact flag, cuboid sides
     const int type = act ? (int)cTyp[jj] : 0;
     const bool dof = type != 0;
     fs.anc_m = act ? (unsigned long long)__double_as_longlong(cRel[jj]) : 0ull;
@@ -487,6 +696,26 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         wt[c] = bt[c] - e2 * (fct[c] + fgt[c]);
         wf[c] = bf[c] - e2 * (-fcf[c] + ms * gv[c]);
     }
+    // ground contact wrench (+ its K/D blocks for the Hessian) of this body, world frame
+    double Kx[(CT && FULL) ? 36 : 1], Dx[(CT && FULL) ? 36 : 1];
+    double eVc = 0.0;
+    bool touched = false;
+    if constexpr (CT) {
+        const bool con = act && cCon[jj] != 0.0;
+        const double sd[3] = {cCon[NP + jj], cCon[2 * NP + jj], cCon[3 * NP + jj]};
+        double Fc[6];
+        if constexpr (FULL) {
+            touched = contact_body<true>(M, con, sd, R, p, phw, phv, Fc, (double (&)[36])Kx, (double (&)[36])Dx, eVc);
+        } else {
+            double k1[36], d1[36];
+            touched = contact_body<false>(M, con, sd, R, p, phw, phv, Fc, k1, d1, eVc);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            wt[c] -= e2 * Fc[c];
+            wf[c] -= e2 * Fc[3 + c];
+        }
+    }
 
     // energies (Body.computeEnergies Body.m:167-173, Joint.computeEnergies Joint.m:616-637)
     const double stiff = act ? cPrm[1 * NP + jj] : 0.0, damp = act ? cPrm[2 * NP + jj] : 0.0;
@@ -503,7 +732,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             eV += 0.5 * stiff * (dq * dq) + 0.5 * qLimK * (dqL * dqL + dqU * dqU);
         }
         out.eT = act ? eT : 0.0;
-        out.eV = act ? eV : 0.0;
+        out.eV = act ? eV + eVc : 0.0;
     }
 
     RMX_STAMP(4)
@@ -588,6 +817,38 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         }
         __syncthreads();   // sAcc is rewritten by the next evaluation
     }
+    if constexpr (CT && FULL) {
+        // contact blocks of the subtree: Kxc, Dxc (72 numbers) through the LDS scan in chunks, then folded at once into the
+        // three vectors the Hessian stage needs; skipped (wave-uniform) while no corner of the tree penetrates
+#pragma unroll
+        for (int c = 0; c < 6; ++c) fs.cxy[c] = fs.cxr2[c] = fs.cxr3[c] = 0.0;
+        if (touched) {
+            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Kx[0]);
+            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Kx[28]);
+            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Dx[0]);
+            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Dx[28]);
+            const double s6[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
+            double m26[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                m26[c] = eta * sw[c] + e2 * xiw[c];
+                m26[3 + c] = eta * sv[c] + e2 * xiv[c];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double ay = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    ay += Dx[6 * r + c] * m26[c] + e2 * Kx[6 * r + c] * s6[c];
+                    a2 += Dx[6 * c + r] * s6[c];
+                    a3 += Kx[6 * c + r] * s6[c];
+                }
+                fs.cxy[r] = ay;
+                fs.cxr2[r] = a2;
+                fs.cxr3[r] = e2 * a3;
+            }
+        }
+    }
     RMX_STAMP(7)
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
     const double fr = (tau + fs.tau_add) + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
@@ -605,11 +866,11 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     RMX_STAMP(8)
 }
 
-template <int NP, bool FULL, bool TIMED = false>
+template <int NP, bool FULL, bool TIMED = false, bool CT = false>
 __device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
                                            const double xqd, const double xv, const double eta, NodeOut& out, FrontState& fs,
                                            unsigned long long* stamps = nullptr) {
-    eval_front_e2<NP, FULL, TIMED>(M, sAcc, lane, xq, xqd, xv, eta, eta * eta, out, fs, stamps);
+    eval_front_e2<NP, FULL, TIMED, CT>(M, sAcc, lane, xq, xqd, xv, eta, eta * eta, out, fs, stamps);
 }
 
 // Reduced mass matrix row M(a,:) = (J' Mm J)(a,:) of this node from the subtree inertias (computeValues :212;
@@ -726,7 +987,7 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 }
 
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle lanes are the identity.
-template <int NP, bool TIMED = false>
+template <int NP, bool TIMED = false, bool CT = false>
 __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -786,6 +1047,10 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
     for (int c = 0; c < 3; ++c) {
         yt[c] -= a3[c] + e2 * kt[c];
         yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c];
+        if (CT) {
+            yt[c] -= fs.cxy[c];
+            yf[c] -= fs.cxy[3 + c];
+        }
     }
     // z = ad(s)' W
     double zt[3], zf[3];
@@ -815,12 +1080,24 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
     cross3(gv, sv, b3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) r3w[c] = e2 * (a3[c] - mS * b3[c]);
+    if (CT) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r2w[c] += fs.cxr2[c];
+            r3w[c] += fs.cxr3[c];
+        }
+    }
     RMX_STAMP(9)
     // column-side vectors stay in this lane's registers (zero on idle lanes); column i is broadcast out of lane i with
     // v_readlane into scalar registers, which the FMAs consume directly: no LDS round trip, no latency per column.
-    double cv[NCOL];
+    constexpr int NCV = CT ? NCOLX : NCOL;
+    double cv[NCV];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+        if (CT) {
+            cv[18 + c] = act ? eta * sv[c] + e2 * xiv[c] : 0.0;   // m2v
+            cv[21 + c] = act ? sv[c] : 0.0;
+        }
         cv[c] = act ? yt[c] - zt[c] : 0.0;
         cv[3 + c] = act ? yf[c] - zf[c] : 0.0;
         cv[6 + c] = act ? m1w[c] : 0.0;
@@ -832,12 +1109,15 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
     const unsigned long long anc_m = fs.anc_m, desc_m = fs.desc_m;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        double Ci[NCOL];
+        double Ci[NCV];
 #pragma unroll
-        for (int c = 0; c < NCOL; ++c) Ci[c] = readlane_d(cv[c], i);
+        for (int c = 0; c < NCV; ++c) Ci[c] = readlane_d(cv[c], i);
         const double up = sw[0] * Ci[0] + sw[1] * Ci[1] + sw[2] * Ci[2] + sv[0] * Ci[3] + sv[1] * Ci[4] + sv[2] * Ci[5];
-        const double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
-                          (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
+        double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
+                    (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
+        if (CT)
+            lo -= fs.cxr2[3] * Ci[18] + fs.cxr2[4] * Ci[19] + fs.cxr2[5] * Ci[20] + fs.cxr3[3] * Ci[21] + fs.cxr3[4] * Ci[22] +
+                  fs.cxr3[5] * Ci[23];
         // branch-free select: relation bits -> 0/1 weights (columns of idle lanes are all-zero vectors)
         const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
         const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
@@ -848,15 +1128,15 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
 }
 
 // One-shot evaluation (parity hook / energy kernels)
-template <int NP, bool WANT_H, bool TIMED = false>
+template <int NP, bool WANT_H, bool TIMED = false, bool CT = false>
 __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict__ sAcc, double* __restrict__ sCol,
                                           const int lane, const double xq, const double xqd, const double xv,
                                           const double eta, NodeOut& out, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr) {
     (void)sCol;
     FrontState fs;
-    eval_front<NP, WANT_H, TIMED>(M, sAcc, lane, xq, xqd, xv, eta, out, fs, stamps);
-    if (WANT_H) eval_hess<NP, TIMED>(M, lane, fs, Hrow, stamps);
+    eval_front<NP, WANT_H, TIMED, CT>(M, sAcc, lane, xq, xqd, xv, eta, out, fs, stamps);
+    if (WANT_H) eval_hess<NP, TIMED, CT>(M, lane, fs, Hrow, stamps);
 }
 
 // ----------------------------------------------------------------------------- dense solve
@@ -966,7 +1246,7 @@ __device__ __forceinline__ void pivot_policy_update(PivotPolicy& piv) {   // aft
 // at most iterLsMax halvings (the last trial is kept), stop on |g|<tol, iter>=iterMax or |dx|>dxMax.
 // The (g,H) evaluation at the top of iteration k+1 is the Hessian stage applied to the state of the line-search
 // evaluation that accepted x_{k+1} (same x, same arithmetic, so the same g the reference recomputes).
-template <int NP, bool PIVOT_ONLY>
+template <int NP, bool PIVOT_ONLY, bool CT = false>
 __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
                                               int& iters, int& halvings, int& status, PivotPolicy& piv) {
@@ -974,10 +1254,10 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     double Hrow[NP];
     FrontState fs;
     NodeOut e;
-    eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+    eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     int iter = 1;
     while (true) {
-        eval_hess<NP>(M, lane, fs, Hrow);
+        eval_hess<NP, false, CT>(M, lane, fs, Hrow);
         const NodeOut e0 = e;
         last = e;
         ++iters;
@@ -995,8 +1275,8 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 // H was destroyed in place.  The front is re-evaluated too (same x, same arithmetic) so that its state does
                 // not have to stay live in registers across the fast-path LU for the sake of this rare branch.
                 NodeOut e2;
-                eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
-                eval_hess<NP>(M, lane, fs, Hrow);
+                eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
+                eval_hess<NP, false, CT>(M, lane, fs, Hrow);
                 dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
             }
         }
@@ -1027,7 +1307,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 e = e0;              // the evaluation at x0
                 break;
             }
-            eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+            eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
             gn2 = wave_sum(e.g * e.g);
             if (0.5 * gn2 < f0) break;
             if (iterLs >= o.iterLsMax) break;
@@ -1052,15 +1332,15 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     return x;
 }
 
-template <int NP>
+template <int NP, bool CT = false>
 __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
                                               int& iters, int& halvings, int& status, PivotPolicy& piv) {
     if (o.lu_mode != 0 || piv.hold > 0) {     // wave-uniform
         if (piv.hold > 0) --piv.hold;
-        return newton_impl<NP, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+        return newton_impl<NP, true, CT>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
     }
-    const double r = newton_impl<NP, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    const double r = newton_impl<NP, false, CT>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
     pivot_policy_update(piv);
     return r;
 }

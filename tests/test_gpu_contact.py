@@ -1,0 +1,139 @@
+"""GPU parity for ground frictional contact (ForceGroundCuboid.m:54-183, SURVEY.md §8(f)-3 / BASELINE.json configs[4]):
+the HIP path through the C ABI (rmx_model_set_ground_contact + rmx_eval / rmx_step_bdf1 / rmx_step_bdf2 / rmx_energy) vs
+the CPU oracle, and the reference's scene-11 goldens through driverRedMaxBDF1/2.
+
+Tolerances (fp64):
+  single evaluation : |dg|/|g| <= 1e-11, |dH|_F/|H|_F <= 1e-11 (penetrating states, both friction branches)
+  energies          : 1e-11 relative
+  scene 11 goldens  : BDF1 1e-9 relative; BDF2 1e-6 relative (the oracle itself lands 9e-8 from the golden through 1200
+                      steps of impact and stick/slip switching; the reference's criterion is 1e-2 absolute, Scene.m:173)
+  rollouts          : contact switching (d <= 0, static vs dynamic friction) makes a trajectory only piecewise smooth, so two
+                      correct solvers that stop Newton at |g| < tol differ by (tol-sized) x (growth through impacts):
+                      |dq| <= 1e-6 |q| over 150 steps through impact, energy history to 1e-6 relative of its range
+"""
+import numpy as np
+import pytest
+
+from redmax_amd.scenes import sceneChainGround, scenesRedMax, syntheticStates
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _penetrating_states(name, nr, h, B, rng):
+    q0 = np.empty((B, nr))
+    qd0 = np.empty((B, nr))
+    for b in range(B):
+        if name == "11":
+            q0[b] = np.array([0.3, rng.uniform(-0.4, 0.4), rng.uniform(-1, 1)])[::-1]     # idx order: theta, y, x
+            qd0[b] = rng.normal(size=nr) * (50 if b % 2 else 0.5)
+        else:
+            q0[b] = rng.uniform(-0.4, 0.4, nr)
+            qd0[b] = rng.normal(size=nr) * (5 if b % 2 else 0.05)
+    return q0, qd0, q0 + h * qd0
+
+
+@pytest.mark.parametrize("name", ["11", "chain6ground", "chain32ground"])
+def test_contact_eval_matches_oracle(oracle_lib, name):
+    from redmax_amd import BatchSim
+    sc = scenesRedMax(11) if name == "11" else sceneChainGround(6 if name == "chain6ground" else 32, ground_z=-1.0)
+    sc.init()
+    B = 6
+    rng = np.random.default_rng(5)
+    nr, h = sc.nr, sc.h
+    q0, qd0, q1 = _penetrating_states(name, nr, h, B, rng)
+    sim = BatchSim(sc, batch=B)
+    o = oracle_lib.Oracle(sc.desc())
+    o_free = oracle_lib.Oracle(dict(sc.desc(), contact=None))
+    touched = 0
+    for eta, qA, qB in ((h, q0, q0 + 0.5 * h * qd0), (2 * h / 3, q0 + 1e-3 * rng.normal(size=(B, nr)), q0)):
+        g, H = sim.eval_residual(q1, qA, qB, eta)
+        g_only = sim.eval_residual(q1, qA, qB, eta, want_H=False)
+        for b in range(B):
+            go, Ho = o.eval_residual(q1[b], qA[b], qB[b], eta)
+            assert _rel(g[b], go) <= 1e-11
+            assert _rel(H[b], Ho) <= 1e-11
+            assert _rel(g_only[b], go) <= 1e-11
+            touched += _rel(o_free.eval_residual(q1[b], qA[b], qB[b], eta)[0], go) > 1e-6
+    assert touched >= B                                   # contact forces really were in play
+    sim.set_state(q1, qd0)
+    T, V = sim.energy()
+    for b in range(B):
+        o.set_state(q1[b], qd0[b])
+        To, Vo = o.energy()
+        assert abs(T[b] - To) <= 1e-11 * max(abs(To), 1) and abs(V[b] - Vo) <= 1e-11 * max(abs(Vo), 1)
+    sim.close()
+
+
+def test_scene11_goldens_through_the_drivers():
+    """driverRedMaxBDF1(11) / driverRedMaxBDF2(11): Hexpected of scenesRedMax.m:292-293."""
+    from redmax_amd import driverRedMaxBDF1, driverRedMaxBDF2
+    sc, H, passed = driverRedMaxBDF1(11, verbose=False)
+    assert passed and abs(H - sc.Hexpected[0]) <= 1e-9 * abs(sc.Hexpected[0])
+    sc, H, passed = driverRedMaxBDF2(11, verbose=False)
+    assert passed and abs(H - sc.Hexpected[1]) <= 1e-6 * abs(sc.Hexpected[1])
+    assert sc.solverInfo["status"] & 7 == 0
+
+
+@pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
+def test_config5_chain_ground_rollout_matches_oracle(oracle_lib, integ):
+    """BASELINE.json configs[4] at test size: the 32-link chain falls onto the frictional ground; 150 steps of h = 5e-4 carry
+    it through the first impacts.  Trajectory 0 is the scene's own initial state, the others synthetic."""
+    from redmax_amd import BatchSim
+    sc = sceneChainGround(32)
+    sc.init()
+    B, nsteps = 3, 150
+    q0, qd0 = syntheticStates(sc.nr, B, sq=0.02, sv=0.1)
+    q0[0], qd0[0] = sc.getQ()
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q0, qd0)
+    step = sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2
+    out = step(nsteps, h=sc.h, stats=True, history=True)
+    q, qd = sim.get_state()
+    assert np.all(out["status"] & 7 == 0)
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q0[b], qd0[b])
+        res = (o.step_bdf1 if integ == "bdf1" else o.step_bdf2)(sc.h, nsteps, history=True)
+        st, To, Vo = res
+        qo, qdo = o.get_state()
+        assert st.diverged == 0 and st.not_converged == 0
+        assert Vo.max() - Vo.min() > 1e3                    # the chain did hit the ground
+        assert _rel(q[b], qo) <= 1e-6
+        assert _rel(qd[b], qdo) <= 1e-5
+        Hg, Ho = out["T"][:, b] + out["V"][:, b], To + Vo
+        assert np.abs(Hg - Ho).max() <= 1e-6 * (np.abs(Ho).max() + 1)
+    sim.close()
+
+
+def test_contact_is_refused_by_euler_and_adjoint():
+    from redmax_amd import BatchSim, RedMaxHipError
+    sc = sceneChainGround(4)
+    sc.init()
+    sim = BatchSim(sc, batch=1)
+    with pytest.raises(RedMaxHipError):
+        sim.step_euler(1, 1e-2)
+    task = {"body": 3, "xlocal": [5.0, 0, 0], "xtarget": [10.0, 0, -10.0], "step": 1, "pscale": 1e5, "wreg": 1e-2, "wpos": 1e2}
+    with pytest.raises(RedMaxHipError):
+        sim.adjoint_bdf1(1, sc.h, task, np.zeros((1, sc.nr)))
+    sim.close()
+
+
+def test_contact_free_scene_takes_the_plain_kernels(oracle_lib):
+    """All flags zero: rmx_model_set_ground_contact removes the contact again (the plain instantiations run)."""
+    from redmax_amd import BatchSim
+    sc = sceneChainGround(6, ground_z=-1.0)
+    sc.init()
+    d = dict(sc.desc())
+    d["contact"] = np.zeros_like(np.asarray(d["contact"]))
+    sim = BatchSim(d, batch=1)
+    rng = np.random.default_rng(1)
+    q0, qd0 = rng.uniform(-0.4, 0.4, (1, sc.nr)), rng.normal(size=(1, sc.nr))
+    g, H = sim.eval_bdf1(q0 + sc.h * qd0, q0, qd0, sc.h)
+    o = oracle_lib.Oracle(dict(d, contact=None))
+    go, Ho = o.eval_bdf1((q0 + sc.h * qd0)[0], q0[0], qd0[0], sc.h)
+    assert _rel(g[0], go) <= 1e-11 and _rel(H[0], Ho) <= 1e-11
+    sim.close()
