@@ -180,7 +180,7 @@ struct FrontState {
     double S[NACC];           // subtree sums: W(6), m, mc(3), Ibar(6), TL(9), hf(3)
     double eta, kd, dd;       // step; -Kr and -Dr of this joint (stiffness/damping incl. active limits)
     double Rw[9], pw[3];      // world transform of this body (only kept alive where a caller reads it)
-    double cxy[6], cxr2[6], cxr3[6];   // ground contact: Dxc m2 + eta^2 Kxc s ; Dxc' s ; eta^2 Kxc' s  (subtree contact blocks)
+    bool touched;             // ground contact: some corner of some body of this tree penetrates (wave-uniform)
     double tau_add = 0.0;     // extra joint torque set by the caller (adjoint task parameters, TaskBDF1PointPos.applyStep)
     unsigned long long anc_m, desc_m;   // bit i: node i is a strict ancestor / descendant of this node
     bool act, dof;
@@ -696,20 +696,14 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         wt[c] = bt[c] - e2 * (fct[c] + fgt[c]);
         wf[c] = bf[c] - e2 * (-fcf[c] + ms * gv[c]);
     }
-    // ground contact wrench (+ its K/D blocks for the Hessian) of this body, world frame
-    double Kx[(CT && FULL) ? 36 : 1], Dx[(CT && FULL) ? 36 : 1];
+    // ground contact wrench of this body, world frame (its K/D blocks are formed by eval_hess, once per Newton iteration)
     double eVc = 0.0;
-    bool touched = false;
+    fs.touched = false;
     if constexpr (CT) {
         const bool con = act && cCon[jj] != 0.0;
         const double sd[3] = {cCon[NP + jj], cCon[2 * NP + jj], cCon[3 * NP + jj]};
-        double Fc[6];
-        if constexpr (FULL) {
-            touched = contact_body<true>(M, con, sd, R, p, phw, phv, Fc, (double (&)[36])Kx, (double (&)[36])Dx, eVc);
-        } else {
-            double k1[36], d1[36];
-            touched = contact_body<false>(M, con, sd, R, p, phw, phv, Fc, k1, d1, eVc);
-        }
+        double Fc[6], k1[36], d1[36];
+        fs.touched = contact_body<false>(M, con, sd, R, p, phw, phv, Fc, k1, d1, eVc);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             wt[c] -= e2 * Fc[c];
@@ -816,38 +810,6 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             }
         }
         __syncthreads();   // sAcc is rewritten by the next evaluation
-    }
-    if constexpr (CT && FULL) {
-        // contact blocks of the subtree: Kxc, Dxc (72 numbers) through the LDS scan in chunks, then folded at once into the
-        // three vectors the Hessian stage needs; skipped (wave-uniform) while no corner of the tree penetrates
-#pragma unroll
-        for (int c = 0; c < 6; ++c) fs.cxy[c] = fs.cxr2[c] = fs.cxr3[c] = 0.0;
-        if (touched) {
-            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Kx[0]);
-            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Kx[28]);
-            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Dx[0]);
-            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Dx[28]);
-            const double s6[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
-            double m26[6];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                m26[c] = eta * sw[c] + e2 * xiw[c];
-                m26[3 + c] = eta * sv[c] + e2 * xiv[c];
-            }
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double ay = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    ay += Dx[6 * r + c] * m26[c] + e2 * Kx[6 * r + c] * s6[c];
-                    a2 += Dx[6 * c + r] * s6[c];
-                    a3 += Kx[6 * c + r] * s6[c];
-                }
-                fs.cxy[r] = ay;
-                fs.cxr2[r] = a2;
-                fs.cxr3[r] = e2 * a3;
-            }
-        }
     }
     RMX_STAMP(7)
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
@@ -989,7 +951,7 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle lanes are the identity.
 template <int NP, bool TIMED = false, bool CT = false>
 __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
-                                          unsigned long long* stamps = nullptr) {
+                                          unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     const double eta = fs.eta, e2 = eta * eta;
     const bool act = fs.act, dof = fs.dof;
@@ -1000,6 +962,47 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
     const double (&phv)[3] = fs.phv;
     const double (&xiw)[3] = fs.xiw;
     const double (&xiv)[3] = fs.xiv;
+    // ground contact: K/D blocks of this body at the state the front left behind, summed over the subtree (72 numbers through
+    // the LDS scan in chunks) and folded at once into the three vectors the Hessian needs:
+    //   cxy = Dxc m2 + eta^2 Kxc s ,  cxr2 = Dxc' s ,  cxr3 = eta^2 Kxc' s      (m2 = eta s + eta^2 xi)
+    // skipped (wave-uniform) while no corner of the tree penetrates.
+    double cxy[6], cxr2[6], cxr3[6];
+    if constexpr (CT) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cxy[c] = cxr2[c] = cxr3[c] = 0.0;
+        if (fs.touched) {
+            const double* cEnd = sAcc + (M.n + 1) * ACC_STRIDE + (NCONST - 5) * NP;
+            const double* cCon = cEnd + NP;
+            const bool con = act && cCon[jj] != 0.0;
+            const double sd[3] = {cCon[NP + jj], cCon[2 * NP + jj], cCon[3 * NP + jj]};
+            double Fc[6], Kx[36], Dx[36], eVc;
+            contact_body<true>(M, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Kx, Dx, eVc);
+            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Kx[0]);
+            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Kx[28]);
+            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Dx[0]);
+            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Dx[28]);
+            const double s6[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
+            double m26[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                m26[c] = eta * sw[c] + e2 * xiw[c];
+                m26[3 + c] = eta * sv[c] + e2 * xiv[c];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double ay = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    ay += Dx[6 * r + c] * m26[c] + e2 * Kx[6 * r + c] * s6[c];
+                    a2 += Dx[6 * c + r] * s6[c];
+                    a3 += Kx[6 * c + r] * s6[c];
+                }
+                cxy[r] = ay;
+                cxr2[r] = a2;
+                cxr3[r] = e2 * a3;
+            }
+        }
+    }
     const double (&bw)[3] = fs.bw;
     const double (&bv)[3] = fs.bv;
     const double* Wt = &fs.S[0];
@@ -1048,8 +1051,8 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
         yt[c] -= a3[c] + e2 * kt[c];
         yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c];
         if (CT) {
-            yt[c] -= fs.cxy[c];
-            yf[c] -= fs.cxy[3 + c];
+            yt[c] -= cxy[c];
+            yf[c] -= cxy[3 + c];
         }
     }
     // z = ad(s)' W
@@ -1083,8 +1086,8 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
     if (CT) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            r2w[c] += fs.cxr2[c];
-            r3w[c] += fs.cxr3[c];
+            r2w[c] += cxr2[c];
+            r3w[c] += cxr3[c];
         }
     }
     RMX_STAMP(9)
@@ -1116,8 +1119,7 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
         double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
                     (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
         if (CT)
-            lo -= fs.cxr2[3] * Ci[18] + fs.cxr2[4] * Ci[19] + fs.cxr2[5] * Ci[20] + fs.cxr3[3] * Ci[21] + fs.cxr3[4] * Ci[22] +
-                  fs.cxr3[5] * Ci[23];
+            lo -= cxr2[3] * Ci[18] + cxr2[4] * Ci[19] + cxr2[5] * Ci[20] + cxr3[3] * Ci[21] + cxr3[4] * Ci[22] + cxr3[5] * Ci[23];
         // branch-free select: relation bits -> 0/1 weights (columns of idle lanes are all-zero vectors)
         const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
         const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
@@ -1136,7 +1138,7 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
     (void)sCol;
     FrontState fs;
     eval_front<NP, WANT_H, TIMED, CT>(M, sAcc, lane, xq, xqd, xv, eta, out, fs, stamps);
-    if (WANT_H) eval_hess<NP, TIMED, CT>(M, lane, fs, Hrow, stamps);
+    if (WANT_H) eval_hess<NP, TIMED, CT>(M, lane, fs, Hrow, stamps, sAcc);
 }
 
 // ----------------------------------------------------------------------------- dense solve
@@ -1257,7 +1259,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     int iter = 1;
     while (true) {
-        eval_hess<NP, false, CT>(M, lane, fs, Hrow);
+        eval_hess<NP, false, CT>(M, lane, fs, Hrow, nullptr, sAcc);
         const NodeOut e0 = e;
         last = e;
         ++iters;
@@ -1276,7 +1278,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 // not have to stay live in registers across the fast-path LU for the sake of this rare branch.
                 NodeOut e2;
                 eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
-                eval_hess<NP, false, CT>(M, lane, fs, Hrow);
+                eval_hess<NP, false, CT>(M, lane, fs, Hrow, nullptr, sAcc);
                 dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
             }
         }

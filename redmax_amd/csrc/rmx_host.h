@@ -1,0 +1,80 @@
+// rmx_host.h -- what the host translation unit (redmax_hip.hip: the C ABI) and the kernel translation units
+// (rmx_kernels.hip, compiled once per padded tree size RMX_NP in {4,8,16,32,64} so the builds run in parallel) share:
+// launch argument blocks, the model / batch objects and the per-size launcher entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "redmax_hip.h"
+#include "rmx_device.h"
+
+using namespace rmx;
+
+enum { INTEG_BDF1 = 1, INTEG_BDF2 = 2 };
+
+struct StepArgs {
+    int B, nsteps;
+    double* q;        // [B][nr] state (in/out)
+    double* qd;
+    double* qp;       // [B][nr] state of step k-1 (BDF2)
+    double* qdp;
+    int* started;     // [1] device flag: 0 => BDF2 must take the SDIRK2 start step first
+    int* it;          // [B] stats (accumulated) or null
+    int* ls;
+    int* status;
+    double* histT;    // [nsteps][B] or null
+    double* histV;
+};
+
+struct AdjArgs {
+    int B, nsteps, task_step, task_node;
+    double xl[3], xt[3], pscale, wreg, wpos;
+    double *q, *qd;
+    const double* p;
+    double *Hs, *Ms, *Ds;     // [B][nsteps][n*n]
+    double* dPdq;             // [B][n]   dP/dq of the task step
+    double* P;                // [B]
+    double* dPdp;             // [B][nr]
+    int *it, *status;
+};
+
+struct rmx_model {
+    int device = 0;
+    int n = 0, nr = 0, nm = 0, NP = 0;
+    std::vector<int> idx_listing;   // reduced index per LISTED joint (-1 fixed)
+    std::vector<int> node_of_listing;   // depth-first node index of each LISTED joint/body
+    void* dbuf = nullptr;           // one device allocation holding all constant arrays
+    void* dcon = nullptr;           // contact flags + cuboid sides (rmx_model_set_ground_contact)
+    DevModel dm{};
+    size_t smem_bytes = 0;
+};
+
+struct rmx_batch {
+    rmx_model* m = nullptr;
+    int B = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *q = nullptr, *qd = nullptr, *qp = nullptr, *qdp = nullptr;
+    double *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;   // [B][nr] scratch for rmx_eval inputs
+    int* started = nullptr;
+    int *it = nullptr, *ls = nullptr, *status = nullptr;
+    double last_ms = 0.0;
+};
+
+// launchers defined by rmx_kernels.hip for one RMX_NP each
+#define RMX_CAT_(a, b) a##b
+#define RMX_CAT(a, b) RMX_CAT_(a, b)
+#define RMX_DECLARE_LAUNCHERS(NPV) \
+    void RMX_CAT(launch_eval_, NPV)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH); \
+    void RMX_CAT(launch_step_np_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a); \
+    void RMX_CAT(launch_euler_, NPV)(const rmx_model* m, const rmx_batch* b, double h, const StepArgs& a); \
+    void RMX_CAT(launch_energy_, NPV)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV); \
+    void RMX_CAT(launch_adjoint_, NPV)(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a); \
+    void RMX_CAT(launch_phase_, NPV)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d);
+RMX_DECLARE_LAUNCHERS(4)
+RMX_DECLARE_LAUNCHERS(8)
+RMX_DECLARE_LAUNCHERS(16)
+RMX_DECLARE_LAUNCHERS(32)
+RMX_DECLARE_LAUNCHERS(64)

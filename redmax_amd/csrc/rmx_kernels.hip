@@ -1,0 +1,477 @@
+// rmx_kernels.hip -- kernel entry points for gfx950 and their launchers, for ONE padded tree size RMX_NP (lanes in use per
+// wavefront: 4, 8, 16, 32 or 64).  __graft_entry__.build() compiles this file once per size, in parallel, and links the
+// objects with redmax_hip.hip (host side / C ABI).  Device code: rmx_device.h.
+#ifndef RMX_NP
+#error "compile with -DRMX_NP=4|8|16|32|64"
+#endif
+#include "rmx_host.h"
+
+// ============================================================================ kernels
+
+
+
+template <int NP>
+__device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, double*& sCol) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    sAcc = smem;
+    sCol = smem + (M.n + 1) * ACC_STRIDE;     // per-node constants, [NCONST][NP] (see eval_front_e2)
+    if (threadIdx.x < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + threadIdx.x] = 0.0;   // zero row n (end-of-tree suffix)
+    if (threadIdx.x < NP) {
+        const int j = threadIdx.x;
+        const bool in = j < M.n;
+        double* c = sCol;
+        for (int r = 0; r < 36; ++r) c[r * NP + j] = in ? M.K[r * MAXN + j] : 0.0;
+        c += 36 * NP;
+        for (int r = 0; r < 6; ++r) c[r * NP + j] = in ? M.sb[r * MAXN + j] : 0.0;
+        c += 6 * NP;
+        for (int r = 0; r < 4; ++r) c[r * NP + j] = in ? M.I4[r * MAXN + j] : 0.0;
+        c += 4 * NP;
+        for (int r = 0; r < 8; ++r) c[r * NP + j] = in ? M.prm[r * MAXN + j] : 0.0;
+        c += 8 * NP;
+        c[j] = in ? (double)M.type[j] : 0.0;
+        c += NP;
+        c[j] = in ? __longlong_as_double((long long)M.rel[j]) : 0.0;
+        c[NP + j] = in ? __longlong_as_double((long long)M.rel[MAXN + j]) : 0.0;
+        c += 2 * NP;
+        for (int r = 0; r < MAXROUNDS; ++r) c[r * NP + j] = in ? (double)M.anc[r * MAXN + j] : -1.0;
+        c += MAXROUNDS * NP;
+        c[j] = in ? (double)M.end[j] : (double)M.n;
+        c += NP;
+        for (int r = 0; r < 4; ++r) c[r * NP + j] = (in && M.con) ? M.con[r * MAXN + j] : 0.0;
+    }
+    __syncthreads();
+}
+
+// simLoop (driverRedMaxBDF1.m:57-91): all steps of one trajectory inside one wavefront.
+template <int NP, bool CT>
+__global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpts o, const StepArgs a) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    int iters = 0, halv = 0, status = 0;
+    PivotPolicy piv;
+    for (int s = 0; s < a.nsteps; ++s) {
+        const double q0 = q, qd0 = qd;
+        const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
+        NodeOut last;
+        const double x = newton_node<NP, CT>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
+        qd = (x - q0) / o.h;                       // (:72)
+        q = x;
+        if (a.histT) {                             // Scene.saveHistory (Scene.m:134-161)
+            const double T = wave_sum(last.eT), V = wave_sum(last.eV);
+            if (lane == 0) {
+                a.histT[(size_t)s * a.B + traj] = T;
+                a.histV[(size_t)s * a.B + traj] = V;
+            }
+        }
+    }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+    }
+    if (lane == 0 && a.it) {
+        a.it[traj] += iters;
+        a.ls[traj] += halv;
+        a.status[traj] |= status;
+    }
+}
+
+// simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.
+template <int NP, bool CT>
+__global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpts o, const StepArgs a) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    double qp = id >= 0 ? a.qp[off] : 0.0;       // step k-1 (Joint.q1 / qdot1 in the reference)
+    double qdp = id >= 0 ? a.qdp[off] : 0.0;
+    const bool started = (*a.started) != 0;
+    const double h = o.h;
+    int iters = 0, halv = 0, status = 0;
+    PivotPolicy piv;
+    for (int s = 0; s < a.nsteps; ++s) {
+        NodeOut last;
+        if (s == 0 && !started) {
+            const double al = (2.0 - sqrt(2.0)) / 2.0;    // (:74)
+            const double q0 = q, qd0 = qd;
+            // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
+            const double xa0 = q0 + al * h * qd0;
+            const double qa = newton_node<NP, CT>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv);
+            const double qda = (qa - q0) / (al * h);
+            // SDIRK2b (evalSDIRK2b :228-260)
+            const double x10 = qa + (1.0 - al) * h * qda;
+            const double qA = q0 + (1.0 - al) * h * qda;
+            const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
+            const double q1 = newton_node<NP, CT>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv);
+            qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
+            q = q1;
+            qp = q0;
+            qdp = qd0;
+        } else {
+            // BDF2 (evalBDF2 :263-293): eta = 2h/3
+            const double q0 = qp, qd0 = qdp, q1 = q, qd1 = qd;
+            const double x0 = q1 + h * qd1;
+            const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
+            const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
+            const double q2 = newton_node<NP, CT>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv);
+            qp = q1;
+            qdp = qd1;
+            qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
+            q = q2;
+            // the Newton residual was evaluated with qdot = (q2-qA)/eta, identical up to rounding
+        }
+        if (a.histT) {
+            const double T = wave_sum(last.eT), V = wave_sum(last.eV);
+            if (lane == 0) {
+                a.histT[(size_t)s * a.B + traj] = T;
+                a.histV[(size_t)s * a.B + traj] = V;
+            }
+        }
+    }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+        a.qp[off] = qp;
+        a.qdp[off] = qdp;
+    }
+    if (lane == 0 && a.it) {
+        a.it[traj] += iters;
+        a.ls[traj] += halv;
+        a.status[traj] |= status;
+    }
+}
+
+// euler (matlab-simple/testRedMax.m:67-109), BASELINE.json configs[0]: linearly-implicit Euler,
+//   Mr = J'MmJ ; (Mr + h Dr - h^2 Kr) qdot1 = Mr qdot0 + h (J'(fm - Mm Jdot qdot0) + fr) ; q1 = q0 + h qdot1
+// with the same front as the implicit integrators: the right-hand side is g(v = qdot0, e2 = -h) plus h*damping*qdot0
+// (matlab-simple drops the joint damping FORCE, testRedMax.m:84), the matrix is eval_mass + the joint diagonals.
+template <int NP>
+__global__ void __launch_bounds__(64) k_step_euler(const DevModel M, const double h, const StepArgs a) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    for (int s = 0; s < a.nsteps; ++s) {
+        FrontState fs;
+        NodeOut e;
+        double Mrow[NP];
+        eval_front_e2<NP, true>(M, sAcc, lane, q, qd, qd, 0.0, -h, e, fs);
+        eval_mass<NP>(M, lane, fs, Mrow);
+        const double rhs = e.g + h * fs.dd * qd;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (i == lane && fs.dof) Mrow[i] += h * fs.dd + h * h * fs.kd;
+        const double qd1 = lu_solve_neg<NP>(M.n, lane, Mrow, -rhs);
+        q = q + h * qd1;
+        qd = qd1;
+        if (a.histT) {
+            eval_front<NP, false>(M, sAcc, lane, q, qd, 0.0, 1.0, e, fs);
+            const double T = wave_sum(e.eT), V = wave_sum(e.eV);
+            if (lane == 0) {
+                a.histT[(size_t)s * a.B + traj] = T;
+                a.histV[(size_t)s * a.B + traj] = V;
+            }
+        }
+    }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+    }
+}
+
+// ---------------------------------------------------------------- adjoint BDF1 (BASELINE.json configs[3])
+//
+// taskObjective of driverRedMaxAdjointBDF1.m:39-62 for TaskBDF1PointPos, batched: parameters p[B][nr] are constant joint
+// torques tau = pscale*p (TaskBDF1PointPos.applyStep :58-64).  Forward = simLoop :65-102 with the line-search-free newton
+// :105-146; per step the H, M, D of the LAST EVALUATED iterate are kept in HBM ([B][nsteps][n*n], column-major over nodes),
+// which is what Scene.saveHistory stores (the reference keeps lu(H), the backward kernel re-factors H').  Backward =
+// TaskBDF1.calcFinal :45-81.
+
+template <int NP>
+__global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
+    const int id = (lane < n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    const double pj = id >= 0 ? a.p[off] : 0.0;
+    const double h = o.h;
+    FrontState fs;
+    fs.tau_add = a.pscale * pj;
+    // does the task body hang below (or at) this lane's joint?  (rows of J(idxM_body, :) that are non-zero)
+    const bool on_path = lane < n && (lane == a.task_node || ((M.rel[MAXN + lane] >> a.task_node) & 1ull));
+    int iters = 0, status = 0;
+    double Ptask = 0.0;
+    const size_t nn = (size_t)n * n;
+    for (int s = 1; s <= a.nsteps; ++s) {
+        const double q0 = q, qd0 = qd;
+        const double xB = q0 + h * qd0;
+        double x = xB;
+        double* Hk = a.Hs + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        double* Mk = a.Ms + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        double* Dk = a.Ds + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        double Jw[3] = {0.0, 0.0, 0.0}, Jv[3] = {0.0, 0.0, 0.0};   // J(idxM_body, this joint) of the last evaluated iterate
+        int iter = 1;
+        while (true) {
+            NodeOut e;
+            double Hrow[NP];
+            eval_front<NP, true>(M, sAcc, lane, x, (x - q0) / h, x - xB, h, e, fs);
+            eval_hess<NP>(M, lane, fs, Hrow);
+            {
+                double Mrow[NP], Drow[NP];
+                eval_MD<NP>(M, lane, fs, Mrow, Drow);
+                if (lane < n) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        if (i < n) {
+                            Hk[(size_t)i * n + lane] = Hrow[i];
+                            Mk[(size_t)i * n + lane] = Mrow[i];
+                            Dk[(size_t)i * n + lane] = Drow[i];
+                        }
+                }
+            }
+            if (s == a.task_step) {   // J(body rows, joint) = Ad(E_body^-1) s_joint : body-frame twist of the task body per unit qdot
+                double Rb[9], pb[3], t3[3], d3[3];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) Rb[c] = readlane_d(fs.Rw[c], a.task_node);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pb[c] = readlane_d(fs.pw[c], a.task_node);
+                cross3(pb, fs.sw, t3);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d3[c] = fs.sv[c] - t3[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {   // R' (.)
+                    Jw[c] = on_path ? (Rb[c] * fs.sw[0] + Rb[3 + c] * fs.sw[1] + Rb[6 + c] * fs.sw[2]) : 0.0;
+                    Jv[c] = on_path ? (Rb[c] * d3[0] + Rb[3 + c] * d3[1] + Rb[6 + c] * d3[2]) : 0.0;
+                }
+            }
+            ++iters;
+            const double dx = lu_solve_neg<NP>(n, lane, Hrow, e.g);      // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128
+            const double dxn2 = wave_sum(dx * dx);
+            if (!(dxn2 == dxn2)) { status |= 4; break; }
+            if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }            // :129-132
+            x = x + dx;                                                   // :134, before the convergence test
+            if (sqrt(wave_sum(e.g * e.g)) < o.tol) break;                 // :135-138
+            if (iter >= o.iterMax) { status |= 2; break; }                // :139-142
+            ++iter;
+        }
+        qd = (x - q0) / h;
+        q = x;
+        if (s == a.task_step) {    // TaskBDF1PointPos.calcStep :67-107 at the final state of this step
+            NodeOut e;
+            eval_front<NP, false>(M, sAcc, lane, q, qd, 0.0, 1.0, e, fs);
+            double Rb[9], pb[3], dxw[3], vl[3], t3[3];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Rb[c] = readlane_d(fs.Rw[c], a.task_node);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pb[c] = readlane_d(fs.pw[c], a.task_node);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dxw[c] = Rb[3 * c] * a.xl[0] + Rb[3 * c + 1] * a.xl[1] + Rb[3 * c + 2] * a.xl[2] + pb[c] - a.xt[c];
+            Ptask += a.wpos * 0.5 * dot3(dxw, dxw);
+            // dPdq = J' * (R*Gamma(xlocal))' * dx * wp ,  Gamma = [brac(xlocal)', I]  =>  R (v + w x xlocal) . dx * wp
+            const double xl[3] = {a.xl[0], a.xl[1], a.xl[2]};
+            cross3(Jw, xl, t3);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vl[c] = Jv[c] + t3[c];
+            double g3[3];
+            mat3v(Rb, vl, g3);
+            if (lane < n) a.dPdq[(size_t)traj * n + lane] = a.wpos * dot3(g3, dxw);
+        }
+    }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+    }
+    const double preg = wave_sum(pj * pj);
+    if (lane == 0) {
+        a.P[traj] = Ptask + a.wreg * 0.5 * preg;      // TaskBDF1.calcFinal :49
+        if (a.it) {
+            a.it[traj] = iters;
+            a.status[traj] = status;
+        }
+    }
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+    const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
+    const int id = (lane < n) ? M.idx[lane] : -1;
+    const size_t nn = (size_t)n * n;
+    const double h = o.h;
+    const int col = lane < n ? lane : 0;
+    double z1 = 0.0, z2 = 0.0, zs = 0.0;
+    for (int k = a.nsteps; k >= 1; --k) {
+        double y = (k == a.task_step && lane < n) ? a.dPdq[(size_t)traj * n + lane] : 0.0;
+        if (k < a.nsteps) {       // yk -= (-2 M_{k+1} + h D_{k+1})' z_{k+1}     TaskBDF1.m:58-64
+            const double* Mc = a.Ms + ((size_t)traj * a.nsteps + k) * nn + (size_t)col * n;
+            const double* Dc = a.Ds + ((size_t)traj * a.nsteps + k) * nn + (size_t)col * n;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double blk = (j < n && lane < n) ? (-2.0 * Mc[j] + h * Dc[j]) : 0.0;
+                y -= blk * readlane_d(z1, j);
+            }
+        }
+        if (k < a.nsteps - 1) {   // yk -= M_{k+2}' z_{k+2}                      :65-70
+            const double* Mc = a.Ms + ((size_t)traj * a.nsteps + k + 1) * nn + (size_t)col * n;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double blk = (j < n && lane < n) ? Mc[j] : 0.0;
+                y -= blk * readlane_d(z2, j);
+            }
+        }
+        // z_k = H_k'^-1 y_k  (zkk0(Hp) = Hl'\(Hu'\yk) :76): this lane's "row" of H' is column `lane` of H
+        double Hrow[NP];
+        const double* Hc = a.Hs + ((size_t)traj * a.nsteps + (k - 1)) * nn + (size_t)col * n;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? Hc[i] : ((i == lane) ? 1.0 : 0.0);
+        const double z = lu_solve_neg<NP>(n, lane, Hrow, -y);
+        zs += z;
+        z2 = z1;
+        z1 = z;
+    }
+    if (id >= 0) {   // dPdp = wreg*p' - z'*dgdp, dgdp(kk,:) = -h^2*pscale*I      :79, TaskBDF1PointPos.m:104-105
+        const size_t off = (size_t)traj * M.nr + id;
+        a.dPdp[off] = a.wreg * a.p[off] + h * h * a.pscale * zs;
+    }
+}
+
+// Parity hook: one residual (+Hessian) evaluation per trajectory, results to HBM.
+template <int NP, bool WANT_H, bool CT>
+__global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, const double* __restrict__ q,
+                                             const double* __restrict__ qA, const double* __restrict__ qB, const double eta,
+                                             double* __restrict__ g, double* __restrict__ H) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    const double x = id >= 0 ? q[off] : 0.0;
+    const double xa = id >= 0 ? qA[off] : 0.0;
+    const double xb = id >= 0 ? qB[off] : 0.0;
+    NodeOut e;
+    double Hrow[NP];
+    eval_node<NP, WANT_H, false, CT>(M, sAcc, sCol, lane, x, (x - xa) / eta, x - xb, eta, e, Hrow);
+    if (id >= 0) g[off] = e.g;
+    if (WANT_H) {
+        double* Ht = H + (size_t)traj * M.nr * M.nr;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i < M.n) {
+                const int ci = M.idx[i];
+                if (id >= 0 && ci >= 0) Ht[(size_t)ci * M.nr + id] = Hrow[i];   // column-major H(id, ci)
+            }
+        }
+    }
+}
+
+// Joint.computeEnergies / Body.computeEnergies at the stored state.
+template <int NP, bool CT>
+__global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, const double* __restrict__ q,
+                                               const double* __restrict__ qd, double* __restrict__ T, double* __restrict__ V) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    NodeOut e;
+    double Hrow[NP];
+    eval_node<NP, false, false, CT>(M, sAcc, sCol, lane, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, e, Hrow);
+    const double t = wave_sum(e.eT), v = wave_sum(e.eV);
+    if (lane == 0) {
+        T[traj] = t;
+        V[traj] = v;
+    }
+}
+
+// Profiling hook: shader-clock cycles (s_memtime) of the phases of one Newton iteration, measured in place with the
+// production device functions at the production occupancy (one wavefront per trajectory).
+template <int NP>
+__global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int reps, const double* __restrict__ q,
+                                                   const double* __restrict__ qd, const double h, unsigned long long* __restrict__ out) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    const double q0 = id >= 0 ? q[off] : 0.0, qd0 = id >= 0 ? qd[off] : 0.0;
+    double x = q0 + h * qd0;
+    unsigned long long tg = 0, tH = 0, tLU = 0, tred = 0;
+    unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double sink = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        NodeOut e;
+        double Hrow[NP];
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        eval_node<NP, false>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow);
+        sink += e.g;
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        eval_node<NP, true, true>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow, stamps);
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        const double dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        const double s1 = wave_sum(dx * dx) + wave_sum(e.g * e.g);
+        unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        sink += s1;
+        x += 1e-3 * dx;   // keep the iterations data dependent
+        tg += t1 - t0; tH += t2 - t1; tLU += t3 - t2; tred += t4 - t3;
+    }
+    if (lane == 0) {
+        out[16 * traj + 0] = tg; out[16 * traj + 1] = tH; out[16 * traj + 2] = tLU; out[16 * traj + 3] = tred;
+        for (int k = 0; k < 12; ++k) out[16 * traj + 4 + k] = stamps[k];
+    }
+    if (sink == 1.2345e301) out[0] = 0;   // keep the results live
+}
+
+// ============================================================================ launchers (declared in rmx_host.h)
+
+void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
+    const dim3 grid(b->B), block(64);
+    const bool ct = m->dm.con != nullptr;   // scenes with ForceGroundCuboid run the contact instantiations
+    if (wantH && ct) k_eval<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    else if (wantH) k_eval<RMX_NP, true, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    else if (ct) k_eval<RMX_NP, false, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    else k_eval<RMX_NP, false, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+}
+
+void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    const bool ct = m->dm.con != nullptr;
+    if (integ == INTEG_BDF1 && ct) k_step_bdf1<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else if (ct) k_step_bdf2<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else k_step_bdf2<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+}
+
+void RMX_CAT(launch_euler_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double h, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    k_step_euler<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, h, a);
+}
+
+void RMX_CAT(launch_energy_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
+    const dim3 grid(b->B), block(64);
+    if (m->dm.con) k_energy<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
+    else k_energy<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
+}
+
+void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a) {
+    const dim3 grid(b->B), block(64);
+    k_adjoint_fwd<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    k_adjoint_bwd<RMX_NP><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+}
+
+void RMX_CAT(launch_phase_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d) {
+    const dim3 grid(b->B), block(64);
+    k_phase_time<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, reps, b->q, b->qd, h, d);
+}
