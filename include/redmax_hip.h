@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 100
+#define RMX_VERSION 101
 
 enum {
     RMX_OK = 0,
@@ -43,7 +43,15 @@ enum {
     RMX_E_NOMEM = -4
 };
 
-enum { RMX_JOINT_FIXED = 0, RMX_JOINT_REVOLUTE = 1, RMX_JOINT_PRISMATIC = 2 };
+enum {
+    RMX_JOINT_FIXED = 0,          /* JointFixed.m                                                              */
+    RMX_JOINT_REVOLUTE = 1,       /* JointRevolute.m    (axis)                                                 */
+    RMX_JOINT_PRISMATIC = 2,      /* JointPrismatic.m   (axis)                                                 */
+    RMX_JOINT_PLANAR = 3,         /* JointPlanar.m        2 DOF, p = B q            (plane, default x-y)       */
+    RMX_JOINT_TRANSLATIONAL = 4,  /* JointTranslational.m 3 DOF, p = q                                         */
+    RMX_JOINT_UNIVERSAL = 5,      /* JointUniversal.m     2 DOF, R = X(q1) Y(q2)                               */
+    RMX_JOINT_FREE2D = 6          /* JointFree2D.m        3 DOF, Q = [Rz(q3) [q1;q2;0]]                        */
+};
 
 /* rmx_stats.status bits */
 /* RMX_ST_STALLED accompanies RMX_ST_MAXITER when the Newton iteration reached a floating-point fixed point
@@ -73,6 +81,11 @@ typedef struct rmx_model_desc {
     const double* qLimK;
     const double* qLimD;
     double grav[3];          /* Scene.grav                                    Scene.m:48           */
+    /* multi-DOF joints (may be NULL when the scene has none) */
+    const double* plane;     /* [n][6] JointPlanar: the two in-plane directions b1, b2 (normalised by the caller,
+                                JointPlanar.m:16-17); NULL = x-y plane                              */
+    const double* qRestR;    /* [nr] rest position of EVERY DOF in reduced order (Joint.m:157 qRest = q); overrides qRest.
+                                qRest[n] alone only reaches the first DOF of a multi-DOF joint      */
 } rmx_model_desc;
 
 /* Newton constants of driverRedMaxBDF1.m:95-98; rmx_opts_default() fills the reference values. */

@@ -64,6 +64,7 @@ def lib():
             getattr(L, f).restype = C.c_int
         L.orc_idxR.argtypes = [C.c_void_p, _ip]
         L.orc_reset.argtypes = [C.c_void_p]
+        L.orc_set_idxR.argtypes = [C.c_void_p, _ip]
         L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_set_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_set_qrest.argtypes = [C.c_void_p, _dp]
@@ -111,15 +112,97 @@ def make_desc(d, normalize_axis=1):
     return s, keep
 
 
+# sub-joints (type, axis) of the reference's multi-DOF joints, parent first; type codes as in Scene.desc()
+_E = np.eye(3)
+
+
+def _composite_subjoints(jtype, plane):
+    if jtype == 3:      # JointPlanar.m:24-31   Q(1:3,4) = B*q, S = [0; B]
+        return [(2, plane[:3]), (2, plane[3:])]
+    if jtype == 4:      # JointTranslational.m:22-26   Q(1:3,4) = q
+        return [(2, _E[0]), (2, _E[1]), (2, _E[2])]
+    if jtype == 5:      # JointUniversal.m:71-74   R = X1(q1)*Y2(q2)
+        return [(1, _E[0]), (1, _E[1])]
+    if jtype == 6:      # JointFree2D.m:20-33   Q = [Rz(q3) [q1;q2;0]]
+        return [(2, _E[0]), (2, _E[1]), (1, _E[2])]
+    raise ValueError("joint type %d" % jtype)
+
+
+def lower_composite(d):
+    """Restates the reference's multi-DOF joints whose Q(q) is a product of one-parameter motions (JointPlanar,
+    JointTranslational, JointUniversal, JointFree2D) as chains of prismatic/revolute joints with massless intermediate links:
+    same world transforms, same generalised coordinates and velocities, hence the same M, f, K, D.  The chain's DOFs keep the
+    reference's reduced indices idxR = nr + (1:ndof) (Joint.m:152) through orc_set_idxR.  Pinned by Hexpected of scenes
+    4, 5, 6, 8 and 11 (scenesRedMax.m:147-148, 166-167, 189-190, 230-231, 292-293)."""
+    typ = np.asarray(d["type"])
+    n = int(d["njoints"])
+    if not np.any(typ > 2):
+        return d
+    ndof = [0 if t == 0 else 1 if t <= 2 else len(_composite_subjoints(t, np.zeros(6))) for t in typ]
+    base = [0] * n
+    nr = 0
+    for L in range(n - 1, -1, -1):
+        base[L] = nr
+        nr += ndof[L]
+    qR = np.asarray(d["qR"], float)
+    qdR = np.asarray(d["qdotR"], float)
+    qrR = np.asarray(d.get("qRestR", qR), float)
+    out = {k: [] for k in ("parent", "type", "axis", "E0_pj", "E0_ji", "I_i", "q", "qdot", "qRest", "tau", "stiffness", "damping",
+                           "qLimL", "qLimU", "qLimK", "qLimD", "idx", "contact", "sides")}
+    eye16 = np.eye(4).reshape(16)
+    last = [0] * n
+    has_contact = d.get("contact") is not None
+    for L in range(n):
+        if typ[L] <= 2:
+            subs = [(int(typ[L]), np.asarray(d["axis"][L], float))]
+        else:
+            subs = _composite_subjoints(int(typ[L]), np.asarray(d["plane"][L], float))
+        for k, (t, ax) in enumerate(subs):
+            final = k == len(subs) - 1
+            out["parent"].append((last[d["parent"][L]] if d["parent"][L] >= 0 else -1) if k == 0 else len(out["type"]) - 1)
+            out["type"].append(t)
+            out["axis"].append(ax)
+            out["E0_pj"].append(np.asarray(d["E0_pj"][L]) if k == 0 else eye16)
+            out["E0_ji"].append(np.asarray(d["E0_ji"][L]) if final else eye16)
+            out["I_i"].append(np.asarray(d["I_i"][L]) if final else np.zeros(6))
+            i = base[L] + k
+            out["idx"].append(i if t != 0 else -1)
+            out["q"].append(qR[i] if t != 0 else 0.0)
+            out["qdot"].append(qdR[i] if t != 0 else 0.0)
+            out["qRest"].append(qrR[i] if t != 0 else 0.0)
+            for key in ("tau", "stiffness", "damping", "qLimL", "qLimU", "qLimK", "qLimD"):
+                out[key].append(d[key][L])
+            out["contact"].append(int(d["contact"][L]) if (has_contact and final) else 0)
+            out["sides"].append(np.asarray(d["sides"][L]) if (has_contact and final) else np.zeros(3))
+        last[L] = len(out["type"]) - 1
+    low = {"njoints": len(out["type"]), "grav": d["grav"], "idx": np.array(out["idx"], dtype=np.int32), "last_of_listing": last}
+    for k in ("parent", "type"):
+        low[k] = np.array(out[k], dtype=np.int32)
+    for k in ("axis", "E0_pj", "E0_ji", "I_i"):
+        low[k] = np.ascontiguousarray(np.stack(out[k]), dtype=np.float64)
+    for k in ("q", "qdot", "qRest", "tau", "stiffness", "damping", "qLimL", "qLimU", "qLimK", "qLimD"):
+        low[k] = np.array(out[k], dtype=np.float64)
+    if has_contact:
+        low["contact"] = np.array(out["contact"], dtype=np.int32)
+        low["sides"] = np.ascontiguousarray(np.stack(out["sides"]), dtype=np.float64)
+        low["ground"] = d["ground"]
+    return low
+
+
 class Oracle:
     """One reference scene on the CPU oracle."""
 
     def __init__(self, desc_dict, normalize_axis=1):
         self._L = lib()
+        desc_dict = lower_composite(desc_dict)
         self._d, self._keep = make_desc(desc_dict, normalize_axis)
         self._h = C.c_void_p(self._L.orc_create(C.byref(self._d)))
         self.nr = self._L.orc_nr(self._h)
         self.nm = self._L.orc_nm(self._h)
+        if "idx" in desc_dict:
+            self._idx = np.ascontiguousarray(desc_dict["idx"], dtype=np.int32)
+            if self._L.orc_set_idxR(self._h, self._idx.ctypes.data_as(_ip)) != 0:
+                raise ValueError("idx is not a permutation of the reduced DOFs")
         if "qRest" in desc_dict:
             self.set_qrest_joint_order(desc_dict["qRest"])
         if desc_dict.get("contact") is not None and np.any(desc_dict["contact"]):

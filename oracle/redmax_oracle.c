@@ -298,6 +298,22 @@ void orc_set_qrest(orc_scene* s, const double* qrest) {
     for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) s->nd[i].qRest = qrest[s->nd[i].idxR];
 }
 
+/* Overrides the reduced numbering: idx[i] for every joint with a DOF (a permutation of 0..nr-1).  Used when a multi-DOF
+ * joint of the reference (JointPlanar / Translational / Universal / Free2D, whose idxR = nr + (1:ndof), Joint.m:152) is
+ * restated as a chain of 1-DOF joints: the chain's DOFs then keep the reference's order q(1), q(2), ... */
+int orc_set_idxR(orc_scene* s, const int* idx) {
+    char* seen = (char*)calloc((size_t)(s->nr > 0 ? s->nr : 1), 1);
+    for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) {
+        if (idx[i] < 0 || idx[i] >= s->nr || seen[idx[i]]) { free(seen); return -1; }
+        seen[idx[i]] = 1;
+    }
+    free(seen);
+    for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) s->nd[i].idxR = idx[i];
+    orc_get_state(s, s->qInit, s->qdotInit);
+    orc_reset(s);
+    return 0;
+}
+
 /* Scene.reset (Scene.m:122-131) */
 void orc_reset(orc_scene* s) {
     set_q(s, s->qInit, s->qdotInit);

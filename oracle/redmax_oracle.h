@@ -55,6 +55,7 @@ void orc_destroy(orc_scene* s);
 int  orc_nr(const orc_scene* s);
 int  orc_nm(const orc_scene* s);
 void orc_idxR(const orc_scene* s, int* idx);            /* [n] 0-based start of each joint's reduced index, -1 if ndof=0 */
+int  orc_set_idxR(orc_scene* s, const int* idx);        /* explicit reduced numbering (lowered multi-DOF joints) */
 void orc_reset(orc_scene* s);                           /* Scene.reset() Scene.m:122-131 */
 void orc_get_state(const orc_scene* s, double* q, double* qdot);   /* Joint.getQ  */
 void orc_set_state(orc_scene* s, const double* q, const double* qdot); /* Joint.setQ + update() */

@@ -41,6 +41,7 @@ class ModelDesc(C.Structure):
         ("qRest", _dp), ("tau", _dp), ("stiffness", _dp), ("damping", _dp),
         ("qLimL", _dp), ("qLimU", _dp), ("qLimK", _dp), ("qLimD", _dp),
         ("grav", C.c_double * 3),
+        ("plane", _dp), ("qRestR", _dp),
     ]
 
 
@@ -146,4 +147,6 @@ def make_desc(d):
         setattr(s, k, f64(k))
     for i in range(3):
         s.grav[i] = float(d["grav"][i])
+    s.plane = f64("plane") if d.get("plane") is not None else None
+    s.qRestR = f64("qRestR") if d.get("qRestR") is not None and len(d["qRestR"]) else None
     return s, keep

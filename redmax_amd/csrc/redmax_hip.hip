@@ -101,7 +101,9 @@ void m3v(const double A[9], const double x[3], double y[3]) {
 
 }  // namespace
 
-extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model** out) {
+// Scene.init() for a listing of fixed / revolute / prismatic joints.  idx_explicit (or NULL): reduced index of every listed
+// joint, given when the listing is the lowered form of a scene with multi-DOF joints (rmx_model_create below).
+static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, int device, rmx_model** out) {
     if (!d || !out) return fail(RMX_E_INVALID, "null argument");
     *out = nullptr;
     int ndev = rmx_device_count();
@@ -113,7 +115,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
         return fail(RMX_E_INVALID, "parent/type/axis/E0_pj/E0_ji/I_i are required");
     // ---- validate the listing: exactly one root first, parents before children (Scene.m:66-67)
     for (int i = 0; i < n; ++i) {
-        if (d->type[i] < 0 || d->type[i] > 2) return fail(RMX_E_INVALID, "unsupported joint type (only fixed/revolute/prismatic are in scope)");
+        if (d->type[i] < 0 || d->type[i] > 2) return fail(RMX_E_INVALID, "unsupported joint type");
         if (i == 0 && d->parent[i] != -1) return fail(RMX_E_INVALID, "joint 0 must be the root");
         if (i > 0 && (d->parent[i] < 0 || d->parent[i] >= i)) return fail(RMX_E_INVALID, "joints must be listed parent-before-child with a single root");
     }
@@ -121,7 +123,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     std::vector<int> idxL(n, -1);
     int nr = 0;
     for (int i = n - 1; i >= 0; --i)
-        if (d->type[i] != RMX_JOINT_FIXED) idxL[i] = nr++;
+        if (d->type[i] != RMX_JOINT_FIXED) idxL[i] = idx_explicit ? idx_explicit[i] : nr, ++nr;
     // ---- depth-first order (children in listing order); identity for the reference's scenes
     std::vector<std::vector<int>> kids(n);
     for (int i = 1; i < n; ++i) kids[d->parent[i]].push_back(i);
@@ -276,6 +278,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     m->device = device;
     m->n = n;
     m->nr = nr;
+    m->nlist = n;
     m->nm = 6 * n;
     m->idx_listing = idxL;
     m->node_of_listing = pos;
@@ -311,6 +314,110 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     return RMX_OK;
 }
 
+// Scene.init() (Scene.m:59-119).  Multi-DOF joints whose Q(q) is a product of one-parameter motions are lowered to a chain of
+// 1-DOF nodes, parent first, the last one carrying the body and the others massless (E0_ji = I, I_i = 0):
+//   JointPlanar        (JointPlanar.m:24-31)          prismatic(b1) . prismatic(b2)
+//   JointTranslational (JointTranslational.m:22-26)   prismatic(x) . prismatic(y) . prismatic(z)
+//   JointUniversal     (JointUniversal.m:71-74)       revolute(x) . revolute(y)            R = X1(q1) Y2(q2)
+//   JointFree2D        (JointFree2D.m:20-33)          prismatic(x) . prismatic(y) . revolute(z)   Q = [Rz(q3) [q1;q2;0]]
+// Same world transforms, coordinates and velocities, hence the same M, f, K, D; DOF k of joint j keeps the reference's reduced
+// index idxR(k) = nr + k with joints counted from the last listed to the first (Joint.countDofs, Joint.m:149-158).
+extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model** out) {
+    if (!d || !out) return fail(RMX_E_INVALID, "null argument");
+    const int n = d->njoints;
+    if (n < 1 || n > MAXN) return fail(RMX_E_INVALID, "njoints must be in [1," + std::to_string(MAXN) + "] (one wavefront per tree)");
+    if (!d->parent || !d->type || !d->axis || !d->E0_pj || !d->E0_ji || !d->I_i)
+        return fail(RMX_E_INVALID, "parent/type/axis/E0_pj/E0_ji/I_i are required");
+    bool composite = false;
+    for (int i = 0; i < n; ++i) {
+        if (d->type[i] < 0 || d->type[i] > RMX_JOINT_FREE2D)
+            return fail(RMX_E_INVALID, "unsupported joint type (fixed/revolute/prismatic/planar/translational/universal/free2D are in scope)");
+        if (d->type[i] > RMX_JOINT_PRISMATIC) composite = true;
+        if (i > 0 && (d->parent[i] < 0 || d->parent[i] >= i)) return fail(RMX_E_INVALID, "joints must be listed parent-before-child with a single root");
+    }
+    if (!composite && !d->qRestR) return model_create_flat(d, nullptr, device, out);
+
+    struct Sub { int type; double ax[3]; };
+    auto subs_of = [&](int L, std::vector<Sub>& v) -> bool {
+        v.clear();
+        const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ez[3] = {0, 0, 1};
+        auto add = [&](int t, const double* a) { v.push_back(Sub{t, {a[0], a[1], a[2]}}); };
+        switch (d->type[L]) {
+            case RMX_JOINT_PLANAR:
+                if (d->plane) { add(RMX_JOINT_PRISMATIC, d->plane + 6 * L); add(RMX_JOINT_PRISMATIC, d->plane + 6 * L + 3); }
+                else { add(RMX_JOINT_PRISMATIC, ex); add(RMX_JOINT_PRISMATIC, ey); }     // JointPlanar.m:13-15 default plane
+                break;
+            case RMX_JOINT_TRANSLATIONAL: add(RMX_JOINT_PRISMATIC, ex); add(RMX_JOINT_PRISMATIC, ey); add(RMX_JOINT_PRISMATIC, ez); break;
+            case RMX_JOINT_UNIVERSAL: add(RMX_JOINT_REVOLUTE, ex); add(RMX_JOINT_REVOLUTE, ey); break;
+            case RMX_JOINT_FREE2D: add(RMX_JOINT_PRISMATIC, ex); add(RMX_JOINT_PRISMATIC, ey); add(RMX_JOINT_REVOLUTE, ez); break;
+            default: add(d->type[L], d->axis + 3 * L); break;
+        }
+        return true;
+    };
+    // reference numbering of every DOF
+    std::vector<int> base(n), ndof(n);
+    std::vector<Sub> sv;
+    int nr = 0;
+    for (int L = n - 1; L >= 0; --L) {
+        subs_of(L, sv);
+        ndof[L] = d->type[L] == RMX_JOINT_FIXED ? 0 : (int)sv.size();
+        base[L] = nr;
+        nr += ndof[L];
+    }
+    std::vector<int> parent, type, idx, last(n);
+    std::vector<double> axis, E0_pj, E0_ji, I_i, qRest, tau, stiff, damp, qLimL, qLimU, qLimK, qLimD;
+    const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int L = 0; L < n; ++L) {
+        subs_of(L, sv);
+        for (size_t k = 0; k < sv.size(); ++k) {
+            const bool fin = k + 1 == sv.size();
+            parent.push_back(k == 0 ? (d->parent[L] < 0 ? -1 : last[d->parent[L]]) : (int)type.size() - 1);
+            type.push_back(sv[k].type);
+            axis.insert(axis.end(), sv[k].ax, sv[k].ax + 3);
+            const double* epj = k == 0 ? d->E0_pj + 16 * L : I16;
+            const double* eji = fin ? d->E0_ji + 16 * L : I16;
+            E0_pj.insert(E0_pj.end(), epj, epj + 16);
+            E0_ji.insert(E0_ji.end(), eji, eji + 16);
+            for (int c = 0; c < 6; ++c) I_i.push_back(fin ? d->I_i[6 * L + c] : 0.0);
+            const int ri = base[L] + (int)k;
+            idx.push_back(sv[k].type == RMX_JOINT_FIXED ? -1 : ri);
+            qRest.push_back(sv[k].type == RMX_JOINT_FIXED ? 0.0 : d->qRestR ? d->qRestR[ri] : (k == 0 && d->qRest) ? d->qRest[L] : 0.0);
+            tau.push_back(d->tau ? d->tau[L] : 0.0);
+            stiff.push_back(d->stiffness ? d->stiffness[L] : 0.0);
+            damp.push_back(d->damping ? d->damping[L] : 0.0);
+            qLimL.push_back(d->qLimL ? d->qLimL[L] : -1e8);
+            qLimU.push_back(d->qLimU ? d->qLimU[L] : 1e8);
+            qLimK.push_back(d->qLimK ? d->qLimK[L] : 1e8);
+            qLimD.push_back(d->qLimD ? d->qLimD[L] : 0.0);
+        }
+        last[L] = (int)type.size() - 1;
+    }
+    if ((int)type.size() > MAXN)
+        return fail(RMX_E_INVALID, "the scene needs " + std::to_string(type.size()) + " 1-DOF nodes after lowering its multi-DOF joints; the limit is " + std::to_string(MAXN));
+    rmx_model_desc x{};
+    x.njoints = (int)type.size();
+    x.parent = parent.data(); x.type = type.data(); x.axis = axis.data();
+    x.E0_pj = E0_pj.data(); x.E0_ji = E0_ji.data(); x.I_i = I_i.data();
+    x.qRest = qRest.data(); x.tau = tau.data(); x.stiffness = stiff.data(); x.damping = damp.data();
+    x.qLimL = qLimL.data(); x.qLimU = qLimU.data(); x.qLimK = qLimK.data(); x.qLimD = qLimD.data();
+    for (int c = 0; c < 3; ++c) x.grav[c] = d->grav[c];
+    rmx_model* m = nullptr;
+    const int rc = model_create_flat(&x, idx.data(), device, &m);
+    if (rc) return rc;
+    // what the caller sees follows ITS listing: body L is the last node of joint L's chain, idxR(L) its first DOF
+    std::vector<int> node_of(n), idxL(n);
+    for (int L = 0; L < n; ++L) {
+        node_of[L] = m->node_of_listing[last[L]];
+        idxL[L] = ndof[L] ? base[L] : -1;
+    }
+    m->nlist = n;
+    m->nm = 6 * n;
+    m->node_of_listing = node_of;
+    m->idx_listing = idxL;
+    *out = m;
+    return RMX_OK;
+}
+
 extern "C" void rmx_model_destroy(rmx_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
@@ -327,7 +434,7 @@ extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_conta
     HIPCHK(hipSetDevice(m->device));
     std::vector<double> con(4 * MAXN, 0.0);
     bool any = false;
-    for (int L = 0; L < m->n; ++L) {
+    for (int L = 0; L < m->nlist; ++L) {
         const int k = m->node_of_listing[L];
         con[k] = gc->flags[L] ? 1.0 : 0.0;
         any = any || gc->flags[L];
@@ -350,7 +457,7 @@ extern "C" int rmx_model_nr(const rmx_model* m) { return m ? m->nr : RMX_E_INVAL
 extern "C" int rmx_model_nm(const rmx_model* m) { return m ? m->nm : RMX_E_INVALID; }
 extern "C" int rmx_model_idxR(const rmx_model* m, int* idx) {
     if (!m || !idx) return fail(RMX_E_INVALID, "null argument");
-    for (int i = 0; i < m->n; ++i) idx[i] = m->idx_listing[i];
+    for (int i = 0; i < m->nlist; ++i) idx[i] = m->idx_listing[i];
     return RMX_OK;
 }
 
@@ -584,7 +691,7 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
     rmx_model* m = b->m;
     if (nsteps < 1) return fail(RMX_E_INVALID, "nsteps < 1");
     if (m->dm.con) return fail(RMX_E_INVALID, "rmx_adjoint_bdf1: ground contact is outside the adjoint path (SURVEY.md 8(f))");
-    if (task->body < 0 || task->body >= m->n) return fail(RMX_E_INVALID, "task body out of range");
+    if (task->body < 0 || task->body >= m->nlist) return fail(RMX_E_INVALID, "task body out of range");
     if (task->step < 1 || task->step > nsteps) return fail(RMX_E_INVALID, "task step must be in [1, nsteps]");
     HIPCHK(hipSetDevice(m->device));
     DevOpts o;

@@ -42,7 +42,8 @@ struct AdjArgs {
 
 struct rmx_model {
     int device = 0;
-    int n = 0, nr = 0, nm = 0, NP = 0;
+    int n = 0, nr = 0, nm = 0, NP = 0;   // n: 1-DOF nodes on the device (after lowering multi-DOF joints)
+    int nlist = 0;                      // joints/bodies in the caller's listing
     std::vector<int> idx_listing;   // reduced index per LISTED joint (-1 fixed)
     std::vector<int> node_of_listing;   // depth-first node index of each LISTED joint/body
     void* dbuf = nullptr;           // one device allocation holding all constant arrays

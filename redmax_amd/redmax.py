@@ -11,8 +11,10 @@ computeMassGrav / newton ...) is replaced by the HIP kernels behind the C ABI.
 
 Only what the path needs is mirrored: Body/BodyCuboid (Body.m, BodyCuboid.m),
 Joint + JointRevolute/JointPrismatic/JointFixed (Joint.m, JointRevolute.m,
-JointPrismatic.m, JointFixed.m) and Scene (Scene.m init/reset/saveHistory/plotEnergies).
-Drawing, FD self-tests and the other joint/force types are out of scope.
+JointPrismatic.m, JointFixed.m), the multi-DOF joints whose motion is a product of one-parameter motions
+(JointPlanar.m, JointTranslational.m, JointUniversal.m, JointFree2D.m; rmx_model_create lowers them to chains of
+1-DOF nodes with massless links), ForceGroundCuboid and Scene (Scene.m init/reset/saveHistory/plotEnergies).
+Drawing, FD self-tests, JointSpherical/JointFree3D and the other force types are out of scope.
 """
 from __future__ import annotations
 
@@ -25,6 +27,10 @@ from . import se3
 JOINT_FIXED = 0
 JOINT_REVOLUTE = 1
 JOINT_PRISMATIC = 2
+JOINT_PLANAR = 3
+JOINT_TRANSLATIONAL = 4
+JOINT_UNIVERSAL = 5
+JOINT_FREE2D = 6
 
 
 class Body:
@@ -150,6 +156,40 @@ class JointFixed(Joint):
         super().__init__(parent, body, 0)
 
 
+class JointPlanar(Joint):
+    """2-DOF translation in the plane spanned by the (normalised) columns of ``plane`` (JointPlanar.m:11-19, 24-31)."""
+    jtype = JOINT_PLANAR
+
+    def __init__(self, parent, body, plane=None):
+        super().__init__(parent, body, 2)
+        B = np.array([[1, 0, 0], [0, 1, 0]], dtype=np.float64).T if plane is None else np.array(plane, dtype=np.float64).reshape(3, 2)
+        self.plane = B / np.linalg.norm(B, axis=0, keepdims=True)
+
+
+class JointTranslational(Joint):
+    """3-DOF translation, Q(1:3,4) = q (JointTranslational.m:22-26)."""
+    jtype = JOINT_TRANSLATIONAL
+
+    def __init__(self, parent, body):
+        super().__init__(parent, body, 3)
+
+
+class JointUniversal(Joint):
+    """Rotation about X then Y, R = X1(q1) Y2(q2) (JointUniversal.m:20-28, 71-74)."""
+    jtype = JOINT_UNIVERSAL
+
+    def __init__(self, parent, body):
+        super().__init__(parent, body, 2)
+
+
+class JointFree2D(Joint):
+    """Free motion in the XY plane, Q = [Rz(q3) [q1;q2;0]] (JointFree2D.m:20-33)."""
+    jtype = JOINT_FREE2D
+
+    def __init__(self, parent, body):
+        super().__init__(parent, body, 3)
+
+
 class ForceGroundCuboid:
     """Penalty ground contact with friction on the 8 corners of a cuboid (matlab-diff/+redmax/ForceGroundCuboid.m:1-47).
     Same setters as the reference; the numerics live in the HIP kernels."""
@@ -231,7 +271,8 @@ class Scene:
             nr += j.ndof
             j.body.idxM = list(range(nm, nm + 6))
             nm += 6
-            j.qRest = float(j.q[0]) if j.ndof else 0.0   # Joint.m:157
+            j.qRest = float(j.q[0]) if j.ndof else 0.0   # Joint.m:157 (qRest = q; every DOF, see desc()["qRestR"])
+            j.qRestAll = np.array(j.q[:j.ndof], dtype=np.float64)
         self.nr, self.nm = nr, nm
         for j in joints:
             if j.parent is not None and j.E0_pj is None:
@@ -251,16 +292,16 @@ class Scene:
         qdot = np.zeros(self.nr)
         for j in self.joints:
             if j.ndof:
-                q[j.idxR[0]] = j.q[0]
-                qdot[j.idxR[0]] = j.qdot[0]
+                q[j.idxR] = j.q[:j.ndof]
+                qdot[j.idxR] = j.qdot[:j.ndof]
         return q, qdot
 
     def setQ(self, q, qdot=None):
         for j in self.joints:
             if j.ndof:
-                j.q[0] = q[j.idxR[0]]
+                j.q[:j.ndof] = np.asarray(q)[j.idxR]
                 if qdot is not None:
-                    j.qdot[0] = qdot[j.idxR[0]]
+                    j.qdot[:j.ndof] = np.asarray(qdot)[j.idxR]
 
     @staticmethod
     def _cm(E):
@@ -292,6 +333,11 @@ class Scene:
             "qLimK": np.array([j.qLimK for j in joints], dtype=np.float64),
             "qLimD": np.array([j.qLimD for j in joints], dtype=np.float64),
             "grav": np.array(self.grav, dtype=np.float64).reshape(3),
+            # multi-DOF joints: plane of JointPlanar, and the state / rest positions of every DOF in reduced order
+            "plane": np.ascontiguousarray(np.stack([getattr(j, "plane", np.zeros((3, 2))).T.reshape(6) for j in joints])),
+            "qR": self.getQ()[0],
+            "qdotR": self.getQ()[1],
+            "qRestR": np.concatenate([np.zeros(0)] + [getattr(j, "qRestAll", np.array(j.q[:j.ndof], dtype=np.float64)) for j in reversed(joints)]),
         }
         if self.forces:
             f0 = self.forces[0]

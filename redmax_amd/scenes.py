@@ -13,7 +13,8 @@ import math
 import numpy as np
 
 from . import se3
-from .redmax import BodyCuboid, ForceGroundCuboid, JointFixed, JointPrismatic, JointRevolute, Scene
+from .redmax import (BodyCuboid, ForceGroundCuboid, JointFixed, JointFree2D, JointPlanar, JointPrismatic, JointRevolute,
+                     JointTranslational, JointUniversal, Scene)
 
 BDF1 = 1
 BDF2 = 2
@@ -125,32 +126,76 @@ def scenesRedMax(sceneID):
             j.setLimitStiffness(1e5)
             j.setLimitDamping(1e2)
             j.setDamping(1e2)
+    elif sceneID == 4 or sceneID == 5:
+        if sceneID == 4:
+            scene.name = "Planar joint"
+            scene.Hexpected[BDF1 - 1] = -4.5738939646068720e04   # scenesRedMax.m:147
+            scene.Hexpected[BDF2 - 1] = -4.7000178355609387e02   # :148
+        else:
+            scene.name = "Translational joint"
+            scene.Hexpected[BDF1 - 1] = 3.3661704151378050e04    # :166
+            scene.Hexpected[BDF2 - 1] = 3.3377464890219308e04    # :167
+            scene.tEnd = 2.0
+            scene.grav = np.zeros(3)
+        b = [BodyCuboid(density, [10, 10, 1]), BodyCuboid(density, [1, 1, 10]), BodyCuboid(density, [1, 1, 10])]
+        scene.bodies = b
+        j1 = JointPlanar(None, b[0]) if sceneID == 4 else JointTranslational(None, b[0])
+        j2 = JointRevolute(j1, b[1], [0, 1, 0])
+        j3 = JointRevolute(j1, b[2], [1, 0, 0])
+        scene.joints = [j1, j2, j3]
+        j1.setJointTransform(np.eye(4))
+        j2.setJointTransform(_T([-5, 0, 0]))
+        j3.setJointTransform(_T([0, -5, 0]))
+        b[0].setBodyTransform(np.eye(4))
+        b[1].setBodyTransform(_T([0, 0, -5]))
+        b[2].setBodyTransform(_T([0, 0, -5]))
+        if sceneID == 4:
+            j2.q[0] = math.pi / 2                                # :162-163
+            j3.q[0] = math.pi / 4
+        else:
+            j2.qdot[0] = -10.0                                   # :182-185
+            j3.qdot[0] = 10.0
+    elif sceneID == 6:
+        scene.name = "Free2D joint"
+        scene.Hexpected[BDF1 - 1] = 2.0322933333333378e04        # :189
+        scene.Hexpected[BDF2 - 1] = 2.1283333333333332e04        # :190
+        scene.h = 5e-3
+        scene.tEnd = 0.4
+        scene.grav = np.array([0.0, -980.0, 0.0])
+        b = BodyCuboid(density, [1, 1, 1])
+        j = JointFree2D(None, b)
+        j.q[:] = [-10.0, -10.0, 0.0]
+        j.qdot[:] = [50.0, 200.0, 20.0]
+        j.setJointTransform(np.eye(4))
+        b.setBodyTransform(np.eye(4))
+        scene.bodies, scene.joints = [b], [j]
+    elif sceneID == 8:
+        scene.name = "Universal joint"
+        scene.Hexpected[BDF1 - 1] = -2.5276246935781084e04       # :230
+        scene.Hexpected[BDF2 - 1] = -1.3781281283808785e03       # :231
+        for i in range(1, 4):
+            scene.bodies.append(BodyCuboid(density, [1, 1, 10]))
+            j = JointUniversal(scene.joints[-1] if i > 1 else None, scene.bodies[-1])
+            j.setJointTransform(np.eye(4) if i == 1 else _T([0, 0, -10]))
+            scene.bodies[-1].setBodyTransform(_T([0, 0, -5]))
+            j.q[0 if i % 2 == 1 else 1] = math.pi / 8            # :242-246
+            scene.joints.append(j)
     elif sceneID == 11:
-        # scenesRedMax.m:290-311 'Free2D with ground'.  JointFree2D (JointFree2D.m:20-33: Q = [Rz(q3) [q1;q2;0]], S = body-frame
-        # twist per (xdot, ydot, thetadot)) is out of scope as a joint type; it is reproduced EXACTLY by a serial chain
-        # prismatic-x / prismatic-y / revolute-z whose two intermediate links are massless (density 0): same transform, same
-        # generalised coordinates and velocities, same M, f.  The reduced index order differs (leaf-to-root per joint) but
-        # energies do not depend on it, so the reference's Hexpected pins ForceGroundCuboid.
+        # scenesRedMax.m:290-311 'Free2D with ground': pins ForceGroundCuboid through Hexpected
         scene.name = "Free2D with ground"
         scene.Hexpected[BDF1 - 1] = -4.4208045000000002e03    # :292 (the reference notes BDF1 "doesn't work" for this scene)
         scene.Hexpected[BDF2 - 1] = -2.7811251900394832e03    # :293
         scene.h = 5e-4
         scene.tEnd = 0.6
         scene.grav = np.array([0.0, -980.0, 0.0])
-        bx = BodyCuboid(0.0, [1, 1, 1])
-        by = BodyCuboid(0.0, [1, 1, 1])
         b = BodyCuboid(density, [3, 1, 1])
-        jx = JointPrismatic(None, bx, [1, 0, 0])
-        jy = JointPrismatic(jx, by, [0, 1, 0])
-        jr = JointRevolute(jy, b, [0, 0, 1])
-        for j in (jx, jy, jr):
-            j.setJointTransform(np.eye(4))
-        for bb in (bx, by, b):
-            bb.setBodyTransform(np.eye(4))
-        jx.q[0], jy.q[0], jr.q[0] = -1.0, 2.0, 0.0
-        jx.qdot[0], jy.qdot[0], jr.qdot[0] = 5.0, 70.0, 2.0
-        scene.bodies = [bx, by, b]
-        scene.joints = [jx, jy, jr]
+        j = JointFree2D(None, b)
+        j.setJointTransform(np.eye(4))
+        b.setBodyTransform(np.eye(4))
+        j.q[:] = [-1.0, 2.0, 0.0]
+        j.qdot[:] = [5.0, 70.0, 2.0]
+        scene.bodies = [b]
+        scene.joints = [j]
         f = ForceGroundCuboid(b)
         f.setTransform(se3.transform(R=se3.aaToMat([1, 0, 0], -math.pi / 2)))
         f.setStiffness(1e5, 1e2)
@@ -164,7 +209,8 @@ def scenesRedMax(sceneID):
     return scene
 
 
-IN_SCOPE_SCENES = (0, 1, 2, 3, 14)
+IN_SCOPE_SCENES = (0, 1, 2, 3, 14)          # 0/1-DOF joints only
+COMPOSITE_SCENES = (4, 5, 6, 8)             # JointPlanar / Translational / Free2D / Universal (lowered to 1-DOF chains)
 
 
 def sceneAdjointChain(n=2):

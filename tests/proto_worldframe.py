@@ -70,6 +70,8 @@ def build_model(d):
         if typ[j] != 0:
             idx[j] = nr
             nr += 1
+    if d.get("idx") is not None:                 # lowered multi-DOF joints keep the reference's numbering
+        idx = [int(k) for k in d["idx"]]
     m.update(L=L, Rt=Rt, sb=sb, axis=axes, idx=idx, nr=nr, I=np.asarray(d["I_i"], float))
     for k in ("tau", "stiffness", "damping", "qRest", "qLimL", "qLimU", "qLimK", "qLimD"):
         m[k] = np.asarray(d[k], float)

@@ -28,7 +28,7 @@ def _penetrating_states(name, nr, h, B, rng):
     qd0 = np.empty((B, nr))
     for b in range(B):
         if name == "11":
-            q0[b] = np.array([0.3, rng.uniform(-0.4, 0.4), rng.uniform(-1, 1)])[::-1]     # idx order: theta, y, x
+            q0[b] = np.array([rng.uniform(-1, 1), rng.uniform(-0.4, 0.4), 0.3])           # JointFree2D: x, y, theta
             qd0[b] = rng.normal(size=nr) * (50 if b % 2 else 0.5)
         else:
             q0[b] = rng.uniform(-0.4, 0.4, nr)

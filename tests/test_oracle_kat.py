@@ -8,7 +8,7 @@ acceptance threshold is |dH| <= 1e-2 (Scene.m:173); we hold the oracle to 1e-9 r
 import numpy as np
 import pytest
 
-from redmax_amd.scenes import IN_SCOPE_SCENES, scenesRedMax
+from redmax_amd.scenes import COMPOSITE_SCENES, IN_SCOPE_SCENES, scenesRedMax
 
 
 @pytest.mark.parametrize("sid", IN_SCOPE_SCENES)
@@ -60,8 +60,8 @@ def test_index_layout_is_leaf_to_root(oracle_lib):
 
 
 def test_ground_contact_scene11_kat(oracle_lib):
-    """Scene 11 'Free2D with ground' (scenesRedMax.m:290-311) pins ForceGroundCuboid.m:54-183.  JointFree2D is reproduced
-    by a prismatic-x / prismatic-y / revolute-z chain with massless links (scenes.py).  BDF1 reproduces the golden to the
+    """Scene 11 'Free2D with ground' (scenesRedMax.m:290-311) pins ForceGroundCuboid.m:54-183.  JointFree2D is restated
+    as a prismatic-x / prismatic-y / revolute-z chain with massless links (oracle.lower_composite).  BDF1 reproduces the golden to the
     last digit; the BDF2 run (1200 steps through impact, stick/slip switching) lands 2.5e-4 from it, 40x inside the
     reference's own 1e-2 criterion (Scene.m:173) - tolerance stated: 1e-6 relative."""
     sc = scenesRedMax(11)
@@ -76,3 +76,36 @@ def test_ground_contact_scene11_kat(oracle_lib):
     H = T[-1] + V[-1] - V0
     assert abs(H - sc.Hexpected[1]) <= 1e-2
     assert abs(H - sc.Hexpected[1]) <= 1e-6 * abs(sc.Hexpected[1])
+
+
+@pytest.mark.parametrize("sid", COMPOSITE_SCENES)
+@pytest.mark.parametrize("itype", [1, 2])
+def test_multi_dof_joint_scenes_kat(oracle_lib, sid, itype):
+    """Scenes 4 (JointPlanar), 5 (JointTranslational), 6 (JointFree2D), 8 (JointUniversal): Hexpected of
+    scenesRedMax.m:147-148, 166-167, 189-190, 230-231.  These pin the restatement of the multi-DOF joints as chains of 1-DOF
+    joints with massless links that keep the reference's reduced numbering (oracle.lower_composite + orc_set_idxR)."""
+    sc = scenesRedMax(sid)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    assert o.nr == sc.nr
+    q, qd = o.get_state()
+    q0, qd0 = sc.getQ()
+    assert np.array_equal(q, q0) and np.array_equal(qd, qd0)          # reference DOF order: idxR = nr + (1:ndof)
+    _, V0 = o.energy()
+    st, T, V = (o.step_bdf1 if itype == 1 else o.step_bdf2)(sc.h, sc.nsteps, history=True)
+    H = T[-1] + V[-1] - V0
+    assert abs(H - sc.Hexpected[itype - 1]) <= 1e-2
+    assert abs(H - sc.Hexpected[itype - 1]) <= 1e-9 * abs(sc.Hexpected[itype - 1])
+    assert st.diverged == 0 and st.not_converged == 0
+
+
+def test_multi_dof_index_layout():
+    """Joint.countDofs (Joint.m:149-158): idxR = nr + (1:ndof), joints counted from the last listed to the first."""
+    sc = scenesRedMax(5)                                  # translational(3) root with two revolute children
+    sc.init()
+    assert [j.idxR for j in sc.joints] == [[2, 3, 4], [1], [0]]
+    sc = scenesRedMax(8)                                  # three universal joints
+    sc.init()
+    assert [j.idxR for j in sc.joints] == [[4, 5], [2, 3], [0, 1]]
+    q, _ = sc.getQ()
+    assert q[4] == pytest.approx(np.pi / 8) and q[3] == pytest.approx(np.pi / 8) and q[0] == pytest.approx(np.pi / 8)

@@ -19,13 +19,13 @@ def _scene(name):
     return scenesRedMax(int(name))
 
 
-@pytest.mark.parametrize("name", ["0", "1", "2", "3", "14", "chain8skew", "chain32", "tree15"])
+@pytest.mark.parametrize("name", ["0", "1", "2", "3", "14", "chain8skew", "chain32", "tree15", "4", "5", "6", "8"])
 def test_worldframe_equals_tensor_formulation(oracle_lib, name):
     sc = _scene(name)
     sc.init()
     d = sc.desc()
     o = oracle_lib.Oracle(d)
-    m = pw.build_model(d)
+    m = pw.build_model(oracle_lib.lower_composite(d))     # scenes 4, 5, 6, 8: multi-DOF joints as 1-DOF chains, massless links
     rng = np.random.default_rng(11)
     nr, h = o.nr, sc.h
     q0 = rng.uniform(-0.7, 0.7, nr)
@@ -59,13 +59,13 @@ def test_worldframe_contact_equals_tensor_formulation(oracle_lib, name):
     sc.init()
     d = sc.desc()
     o = oracle_lib.Oracle(d)
-    m = pw.build_model(d)
+    m = pw.build_model(oracle_lib.lower_composite(d))    # scene 11's JointFree2D as its 1-DOF chain
     rng = np.random.default_rng(5)
     nr, h = o.nr, sc.h
     hits = 0
     for trial in range(6):
         if name == "11":
-            q0 = np.array([0.3, rng.uniform(-0.4, 0.4), rng.uniform(-1, 1)])[::-1]   # idx order: theta, y, x
+            q0 = np.array([rng.uniform(-1, 1), rng.uniform(-0.4, 0.4), 0.3])         # JointFree2D: x, y, theta
             qd0 = rng.normal(size=nr) * (50 if trial % 2 else 0.5)
         else:
             q0 = rng.uniform(-0.4, 0.4, nr)
