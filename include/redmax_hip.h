@@ -169,6 +169,18 @@ typedef struct rmx_stats {
 int rmx_step_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats,
                   double* hist_T, double* hist_V);
 
+/* The same two loops with the full per-step record of Scene.saveHistory (Scene.m:134-161: q, qdot, T, V after every step;
+ * t = k*h).  integrator: 1 = BDF1 (driverRedMaxBDF1.m), 2 = BDF2 (driverRedMaxBDF2.m), the reference's itype numbering
+ * (scenesRedMax.m:5-6).  Host arrays, any pair may be NULL. */
+typedef struct rmx_history {
+    double* T;       /* [nsteps][batch]      kinetic energy   (with V)      */
+    double* V;       /* [nsteps][batch]      potential energy                */
+    double* q;       /* [nsteps][batch][nr]  reduced positions (with qdot)   */
+    double* qdot;    /* [nsteps][batch][nr]  reduced velocities              */
+} rmx_history;
+int rmx_step_history(rmx_batch* b, const rmx_opts* opts, int nsteps, int integrator, rmx_stats* stats,
+                     const rmx_history* hist);
+
 /* simLoop of driverRedMaxBDF2.m:57-125: the first call after set_state takes the SDIRK2 start step
  * (two Newton solves, :64-88), later steps are BDF2 (:89-106).  The batch keeps (q,qdot) of step k-1. */
 int rmx_step_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats,

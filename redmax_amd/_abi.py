@@ -23,7 +23,7 @@ SYMBOLS = (
     "rmx_model_set_ground_contact",
     "rmx_batch_create", "rmx_batch_destroy", "rmx_batch_size",
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
-    "rmx_eval", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_energy",
+    "rmx_eval", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_history", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_energy",
     "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_sync",
     "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases",
 )
@@ -58,6 +58,10 @@ class TaskPointPos(C.Structure):
 class GroundContact(C.Structure):
     _fields_ = [("flags", _ip), ("sides", _dp), ("E", C.c_double * 16), ("kn", C.c_double), ("kt", C.c_double),
                 ("mu", C.c_double), ("kd", C.c_double)]
+
+
+class History(C.Structure):
+    _fields_ = [("T", _dp), ("V", _dp), ("q", _dp), ("qdot", _dp)]
 
 
 class Stats(C.Structure):
@@ -98,6 +102,7 @@ def lib():
     L.rmx_eval.argtypes = [vp, _dp, _dp, _dp, C.c_double, _dp, _dp]
     L.rmx_step_bdf1.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(Stats), _dp, _dp]
     L.rmx_step_bdf2.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(Stats), _dp, _dp]
+    L.rmx_step_history.argtypes = [vp, C.POINTER(Opts), C.c_int, C.c_int, C.POINTER(Stats), C.POINTER(History)]
     L.rmx_step_euler.argtypes = [vp, C.c_double, C.c_int, _dp, _dp]
     L.rmx_adjoint_bdf1.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(TaskPointPos), _dp, _dp, _dp, C.POINTER(Stats)]
     L.rmx_energy.argtypes = [vp, _dp, _dp]

@@ -111,16 +111,25 @@ class BatchSim:
             T = np.empty((nsteps, self.B))
             V = np.empty((nsteps, self.B))
             out["T"], out["V"] = T, V
-        _abi.check(fn(self._batch, C.byref(self.opts), int(nsteps), C.byref(st) if st is not None else None,
-                      _abi.dptr(T), _abi.dptr(V)), "rmx_step")
+        stp = C.byref(st) if st is not None else None
+        if history == "full":                     # Scene.saveHistory: q, qdot of every step as well (Scene.m:134-161)
+            out["q"] = np.empty((nsteps, self.B, self.nr))
+            out["qdot"] = np.empty((nsteps, self.B, self.nr))
+            hist = _abi.History(_abi.dptr(T), _abi.dptr(V), _abi.dptr(out["q"]), _abi.dptr(out["qdot"]))
+            _abi.check(self._L.rmx_step_history(self._batch, C.byref(self.opts), int(nsteps), 1 if fn == "bdf1" else 2, stp,
+                                                C.byref(hist)), "rmx_step_history")
+        else:
+            f = self._L.rmx_step_bdf1 if fn == "bdf1" else self._L.rmx_step_bdf2
+            _abi.check(f(self._batch, C.byref(self.opts), int(nsteps), stp, _abi.dptr(T), _abi.dptr(V)), "rmx_step")
         out["ms"] = self._L.rmx_last_step_ms(self._batch)
         return out
 
     def step_bdf1(self, nsteps, h=None, stats=False, history=False):
-        return self._step(self._L.rmx_step_bdf1, nsteps, h, stats, history)
+        """history: False | True (T, V per step) | "full" (T, V, q, qdot per step: Scene.saveHistory)."""
+        return self._step("bdf1", nsteps, h, stats, history)
 
     def step_bdf2(self, nsteps, h=None, stats=False, history=False):
-        return self._step(self._L.rmx_step_bdf2, nsteps, h, stats, history)
+        return self._step("bdf2", nsteps, h, stats, history)
 
     def step_euler(self, nsteps, h, history=False):
         """euler() of matlab-simple/testRedMax.m:67-109 (linearly-implicit Euler, config 1)."""

@@ -576,7 +576,8 @@ static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
     return RMX_OK;
 }
 
-static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ, bool with_stats, double* dT, double* dV) {
+static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ, bool with_stats, double* dT, double* dV,
+                       double* dQ = nullptr, double* dQd = nullptr) {
     rmx_model* m = b->m;
     DevOpts o;
     int rc = make_opts(b, opts, o);
@@ -587,6 +588,7 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.q = b->q; a.qd = b->qd; a.qp = b->qp; a.qdp = b->qdp; a.started = b->started;
     a.it = with_stats ? b->it : nullptr; a.ls = b->ls; a.status = b->status;
     a.histT = dT; a.histV = dV;
+    a.histQ = dQ; a.histQd = dQd;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
     if (integ == INTEG_BDF2) HIPCHK(hipMemsetAsync(b->started, 1, sizeof(int), b->stream));   // any non-zero value
@@ -595,19 +597,31 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     return RMX_OK;
 }
 
-static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* st, double* hT, double* hV, int integ) {
+static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* st, double* hT, double* hV, int integ,
+                     double* hQ = nullptr, double* hQd = nullptr) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     if (nsteps < 0) return fail(RMX_E_INVALID, "nsteps < 0");
     if ((hT == nullptr) != (hV == nullptr)) return fail(RMX_E_INVALID, "hist_T and hist_V must be given together");
+    if ((hQ == nullptr) != (hQd == nullptr)) return fail(RMX_E_INVALID, "history q and qdot must be given together");
     rmx_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
     if (nsteps == 0 || m->nr == 0) return RMX_OK;
-    double *dT = nullptr, *dV = nullptr;
-    const size_t nh = (size_t)nsteps * b->B;
+    double *dT = nullptr, *dV = nullptr, *dQ = nullptr, *dQd = nullptr;
+    const size_t nh = (size_t)nsteps * b->B, nq = nh * m->nr;
     if (hT) {
         HIPCHK(hipMalloc((void**)&dT, nh * sizeof(double)));
         hipError_t e = hipMalloc((void**)&dV, nh * sizeof(double));
         if (e != hipSuccess) { (void)hipFree(dT); return fail(RMX_E_NOMEM, "hipMalloc(hist)"); }
+    }
+    if (hQ) {
+        hipError_t e = hipMalloc((void**)&dQ, nq * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&dQd, nq * sizeof(double));
+        if (e != hipSuccess) {
+            if (dT) (void)hipFree(dT);
+            if (dV) (void)hipFree(dV);
+            if (dQ) (void)hipFree(dQ);
+            return fail(RMX_E_NOMEM, "hipMalloc(state history)");
+        }
     }
     const bool ws = st != nullptr;
     if (ws) {
@@ -615,12 +629,16 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
         (void)hipMemsetAsync(b->ls, 0, sizeof(int) * b->B, b->stream);
         (void)hipMemsetAsync(b->status, 0, sizeof(int) * b->B, b->stream);
     }
-    int rc = launch_step(b, opts, nsteps, integ, ws, dT, dV);
+    int rc = launch_step(b, opts, nsteps, integ, ws, dT, dV, dQ, dQd);
     hipError_t e = hipSuccess;
     if (rc == RMX_OK) {
         if (hT) {
             e = hipMemcpyAsync(hT, dT, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(hV, dV, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+        }
+        if (e == hipSuccess && hQ) {
+            e = hipMemcpyAsync(hQ, dQ, nq * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hQd, dQd, nq * sizeof(double), hipMemcpyDeviceToHost, b->stream);
         }
         if (e == hipSuccess && ws) {
             if (st->newton_iters) e = hipMemcpyAsync(st->newton_iters, b->it, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
@@ -635,9 +653,18 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
     }
     if (dT) (void)hipFree(dT);
     if (dV) (void)hipFree(dV);
+    if (dQ) (void)hipFree(dQ);
+    if (dQd) (void)hipFree(dQd);
     if (rc) return rc;
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_step: ") + hipGetErrorString(e));
     return RMX_OK;
+}
+
+// Scene.saveHistory (Scene.m:134-161) for every step and trajectory: t is k*h, the rest comes back here.
+extern "C" int rmx_step_history(rmx_batch* b, const rmx_opts* opts, int nsteps, int integrator, rmx_stats* stats, const rmx_history* hist) {
+    if (integrator != 1 && integrator != 2) return fail(RMX_E_INVALID, "integrator must be 1 (BDF1) or 2 (BDF2)");
+    if (!hist) return fail(RMX_E_INVALID, "null history");
+    return step_sync(b, opts, nsteps, stats, hist->T, hist->V, integrator == 1 ? INTEG_BDF1 : INTEG_BDF2, hist->q, hist->qdot);
 }
 
 extern "C" int rmx_step_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats, double* hist_T, double* hist_V) {

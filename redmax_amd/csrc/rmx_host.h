@@ -26,6 +26,8 @@ struct StepArgs {
     int* status;
     double* histT;    // [nsteps][B] or null
     double* histV;
+    double* histQ;    // [nsteps][B][nr] or null: q, qdot after every step (Scene.saveHistory, Scene.m:134-161)
+    double* histQd;
 };
 
 struct AdjArgs {

@@ -68,6 +68,10 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
                 a.histV[(size_t)s * a.B + traj] = V;
             }
         }
+        if (a.histQ && id >= 0) {
+            a.histQ[(size_t)s * a.B * M.nr + off] = q;
+            a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+        }
     }
     if (id >= 0) {
         a.q[off] = q;
@@ -133,6 +137,10 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
                 a.histT[(size_t)s * a.B + traj] = T;
                 a.histV[(size_t)s * a.B + traj] = V;
             }
+        }
+        if (a.histQ && id >= 0) {
+            a.histQ[(size_t)s * a.B * M.nr + off] = q;
+            a.histQd[(size_t)s * a.B * M.nr + off] = qd;
         }
     }
     if (id >= 0) {

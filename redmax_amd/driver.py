@@ -20,15 +20,15 @@ def simLoop(scene, itype=1, device=0):
     T0, V0 = sim.energy()                      # Scene.reset: T0, V0 at the initial state (Scene.m:126-127)
     scene.T0, scene.V0 = float(T0[0]), float(V0[0])
     step = sim.step_bdf1 if itype == 1 else sim.step_bdf2
-    out = step(scene.nsteps, h=scene.h, stats=True, history=True)
+    out = step(scene.nsteps, h=scene.h, stats=True, history="full")
     q, qd = sim.get_state()
     scene.setQ(q[0], qd[0])
     scene.history = []
-    for k in range(scene.nsteps):              # per-step q/qdot stay on the device; energies are recorded per step
+    for k in range(scene.nsteps):              # Scene.saveHistory (Scene.m:134-161): the record of every step
         scene.t = (k + 1) * scene.h
         scene.k = k + 1
-        scene.history.append({"t": scene.t, "T": float(out["T"][k, 0]), "V": float(out["V"][k, 0])})
-    scene.history[-1]["q"], scene.history[-1]["qdot"] = q[0].copy(), qd[0].copy()
+        scene.history.append({"t": scene.t, "T": float(out["T"][k, 0]), "V": float(out["V"][k, 0]),
+                              "q": out["q"][k, 0].copy(), "qdot": out["qdot"][k, 0].copy()})
     scene.solverInfo = {"newton_iters": int(out["newton_iters"][0]), "ls_halvings": int(out["ls_halvings"][0]),
                         "status": int(out["status"][0]), "kernel_ms": out["ms"]}
     sim.close()

@@ -317,3 +317,34 @@ def test_adjoint_bdf1_matches_oracle(oracle_lib, n):
         assert abs(P[b] - Po) <= 1e-9 * abs(Po), (n, b, P[b], Po)
         assert _rel(dPdp[b], dPo) <= 1e-7, (n, b, _rel(dPdp[b], dPo))
         assert info["newton_iters"][b] == st.newton_iters
+
+
+@pytest.mark.parametrize("name,integ", [("2", "bdf1"), ("chain32", "bdf1"), ("3", "bdf2")])
+def test_per_step_trajectory_matches_oracle(oracle_lib, name, integ):
+    """rmx_step_history (Scene.saveHistory, Scene.m:134-161): q and qdot after EVERY step vs the oracle stepped one step at a
+    time - the 'q/qdot trajectories matching the reference integrator' statement of BASELINE.json, step by step.
+    Tolerance: |dq| <= 1e-8 |q| + 1e-10 and |dqdot| <= 1e-6 |qdot| + 1e-8 at every step of a 30-step rollout."""
+    from redmax_amd import BatchSim
+    sc = _scene(name)
+    sc.init()
+    B, nsteps = 2, 30
+    q0, qd0 = syntheticStates(sc.nr, B, first=1)
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q0, qd0)
+    out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(nsteps, h=sc.h, stats=True, history="full")
+    qf, qdf = sim.get_state()
+    assert np.array_equal(out["q"][-1], qf) and np.array_equal(out["qdot"][-1], qdf)
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q0[b], qd0[b])
+        for k in range(nsteps):
+            if integ == "bdf1":
+                st, T, V = o.step_bdf1(sc.h, 1, history=True)
+            else:
+                st, T, V = o.step_bdf2(sc.h, 1, step0=k, history=True)
+            qo, qdo = o.get_state()
+            assert _close(out["q"][k, b], qo, 1e-8, 1e-10), (k, b)
+            assert _close(out["qdot"][k, b], qdo, 1e-6, 1e-8), (k, b)
+            assert abs(out["T"][k, b] - T[0]) <= 1e-7 * max(abs(T[0]), 1.0)
+            assert abs(out["V"][k, b] - V[0]) <= 1e-7 * max(abs(V[0]), 1.0)
+    sim.close()
