@@ -32,7 +32,7 @@ class _Desc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("newton_iters", C.c_int), ("ls_halvings", C.c_int), ("residual_evals", C.c_int),
-                ("hessian_evals", C.c_int), ("diverged", C.c_int), ("not_converged", C.c_int)]
+                ("hessian_evals", C.c_int), ("diverged", C.c_int), ("not_converged", C.c_int), ("chart_switches", C.c_int)]
 
 
 class TaskPointPos(C.Structure):
@@ -65,6 +65,12 @@ def lib():
         L.orc_idxR.argtypes = [C.c_void_p, _ip]
         L.orc_reset.argtypes = [C.c_void_p]
         L.orc_set_idxR.argtypes = [C.c_void_p, _ip]
+        L.orc_set_spherical.argtypes = [C.c_void_p, C.c_int, _ip]
+        L.orc_get_charts.argtypes = [C.c_void_p, _ip]
+        L.orc_set_charts.argtypes = [C.c_void_p, _ip]
+        L.orc_euler.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.orc_euler.restype = C.c_double
+        L.orc_euler_inv.argtypes = [C.c_int, _dp, _dp]
         L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_set_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_set_qrest.argtypes = [C.c_void_p, _dp]
@@ -125,6 +131,10 @@ def _composite_subjoints(jtype, plane):
         return [(1, _E[0]), (1, _E[1])]
     if jtype == 6:      # JointFree2D.m:20-33   Q = [Rz(q3) [q1;q2;0]]
         return [(2, _E[0]), (2, _E[1]), (1, _E[2])]
+    if jtype == 7:      # JointSpherical.m:33, 247-262   chart XYZ at construction: R = X1*Y2*Z3 (chart switches: orc_set_spherical)
+        return [(1, _E[0]), (1, _E[1]), (1, _E[2])]
+    if jtype == 8:      # JointFree3D.m:16-34   JointTranslational then JointSpherical
+        return [(2, _E[0]), (2, _E[1]), (2, _E[2]), (1, _E[0]), (1, _E[1]), (1, _E[2])]
     raise ValueError("joint type %d" % jtype)
 
 
@@ -133,7 +143,9 @@ def lower_composite(d):
     JointTranslational, JointUniversal, JointFree2D) as chains of prismatic/revolute joints with massless intermediate links:
     same world transforms, same generalised coordinates and velocities, hence the same M, f, K, D.  The chain's DOFs keep the
     reference's reduced indices idxR = nr + (1:ndof) (Joint.m:152) through orc_set_idxR.  Pinned by Hexpected of scenes
-    4, 5, 6, 8 and 11 (scenesRedMax.m:147-148, 166-167, 189-190, 230-231, 292-293)."""
+    4, 5, 6, 8 and 11 (scenesRedMax.m:147-148, 166-167, 189-190, 230-231, 292-293).  JointSpherical / JointFree3D (Euler charts,
+    types 7 / 8) lower the same way; "sph_first" lists the first revolute node of every spherical group for orc_set_spherical,
+    which adds the chart switching of reparam_ (pinned by scenes 7 and 9, :206-207, 250-251)."""
     typ = np.asarray(d["type"])
     n = int(d["njoints"])
     if not np.any(typ > 2):
@@ -151,12 +163,15 @@ def lower_composite(d):
                            "qLimL", "qLimU", "qLimK", "qLimD", "idx", "contact", "sides")}
     eye16 = np.eye(4).reshape(16)
     last = [0] * n
+    sph_first = []
     has_contact = d.get("contact") is not None
     for L in range(n):
         if typ[L] <= 2:
             subs = [(int(typ[L]), np.asarray(d["axis"][L], float))]
         else:
             subs = _composite_subjoints(int(typ[L]), np.asarray(d["plane"][L], float))
+        if typ[L] in (7, 8):
+            sph_first.append(len(out["type"]) + (3 if typ[L] == 8 else 0))
         for k, (t, ax) in enumerate(subs):
             final = k == len(subs) - 1
             out["parent"].append((last[d["parent"][L]] if d["parent"][L] >= 0 else -1) if k == 0 else len(out["type"]) - 1)
@@ -175,7 +190,8 @@ def lower_composite(d):
             out["contact"].append(int(d["contact"][L]) if (has_contact and final) else 0)
             out["sides"].append(np.asarray(d["sides"][L]) if (has_contact and final) else np.zeros(3))
         last[L] = len(out["type"]) - 1
-    low = {"njoints": len(out["type"]), "grav": d["grav"], "idx": np.array(out["idx"], dtype=np.int32), "last_of_listing": last}
+    low = {"njoints": len(out["type"]), "grav": d["grav"], "idx": np.array(out["idx"], dtype=np.int32), "last_of_listing": last,
+           "sph_first": np.array(sph_first, dtype=np.int32)}
     for k in ("parent", "type"):
         low[k] = np.array(out[k], dtype=np.int32)
     for k in ("axis", "E0_pj", "E0_ji", "I_i"):
@@ -203,6 +219,12 @@ class Oracle:
             self._idx = np.ascontiguousarray(desc_dict["idx"], dtype=np.int32)
             if self._L.orc_set_idxR(self._h, self._idx.ctypes.data_as(_ip)) != 0:
                 raise ValueError("idx is not a permutation of the reduced DOFs")
+        self.nsph = 0
+        if len(desc_dict.get("sph_first", ())):
+            self._sph = np.ascontiguousarray(desc_dict["sph_first"], dtype=np.int32)
+            self.nsph = len(self._sph)
+            if self._L.orc_set_spherical(self._h, self.nsph, self._sph.ctypes.data_as(_ip)) != 0:
+                raise ValueError("bad spherical groups")
         if "qRest" in desc_dict:
             self.set_qrest_joint_order(desc_dict["qRest"])
         if desc_dict.get("contact") is not None and np.any(desc_dict["contact"]):
@@ -236,6 +258,17 @@ class Oracle:
 
     def reset(self):
         self._L.orc_reset(self._h)
+
+    def charts(self):
+        """Current Euler chart (reference numbering 1..12) of every JointSpherical / JointFree3D, in listing order."""
+        c = np.zeros(max(self.nsph, 1), dtype=np.int32)
+        self._L.orc_get_charts(self._h, c.ctypes.data_as(_ip))
+        return c[:self.nsph]
+
+    def set_charts(self, charts):
+        c = np.ascontiguousarray(charts, dtype=np.int32)
+        if len(c) != self.nsph or self._L.orc_set_charts(self._h, c.ctypes.data_as(_ip)) != 0:
+            raise ValueError("charts must be %d values in 1..12" % self.nsph)
 
     def get_state(self):
         q = np.zeros(self.nr)
@@ -352,3 +385,18 @@ def batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0):
     assert q.flags.c_contiguous and qdot.flags.c_contiguous and q.dtype == np.float64
     # qRest: the batch helper takes it from the descriptor's q (model constant)
     return int(L.orc_batch_step_bdf1(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads)))
+
+
+def euler(chart, q):
+    """redmax.JointSpherical.getEuler(chart, q, 0): (R, T, detT)."""
+    R = np.zeros(9)
+    T = np.zeros(9)
+    d = lib().orc_euler(int(chart), _p(np.ascontiguousarray(q, dtype=np.float64)), _p(R), _p(T))
+    return R.reshape(3, 3), T.reshape(3, 3), d
+
+
+def euler_inv(chart, R):
+    """redmax.JointSpherical.getEulerInv(chart, R)."""
+    q = np.zeros(3)
+    lib().orc_euler_inv(int(chart), _p(np.ascontiguousarray(R, dtype=np.float64).reshape(9)), _p(q))
+    return q

@@ -176,6 +176,8 @@ struct orc_scene {
     int* contact;                        /* [n] flag */
     double* sides;                       /* [n][3]   */
     m4 groundE; double kn, kt, mu, kd;
+    /* JointSpherical groups (three consecutive revolute nodes each) and their Euler charts */
+    int nsph; int* sph_first; int* sph_chart; int* sph_chart1;
 };
 
 #define JX(s, r, c) ((s)->J[(size_t)(c) * (s)->nm + (r)])
@@ -394,6 +396,7 @@ void orc_destroy(orc_scene* s) {
     free(s->J); free(s->Jdot); free(s->dJdq); free(s->dJdotdq);
     free(s->Mm); free(s->Km); free(s->Dm); free(s->fm); free(s->fr); free(s->Kr); free(s->Dr);
     free(s->contact); free(s->sides);
+    free(s->sph_first); free(s->sph_chart); free(s->sph_chart1);
     free(s);
 }
 
@@ -946,6 +949,171 @@ static void newton(orc_scene* s, double* x, const double* qA, const double* qB, 
     free(g); free(H); free(dx); free(x0);
 }
 
+
+/* ------------------------------------------------------------ JointSpherical: Euler-angle charts and reparam
+ *
+ * JointSpherical (matlab-diff/+redmax/JointSpherical.m) parameterises the rotation by one of 12 Euler charts, R = R_a1(q1)
+ * R_a2(q2) R_a3(q3) (codegen :247-262: XYX = X1*Y2*X3, ..., XYZ = X1*Y2*Z3, ...), i.e. by a chain of three revolute joints about
+ * the chart's axes; S(1:3,1:3) = T with T(:,i) = vee(R' dR/dq_i) (:298-303) is that chain's body-frame Jacobian.  The oracle
+ * holds such a joint as its three 1-DOF nodes (two massless links) and restates what is NOT a property of the chain:
+ * reparam_ (:63-102), the chart switch after a step when |det T| <= 0.5, with getEulerInv (:181-208, XYXinv..ZYXinv :1809-1949).
+ * JointFree3D (JointFree3D.m:16-34) = JointTranslational + JointSpherical.  Pinned by Hexpected of scenes 7 and 9
+ * (scenesRedMax.m:206-207, 250-251); scene 7 under BDF2 switches charts. */
+static const int CHART_AX[13][3] = { {0,0,0},
+    {0,1,0}, {0,2,0}, {1,2,1}, {1,0,1}, {2,0,2}, {2,1,2},       /* XYX XZX YZY YXY ZXZ ZYZ   (JointSpherical.m:5-10)  */
+    {0,1,2}, {0,2,1}, {1,2,0}, {1,0,2}, {2,0,1}, {2,1,0} };     /* XYZ XZY YZX YXZ ZXY ZYX   (:11-16)                 */
+
+static void rot_elem(double R[3][3], int a, double q) {         /* X1/Y1/Z1 of codegen :247-255 */
+    const double c = cos(q), s = sin(q);
+    const int b = (a + 1) % 3, d = (a + 2) % 3;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = (i == j) ? 1.0 : 0.0;
+    R[b][b] = c; R[b][d] = -s; R[d][b] = s; R[d][d] = c;
+}
+static void mm3(double C[3][3], const double A[3][3], const double B[3][3]) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double t = 0; for (int k = 0; k < 3; k++) t += A[i][k] * B[k][j]; C[i][j] = t; }
+}
+static void euler_R(int chart, const double q[3], double R[3][3]) {
+    double R1[3][3], R2[3][3], R3[3][3], T[3][3];
+    rot_elem(R1, CHART_AX[chart][0], q[0]); rot_elem(R2, CHART_AX[chart][1], q[1]); rot_elem(R3, CHART_AX[chart][2], q[2]);
+    mm3(T, R1, R2); mm3(R, T, R3);
+}
+/* T(:,1) = R3'R2' e_a1, T(:,2) = R3' e_a2, T(:,3) = e_a3 ; det T = +-cos q2 (Tait-Bryan) or +-sin q2 (proper Euler) */
+static double euler_T(int chart, const double q[3], double T[3][3]) {
+    double R2[3][3], R3[3][3];
+    const int* ax = CHART_AX[chart];
+    rot_elem(R2, ax[1], q[1]); rot_elem(R3, ax[2], q[2]);
+    double e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0}, t[3];
+    e1[ax[0]] = 1.0; e2[ax[1]] = 1.0;
+    for (int i = 0; i < 3; i++) { t[i] = 0; for (int k = 0; k < 3; k++) t[i] += R2[k][i] * e1[k]; }
+    for (int i = 0; i < 3; i++) { T[i][0] = 0; for (int k = 0; k < 3; k++) T[i][0] += R3[k][i] * t[k]; }
+    for (int i = 0; i < 3; i++) { T[i][1] = 0; for (int k = 0; k < 3; k++) T[i][1] += R3[k][i] * e2[k]; }
+    for (int i = 0; i < 3; i++) T[i][2] = (i == ax[2]) ? 1.0 : 0.0;
+    return T[0][0] * (T[1][1] * T[2][2] - T[1][2] * T[2][1]) - T[0][1] * (T[1][0] * T[2][2] - T[1][2] * T[2][0]) +
+           T[0][2] * (T[1][0] * T[2][1] - T[1][1] * T[2][0]);
+}
+/* XYXinv .. ZYXinv (:1809-1949) in one rule.  With (i,j,k) = (a1, a2, remaining axis) and e = +1 if (i,j,k) is a cyclic
+ * permutation of (x,y,z), -1 otherwise:
+ *   proper Euler (a3 == a1): q2 = acos(R_ii),   q1 = atan2(R_ji, -e R_ki), q3 = atan2(R_ij,  e R_ik)
+ *   Tait-Bryan   (a3 == k) : q2 = asin(e R_ik), q1 = atan2(-e R_jk, R_kk), q3 = atan2(-e R_ij, R_ii)
+ * NaN at gimbal lock (the guarded entry not strictly inside (-1,1)), as the reference. */
+static void euler_inv(int chart, const double R[3][3], double q[3]) {
+    const int* ax = CHART_AX[chart];
+    const int i = ax[0], j = ax[1], k = 3 - i - j;
+    const double e = ((j - i + 3) % 3 == 1) ? 1.0 : -1.0;
+    if (ax[2] == ax[0]) {
+        const double r = R[i][i];
+        if (-1.0 < r && r < 1.0) { q[0] = atan2(R[j][i], -e * R[k][i]); q[1] = acos(r); q[2] = atan2(R[i][j], e * R[i][k]); return; }
+    } else {
+        const double r = R[i][k];
+        if (-1.0 < r && r < 1.0) { q[0] = atan2(-e * R[j][k], R[k][k]); q[1] = asin(e * r); q[2] = atan2(-e * R[i][j], R[i][i]); return; }
+    }
+    q[0] = q[1] = q[2] = NAN;
+}
+/* x = A\b for a 3x3 (MATLAB mldivide: LU with partial pivoting) */
+static void solve3(const double Ain[3][3], const double b[3], double x[3]) {
+    double A[3][4];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) A[i][j] = Ain[i][j]; A[i][3] = b[i]; }
+    for (int c = 0; c < 3; c++) {
+        int p = c;
+        for (int r = c + 1; r < 3; r++) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+        if (p != c) for (int j = 0; j < 4; j++) { double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+        for (int r = c + 1; r < 3; r++) { const double l = A[r][c] / A[c][c]; for (int j = c; j < 4; j++) A[r][j] -= l * A[c][j]; }
+    }
+    for (int r = 2; r >= 0; r--) { double t = A[r][3]; for (int j = r + 1; j < 3; j++) t -= A[r][j] * x[j]; x[r] = t / A[r][r]; }
+}
+static void sph_apply_chart(orc_scene* s, int g) {
+    for (int k = 0; k < 3; k++) {
+        onode* j = &s->nd[s->sph_first[g] + k];
+        for (int a = 0; a < 3; a++) j->axis[a] = (a == CHART_AX[s->sph_chart[g]][k]) ? 1.0 : 0.0;
+    }
+}
+/* Joint.reparam -> JointSpherical.reparam_ (:63-102), called after setQ at the end of every step (driverRedMaxBDF1.m:78,
+ * driverRedMaxBDF2.m:112).  with_prev: the BDF2 drivers keep step k in q1/chart1 (setQ1/setAux1_), which reparam_ uses and
+ * rewrites too.  The BDF1 driver never calls setQ1, so chart1 is empty there and the reference's reparam_ would fail at
+ * getEuler(this.chart1,...) should a switch come up; here BDF1 chooses the chart from R alone (documented deviation; none of
+ * the reference's BDF1 runs switches). */
+static int reparam(orc_scene* s, int with_prev) {
+    int switched = 0;
+    for (int g = 0; g < s->nsph; g++) {
+        onode* n0 = &s->nd[s->sph_first[g]];
+        double q[3] = { n0[0].q, n0[1].q, n0[2].q }, qd[3] = { n0[0].qdot, n0[1].qdot, n0[2].qdot };
+        double q1[3] = { n0[0].q1, n0[1].q1, n0[2].q1 }, qd1[3] = { n0[0].qdot1, n0[1].qdot1, n0[2].qdot1 };
+        double Told[3][3], R[3][3], R1[3][3], Tt[3][3];
+        const double detTold = euler_T(s->sph_chart[g], q, Told);
+        if (fabs(detTold) > 0.5) continue;                                       /* :66-68 */
+        euler_R(s->sph_chart[g], q, R);
+        if (with_prev) euler_R(s->sph_chart1[g], q1, R1);                        /* :73 */
+        int best = 1; double bestv = -1.0;
+        for (int k = 1; k <= 12; k++) {                                          /* :75-83 */
+            double qk[3], d0, d1 = INFINITY;
+            euler_inv(k, R, qk); d0 = fabs(euler_T(k, qk, Tt)); if (isnan(d0)) d0 = 0.0;
+            if (with_prev) { euler_inv(k, R1, qk); d1 = fabs(euler_T(k, qk, Tt)); if (isnan(d1)) d1 = 0.0; }
+            const double v = d0 < d1 ? d0 : d1;
+            if (v > bestv) { bestv = v; best = k; }                              /* max() keeps the first maximum */
+        }
+        double w[3], Tnew[3][3];
+        for (int i = 0; i < 3; i++) w[i] = Told[i][0] * qd[0] + Told[i][1] * qd[1] + Told[i][2] * qd[2];
+        const int chart_prev = s->sph_chart1[g];
+        s->sph_chart[g] = best;
+        euler_inv(best, R, q);                                                   /* :87 */
+        euler_T(best, q, Tnew);                                                  /* :89 */
+        solve3(Tnew, w, qd);                                                     /* :91 */
+        for (int k = 0; k < 3; k++) { n0[k].q = q[k]; n0[k].qdot = qd[k]; }
+        if (with_prev) {                                                         /* :97-101 */
+            euler_T(chart_prev, q1, Told);
+            for (int i = 0; i < 3; i++) w[i] = Told[i][0] * qd1[0] + Told[i][1] * qd1[1] + Told[i][2] * qd1[2];
+            euler_inv(best, R1, q1);
+            euler_T(best, q1, Tnew);
+            solve3(Tnew, w, qd1);
+            for (int k = 0; k < 3; k++) { n0[k].q1 = q1[k]; n0[k].qdot1 = qd1[k]; }
+        }
+        s->sph_chart1[g] = best;
+        sph_apply_chart(s, g);
+        switched++;
+    }
+    return switched;
+}
+
+/* groups: first[g] = index of the first of the three consecutive revolute nodes of spherical joint g (chart XYZ at start,
+ * JointSpherical.m:33). */
+int orc_set_spherical(orc_scene* s, int ngroups, const int* first) {
+    for (int g = 0; g < ngroups; g++) {
+        if (first[g] < 0 || first[g] + 2 >= s->n) return -1;
+        for (int k = 0; k < 3; k++) {
+            const onode* j = &s->nd[first[g] + k];
+            if (j->type != ORC_JOINT_REVOLUTE || (k > 0 && j->parent != first[g] + k - 1)) return -1;
+        }
+    }
+    free(s->sph_first); free(s->sph_chart); free(s->sph_chart1);
+    s->nsph = ngroups;
+    s->sph_first = (int*)calloc((size_t)ngroups + 1, sizeof(int));
+    s->sph_chart = (int*)calloc((size_t)ngroups + 1, sizeof(int));
+    s->sph_chart1 = (int*)calloc((size_t)ngroups + 1, sizeof(int));
+    for (int g = 0; g < ngroups; g++) { s->sph_first[g] = first[g]; s->sph_chart[g] = s->sph_chart1[g] = 7; sph_apply_chart(s, g); }
+    scene_update(s);
+    return 0;
+}
+void orc_get_charts(const orc_scene* s, int* charts) { for (int g = 0; g < s->nsph; g++) charts[g] = s->sph_chart[g]; }
+int orc_set_charts(orc_scene* s, const int* charts) {
+    for (int g = 0; g < s->nsph; g++) if (charts[g] < 1 || charts[g] > 12) return -1;
+    for (int g = 0; g < s->nsph; g++) { s->sph_chart[g] = s->sph_chart1[g] = charts[g]; sph_apply_chart(s, g); }
+    scene_update(s);
+    return 0;
+}
+/* the static helpers of JointSpherical for tests: R (row-major 3x3), T and det T of getEuler (:151-178), getEulerInv (:181-208) */
+double orc_euler(int chart, const double* q, double* R9, double* T9) {
+    double R[3][3], T[3][3];
+    euler_R(chart, q, R);
+    const double d = euler_T(chart, q, T);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { if (R9) R9[3 * i + j] = R[i][j]; if (T9) T9[3 * i + j] = T[i][j]; }
+    return d;
+}
+void orc_euler_inv(int chart, const double* R9, double* q) {
+    double R[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i][j] = R9[3 * i + j];
+    euler_inv(chart, R, q);
+}
+
 /* simLoop (driverRedMaxBDF1.m:57-91) */
 void orc_step_bdf1(orc_scene* s, double h, int nsteps, orc_stats* st, double* Hist_T, double* Hist_V) {
     const int nr = s->nr;
@@ -962,6 +1130,7 @@ void orc_step_bdf1(orc_scene* s, double h, int nsteps, orc_stats* st, double* Hi
         newton(s, q1, q0, qB, h, st);
         for (int i = 0; i < nr; i++) qd1[i] = (q1[i] - q0[i]) / h;
         set_q(s, q1, qd1);
+        if (s->nsph && st) st->chart_switches += reparam(s, 0); else if (s->nsph) reparam(s, 0);   /* jroot.reparam() :78 */
         scene_update(s);
         if (Hist_T || Hist_V) { double T, V; orc_energy(s, &T, &V); if (Hist_T) Hist_T[k] = T; if (Hist_V) Hist_V[k] = V; }
     }
@@ -1008,6 +1177,7 @@ void orc_step_bdf2(orc_scene* s, double h, int step0, int nsteps, orc_stats* st,
             for (int i = 0; i < nr; i++) xd[i] = (3.0 / (2.0 * h)) * (x[i] - (4.0 / 3.0) * q1[i] + (1.0 / 3.0) * q0[i]);
             set_q(s, x, xd);
         }
+        if (s->nsph && st) st->chart_switches += reparam(s, 1); else if (s->nsph) reparam(s, 1);   /* jroot.reparam() :112 */
         scene_update(s);
         if (Hist_T || Hist_V) { double T, V; orc_energy(s, &T, &V); if (Hist_T) Hist_T[k - step0] = T; if (Hist_V) Hist_V[k - step0] = V; }
     }

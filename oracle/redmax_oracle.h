@@ -55,6 +55,14 @@ void orc_destroy(orc_scene* s);
 int  orc_nr(const orc_scene* s);
 int  orc_nm(const orc_scene* s);
 void orc_idxR(const orc_scene* s, int* idx);            /* [n] 0-based start of each joint's reduced index, -1 if ndof=0 */
+/* JointSpherical / JointFree3D (JointSpherical.m, JointFree3D.m) held as three revolute nodes per joint: first[g] = the first
+ * node of group g.  Charts are the reference's CHART_* numbers 1..12 (XYX XZX YZY YXY ZXZ ZYZ XYZ XZY YZX YXZ ZXY ZYX),
+ * 7 = XYZ at construction; orc_step_bdf1/bdf2 run reparam_ (:63-102) after every step. */
+int  orc_set_spherical(orc_scene* s, int ngroups, const int* first);
+void orc_get_charts(const orc_scene* s, int* charts);
+int  orc_set_charts(orc_scene* s, const int* charts);
+double orc_euler(int chart, const double* q, double* R9, double* T9);   /* getEuler: R, T row-major; returns det T */
+void orc_euler_inv(int chart, const double* R9, double* q);             /* getEulerInv */
 int  orc_set_idxR(orc_scene* s, const int* idx);        /* explicit reduced numbering (lowered multi-DOF joints) */
 void orc_reset(orc_scene* s);                           /* Scene.reset() Scene.m:122-131 */
 void orc_get_state(const orc_scene* s, double* q, double* qdot);   /* Joint.getQ  */
@@ -89,6 +97,7 @@ typedef struct orc_stats {
     int hessian_evals;    /* number of (g,H) evaluations                              */
     int diverged;         /* steps that hit "Newton diverged"                         */
     int not_converged;    /* steps that hit iterMax                                   */
+    int chart_switches;   /* JointSpherical.reparam_ chart changes                    */
 } orc_stats;
 
 /* Newton constants used by every orc_step_* call (process-global).  Defaults = the reference's hard-coded

@@ -31,6 +31,8 @@ JOINT_PLANAR = 3
 JOINT_TRANSLATIONAL = 4
 JOINT_UNIVERSAL = 5
 JOINT_FREE2D = 6
+JOINT_SPHERICAL = 7
+JOINT_FREE3D = 8
 
 
 class Body:
@@ -188,6 +190,59 @@ class JointFree2D(Joint):
 
     def __init__(self, parent, body):
         super().__init__(parent, body, 3)
+
+
+class JointSpherical(Joint):
+    """Ball joint parameterised by Euler angles in one of 12 charts, switched when the chart nears gimbal lock
+    (JointSpherical.m:4-17, 28-34, 63-102).  The device holds it as three revolute nodes about the chart's axes and runs
+    reparam_ after every step; ``chart`` is the construction-time chart (always XYZ in the reference)."""
+    jtype = JOINT_SPHERICAL
+    CHART_XYX, CHART_XZX, CHART_YZY, CHART_YXY, CHART_ZXZ, CHART_ZYZ = 1, 2, 3, 4, 5, 6
+    CHART_XYZ, CHART_XZY, CHART_YZX, CHART_YXZ, CHART_ZXY, CHART_ZYX = 7, 8, 9, 10, 11, 12
+    _AXES = {1: (0, 1, 0), 2: (0, 2, 0), 3: (1, 2, 1), 4: (1, 0, 1), 5: (2, 0, 2), 6: (2, 1, 2),
+             7: (0, 1, 2), 8: (0, 2, 1), 9: (1, 2, 0), 10: (1, 0, 2), 11: (2, 0, 1), 12: (2, 1, 0)}
+
+    def __init__(self, parent, body):
+        super().__init__(parent, body, 3)
+        self.radius = 1.0
+        self.chart = JointSpherical.CHART_XYZ
+
+    def setGeometry(self, radius):
+        self.radius = float(radius)
+
+    @staticmethod
+    def getEuler(chart, q):
+        """R of getEuler (JointSpherical.m:151-178): the product of the chart's three elementary rotations (codegen :247-262)."""
+        R = np.eye(3)
+        for a, qa in zip(JointSpherical._AXES[int(chart)], q):
+            R = R @ se3.aaToMat(np.eye(3)[a], qa)
+        return R
+
+    @staticmethod
+    def getEulerInv(chart, R):
+        """getEulerInv (JointSpherical.m:181-208, XYXinv..ZYXinv :1809-1949); NaN at gimbal lock."""
+        R = np.asarray(R, dtype=np.float64)
+        i, j, a3 = JointSpherical._AXES[int(chart)]
+        k = 3 - i - j
+        e = 1.0 if (j - i) % 3 == 1 else -1.0
+        if a3 == i:
+            r = R[i, i]
+            if -1.0 < r < 1.0:
+                return np.array([math.atan2(R[j, i], -e * R[k, i]), math.acos(r), math.atan2(R[i, j], e * R[i, k])])
+        else:
+            r = R[i, k]
+            if -1.0 < r < 1.0:
+                return np.array([math.atan2(-e * R[j, k], R[k, k]), math.asin(e * r), math.atan2(-e * R[i, j], R[i, i])])
+        return np.full(3, np.nan)
+
+
+class JointFree3D(Joint):
+    """6-DOF free joint = JointTranslational (q1..q3) followed by JointSpherical (q4..q6) (JointFree3D.m:1-34)."""
+    jtype = JOINT_FREE3D
+
+    def __init__(self, parent, body):
+        super().__init__(parent, body, 6)
+        self.chart = JointSpherical.CHART_XYZ
 
 
 class ForceGroundCuboid:

@@ -13,8 +13,8 @@ import math
 import numpy as np
 
 from . import se3
-from .redmax import (BodyCuboid, ForceGroundCuboid, JointFixed, JointFree2D, JointPlanar, JointPrismatic, JointRevolute,
-                     JointTranslational, JointUniversal, Scene)
+from .redmax import (BodyCuboid, ForceGroundCuboid, JointFixed, JointFree2D, JointFree3D, JointPlanar, JointPrismatic,
+                     JointRevolute, JointSpherical, JointTranslational, JointUniversal, Scene)
 
 BDF1 = 1
 BDF2 = 2
@@ -169,6 +169,36 @@ def scenesRedMax(sceneID):
         j.setJointTransform(np.eye(4))
         b.setBodyTransform(np.eye(4))
         scene.bodies, scene.joints = [b], [j]
+    elif sceneID == 7:
+        scene.name = "Spherical joint"
+        scene.Hexpected[BDF1 - 1] = -8.7859815791305155e03       # scenesRedMax.m:206
+        scene.Hexpected[BDF2 - 1] = 8.6544602745403390e03        # :207 (this run switches Euler charts)
+        scene.tEnd = 1.0
+        scene.h = 2e-3
+        b = [BodyCuboid(density, [1, 1, 10]), BodyCuboid(density, [1, 1, 10])]
+        j1 = JointSpherical(None, b[0])
+        j1.setJointTransform(np.eye(4))
+        j1.q[:] = JointSpherical.getEulerInv(j1.chart, se3.aaToMat([1, 0, 0], math.pi / 8))   # :217
+        j1.qdot[:] = [2.0, 2.0, 2.0]
+        j2 = JointSpherical(j1, b[1])
+        j2.setJointTransform(_T([0, 0, -10]))
+        j2.q[0] = math.pi / 2
+        for bb in b:
+            bb.setBodyTransform(_T([0, 0, -5]))
+        scene.bodies, scene.joints = b, [j1, j2]
+    elif sceneID == 9:
+        scene.name = "Free3D joint"
+        scene.Hexpected[BDF1 - 1] = 4.3970920953724946e00        # :250
+        scene.Hexpected[BDF2 - 1] = 4.5466508559364156e00        # :251
+        scene.h = 5e-2
+        scene.tEnd = 6.0
+        scene.grav = np.array([0.0, 0.0, -1.0])
+        b = BodyCuboid(density, [1, 1, 1])
+        j = JointFree3D(None, b)
+        j.qdot[:] = [0.0, 0.0, 3.0, 0.2, 0.4, 0.6]
+        j.setJointTransform(np.eye(4))
+        b.setBodyTransform(np.eye(4))
+        scene.bodies, scene.joints = [b], [j]
     elif sceneID == 8:
         scene.name = "Universal joint"
         scene.Hexpected[BDF1 - 1] = -2.5276246935781084e04       # :230
@@ -211,6 +241,7 @@ def scenesRedMax(sceneID):
 
 IN_SCOPE_SCENES = (0, 1, 2, 3, 14)          # 0/1-DOF joints only
 COMPOSITE_SCENES = (4, 5, 6, 8)             # JointPlanar / Translational / Free2D / Universal (lowered to 1-DOF chains)
+SPHERICAL_SCENES = (7, 9)                   # JointSpherical / JointFree3D (Euler charts with switching)
 
 
 def sceneAdjointChain(n=2):

@@ -8,7 +8,8 @@ acceptance threshold is |dH| <= 1e-2 (Scene.m:173); we hold the oracle to 1e-9 r
 import numpy as np
 import pytest
 
-from redmax_amd.scenes import COMPOSITE_SCENES, IN_SCOPE_SCENES, scenesRedMax
+from redmax_amd.redmax import JointSpherical
+from redmax_amd.scenes import COMPOSITE_SCENES, IN_SCOPE_SCENES, SPHERICAL_SCENES, scenesRedMax
 
 
 @pytest.mark.parametrize("sid", IN_SCOPE_SCENES)
@@ -109,3 +110,51 @@ def test_multi_dof_index_layout():
     assert [j.idxR for j in sc.joints] == [[4, 5], [2, 3], [0, 1]]
     q, _ = sc.getQ()
     assert q[4] == pytest.approx(np.pi / 8) and q[3] == pytest.approx(np.pi / 8) and q[0] == pytest.approx(np.pi / 8)
+
+
+@pytest.mark.parametrize("sid", SPHERICAL_SCENES)
+@pytest.mark.parametrize("itype", [1, 2])
+def test_spherical_joint_scenes_kat(oracle_lib, sid, itype):
+    """Scenes 7 (two JointSpherical) and 9 (JointFree3D): Hexpected of scenesRedMax.m:206-207, 250-251.  The joints are held as
+    three revolute nodes per Euler chart; scene 7 under BDF2 goes through reparam_ (JointSpherical.m:63-102) twice and ends
+    with joint 2 in chart YXZ - without the chart switch the run ends 1.2e-3 (relative) away from the golden."""
+    sc = scenesRedMax(sid)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    assert o.nr == sc.nr == 6
+    _, V0 = o.energy()
+    st, T, V = (o.step_bdf1 if itype == 1 else o.step_bdf2)(sc.h, sc.nsteps, history=True)
+    H = T[-1] + V[-1] - V0
+    assert abs(H - sc.Hexpected[itype - 1]) <= 1e-2
+    assert abs(H - sc.Hexpected[itype - 1]) <= 1e-9 * abs(sc.Hexpected[itype - 1])
+    assert st.diverged == 0 and st.not_converged == 0
+    if (sid, itype) == (7, 2):
+        assert st.chart_switches == 2 and list(o.charts()) == [7, 10]
+    else:
+        assert st.chart_switches == 0 and set(o.charts()) == {7}
+
+
+def test_euler_charts(oracle_lib):
+    """getEuler / getEulerInv of all 12 charts (JointSpherical.m:151-208): inverse round trip (JointSpherical.testEuler :42-47),
+    |det T| = |sin q2| (proper Euler) or |cos q2| (Tait-Bryan), T(:,i) = vee(R' dR/dq_i) (:298-303) by central differences, NaN
+    at gimbal lock, and the host mirror agrees with the oracle."""
+    rng = np.random.default_rng(0)
+    for c in range(1, 13):
+        for _ in range(10):
+            q = rng.uniform(-1.2, 1.2, 3)
+            if c <= 6:
+                q[1] = abs(q[1]) + 0.1
+            R, T, d = oracle_lib.euler(c, q)
+            assert np.allclose(R, JointSpherical.getEuler(c, q), atol=1e-15)
+            assert np.allclose(R @ R.T, np.eye(3), atol=1e-15)
+            qi = oracle_lib.euler_inv(c, R)
+            assert np.allclose(qi, q, atol=1e-12)
+            assert np.allclose(qi, JointSpherical.getEulerInv(c, R), atol=1e-15)
+            assert abs(abs(d) - (abs(np.sin(q[1])) if c <= 6 else abs(np.cos(q[1])))) < 1e-14
+            for i in range(3):
+                dq = np.zeros(3)
+                dq[i] = 1e-6
+                W = R.T @ (oracle_lib.euler(c, q + dq)[0] - oracle_lib.euler(c, q - dq)[0]) / 2e-6
+                assert np.allclose([W[2, 1], W[0, 2], W[1, 0]], T[:, i], atol=1e-8)
+        lock = np.array([0.3, 0.0 if c <= 6 else np.pi / 2, -0.4])
+        assert np.all(np.isnan(oracle_lib.euler_inv(c, oracle_lib.euler(c, lock)[0]))) or abs(oracle_lib.euler(c, lock)[2]) < 1e-15
