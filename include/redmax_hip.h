@@ -50,7 +50,9 @@ enum {
     RMX_JOINT_PLANAR = 3,         /* JointPlanar.m        2 DOF, p = B q            (plane, default x-y)       */
     RMX_JOINT_TRANSLATIONAL = 4,  /* JointTranslational.m 3 DOF, p = q                                         */
     RMX_JOINT_UNIVERSAL = 5,      /* JointUniversal.m     2 DOF, R = X(q1) Y(q2)                               */
-    RMX_JOINT_FREE2D = 6          /* JointFree2D.m        3 DOF, Q = [Rz(q3) [q1;q2;0]]                        */
+    RMX_JOINT_FREE2D = 6,         /* JointFree2D.m        3 DOF, Q = [Rz(q3) [q1;q2;0]]                        */
+    RMX_JOINT_SPHERICAL = 7,      /* JointSpherical.m     3 DOF, Euler angles in 12 switching charts           */
+    RMX_JOINT_FREE3D = 8          /* JointFree3D.m        6 DOF, JointTranslational then JointSpherical        */
 };
 
 /* rmx_stats.status bits */
@@ -59,7 +61,8 @@ enum {
  * the library returns the same x without spinning. */
 /* RMX_ST_PIVOTED is informational: at least one linear solve tripped the diagonal-pivot growth guard and was redone
  * with full partial pivoting (see rmx_device.h lu_solve_neg_diag). */
-enum { RMX_ST_DIVERGED = 1, RMX_ST_MAXITER = 2, RMX_ST_NAN = 4, RMX_ST_STALLED = 8, RMX_ST_PIVOTED = 16 };
+enum { RMX_ST_DIVERGED = 1, RMX_ST_MAXITER = 2, RMX_ST_NAN = 4, RMX_ST_STALLED = 8, RMX_ST_PIVOTED = 16,
+       RMX_ST_CHART = 32 /* informational: a JointSpherical changed its Euler chart (the reference prints 'XYZ->YXZ') */ };
 
 /* Scene listing, one entry per joint/body pair in the order the scene file lists them
  * (parent before child; scenesRedMax.m).  Replaces the handle-object graph that Scene.init()
@@ -133,6 +136,16 @@ typedef struct rmx_ground_contact {
     double kd;               /* setDamping(kd)         :41-43 */
 } rmx_ground_contact;
 int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc);
+
+/* JointSpherical / JointFree3D (JointSpherical.m:4-17, 28-34, 63-102): every such joint is in one of 12 Euler charts, numbered as
+ * the reference's CHART_* constants (1 XYX, 2 XZX, 3 YZY, 4 YXY, 5 ZXZ, 6 ZYZ, 7 XYZ, 8 XZY, 9 YZX, 10 YXZ, 11 ZXY, 12 ZYX) and
+ * constructed in CHART_XYZ.  rmx_step_bdf1/bdf2 run reparam_ after every step per trajectory (status bit RMX_ST_CHART when a
+ * chart changed), so q/qdot returned by rmx_get_state are coordinates in the charts rmx_get_charts reports.  rmx_set_state
+ * puts every joint back to CHART_XYZ; rmx_set_charts (after it) declares other charts for the given coordinates.
+ * charts: host [batch][nsph], spherical joints in listing order.  rmx_step_euler / rmx_adjoint_bdf1 refuse such models. */
+int rmx_model_nsph(const rmx_model* m);
+int rmx_get_charts(rmx_batch* b, int* charts);
+int rmx_set_charts(rmx_batch* b, const int* charts);
 
 /* `batch` independent trajectories of the model, state resident in HBM on the model's device. */
 int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out);

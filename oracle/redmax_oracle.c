@@ -988,8 +988,11 @@ static double euler_T(int chart, const double q[3], double T[3][3]) {
     for (int i = 0; i < 3; i++) { T[i][0] = 0; for (int k = 0; k < 3; k++) T[i][0] += R3[k][i] * t[k]; }
     for (int i = 0; i < 3; i++) { T[i][1] = 0; for (int k = 0; k < 3; k++) T[i][1] += R3[k][i] * e2[k]; }
     for (int i = 0; i < 3; i++) T[i][2] = (i == ax[2]) ? 1.0 : 0.0;
-    return T[0][0] * (T[1][1] * T[2][2] - T[1][2] * T[2][1]) - T[0][1] * (T[1][0] * T[2][2] - T[1][2] * T[2][0]) +
-           T[0][2] * (T[1][0] * T[2][1] - T[1][1] * T[2][0]);
+    /* det T in closed form, as the reference's generated code has it (detS = simplify(det(S)), :304-306): +-sin q2 for the
+     * proper-Euler charts, +-cos q2 for the Tait-Bryan ones (only |det T| is ever used, :66, :84).  The closed form matters:
+     * XYX/XZX, YZY/YXY and ZXZ/ZYZ share q2 = acos(R_ii), so their |det T| tie EXACTLY and max() takes the first (:84);
+     * a determinant evaluated from the matrix entries would break those ties by roundoff. */
+    return (ax[2] == ax[0]) ? sin(q[1]) : cos(q[1]);
 }
 /* XYXinv .. ZYXinv (:1809-1949) in one rule.  With (i,j,k) = (a1, a2, remaining axis) and e = +1 if (i,j,k) is a cyclic
  * permutation of (x,y,z), -1 otherwise:
@@ -1053,7 +1056,7 @@ static int reparam(orc_scene* s, int with_prev) {
         }
         double w[3], Tnew[3][3];
         for (int i = 0; i < 3; i++) w[i] = Told[i][0] * qd[0] + Told[i][1] * qd[1] + Told[i][2] * qd[2];
-        const int chart_prev = s->sph_chart1[g];
+        const int chart_prev = s->sph_chart1[g], chart_old = s->sph_chart[g];
         s->sph_chart[g] = best;
         euler_inv(best, R, q);                                                   /* :87 */
         euler_T(best, q, Tnew);                                                  /* :89 */
@@ -1069,7 +1072,7 @@ static int reparam(orc_scene* s, int with_prev) {
         }
         s->sph_chart1[g] = best;
         sph_apply_chart(s, g);
-        switched++;
+        if (best != chart_old) switched++;
     }
     return switched;
 }

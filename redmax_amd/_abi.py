@@ -20,7 +20,7 @@ _ip = C.POINTER(C.c_int)
 SYMBOLS = (
     "rmx_last_error", "rmx_version", "rmx_device_count", "rmx_opts_default",
     "rmx_model_create", "rmx_model_destroy", "rmx_model_nr", "rmx_model_nm", "rmx_model_idxR",
-    "rmx_model_set_ground_contact",
+    "rmx_model_set_ground_contact", "rmx_model_nsph", "rmx_get_charts", "rmx_set_charts",
     "rmx_batch_create", "rmx_batch_destroy", "rmx_batch_size",
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
     "rmx_eval", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_history", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_energy",
@@ -92,6 +92,9 @@ def lib():
     L.rmx_model_nm.argtypes = [vp]
     L.rmx_model_idxR.argtypes = [vp, _ip]
     L.rmx_model_set_ground_contact.argtypes = [vp, C.POINTER(GroundContact)]
+    L.rmx_model_nsph.argtypes = [vp]
+    L.rmx_get_charts.argtypes = [vp, _ip]
+    L.rmx_set_charts.argtypes = [vp, _ip]
     L.rmx_batch_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rmx_batch_destroy.argtypes = [vp]
     L.rmx_batch_size.argtypes = [vp]

@@ -32,6 +32,7 @@ class BatchSim:
             gc.E[:] = list(np.asarray(g["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
             gc.kn, gc.kt, gc.mu, gc.kd = float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"])
             _abi.check(self._L.rmx_model_set_ground_contact(self._model, C.byref(gc)), "rmx_model_set_ground_contact")
+        self.nsph = self._L.rmx_model_nsph(self._model)
         self.B = int(batch)
         self.device = int(device)
         _abi.check(self._L.rmx_batch_create(self._model, self.B, C.byref(self._batch)), "rmx_batch_create")
@@ -58,6 +59,19 @@ class BatchSim:
         if a.shape != (self.B, self.nr):
             a = np.ascontiguousarray(np.broadcast_to(a, (self.B, self.nr)))
         return a
+
+    def charts(self):
+        """JointSpherical.chart of every spherical joint and trajectory, [B][nsph] (reference numbering 1..12)."""
+        c = np.zeros((self.B, max(self.nsph, 1)), dtype=np.int32)
+        if self.nsph:
+            c = np.zeros((self.B, self.nsph), dtype=np.int32)
+            _abi.check(self._L.rmx_get_charts(self._batch, _abi.iptr(c)), "rmx_get_charts")
+            return c
+        return c[:, :0]
+
+    def set_charts(self, charts):
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(charts, dtype=np.int32), (self.B, self.nsph)))
+        _abi.check(self._L.rmx_set_charts(self._batch, _abi.iptr(c)), "rmx_set_charts")
 
     def idxR(self):
         idx = np.zeros(self._desc.njoints, dtype=np.int32)

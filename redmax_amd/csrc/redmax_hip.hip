@@ -103,7 +103,8 @@ void m3v(const double A[9], const double x[3], double y[3]) {
 
 // Scene.init() for a listing of fixed / revolute / prismatic joints.  idx_explicit (or NULL): reduced index of every listed
 // joint, given when the listing is the lowered form of a scene with multi-DOF joints (rmx_model_create below).
-static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, int device, rmx_model** out) {
+static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, const std::vector<int>* sph_first, int device,
+                             rmx_model** out) {
     if (!d || !out) return fail(RMX_E_INVALID, "null argument");
     *out = nullptr;
     int ndev = rmx_device_count();
@@ -158,38 +159,16 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, i
     int rounds = 0;
     while ((1 << rounds) < maxdepth + 1) ++rounds;
 
-    // ---- constants per node
-    std::vector<double> K(36 * MAXN, 0.0), sb(6 * MAXN, 0.0), I4(4 * MAXN, 0.0), prm(8 * MAXN, 0.0);
-    std::vector<int> type(MAXN, 0), idx(MAXN, -1), endd(MAXN, 0), anc(MAXROUNDS * MAXN, -1);
-    std::vector<unsigned long long> rel(2 * MAXN, 0ull);
-    for (int k = 0; k < n; ++k) {
-        const int L = order[k];
-        type[k] = d->type[L];
-        idx[k] = idxL[L];
-        endd[k] = endv[k];
-        int a = par[k];
-        // ancestor 2^r levels up
-        {
-            std::vector<int> chain;   // chain[t] = ancestor t+1 levels up
-            for (int t = par[k]; t >= 0; t = par[t]) {
-                chain.push_back(t);
-                rel[k] |= 1ull << t;            // t is a strict ancestor of k
-                rel[MAXN + t] |= 1ull << k;     // k is a strict descendant of t
-            }
-            for (int r = 0; r < MAXROUNDS; ++r) {
-                int lv = 1 << r;
-                anc[r * MAXN + k] = (lv <= (int)chain.size()) ? chain[lv - 1] : -1;
-            }
-        }
-        (void)a;
+    // constants of listed joint L for joint type jtype about axis_in: Kc[36] = rows R(9),p(3) of K0,K1,K2 ; sbc[6] = A0_ij S
+    auto joint_consts = [&](const int L, const int jtype, const double* axis_in, double* Kc, double* sbc) -> bool {
         const M4 E0_pj = from_cm(d->E0_pj + 16 * L);
         const M4 E0_ji = from_cm(d->E0_ji + 16 * L);
         M4 Lm = E0_pj;   // root: E_wj = E0_pj Q  (Joint.m:404-415)
         if (d->parent[L] >= 0) Lm = mul(inv(from_cm(d->E0_ji + 16 * d->parent[L])), E0_pj);   // parent body -> joint frame
-        double ax[3] = {d->axis[3 * L], d->axis[3 * L + 1], d->axis[3 * L + 2]};
-        if (type[k] != RMX_JOINT_FIXED) {   // JointRevolute.m:14 / JointPrismatic.m:15
+        double ax[3] = {axis_in[0], axis_in[1], axis_in[2]};
+        if (jtype != RMX_JOINT_FIXED) {   // JointRevolute.m:14 / JointPrismatic.m:15
             double nn = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-            if (!(nn > 0)) return fail(RMX_E_INVALID, "zero joint axis");
+            if (!(nn > 0)) return false;
             for (double& v : ax) v /= nn;
         }
         double LR[9], Lp[3], RR[9], Rp[3];
@@ -202,7 +181,7 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, i
             Rp[i] = E0_ji.a[i][3];
         }
         double K0R[9], K0p[3], K1R[9] = {0}, K1p[3] = {0}, K2R[9] = {0}, K2p[3] = {0};
-        if (type[k] == RMX_JOINT_REVOLUTE) {
+        if (jtype == RMX_JOINT_REVOLUTE) {
             // se3.aaToMat (se3.m:111-176) special-cases axis-aligned rotations: snap the ROTATION axis exactly
             // as those branches do, so R(q) has the same exact zeros / ones; S keeps the given axis.
             double ar[3] = {ax[0], ax[1], ax[2]};
@@ -227,24 +206,24 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, i
             m3mul(LR, RR, K0R);
             m3v(LR, Rp, t3);
             for (int i = 0; i < 3; ++i) K0p[i] = Lp[i] + t3[i];
-            if (type[k] == RMX_JOINT_PRISMATIC) m3v(LR, ax, K1p);   // p(q) = a q  (JointPrismatic.m:29-33)
+            if (jtype == RMX_JOINT_PRISMATIC) m3v(LR, ax, K1p);   // p(q) = a q  (JointPrismatic.m:29-33)
         }
         for (int c = 0; c < 9; ++c) {
-            K[c * MAXN + k] = K0R[c];
-            K[(12 + c) * MAXN + k] = K1R[c];
-            K[(24 + c) * MAXN + k] = K2R[c];
+            Kc[c] = K0R[c];
+            Kc[12 + c] = K1R[c];
+            Kc[24 + c] = K2R[c];
         }
         for (int c = 0; c < 3; ++c) {
-            K[(9 + c) * MAXN + k] = K0p[c];
-            K[(21 + c) * MAXN + k] = K1p[c];
-            K[(33 + c) * MAXN + k] = K2p[c];
+            Kc[9 + c] = K0p[c];
+            Kc[21 + c] = K1p[c];
+            Kc[33 + c] = K2p[c];
         }
         // body-frame joint screw A0_ij S  (Body.setBodyTransform Body.m:46-51, Joint.m:508): Ad(E0_ij) [w; v]
         {
             const M4 E0_ij = inv(E0_ji);
             double S[6] = {0, 0, 0, 0, 0, 0};
-            if (type[k] == RMX_JOINT_REVOLUTE) { S[0] = ax[0]; S[1] = ax[1]; S[2] = ax[2]; }
-            if (type[k] == RMX_JOINT_PRISMATIC) { S[3] = ax[0]; S[4] = ax[1]; S[5] = ax[2]; }
+            if (jtype == RMX_JOINT_REVOLUTE) { S[0] = ax[0]; S[1] = ax[1]; S[2] = ax[2]; }
+            if (jtype == RMX_JOINT_PRISMATIC) { S[3] = ax[0]; S[4] = ax[1]; S[5] = ax[2]; }
             double Rm[9], pm[3] = {E0_ij.a[0][3], E0_ij.a[1][3], E0_ij.a[2][3]};
             for (int i = 0; i < 3; ++i)
                 for (int j = 0; j < 3; ++j) Rm[3 * i + j] = E0_ij.a[i][j];
@@ -253,9 +232,41 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, i
             m3v(Rm, S + 3, v3);
             const double cx[3] = {pm[1] * w3[2] - pm[2] * w3[1], pm[2] * w3[0] - pm[0] * w3[2], pm[0] * w3[1] - pm[1] * w3[0]};
             for (int c = 0; c < 3; ++c) {
-                sb[c * MAXN + k] = w3[c];
-                sb[(3 + c) * MAXN + k] = v3[c] + cx[c];
+                sbc[c] = w3[c];
+                sbc[3 + c] = v3[c] + cx[c];
             }
+        }
+        return true;
+    };
+    // ---- constants per node
+    std::vector<double> K(36 * MAXN, 0.0), sb(6 * MAXN, 0.0), I4(4 * MAXN, 0.0), prm(8 * MAXN, 0.0);
+    std::vector<int> type(MAXN, 0), idx(MAXN, -1), endd(MAXN, 0), anc(MAXROUNDS * MAXN, -1);
+    std::vector<unsigned long long> rel(2 * MAXN, 0ull);
+    for (int k = 0; k < n; ++k) {
+        const int L = order[k];
+        type[k] = d->type[L];
+        idx[k] = idxL[L];
+        endd[k] = endv[k];
+        int a = par[k];
+        // ancestor 2^r levels up
+        {
+            std::vector<int> chain;   // chain[t] = ancestor t+1 levels up
+            for (int t = par[k]; t >= 0; t = par[t]) {
+                chain.push_back(t);
+                rel[k] |= 1ull << t;            // t is a strict ancestor of k
+                rel[MAXN + t] |= 1ull << k;     // k is a strict descendant of t
+            }
+            for (int r = 0; r < MAXROUNDS; ++r) {
+                int lv = 1 << r;
+                anc[r * MAXN + k] = (lv <= (int)chain.size()) ? chain[lv - 1] : -1;
+            }
+        }
+        (void)a;
+        {
+            double Kc[36], sbc[6];
+            if (!joint_consts(L, type[k], d->axis + 3 * L, Kc, sbc)) return fail(RMX_E_INVALID, "zero joint axis");
+            for (int c = 0; c < 36; ++c) K[c * MAXN + k] = Kc[c];
+            for (int c = 0; c < 6; ++c) sb[c * MAXN + k] = sbc[c];
         }
         // inertia: the reference allows a general diagonal, but mass entries must agree (Body.m:107 uses M_i(4,4))
         const double* Ii = d->I_i + 6 * L;
@@ -273,6 +284,19 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, i
         prm[6 * MAXN + k] = d->qLimK ? d->qLimK[L] : 1e8;
         prm[7 * MAXN + k] = d->qLimD ? d->qLimD[L] : 0.0;
     }
+
+    // axis variants of the spherical group nodes: chart switches (JointSpherical.reparam_) swap them into LDS on the device
+    const int nsph = sph_first ? (int)sph_first->size() : 0;
+    if (nsph > MAXSPH) return fail(RMX_E_INVALID, "too many spherical joints");
+    std::vector<double> sphV((size_t)nsph * 9 * SPH_ROWS + 1, 0.0);
+    for (int g = 0; g < nsph; ++g)
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) {
+                const double ea[3] = {a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0};
+                double* v = &sphV[((size_t)(g * 3 + k) * 3 + a) * SPH_ROWS];
+                if (pos[(*sph_first)[g] + k] != pos[(*sph_first)[g]] + k) return fail(RMX_E_INVALID, "spherical group is not contiguous");
+                joint_consts((*sph_first)[g] + k, RMX_JOINT_REVOLUTE, ea, v, v + 36);
+            }
 
     rmx_model* m = new rmx_model();
     m->device = device;
@@ -310,6 +334,14 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, i
     for (int c = 0; c < 3; ++c) m->dm.grav[c] = d->grav[c];
     e = hipMemcpy(m->dbuf, host.data(), bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(m->dbuf); delete m; return fail(RMX_E_HIP, std::string("hipMemcpy(model): ") + hipGetErrorString(e)); }
+    m->dm.nsph = nsph;
+    if (nsph) {
+        for (int g = 0; g < nsph; ++g) m->dm.sph_first[g] = (signed char)pos[(*sph_first)[g]];
+        e = hipMalloc(&m->dsph, sphV.size() * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(m->dsph, sphV.data(), sphV.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(m->dbuf); if (m->dsph) (void)hipFree(m->dsph); delete m; return fail(RMX_E_HIP, "spherical variant table"); }
+        m->dm.sphV = (const double*)m->dsph;
+    }
     *out = m;
     return RMX_OK;
 }
@@ -330,12 +362,11 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
         return fail(RMX_E_INVALID, "parent/type/axis/E0_pj/E0_ji/I_i are required");
     bool composite = false;
     for (int i = 0; i < n; ++i) {
-        if (d->type[i] < 0 || d->type[i] > RMX_JOINT_FREE2D)
-            return fail(RMX_E_INVALID, "unsupported joint type (fixed/revolute/prismatic/planar/translational/universal/free2D are in scope)");
+        if (d->type[i] < 0 || d->type[i] > RMX_JOINT_FREE3D) return fail(RMX_E_INVALID, "unsupported joint type");
         if (d->type[i] > RMX_JOINT_PRISMATIC) composite = true;
         if (i > 0 && (d->parent[i] < 0 || d->parent[i] >= i)) return fail(RMX_E_INVALID, "joints must be listed parent-before-child with a single root");
     }
-    if (!composite && !d->qRestR) return model_create_flat(d, nullptr, device, out);
+    if (!composite && !d->qRestR) return model_create_flat(d, nullptr, nullptr, device, out);
 
     struct Sub { int type; double ax[3]; };
     auto subs_of = [&](int L, std::vector<Sub>& v) -> bool {
@@ -350,6 +381,8 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
             case RMX_JOINT_TRANSLATIONAL: add(RMX_JOINT_PRISMATIC, ex); add(RMX_JOINT_PRISMATIC, ey); add(RMX_JOINT_PRISMATIC, ez); break;
             case RMX_JOINT_UNIVERSAL: add(RMX_JOINT_REVOLUTE, ex); add(RMX_JOINT_REVOLUTE, ey); break;
             case RMX_JOINT_FREE2D: add(RMX_JOINT_PRISMATIC, ex); add(RMX_JOINT_PRISMATIC, ey); add(RMX_JOINT_REVOLUTE, ez); break;
+            case RMX_JOINT_FREE3D: add(RMX_JOINT_PRISMATIC, ex); add(RMX_JOINT_PRISMATIC, ey); add(RMX_JOINT_PRISMATIC, ez);   // fallthrough
+            case RMX_JOINT_SPHERICAL: add(RMX_JOINT_REVOLUTE, ex); add(RMX_JOINT_REVOLUTE, ey); add(RMX_JOINT_REVOLUTE, ez); break;   // chart XYZ
             default: add(d->type[L], d->axis + 3 * L); break;
         }
         return true;
@@ -364,11 +397,13 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
         base[L] = nr;
         nr += ndof[L];
     }
-    std::vector<int> parent, type, idx, last(n);
+    std::vector<int> parent, type, idx, last(n), sph_first;
     std::vector<double> axis, E0_pj, E0_ji, I_i, qRest, tau, stiff, damp, qLimL, qLimU, qLimK, qLimD;
     const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int L = 0; L < n; ++L) {
         subs_of(L, sv);
+        if (d->type[L] == RMX_JOINT_SPHERICAL || d->type[L] == RMX_JOINT_FREE3D)
+            sph_first.push_back((int)type.size() + (d->type[L] == RMX_JOINT_FREE3D ? 3 : 0));
         for (size_t k = 0; k < sv.size(); ++k) {
             const bool fin = k + 1 == sv.size();
             parent.push_back(k == 0 ? (d->parent[L] < 0 ? -1 : last[d->parent[L]]) : (int)type.size() - 1);
@@ -402,7 +437,7 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
     x.qLimL = qLimL.data(); x.qLimU = qLimU.data(); x.qLimK = qLimK.data(); x.qLimD = qLimD.data();
     for (int c = 0; c < 3; ++c) x.grav[c] = d->grav[c];
     rmx_model* m = nullptr;
-    const int rc = model_create_flat(&x, idx.data(), device, &m);
+    const int rc = model_create_flat(&x, idx.data(), &sph_first, device, &m);
     if (rc) return rc;
     // what the caller sees follows ITS listing: body L is the last node of joint L's chain, idxR(L) its first DOF
     std::vector<int> node_of(n), idxL(n);
@@ -423,6 +458,7 @@ extern "C" void rmx_model_destroy(rmx_model* m) {
     (void)hipSetDevice(m->device);
     if (m->dbuf) (void)hipFree(m->dbuf);
     if (m->dcon) (void)hipFree(m->dcon);
+    if (m->dsph) (void)hipFree(m->dsph);
     delete m;
 }
 
@@ -475,6 +511,11 @@ extern "C" int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out) {
     alloc((void**)&b->tmpA, nb); alloc((void**)&b->tmpB, nb); alloc((void**)&b->tmpC, nb);
     alloc((void**)&b->started, sizeof(int));
     alloc((void**)&b->it, sizeof(int) * batch); alloc((void**)&b->ls, sizeof(int) * batch); alloc((void**)&b->status, sizeof(int) * batch);
+    if (m->dm.nsph) {   // every JointSpherical starts in CHART_XYZ (JointSpherical.m:33)
+        const std::vector<int> c7((size_t)batch * m->dm.nsph, 7);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->chart, c7.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(b->chart, c7.data(), c7.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&b->ev0);
     if (e == hipSuccess) e = hipEventCreate(&b->ev1);
@@ -492,7 +533,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     (void)hipSetDevice(b->m->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->chart})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -512,10 +553,36 @@ static int copy_state(rmx_batch* b, const double* q, const double* qd, hipMemcpy
         if (q) HIPCHK(hipMemcpyAsync(b->q, q, nb, kind, b->stream));
         if (qd) HIPCHK(hipMemcpyAsync(b->qd, qd, nb, kind, b->stream));
         HIPCHK(hipMemsetAsync(b->started, 0, sizeof(int), b->stream));   // a new state restarts BDF2 with SDIRK2
+        if (b->chart && q) {   // the new coordinates are read in CHART_XYZ (rmx_set_charts afterwards says otherwise)
+            const std::vector<int> c7((size_t)b->B * b->m->dm.nsph, 7);
+            HIPCHK(hipMemcpyAsync(b->chart, c7.data(), c7.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+        }
     } else {
         if (q) HIPCHK(hipMemcpyAsync((void*)q, b->q, nb, kind, b->stream));
         if (qd) HIPCHK(hipMemcpyAsync((void*)qd, b->qd, nb, kind, b->stream));
     }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RMX_OK;
+}
+extern "C" int rmx_model_nsph(const rmx_model* m) { return m ? m->dm.nsph : RMX_E_INVALID; }
+// JointSpherical.chart of every spherical joint and trajectory (reference numbering 1..12); host [batch][nsph]
+extern "C" int rmx_get_charts(rmx_batch* b, int* charts) {
+    if (!b || !charts) return fail(RMX_E_INVALID, "null argument");
+    if (!b->chart) return RMX_OK;
+    HIPCHK(hipSetDevice(b->m->device));
+    HIPCHK(hipMemcpyAsync(charts, b->chart, sizeof(int) * (size_t)b->B * b->m->dm.nsph, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RMX_OK;
+}
+extern "C" int rmx_set_charts(rmx_batch* b, const int* charts) {
+    if (!b || !charts) return fail(RMX_E_INVALID, "null argument");
+    if (!b->chart) return RMX_OK;
+    const size_t nc = (size_t)b->B * b->m->dm.nsph;
+    for (size_t i = 0; i < nc; ++i)
+        if (charts[i] < 1 || charts[i] > 12) return fail(RMX_E_INVALID, "charts must be in 1..12 (JointSpherical.CHART_*)");
+    HIPCHK(hipSetDevice(b->m->device));
+    HIPCHK(hipMemcpyAsync(b->chart, charts, sizeof(int) * nc, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return RMX_OK;
 }
@@ -589,6 +656,7 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.it = with_stats ? b->it : nullptr; a.ls = b->ls; a.status = b->status;
     a.histT = dT; a.histV = dV;
     a.histQ = dQ; a.histQd = dQd;
+    a.chart = b->chart;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
     if (integ == INTEG_BDF2) HIPCHK(hipMemsetAsync(b->started, 1, sizeof(int), b->stream));   // any non-zero value
@@ -677,6 +745,7 @@ extern "C" int rmx_step_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx
 extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, double* hV) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     if (b->m->dm.con) return fail(RMX_E_INVALID, "rmx_step_euler: matlab-simple has no ForceGroundCuboid; use rmx_step_bdf1/bdf2");
+    if (b->m->dm.nsph) return fail(RMX_E_INVALID, "rmx_step_euler: matlab-simple has no JointSpherical; use rmx_step_bdf1/bdf2");
     if (nsteps < 0 || !(h > 0)) return fail(RMX_E_INVALID, "bad nsteps / h");
     if ((hT == nullptr) != (hV == nullptr)) return fail(RMX_E_INVALID, "hist_T and hist_V must be given together");
     rmx_model* m = b->m;
@@ -718,6 +787,7 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
     rmx_model* m = b->m;
     if (nsteps < 1) return fail(RMX_E_INVALID, "nsteps < 1");
     if (m->dm.con) return fail(RMX_E_INVALID, "rmx_adjoint_bdf1: ground contact is outside the adjoint path (SURVEY.md 8(f))");
+    if (m->dm.nsph) return fail(RMX_E_INVALID, "rmx_adjoint_bdf1: spherical joints are outside the adjoint path (SURVEY.md 8(f))");
     if (task->body < 0 || task->body >= m->nlist) return fail(RMX_E_INVALID, "task body out of range");
     if (task->step < 1 || task->step > nsteps) return fail(RMX_E_INVALID, "task step must be in [1, nsteps]");
     HIPCHK(hipSetDevice(m->device));

@@ -22,6 +22,8 @@ constexpr int NCOL = 18;          // column-side Hessian vectors per node (yz6, 
 constexpr int COL_STRIDE = 19;
 constexpr int MAXROUNDS = 6;      // log2(MAXN)
 constexpr int NCONST = 68;        // per-node constants staged in LDS: K(36) sb(6) I4(4) prm(8) type(1) rel(2) anc(6) end(1) contact(1) sides(3)
+constexpr int MAXSPH = 21;        // spherical joints per tree (three nodes each)
+constexpr int SPH_ROWS = 42;      // per-node constants that depend on a spherical node's axis: K(36) + sb(6), the first LDS rows
 constexpr int NCOLX = 24;         // with ground contact the column side also needs m2v(3) and sv(3)
 
 // Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
@@ -44,6 +46,10 @@ struct DevModel {
     const double* con;   // [4][MAXN]  contact flag, cuboid sides(3)
     double gn[3], gx[3]; // plane normal (Z axis of the ground frame) and origin   ForceGroundCuboid.m:56-57
     double kn, kt, mu, kdc;   // setStiffness(kn, kt), setFriction(mu), setDamping(kd)
+    // JointSpherical / JointFree3D: group g = nodes sph_first[g] .. +2 (revolute about the axes of the group's Euler chart)
+    int nsph;
+    const double* sphV;  // [nsph][3 nodes][3 axes][SPH_ROWS]  K and sb of each group node for axis x, y, z
+    signed char sph_first[MAXSPH + 3];
 };
 
 struct DevOpts {
@@ -1139,6 +1145,228 @@ __device__ __forceinline__ void eval_node(const DevModel& M, double* __restrict_
     FrontState fs;
     eval_front<NP, WANT_H, TIMED, CT>(M, sAcc, lane, xq, xqd, xv, eta, out, fs, stamps);
     if (WANT_H) eval_hess<NP, TIMED, CT>(M, lane, fs, Hrow, stamps, sAcc);
+}
+
+// ----------------------------------------------------------------------------- JointSpherical: Euler charts
+//
+// JointSpherical (matlab-diff/+redmax/JointSpherical.m) parameterises a ball joint by Euler angles in one of 12 charts,
+// R = R_a1(q1) R_a2(q2) R_a3(q3) (codegen :247-262), i.e. by three revolute joints about the chart's axes: the tree holds
+// such a joint as three consecutive nodes (two massless links), and everything above (kinematics, residual, Hessian) already
+// covers it.  What is left is reparam_ (:63-102): after every step, a joint whose chart nears gimbal lock (|det T| <= 0.5,
+// det T = +-sin q2 for the proper-Euler charts 1..6, +-cos q2 for the Tait-Bryan charts 7..12) moves to the chart with the
+// largest min(|det T(R)|, |det T(R1)|), R1 the rotation of the previous step, and q, qdot (and q1, qdot1) are re-expressed.
+// A chart switch swaps the K / sb constants of the group's three nodes in LDS for the new axes (DevModel::sphV).
+// Charts are numbered as in the reference: 1 XYX 2 XZX 3 YZY 4 YXY 5 ZXZ 6 ZYZ 7 XYZ 8 XZY 9 YZX 10 YXZ 11 ZXY 12 ZYX.
+__device__ __forceinline__ void chart_axes(const int chart, int& a1, int& a2, int& a3) {
+    const int p = (chart - 1) % 6;
+    a1 = p >> 1;
+    a2 = (a1 + 1 + (p & 1)) % 3;
+    a3 = chart <= 6 ? a1 : 3 - a1 - a2;
+}
+__device__ __forceinline__ double m3at(const double (&R)[9], const int i, const int j) {   // R[i][j], runtime i, j, no scratch
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) v = (c == 3 * i + j) ? R[c] : v;
+    return v;
+}
+__device__ __forceinline__ void rot_elem(const int a, const double q, double (&R)[9]) {
+    double sn, cs;
+    sincos(q, &sn, &cs);
+    const int b = (a + 1) % 3, d = (a + 2) % 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            R[3 * i + j] = (i == j) ? (i == a ? 1.0 : cs) : ((i == b && j == d) ? -sn : ((i == d && j == b) ? sn : 0.0));
+}
+__device__ __forceinline__ void mm3(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void euler_R(const int chart, const double (&q)[3], double (&R)[9]) {
+    int a1, a2, a3;
+    chart_axes(chart, a1, a2, a3);
+    double R1[9], R2[9], R3[9], T[9];
+    rot_elem(a1, q[0], R1);
+    rot_elem(a2, q[1], R2);
+    rot_elem(a3, q[2], R3);
+    mm3(R1, R2, T);
+    mm3(T, R3, R);
+}
+// T(:,1) = R3'R2' e_a1, T(:,2) = R3' e_a2, T(:,3) = e_a3 (vee(R' dR/dq_i), :298-303); returns det T
+__device__ __forceinline__ double euler_T(const int chart, const double (&q)[3], double (&T)[9]) {
+    int a1, a2, a3;
+    chart_axes(chart, a1, a2, a3);
+    double R2[9], R3[9], t[3];
+    rot_elem(a2, q[1], R2);
+    rot_elem(a3, q[2], R3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = m3at(R2, a1, i);                                   // R2' e_a1
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        T[3 * i + 0] = R3[i] * t[0] + R3[3 + i] * t[1] + R3[6 + i] * t[2];               // R3' t
+        T[3 * i + 1] = m3at(R3, a2, i);                                                  // R3' e_a2
+        T[3 * i + 2] = (i == a3) ? 1.0 : 0.0;
+    }
+    // det T in closed form like the reference's generated code (+-sin q2 proper Euler, +-cos q2 Tait-Bryan; only |det T| is
+    // used): XYX/XZX, YZY/YXY, ZXZ/ZYZ share q2 = acos(R_ii), so their |det T| tie exactly and the first chart wins (:84).
+    return (a3 == a1) ? sin(q[1]) : cos(q[1]);
+}
+// getEulerInv (:181-208; XYXinv..ZYXinv :1809-1949) as one rule: (i,j,k) = (a1, a2, the third axis), e = +1 when (i,j,k) is a
+// cyclic permutation of (x,y,z): proper Euler q2 = acos(R_ii), q1 = atan2(R_ji, -e R_ki), q3 = atan2(R_ij, e R_ik);
+// Tait-Bryan q2 = asin(e R_ik), q1 = atan2(-e R_jk, R_kk), q3 = atan2(-e R_ij, R_ii); NaN at gimbal lock.
+__device__ __forceinline__ void euler_inv(const int chart, const double (&R)[9], double (&q)[3]) {
+    int i, j, a3;
+    chart_axes(chart, i, j, a3);
+    const int k = 3 - i - j;
+    const double e = ((j - i + 3) % 3 == 1) ? 1.0 : -1.0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    if (a3 == i) {
+        const double r = m3at(R, i, i);
+        const bool ok = -1.0 < r && r < 1.0;
+        q[0] = ok ? atan2(m3at(R, j, i), -e * m3at(R, k, i)) : nan;
+        q[1] = ok ? acos(r) : nan;
+        q[2] = ok ? atan2(m3at(R, i, j), e * m3at(R, i, k)) : nan;
+    } else {
+        const double r = m3at(R, i, k);
+        const bool ok = -1.0 < r && r < 1.0;
+        q[0] = ok ? atan2(-e * m3at(R, j, k), m3at(R, k, k)) : nan;
+        q[1] = ok ? asin(e * r) : nan;
+        q[2] = ok ? atan2(-e * m3at(R, i, j), m3at(R, i, i)) : nan;
+    }
+}
+// x = A\b, 3x3, Gaussian elimination with partial pivoting (MATLAB mldivide), rows swapped by value
+__device__ __forceinline__ void solve3(const double (&Ain)[9], const double (&b)[3], double (&x)[3]) {
+    double A[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) A[i][j] = Ain[3 * i + j];
+        A[i][3] = b[i];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int r = c + 1; r < 3; ++r) {      // bring the larger pivot candidate up (first maximum wins, as in LAPACK)
+            const bool sw = fabs(A[r][c]) > fabs(A[c][c]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double u = A[c][j], v = A[r][j];
+                A[c][j] = sw ? v : u;
+                A[r][j] = sw ? u : v;
+            }
+        }
+#pragma unroll
+        for (int r = c + 1; r < 3; ++r) {
+            const double l = A[r][c] / A[c][c];
+#pragma unroll
+            for (int j = c; j < 4; ++j) A[r][j] -= l * A[c][j];
+        }
+    }
+    x[2] = A[2][3] / A[2][2];
+    x[1] = (A[1][3] - A[1][2] * x[2]) / A[1][1];
+    x[0] = (A[0][3] - A[0][1] * x[1] - A[0][2] * x[2]) / A[0][0];
+}
+// put the K / sb constants of group g's three nodes for `chart` into this wavefront's LDS copy (rows 0..41 of the constants)
+template <int NP>
+__device__ __forceinline__ void sph_apply_chart(const DevModel& M, double* __restrict__ sCol, const int lane, const int g, const int chart) {
+    const int first = M.sph_first[g];
+    const int k = lane - first;
+    if (k >= 0 && k < 3) {
+        int a1, a2, a3;
+        chart_axes(chart, a1, a2, a3);
+        const int a = k == 0 ? a1 : (k == 1 ? a2 : a3);
+        const double* src = M.sphV + ((size_t)(g * 3 + k) * 3 + a) * SPH_ROWS;
+        for (int r = 0; r < SPH_ROWS; ++r) sCol[r * NP + lane] = src[r];
+    }
+}
+// kernel prologue: bring the LDS constants in line with the stored charts (smem_setup staged CHART_XYZ)
+template <int NP>
+__device__ __forceinline__ void sph_setup(const DevModel& M, double* __restrict__ sCol, const int lane, const int* __restrict__ chart) {
+    bool any = false;
+    for (int g = 0; g < M.nsph; ++g) {
+        const int c = chart[g];
+        if (c != 7) {
+            sph_apply_chart<NP>(M, sCol, lane, g, c);
+            any = true;
+        }
+    }
+    if (any) __syncthreads();
+}
+// Joint.reparam -> JointSpherical.reparam_ (:63-102) for every spherical group of this trajectory, after setQ at the end of a step
+// (driverRedMaxBDF1.m:78, driverRedMaxBDF2.m:112).  q, qd: this lane's DOF of the new state; qp, qdp: of the previous step
+// (the reference's q1, qdot1 with chart1 == chart at this point; WITH_PREV = the BDF2 driver).  The BDF1 driver never sets
+// q1 / chart1, so the reference's reparam_ would fail there if a switch came up; BDF1 here picks the chart from R alone.
+// Returns true if any chart changed.
+template <int NP, bool WITH_PREV>
+__device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restrict__ sCol, const int lane, int* __restrict__ chart,
+                                            double& q, double& qd, double& qp, double& qdp) {
+    bool switched = false;
+    for (int g = 0; g < M.nsph; ++g) {
+        const int first = M.sph_first[g];
+        const int c0 = chart[g];
+        const double qv[3] = {readlane_d(q, first), readlane_d(q, first + 1), readlane_d(q, first + 2)};
+        double Told[9];
+        const double detTold = euler_T(c0, qv, Told);
+        if (fabs(detTold) > 0.5) continue;                                        // :66-68
+        const double qdv[3] = {readlane_d(qd, first), readlane_d(qd, first + 1), readlane_d(qd, first + 2)};
+        const double q1v[3] = {readlane_d(qp, first), readlane_d(qp, first + 1), readlane_d(qp, first + 2)};
+        const double qd1v[3] = {readlane_d(qdp, first), readlane_d(qdp, first + 1), readlane_d(qdp, first + 2)};
+        double R[9], R1[9], Tt[9];
+        euler_R(c0, qv, R);
+        if (WITH_PREV) euler_R(c0, q1v, R1);                                      // :73
+        int best = 1;
+        double bestv = -1.0;
+        for (int k = 1; k <= 12; ++k) {                                           // :75-85
+            double qk[3];
+            euler_inv(k, R, qk);
+            double v = fabs(euler_T(k, qk, Tt));
+            v = (v == v) ? v : 0.0;
+            if (WITH_PREV) {
+                euler_inv(k, R1, qk);
+                double v1 = fabs(euler_T(k, qk, Tt));
+                v1 = (v1 == v1) ? v1 : 0.0;
+                v = v1 < v ? v1 : v;
+            }
+            if (v > bestv) {                                                      // max() keeps the first maximum
+                bestv = v;
+                best = k;
+            }
+        }
+        double w[3], Tn[9], qn[3], qdn[3], q1n[3] = {0, 0, 0}, qd1n[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = Told[3 * i] * qdv[0] + Told[3 * i + 1] * qdv[1] + Told[3 * i + 2] * qdv[2];
+        euler_inv(best, R, qn);                                                   // :87
+        euler_T(best, qn, Tn);                                                    // :89
+        solve3(Tn, w, qdn);                                                       // :91
+        if (WITH_PREV) {                                                          // :97-101
+            euler_T(c0, q1v, Told);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = Told[3 * i] * qd1v[0] + Told[3 * i + 1] * qd1v[1] + Told[3 * i + 2] * qd1v[2];
+            euler_inv(best, R1, q1n);
+            euler_T(best, q1n, Tn);
+            solve3(Tn, w, qd1n);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (lane == first + k) {
+                q = qn[k];
+                qd = qdn[k];
+                if (WITH_PREV) {
+                    qp = q1n[k];
+                    qdp = qd1n[k];
+                }
+            }
+        if (best != c0) {
+            if (lane == 0) chart[g] = best;
+            sph_apply_chart<NP>(M, sCol, lane, g, best);
+            switched = true;
+        }
+    }
+    if (switched) __syncthreads();
+    return switched;
 }
 
 // ----------------------------------------------------------------------------- dense solve

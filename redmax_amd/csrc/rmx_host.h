@@ -26,6 +26,7 @@ struct StepArgs {
     int* status;
     double* histT;    // [nsteps][B] or null
     double* histV;
+    int* chart;       // [B][nsph] Euler charts of the spherical joints (in/out) or null
     double* histQ;    // [nsteps][B][nr] or null: q, qdot after every step (Scene.saveHistory, Scene.m:134-161)
     double* histQd;
 };
@@ -50,6 +51,7 @@ struct rmx_model {
     std::vector<int> node_of_listing;   // depth-first node index of each LISTED joint/body
     void* dbuf = nullptr;           // one device allocation holding all constant arrays
     void* dcon = nullptr;           // contact flags + cuboid sides (rmx_model_set_ground_contact)
+    void* dsph = nullptr;           // axis variants of the spherical group nodes
     DevModel dm{};
     size_t smem_bytes = 0;
 };
@@ -62,6 +64,7 @@ struct rmx_batch {
     double *q = nullptr, *qd = nullptr, *qp = nullptr, *qdp = nullptr;
     double *tmpA = nullptr, *tmpB = nullptr, *tmpC = nullptr;   // [B][nr] scratch for rmx_eval inputs
     int* started = nullptr;
+    int* chart = nullptr;           // [B][nsph] current Euler chart of every spherical joint (JointSpherical.chart), 1..12
     int *it = nullptr, *ls = nullptr, *status = nullptr;
     double last_ms = 0.0;
 };

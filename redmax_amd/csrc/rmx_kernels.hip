@@ -54,6 +54,10 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
     double qd = id >= 0 ? a.qd[off] : 0.0;
     int iters = 0, halv = 0, status = 0;
     PivotPolicy piv;
+    int* const chart = (CT && M.nsph) ? a.chart + (size_t)traj * M.nsph : nullptr;
+    if constexpr (CT) {
+        if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
+    }
     for (int s = 0; s < a.nsteps; ++s) {
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
@@ -61,6 +65,10 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
         const double x = newton_node<NP, CT>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
         qd = (x - q0) / o.h;                       // (:72)
         q = x;
+        if constexpr (CT) {                        // jroot.reparam() (:78)
+            double np0 = 0.0, np1 = 0.0;
+            if (M.nsph && sph_reparam<NP, false>(M, sCol, lane, chart, q, qd, np0, np1)) status |= 32;
+        }
         if (a.histT) {                             // Scene.saveHistory (Scene.m:134-161)
             const double T = wave_sum(last.eT), V = wave_sum(last.eV);
             if (lane == 0) {
@@ -100,6 +108,10 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
     const double h = o.h;
     int iters = 0, halv = 0, status = 0;
     PivotPolicy piv;
+    int* const chart = (CT && M.nsph) ? a.chart + (size_t)traj * M.nsph : nullptr;
+    if constexpr (CT) {
+        if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
+    }
     for (int s = 0; s < a.nsteps; ++s) {
         NodeOut last;
         if (s == 0 && !started) {
@@ -130,6 +142,9 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
             q = q2;
             // the Newton residual was evaluated with qdot = (q2-qA)/eta, identical up to rounding
+        }
+        if constexpr (CT) {                        // jroot.reparam() (:112): q, qdot and the previous step's q1, qdot1
+            if (M.nsph && sph_reparam<NP, true>(M, sCol, lane, chart, q, qd, qp, qdp)) status |= 32;
         }
         if (a.histT) {
             const double T = wave_sum(last.eT), V = wave_sum(last.eV);
@@ -359,10 +374,13 @@ __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevO
 template <int NP, bool WANT_H, bool CT>
 __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, const double* __restrict__ q,
                                              const double* __restrict__ qA, const double* __restrict__ qB, const double eta,
-                                             double* __restrict__ g, double* __restrict__ H) {
+                                             double* __restrict__ g, double* __restrict__ H, const int* __restrict__ chart) {
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x, traj = blockIdx.x;
+    if constexpr (CT) {
+        if (M.nsph) sph_setup<NP>(M, sCol, lane, chart + (size_t)traj * M.nsph);
+    }
     const int id = (lane < M.n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     const double x = id >= 0 ? q[off] : 0.0;
@@ -387,9 +405,13 @@ __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, cons
 // Joint.computeEnergies / Body.computeEnergies at the stored state.
 template <int NP, bool CT>
 __global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, const double* __restrict__ q,
-                                               const double* __restrict__ qd, double* __restrict__ T, double* __restrict__ V) {
+                                               const double* __restrict__ qd, double* __restrict__ T, double* __restrict__ V,
+                                               const int* __restrict__ chart) {
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
+    if constexpr (CT) {
+        if (M.nsph) sph_setup<NP>(M, sCol, threadIdx.x, chart + (size_t)blockIdx.x * M.nsph);
+    }
     const int lane = threadIdx.x, traj = blockIdx.x;
     const int id = (lane < M.n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
@@ -446,16 +468,17 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
 
 void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
     const dim3 grid(b->B), block(64);
-    const bool ct = m->dm.con != nullptr;   // scenes with ForceGroundCuboid run the contact instantiations
-    if (wantH && ct) k_eval<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
-    else if (wantH) k_eval<RMX_NP, true, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
-    else if (ct) k_eval<RMX_NP, false, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
-    else k_eval<RMX_NP, false, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH);
+    // scenes with ForceGroundCuboid or JointSpherical run the extended instantiations (CT), everything else the plain ones
+    const bool ct = m->dm.con != nullptr || m->dm.nsph > 0;
+    if (wantH && ct) k_eval<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
+    else if (wantH) k_eval<RMX_NP, true, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
+    else if (ct) k_eval<RMX_NP, false, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
+    else k_eval<RMX_NP, false, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
 }
 
 void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
-    const bool ct = m->dm.con != nullptr;
+    const bool ct = m->dm.con != nullptr || m->dm.nsph > 0;
     if (integ == INTEG_BDF1 && ct) k_step_bdf1<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
     else if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
     else if (ct) k_step_bdf2<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
@@ -469,8 +492,8 @@ void RMX_CAT(launch_euler_, RMX_NP)(const rmx_model* m, const rmx_batch* b, doub
 
 void RMX_CAT(launch_energy_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);
-    if (m->dm.con) k_energy<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
-    else k_energy<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV);
+    if (m->dm.con || m->dm.nsph) k_energy<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, b->chart);
+    else k_energy<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, nullptr);
 }
 
 void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a) {
