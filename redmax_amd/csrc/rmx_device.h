@@ -956,7 +956,7 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle lanes are the identity.
 template <int NP, bool TIMED = false, bool CT = false>
-__device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
+__device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     const double eta = fs.eta, e2 = eta * eta;
@@ -1133,6 +1133,7 @@ __device__ __forceinline__ void eval_hess(const DevModel& M, const int lane, con
         Hrow[i] = (i == lane) ? Hdiag : hv;
     }
     RMX_STAMP(11)
+    return Hdiag;    // H(lane,lane): the scale of this row for the solver's pivot guard
 }
 
 // One-shot evaluation (parity hook / energy kernels)
@@ -1374,23 +1375,30 @@ __device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restric
 // dx = -H\g (driverRedMaxBDF1.m:117: MATLAB mldivide = LU with partial pivoting).  Lane = row; the row
 // lives in registers; rows are never moved (implicit permutation); the pivot row is broadcast with
 // v_readlane into scalar registers; the right-hand side is eliminated alongside.
-// Fast path: eliminate on the diagonal (no search, static lanes) under a growth guard.  Every multiplier must satisfy
-// |l| <= LU_GROWTH_MAX, i.e. the diagonal passes threshold pivoting with tau = 1/LU_GROWTH_MAX (the criterion sparse direct
-// solvers use); H = M - eta D - eta^2 K + dMdq.v is a modest perturbation of the SPD mass matrix, so this nearly always
-// holds.  If any multiplier violates it (or is NaN) `ok` comes back false and the caller redoes the solve with full
-// partial pivoting (lu_solve_neg) on a re-assembled H: pivoting semantics are kept, its cost is paid only when needed.
+// Fast path: eliminate on the diagonal (no search, static lanes) under a growth guard.  Every multiplier of the symmetrically
+// equilibrated matrix D^-1/2 H D^-1/2 (D = diag H) must satisfy |l'| <= LU_GROWTH_MAX, i.e. the diagonal passes threshold
+// pivoting with tau = 1/LU_GROWTH_MAX (the criterion sparse direct solvers use) on the scaled matrix, and every pivot must be
+// positive: l'_ik^2 = l_ik^2 u_kk / d_i <= 64.  For a symmetric positive definite matrix l' <= 1 always (a_ik^2 <= a_ii a_kk
+// on every Schur complement), and H = M - eta D - eta^2 K + dMdq.v is a modest perturbation of the SPD mass matrix, so this
+// nearly always holds - also for trees that mix prismatic (mass-sized diagonal) and revolute (inertia-sized) DOFs, where the
+// raw multipliers are large for scaling reasons only.  If any step violates the guard (or is NaN) `ok` comes back false and
+// the caller redoes the solve with full partial pivoting (lu_solve_neg) on a re-assembled H: pivoting semantics are kept,
+// its cost is paid only when needed.
 constexpr double LU_GROWTH_MAX = 8.0;
 template <int NP>
-__device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, bool& ok) {
+__device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, const double diag_own,
+                                                    bool& ok) {
     double b = -g;
     bool bad = false;
     double rinv_own = 0.0;    // 1/U(lane,lane), kept for the back substitution
+    const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const double rinv = recip(readlane_d(Hrow[k], k));
+        const double piv = readlane_d(Hrow[k], k);
+        const double rinv = recip(piv);
         rinv_own = (lane == k) ? rinv : rinv_own;
         const double l = (lane > k) ? Hrow[k] * rinv : 0.0;
-        bad = bad || !(fabs(l) <= LU_GROWTH_MAX);
+        bad = bad || !(l * l * piv <= lim) || !(piv > 0.0);
 #pragma unroll
         for (int c = k + 1; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], k);
         b -= l * readlane_d(b, k);
@@ -1487,7 +1495,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     int iter = 1;
     while (true) {
-        eval_hess<NP, false, CT>(M, lane, fs, Hrow, nullptr, sAcc);
+        const double hdiag = eval_hess<NP, false, CT>(M, lane, fs, Hrow, nullptr, sAcc);
         const NodeOut e0 = e;
         last = e;
         ++iters;
@@ -1496,7 +1504,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
             dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
         } else {
             bool lu_ok;
-            dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, lu_ok);
+            dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
             if (lu_ok) {
                 piv.streak = 0;
             } else {             // growth guard tripped: redo this solve with partial pivoting
