@@ -166,3 +166,114 @@ def test_nonconverging_solve_is_a_status_not_an_error():
     assert out["status"][0] & 2
     q, _ = sim.get_state()
     assert np.isfinite(q).all()
+
+
+@pytest.mark.parametrize("name", ["2", "chain8", "4", "8", "9", "11", "chain6ground"])
+def test_hessian_is_the_jacobian_of_g_on_the_device(name):
+    """The reference's own gradient check inside newton (testGrad, driverRedMaxBDF1.m:104-115) run on the HIP path alone:
+    central differences of rmx_eval's g reproduce its H (1e-6 relative, the pass criterion of Scene.printError, Scene.m:424-450).
+    No oracle involved; covers revolute/prismatic trees, multi-DOF joints, Euler-chart joints and ground contact."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainGround
+    if name == "chain8":
+        sc = sceneChain(8, axis=(0.3, 1.0, 0.2))
+    elif name == "chain6ground":
+        sc = sceneChainGround(6, ground_z=-1.0)
+    else:
+        sc = scenesRedMax(int(name))
+    sc.init()
+    nr, h = sc.nr, sc.h
+    rng = np.random.default_rng(21)
+    q0 = rng.uniform(-0.4, 0.4, nr)
+    if name == "11":
+        q0 = np.array([0.2, -0.1, 0.3])                      # corners below the ground plane
+    qd0 = rng.uniform(-1, 1, nr)
+    q1 = q0 + h * qd0
+    B = 2 * nr + 1
+    X = np.tile(q1, (B, 1))
+    step = 1e-6
+    for i in range(nr):
+        X[1 + 2 * i, i] += step
+        X[2 + 2 * i, i] -= step
+    sim = BatchSim(sc, batch=B)
+    g, H = sim.eval_bdf1(X, np.tile(q0, (B, 1)), np.tile(qd0, (B, 1)), h)
+    Hfd = np.stack([(g[1 + 2 * i] - g[2 + 2 * i]) / (2 * step) for i in range(nr)], axis=1)
+    assert _rel(Hfd, H[0]) < 1e-6
+    sim.close()
+
+
+def test_planar_joint_with_a_skew_plane_matches_oracle(oracle_lib):
+    """JointPlanar(parent, body, plane) with non-orthogonal in-plane directions (JointPlanar.m:11-19 only normalises the
+    columns): rmx_model_desc.plane reaches the lowered prismatic pair."""
+    from redmax_amd import BatchSim
+    from redmax_amd.redmax import JointPlanar
+    sc = Scene()
+    b1 = BodyCuboid(1.0, [4, 4, 1])
+    j1 = JointPlanar(None, b1, plane=np.array([[1.0, 0.2, 0.0], [0.3, 1.0, 0.5]]).T)
+    j1.setJointTransform(se3.transform(R=se3.aaToMat([0, 0, 1], 0.3)))
+    b1.setBodyTransform(se3.transform(p=[0.5, 0, 0]))
+    b2 = BodyCuboid(1.0, [1, 1, 6])
+    j2 = JointRevolute(j1, b2, [0, 1, 0])
+    j2.setJointTransform(se3.transform(p=[-2, 0, 0]))
+    b2.setBodyTransform(se3.transform(p=[0, 0, -3]))
+    j1.setStiffness(5e3)
+    j1.q[:] = [0.3, -0.2]
+    j1.qdot[:] = [1.0, 2.0]
+    j2.q[0] = 0.4
+    sc.bodies, sc.joints = [b1, b2], [j1, j2]
+    sc.init()
+    assert sc.nr == 3 and [j.idxR for j in sc.joints] == [[1, 2], [0]]
+    sim = BatchSim(sc, batch=1)
+    q0, qd0 = sc.getQ()
+    sim.set_state(q0[None], qd0[None])
+    o = oracle_lib.Oracle(sc.desc())
+    g, H = sim.eval_bdf1((q0 + 1e-2 * qd0)[None], q0[None], qd0[None], 1e-2)
+    go, Ho = o.eval_bdf1(q0 + 1e-2 * qd0, q0, qd0, 1e-2)
+    assert _rel(g[0], go) <= 1e-11 and _rel(H[0], Ho) <= 1e-11
+    sim.step_bdf1(20, h=1e-2)
+    o.set_state(q0, qd0)                                             # eval_bdf1 left the oracle at the evaluation point
+    o.step_bdf1(1e-2, 20)
+    assert _rel(sim.get_state()[0][0], o.get_state()[0]) <= 1e-9     # the joint spring pulls towards qRest = initial q (both DOFs)
+    sim.close()
+
+
+def test_lowered_tree_larger_than_a_wavefront_is_an_error():
+    from redmax_amd import BatchSim, RedMaxHipError
+    from redmax_amd.redmax import JointFree3D
+    sc = Scene()
+    prev = None
+    for i in range(11):                                       # 11 x 6 DOF = 66 nodes after lowering
+        b = BodyCuboid(1.0, [1, 1, 1])
+        j = JointFree3D(prev, b)
+        j.setJointTransform(se3.transform(p=[1, 0, 0]))
+        sc.bodies.append(b)
+        sc.joints.append(j)
+        prev = j
+    sc.init()
+    with pytest.raises(RedMaxHipError, match="1-DOF nodes"):
+        BatchSim(sc, batch=1)
+
+
+def test_chart_api_validation():
+    from redmax_amd import BatchSim, RedMaxHipError
+    sc = scenesRedMax(7)
+    sc.init()
+    sim = BatchSim(sc, batch=3)
+    assert sim.nsph == 2 and sim.charts().shape == (3, 2) and np.all(sim.charts() == 7)
+    sim.set_charts([1, 12])
+    assert np.array_equal(sim.charts(), np.tile([1, 12], (3, 1)))
+    with pytest.raises(RedMaxHipError):
+        sim.set_charts([0, 13])
+    q0, qd0 = sc.getQ()
+    sim.set_state(np.tile(q0, (3, 1)), np.tile(qd0, (3, 1)))          # a new state is read in CHART_XYZ
+    assert np.all(sim.charts() == 7)
+    sim.close()
+    plain = BatchSim(scenesRedMaxInit(0), batch=1)
+    assert plain.nsph == 0 and plain.charts().shape == (1, 0)
+    plain.close()
+
+
+def scenesRedMaxInit(sid):
+    sc = scenesRedMax(sid)
+    sc.init()
+    return sc
