@@ -24,6 +24,11 @@ constexpr int MAXROUNDS = 6;      // log2(MAXN)
 constexpr int NCONST = 68;        // per-node constants staged in LDS: K(36) sb(6) I4(4) prm(8) type(1) rel(2) anc(6) end(1) contact(1) sides(3)
 constexpr int MAXSPH = 21;        // spherical joints per tree (three nodes each)
 constexpr int SPH_ROWS = 42;      // per-node constants that depend on a spherical node's axis: K(36) + sb(6), the first LDS rows
+// doubles of the accumulation scratch at the start of a wavefront's LDS: (n+1) rows of the subtree scan, or the Hessian's
+// column vectors [NP][NCOLX], whichever is larger; the per-node constants follow it
+__host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
+    return (n + 1) * ACC_STRIDE > NP * 24 ? (n + 1) * ACC_STRIDE : NP * 24;
+}
 constexpr int NCOLX = 24;         // with ground contact the column side also needs m2v(3) and sv(3)
 
 // Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
@@ -88,6 +93,22 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     lo = __builtin_amdgcn_readlane(lo, l);
     hi = __builtin_amdgcn_readlane(hi, l);
     return __hiloint2double(hi, lo);
+}
+
+// v_permlane32_swap (gfx950): swaps lanes 32..63 of its first operand with lanes 0..31 of the second.
+// dup_lo: every lane l >= 32 receives the value of lane l-32 (lanes < 32 keep theirs); take_hi: every lane l < 32 receives
+// the value of lane l+32.
+__device__ __forceinline__ double dup_lo(const double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]);
+}
+__device__ __forceinline__ double take_hi(const double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[1], a[1]);
 }
 
 // DPP lane permutations inside a 16-lane row (no LDS traffic, a few cycles each)
@@ -515,7 +536,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     const int jj = act ? lane : 0;
     // per-node constants staged in LDS by smem_setup (stride NP): reading them from L2 at every evaluation left the single
     // resident wave parked at s_waitcnt (SQ_WAIT_ANY 31 % of wave cycles)
-    const double* cK = sAcc + (n + 1) * ACC_STRIDE;
+    const double* cK = sAcc + acc_doubles(n, NP);
     const double* cSb = cK + 36 * NP;
     const double* cI4 = cSb + 6 * NP;
     const double* cPrm = cI4 + 4 * NP;
@@ -977,7 +998,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
         for (int c = 0; c < 6; ++c) cxy[c] = cxr2[c] = cxr3[c] = 0.0;
         if (fs.touched) {
-            const double* cEnd = sAcc + (M.n + 1) * ACC_STRIDE + (NCONST - 5) * NP;
+            const double* cEnd = sAcc + acc_doubles(M.n, NP) + (NCONST - 5) * NP;
             const double* cCon = cEnd + NP;
             const bool con = act && cCon[jj] != 0.0;
             const double sd[3] = {cCon[NP + jj], cCon[2 * NP + jj], cCon[3 * NP + jj]};
@@ -1097,8 +1118,8 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         }
     }
     RMX_STAMP(9)
-    // column-side vectors stay in this lane's registers (zero on idle lanes); column i is broadcast out of lane i with
-    // v_readlane into scalar registers, which the FMAs consume directly: no LDS round trip, no latency per column.
+    // column-side vectors of this node (zero on idle lanes).  NP != 32: column i is broadcast out of lane i with v_readlane
+    // into scalar registers, which the FMAs consume directly.  NP == 32: see below.
     constexpr int NCV = CT ? NCOLX : NCOL;
     double cv[NCV];
 #pragma unroll
@@ -1116,21 +1137,88 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
     }
     RMX_STAMP(10)
     const unsigned long long anc_m = fs.anc_m, desc_m = fs.desc_m;
+    if constexpr (NP == 32) {
+        // Trees of at most 32 nodes leave lanes 32..63 idle: they mirror the row-side state of lanes 0..31 and take columns
+        // 16..31 while lanes 0..31 take columns 0..15, so the column loop runs 16 times instead of 32.  The column vectors go
+        // through LDS (each half-wave reads ONE address per column: two-address broadcast, no bank conflict); the upper
+        // half's 16 results come back with v_permlane32_swap.  sAcc is free here (the front is done with it).
+        if (lane < NP) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        double Ci[NCV];
+            for (int c = 0; c < NCV; ++c) sAcc[lane * NCV + c] = cv[c];
+        }
+        __syncthreads();
+        const bool hi = lane >= 32;
+        double rsw[3], rsv[3], q1t[3], q1f[3], q2w[3], q3w[3], x2v[3], x3v[3];
 #pragma unroll
-        for (int c = 0; c < NCV; ++c) Ci[c] = readlane_d(cv[c], i);
-        const double up = sw[0] * Ci[0] + sw[1] * Ci[1] + sw[2] * Ci[2] + sv[0] * Ci[3] + sv[1] * Ci[4] + sv[2] * Ci[5];
-        double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
-                    (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
-        if (CT)
-            lo -= cxr2[3] * Ci[18] + cxr2[4] * Ci[19] + cxr2[5] * Ci[20] + cxr3[3] * Ci[21] + cxr3[4] * Ci[22] + cxr3[5] * Ci[23];
-        // branch-free select: relation bits -> 0/1 weights (columns of idle lanes are all-zero vectors)
-        const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
-        const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
-        const double hv = mu * up + ml * lo;
-        Hrow[i] = (i == lane) ? Hdiag : hv;
+        for (int c = 0; c < 3; ++c) {
+            rsw[c] = dup_lo(sw[c]);
+            rsv[c] = dup_lo(sv[c]);
+            q1t[c] = dup_lo(r1t[c]);
+            q1f[c] = dup_lo(r1f[c]);
+            q2w[c] = dup_lo(r2w[c]);
+            q3w[c] = dup_lo(r3w[c]);
+            if (CT) {
+                x2v[c] = dup_lo(cxr2[3 + c]);
+                x3v[c] = dup_lo(cxr3[3 + c]);
+            }
+        }
+        const double hd = dup_lo(Hdiag);
+        // relation masks of the mirrored row, shifted so that bit i is this half's column i
+        const unsigned long long am = __double_as_longlong(dup_lo(__longlong_as_double((long long)anc_m))) >> (hi ? 16 : 0);
+        const unsigned long long dm = __double_as_longlong(dup_lo(__longlong_as_double((long long)desc_m))) >> (hi ? 16 : 0);
+        const int drow = (lane & 31) - (hi ? 16 : 0);                 // the row's own column, counted inside this half
+        const double* cb = sAcc + (hi ? 16 * NCV : 0);
+        double Hh[16], Cn[NCV];
+#pragma unroll
+        for (int c = 0; c < NCV; ++c) Cn[c] = cb[c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double Ci[NCV];
+#pragma unroll
+            for (int c = 0; c < NCV; ++c) Ci[c] = Cn[c];
+            if (i + 1 < 16) {                  // two columns in flight
+#pragma unroll
+                for (int c = 0; c < NCV; ++c) Cn[c] = cb[(i + 1) * NCV + c];
+            }
+            const double up = rsw[0] * Ci[0] + rsw[1] * Ci[1] + rsw[2] * Ci[2] + rsv[0] * Ci[3] + rsv[1] * Ci[4] + rsv[2] * Ci[5];
+            double lo = q1t[0] * Ci[6] + q1t[1] * Ci[7] + q1t[2] * Ci[8] + q1f[0] * Ci[9] + q1f[1] * Ci[10] + q1f[2] * Ci[11] -
+                        (q2w[0] * Ci[12] + q2w[1] * Ci[13] + q2w[2] * Ci[14]) - (q3w[0] * Ci[15] + q3w[1] * Ci[16] + q3w[2] * Ci[17]);
+            if (CT) lo -= x2v[0] * Ci[18] + x2v[1] * Ci[19] + x2v[2] * Ci[20] + x3v[0] * Ci[21] + x3v[1] * Ci[22] + x3v[2] * Ci[23];
+            const double mu = (double)(unsigned)((dm >> i) & 1ull);
+            const double ml = (double)(unsigned)((am >> i) & 1ull);
+            const double hv = mu * up + ml * lo;
+            Hh[i] = (i == drow) ? hd : hv;
+            // pins column i's arithmetic between the loads of columns i+1 and i+2: otherwise the scheduler requests every
+            // column first and spills hundreds of registers
+            asm volatile("" : "+v"(Hh[i]) : : "memory");
+        }
+        // rows live in lanes 0..31: columns 16..31 come over from the upper half; lanes 32..63 go back to all-zero rows
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double t = take_hi(Hh[i]);
+            Hrow[i] = hi ? 0.0 : Hh[i];
+            Hrow[16 + i] = hi ? 0.0 : t;
+        }
+        __syncthreads();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            double Ci[NCV];
+#pragma unroll
+            for (int c = 0; c < NCV; ++c) Ci[c] = readlane_d(cv[c], i);
+            const double up = sw[0] * Ci[0] + sw[1] * Ci[1] + sw[2] * Ci[2] + sv[0] * Ci[3] + sv[1] * Ci[4] + sv[2] * Ci[5];
+            double lo = r1t[0] * Ci[6] + r1t[1] * Ci[7] + r1t[2] * Ci[8] + r1f[0] * Ci[9] + r1f[1] * Ci[10] + r1f[2] * Ci[11] -
+                        (r2w[0] * Ci[12] + r2w[1] * Ci[13] + r2w[2] * Ci[14]) - (r3w[0] * Ci[15] + r3w[1] * Ci[16] + r3w[2] * Ci[17]);
+            if (CT)
+                lo -= cxr2[3] * Ci[18] + cxr2[4] * Ci[19] + cxr2[5] * Ci[20] + cxr3[3] * Ci[21] + cxr3[4] * Ci[22] + cxr3[5] * Ci[23];
+            // branch-free select: relation bits -> 0/1 weights (columns of idle lanes are all-zero vectors)
+            const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
+            const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
+            const double hv = mu * up + ml * lo;
+            Hrow[i] = (i == lane) ? Hdiag : hv;
+        }
     }
     RMX_STAMP(11)
     return Hdiag;    // H(lane,lane): the scale of this row for the solver's pivot guard
@@ -1392,15 +1480,22 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     bool bad = false;
     double rinv_own = 0.0;    // 1/U(lane,lane), kept for the back substitution
     const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
+    // the reciprocal of pivot k+1 is started as soon as column k+1 has seen step k, ahead of the other trailing columns, so
+    // that its latency chain (readlane -> rcp -> 2 Newton steps) overlaps their updates
+    double piv = readlane_d(Hrow[0], 0);
+    double rinv = recip(piv);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const double piv = readlane_d(Hrow[k], k);
-        const double rinv = recip(piv);
         rinv_own = (lane == k) ? rinv : rinv_own;
         const double l = (lane > k) ? Hrow[k] * rinv : 0.0;
-        bad = bad || !(l * l * piv <= lim) || !(piv > 0.0);
+        bad = bad | !(l * l * piv <= lim) | !(piv > 0.0);   // bitwise: no branches in the elimination loop
+        if (k + 1 < NP) {
+            Hrow[k + 1] -= l * readlane_d(Hrow[k + 1], k);
+            piv = readlane_d(Hrow[k + 1], k + 1);
+            rinv = recip(piv);
+        }
 #pragma unroll
-        for (int c = k + 1; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], k);
+        for (int c = k + 2; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], k);
         b -= l * readlane_d(b, k);
     }
     double dx = 0.0;

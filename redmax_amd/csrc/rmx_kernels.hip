@@ -14,7 +14,7 @@ template <int NP>
 __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, double*& sCol) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     sAcc = smem;
-    sCol = smem + (M.n + 1) * ACC_STRIDE;     // per-node constants, [NCONST][NP] (see eval_front_e2)
+    sCol = smem + acc_doubles(M.n, NP);       // per-node constants, [NCONST][NP] (see eval_front_e2)
     if (threadIdx.x < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + threadIdx.x] = 0.0;   // zero row n (end-of-tree suffix)
     if (threadIdx.x < NP) {
         const int j = threadIdx.x;
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
             NodeOut e;
             double Hrow[NP];
             eval_front<NP, true>(M, sAcc, lane, x, (x - q0) / h, x - xB, h, e, fs);
-            eval_hess<NP>(M, lane, fs, Hrow);
+            eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
             {
                 double Mrow[NP], Drow[NP];
                 eval_MD<NP>(M, lane, fs, Mrow, Drow);
