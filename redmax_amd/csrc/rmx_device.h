@@ -26,9 +26,15 @@ constexpr int MAXSPH = 21;        // spherical joints per tree (three nodes each
 constexpr int SPH_ROWS = 42;      // per-node constants that depend on a spherical node's axis: K(36) + sb(6), the first LDS rows
 // doubles of the accumulation scratch at the start of a wavefront's LDS: (n+1) rows of the subtree scan, or the Hessian's
 // column vectors [NP][NCOLX], whichever is larger; the per-node constants follow it
+constexpr int HM_OP_STRIDE = 33;  // MFMA Hessian (NP = 32): operand rows [k][node], odd stride in doubles
+constexpr int HM_ROWS = 57;       // RU 8, RL 12|20, CU 8, CL 12|20, Hdiag 1 (|: with ground contact)
+constexpr int HM_H_STRIDE = 34;   // H staged row-major [32][34] for the hand-over to row-per-lane (16-byte aligned rows)
 __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
-    return (n + 1) * ACC_STRIDE > NP * 24 ? (n + 1) * ACC_STRIDE : NP * 24;
+    const int a = (n + 1) * ACC_STRIDE;
+    const int b = NP == 32 ? HM_ROWS * HM_OP_STRIDE : 0;     // 1881 doubles; also covers H: 32*34 = 1088
+    return a > b ? a : b;
 }
+constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matrix cores (false: half-wave split of the column loop)
 constexpr int NCOLX = 24;         // with ground contact the column side also needs m2v(3) and sv(3)
 
 // Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
@@ -1163,7 +1169,136 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
     }
     RMX_STAMP(10)
     const unsigned long long anc_m = fs.anc_m, desc_m = fs.desc_m;
-    if constexpr (NP == 32) {
+    if constexpr (NP == 32 && HESS_MFMA) {
+        // H as two small matrix products on the fp64 matrix cores.  With the row-side vectors RU_a = (s_a) [6], RL_a = (r1_a,
+        // -r2w_a, -r3w_a [, -contact]) [12|18] and the column-side vectors CU_i = (y_i - z_i) [6], CL_i = (m1_i, m2w_i, sw_i
+        // [, m2v_i, sv_i]) [12|18]:   H(a,i) = [a strict ancestor of i] RU_a.CU_i + [a strict descendant of i] RL_a.CL_i, Hdiag
+        // on the diagonal.  UP = RU CU' (K = 6 -> 8) and LO = RL CL' (K = 12|18 -> 12|20) are 32x32 products =
+        // 2x2 tiles of v_mfma_f64_16x16x4_f64, 2 + 3|5 instructions per tile.  Operands go through LDS in [k][node] order (A:
+        // lane l supplies A[row l&15][k l>>4], B: B[k l>>4][col l&15]); each lane then owns columns c = 16 nb + (l&15) and rows
+        // a = 16 mb + (l>>4) + 4 r of the results (C/D layout of the f64 MFMA), masks them with the relation bits of ITS TWO
+        // COLUMN nodes, and the matrix returns to row-per-lane through LDS for the solve.  All 64 lanes work; n <= 32.
+        constexpr int KL = CT ? 20 : 12;                 // padded K of the LO product
+        constexpr int R_RU = 0, R_RL = 8, R_CU = 8 + KL, R_CL = 16 + KL, R_HD = 16 + 2 * KL;   // operand rows in LDS
+        static_assert(R_HD + 1 <= HM_ROWS, "operand rows");
+        double* sOp = sAcc;
+        if (lane < NP) {
+            double* o = sOp + lane;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[(R_RU + c) * HM_OP_STRIDE] = sw[c];
+                o[(R_RU + 3 + c) * HM_OP_STRIDE] = sv[c];
+                o[(R_RL + c) * HM_OP_STRIDE] = r1t[c];
+                o[(R_RL + 3 + c) * HM_OP_STRIDE] = r1f[c];
+                o[(R_RL + 6 + c) * HM_OP_STRIDE] = -r2w[c];
+                o[(R_RL + 9 + c) * HM_OP_STRIDE] = -r3w[c];
+                if (CT) {
+                    o[(R_RL + 12 + c) * HM_OP_STRIDE] = -cxr2[3 + c];
+                    o[(R_RL + 15 + c) * HM_OP_STRIDE] = -cxr3[3 + c];
+                }
+            }
+            o[(R_RU + 6) * HM_OP_STRIDE] = 0.0;
+            o[(R_RU + 7) * HM_OP_STRIDE] = 0.0;
+            o[(R_CU + 6) * HM_OP_STRIDE] = 0.0;
+            o[(R_CU + 7) * HM_OP_STRIDE] = 0.0;
+            if (CT) {
+                o[(R_RL + 18) * HM_OP_STRIDE] = 0.0;
+                o[(R_RL + 19) * HM_OP_STRIDE] = 0.0;
+                o[(R_CL + 18) * HM_OP_STRIDE] = 0.0;
+                o[(R_CL + 19) * HM_OP_STRIDE] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[(R_CU + c) * HM_OP_STRIDE] = cv[c];
+#pragma unroll
+            for (int c = 6; c < NCV; ++c) o[(R_CL + c - 6) * HM_OP_STRIDE] = cv[c];
+            o[R_HD * HM_OP_STRIDE] = Hdiag;
+        }
+        __syncthreads();
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int g = lane >> 4, j = lane & 15;
+        const double* cRel = sAcc + acc_doubles(M.n, NP) + (36 + 6 + 4 + 8 + 1) * NP;   // relation bit masks of the nodes (as doubles)
+        v4d up[2][2], lw[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                up[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
+                lw[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
+            }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            double a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = sOp[(R_RU + 4 * kk + g) * HM_OP_STRIDE + 16 * t + j];
+                b[t] = sOp[(R_CU + 4 * kk + g) * HM_OP_STRIDE + 16 * t + j];
+            }
+            // depth-first numbering: an ancestor has the smaller index, so the UP tile (rows 16..31, columns 0..15) and the
+            // LO tile (rows 0..15, columns 16..31) are masked out entirely and are not computed
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = mb; nb < 2; ++nb) up[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], up[mb][nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KL / 4; ++kk) {
+            double a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = sOp[(R_RL + 4 * kk + g) * HM_OP_STRIDE + 16 * t + j];
+                b[t] = sOp[(R_CL + 4 * kk + g) * HM_OP_STRIDE + 16 * t + j];
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb <= mb; ++nb) lw[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], lw[mb][nb], 0, 0, 0);
+        }
+        // relation bits of this lane's two column nodes c = 16 nb + j: bit a of the ancestor mask -> UP applies, of the
+        // descendant mask -> LO applies; shifted by g so that the row a = 16 mb + 4 r + g needs a constant shift
+        unsigned long long am[2], dm[2];
+        double hd[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            am[nb] = (unsigned long long)__double_as_longlong(cRel[16 * nb + j]) >> g;
+            dm[nb] = (unsigned long long)__double_as_longlong(cRel[NP + 16 * nb + j]) >> g;
+            hd[nb] = sOp[R_HD * HM_OP_STRIDE + 16 * nb + j];
+        }
+        double hv[2][2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int sh = 16 * mb + 4 * r;
+                    double v = 0.0;
+                    if (nb >= mb) v = (double)(unsigned)((am[nb] >> sh) & 1ull) * up[mb][nb][r];
+                    if (nb <= mb) v += (double)(unsigned)((dm[nb] >> sh) & 1ull) * lw[mb][nb][r];
+                    hv[mb][nb][r] = (mb == nb && 4 * r + g == j) ? hd[nb] : v;
+                }
+        __syncthreads();             // every lane is done with the operands: the same LDS now takes H, row-major
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sOp[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
+        __syncthreads();
+        {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d* hr = reinterpret_cast<const v2d*>(sOp + (lane & 31) * HM_H_STRIDE);   // rows are 16-byte aligned
+            const bool lo_half = lane < 32;
+#pragma unroll
+            for (int c = 0; c < NP / 2; ++c) {
+                const v2d t = hr[c];
+                Hrow[2 * c] = lo_half ? t[0] : 0.0;
+                Hrow[2 * c + 1] = lo_half ? t[1] : 0.0;
+            }
+        }
+        __syncthreads();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+        __syncthreads();
+    } else if constexpr (NP == 32) {
         // Trees of at most 32 nodes leave lanes 32..63 idle: they mirror the row-side state of lanes 0..31 and take columns
         // 16..31 while lanes 0..31 take columns 0..15, so the column loop runs 16 times instead of 32.  The column vectors go
         // through LDS (each half-wave reads ONE address per column: two-address broadcast, no bank conflict); the upper
