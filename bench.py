@@ -31,7 +31,7 @@ import numpy as np
 F_G = 363712        # one residual evaluation
 F_H = 1418432       # one residual + Hessian evaluation
 F_LU = 23893        # one 32x32 LU solve
-HBM_TRAFFIC_BYTES = int((2101.625 + 608.0) * 1024)   # measured with PMC counters, see roofline.traffic_note
+HBM_TRAFFIC_BYTES = int((1073.625 + 608.0) * 1024)   # measured with PMC counters, see roofline.traffic_note
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the
                           # microarch guide lists no fp64 row, so the datasheet value is used and stated)
 
@@ -132,14 +132,17 @@ def main():
             ach = flops / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP64_PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_BYTES if (B == 1024 and K == 100 and n == 32) else None,
-                    "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01c_pmc_*.csv): 2101.6 KB + 608 KB per "
+                    "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01d_pmc_*.csv): 1073.6 KB + 608 KB per "
                                     "launch of 100 steps x 1024 rollouts, reported uncorrected (8-byte-per-lane accesses: the guide's x2 FETCH "
                                     "correction is calibrated for 16 B/lane streams only); algorithmic = 1 MiB (q,qdot in + out)",
-                    "kernel": "k_step_bdf1<32>", "kernel_ms": round(kernel_ms, 4),
+                    "kernel": "k_step_bdf1<32,false>", "kernel_ms": round(kernel_ms, 4),
+                    "executed_tflops_estimate": round(iters * 1.65e5 / (kernel_ms * 1e-3) / 1e12, 2),
                     "newton_iters_per_step": round(iters / (B * K), 3), "ls_halvings_per_step": round(halv / (B * K), 4),
-                    "note": "fp64 path: FP64 vector == FP64 matrix peak on MI355X (78.6 TF, datasheet); algorithmic flops = SURVEY.md "
-                            "§8(d) figures x measured iteration counts; the kernel EXECUTES ~10x fewer flops (O(n^2) world-frame "
-                            "recursion instead of the J/dJdq contraction), see DESIGN.md"}
+                    "note": "fp64 path: FP64 vector == FP64 matrix peak on MI355X (78.6 TF, datasheet); achieved = ALGORITHMIC flops "
+                            "(SURVEY.md §8(d) figures x measured iteration counts) / kernel time, as the contract asks - it can exceed "
+                            "the peak because the kernel EXECUTES ~10x fewer flops (O(n^2) world-frame recursion instead of the "
+                            "J/dJdq contraction; ~1.65e5 per Newton iteration = executed_tflops_estimate); one wave per SIMD: the "
+                            "kernel is issue/latency-bound, see DESIGN.md §4 and §6"}
         out = {
             "metric": "sim steps/sec (whole node), 1024-batch 32-DOF chain BDF1",
             "value": round(value, 1), "unit": "rollout-steps/s",
