@@ -277,3 +277,49 @@ def scenesRedMaxInit(sid):
     sc = scenesRedMax(sid)
     sc.init()
     return sc
+
+
+@pytest.mark.parametrize("name", ["chain20", "tree25", "chain21fixed", "chain17ground"])
+def test_partially_filled_32_lane_trees_match_oracle(oracle_lib, name):
+    """17 <= n <= 31 nodes run the n <= 32 code (MFMA Hessian, two lanes per component in the subtree scan) with idle node
+    slots: (g, H), energies and a short rollout vs the oracle; also with fixed joints (no DOF) and with ground contact."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainGround, sceneTree
+    if name == "chain20":
+        sc = sceneChain(20, axis=(0.2, 1.0, -0.3))
+    elif name == "tree25":
+        sc = sceneTree(25)
+    elif name == "chain17ground":
+        sc = sceneChainGround(17, ground_z=-1.0)
+    else:
+        sc = Scene()
+        for i in range(21):                                   # scene 0's pattern (scenesRedMax.m:52-79): every other joint fixed
+            sc.bodies.append(BodyCuboid(1.0, [4, 1, 1]))
+            parent = sc.joints[i - 1] if i else None
+            j = JointRevolute(parent, sc.bodies[-1], [0, 1, 0]) if i % 2 == 0 else JointFixed(parent, sc.bodies[-1])
+            j.setJointTransform(np.eye(4) if i == 0 else se3.transform(p=[4, 0, 0]))
+            sc.bodies[-1].setBodyTransform(se3.transform(p=[2, 0, 0]))
+            sc.joints.append(j)
+    sc.init()
+    nr, h = sc.nr, sc.h
+    rng = np.random.default_rng(17)
+    B = 3
+    q0 = rng.uniform(-0.3, 0.3, (B, nr))
+    qd0 = rng.uniform(-1, 1, (B, nr))
+    q1 = q0 + h * qd0 + rng.uniform(-1e-3, 1e-3, (B, nr))
+    sim = BatchSim(sc, batch=B)
+    o = oracle_lib.Oracle(sc.desc())
+    g, H = sim.eval_bdf1(q1, q0, qd0, h)
+    for b in range(B):
+        go, Ho = o.eval_bdf1(q1[b], q0[b], qd0[b], h)
+        assert _rel(g[b], go) <= 1e-11 and _rel(H[b], Ho) <= 1e-11
+    sim.set_state(q0, qd0)
+    out = sim.step_bdf1(8, h=h, stats=True)
+    qg, qdg = sim.get_state()
+    assert np.all(out["status"] & 7 == 0)
+    for b in range(B):
+        o.set_state(q0[b], qd0[b])
+        o.step_bdf1(h, 8)
+        qo, qdo = o.get_state()
+        assert np.linalg.norm(qg[b] - qo) <= 1e-9 * np.linalg.norm(qo) + 1e-10
+    sim.close()
