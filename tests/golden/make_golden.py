@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.oracle import Oracle  # noqa: E402
-from redmax_amd.scenes import sceneChain, scenesRedMax, sceneTree, syntheticStates  # noqa: E402
+from redmax_amd.scenes import sceneChain, sceneChainGround, scenesRedMax, sceneTree, syntheticStates  # noqa: E402
 
 
 def main():
@@ -54,6 +54,33 @@ def main():
     o = Oracle(sc.desc())
     o.step_bdf1(sc.h, 10)
     out["tree15_bdf1_step10_q"], out["tree15_bdf1_step10_qdot"] = o.get_state()
+    # multi-DOF joints (scenes 4, 5, 6, 8), Euler-chart joints (7, 9: BDF2, scene 7 switches charts) and ground contact (11)
+    for sid in (4, 5, 6, 8):
+        sc = scenesRedMax(sid)
+        sc.init()
+        o = Oracle(sc.desc())
+        o.step_bdf1(sc.h, 10)
+        out["scene%d_bdf1_step10_q" % sid], out["scene%d_bdf1_step10_qdot" % sid] = o.get_state()
+    for sid in (7, 9, 11):
+        sc = scenesRedMax(sid)
+        sc.init()
+        o = Oracle(sc.desc())
+        n = sc.nsteps if sid != 11 else 400
+        o.step_bdf2(sc.h, n)
+        out["scene%d_bdf2_end_q" % sid], out["scene%d_bdf2_end_qdot" % sid] = o.get_state()
+        if sid != 11:
+            out["scene%d_bdf2_end_charts" % sid] = o.charts()
+    sc = sceneChainGround(6, ground_z=-1.0)
+    sc.init()
+    o = Oracle(sc.desc())
+    rng = np.random.default_rng(77)
+    q0 = rng.uniform(-0.4, 0.4, 6)
+    qd0 = rng.normal(size=6) * 3
+    q1 = q0 + sc.h * qd0
+    g, H = o.eval_bdf1(q1, q0, qd0, sc.h)
+    out["chain6ground_eval_inputs"] = np.stack([q1, q0, qd0])
+    out["chain6ground_eval_g"] = g
+    out["chain6ground_eval_H"] = H
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_vectors.npz"), **out)
     print("wrote %d arrays" % len(out))
 

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from redmax_amd.scenes import sceneChain, scenesRedMax, sceneTree, syntheticStates
+from redmax_amd.scenes import sceneChain, sceneChainGround, scenesRedMax, sceneTree, syntheticStates
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.npz"))
 
@@ -91,3 +91,62 @@ def test_gpu_matches_frozen_tree15():
     sim.step_bdf1(10, h=sc.h)
     q, qd = sim.get_state()
     assert _rel(q[0], G["tree15_bdf1_step10_q"]) <= 1e-9
+
+
+def test_oracle_reproduces_frozen_multidof_contact_vectors(oracle_lib):
+    for sid in (4, 5, 6, 8):
+        sc = scenesRedMax(sid)
+        sc.init()
+        o = oracle_lib.Oracle(sc.desc())
+        o.step_bdf1(sc.h, 10)
+        assert _rel(o.get_state()[0], G["scene%d_bdf1_step10_q" % sid]) <= 1e-12
+    for sid in (7, 9, 11):
+        sc = scenesRedMax(sid)
+        sc.init()
+        o = oracle_lib.Oracle(sc.desc())
+        o.step_bdf2(sc.h, sc.nsteps if sid != 11 else 400)
+        assert _rel(o.get_state()[0], G["scene%d_bdf2_end_q" % sid]) <= 1e-10
+        if sid != 11:
+            assert list(o.charts()) == list(G["scene%d_bdf2_end_charts" % sid])
+    sc = sceneChainGround(6, ground_z=-1.0)
+    sc.init()
+    o = oracle_lib.Oracle(sc.desc())
+    q1, q0, qd0 = G["chain6ground_eval_inputs"]
+    g, H = o.eval_bdf1(q1, q0, qd0, sc.h)
+    assert _rel(g, G["chain6ground_eval_g"]) <= 1e-13 and _rel(H, G["chain6ground_eval_H"]) <= 1e-13
+
+
+@pytest.mark.gpu
+def test_gpu_matches_frozen_multidof_contact_vectors():
+    """Data-only check (no oracle library): multi-DOF joints, Euler-chart switching under BDF2, ground contact."""
+    from redmax_amd import BatchSim
+    for sid in (4, 5, 6, 8):
+        sc = scenesRedMax(sid)
+        sc.init()
+        sim = BatchSim(sc, batch=1)
+        q0, qd0 = sc.getQ()
+        sim.set_state(q0[None], qd0[None])
+        sim.step_bdf1(10, h=sc.h)
+        q, qd = sim.get_state()
+        assert _rel(q[0], G["scene%d_bdf1_step10_q" % sid]) <= 1e-9, sid
+        assert _rel(qd[0], G["scene%d_bdf1_step10_qdot" % sid]) <= 1e-7, sid
+        sim.close()
+    for sid in (7, 9, 11):
+        sc = scenesRedMax(sid)
+        sc.init()
+        sim = BatchSim(sc, batch=1)
+        q0, qd0 = sc.getQ()
+        sim.set_state(q0[None], qd0[None])
+        sim.step_bdf2(sc.nsteps if sid != 11 else 400, h=sc.h)
+        q, qd = sim.get_state()
+        assert _rel(q[0], G["scene%d_bdf2_end_q" % sid]) <= 1e-6, sid
+        if sid != 11:
+            assert list(sim.charts()[0]) == list(G["scene%d_bdf2_end_charts" % sid])
+        sim.close()
+    sc = sceneChainGround(6, ground_z=-1.0)
+    sc.init()
+    sim = BatchSim(sc, batch=1)
+    q1, q0, qd0 = G["chain6ground_eval_inputs"]
+    g, H = sim.eval_bdf1(q1[None], q0[None], qd0[None], sc.h)
+    assert _rel(g[0], G["chain6ground_eval_g"]) <= 1e-11 and _rel(H[0], G["chain6ground_eval_H"]) <= 1e-11
+    sim.close()
