@@ -133,8 +133,10 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP64_PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_BYTES if (B == 1024 and K == 100 and n == 32) else None,
                     "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01d_pmc_*.csv): 1073.6 KB + 608 KB per "
-                                    "launch of 100 steps x 1024 rollouts, reported uncorrected (8-byte-per-lane accesses: the guide's x2 FETCH "
-                                    "correction is calibrated for 16 B/lane streams only); algorithmic = 1 MiB (q,qdot in + out)",
+                                    "launch of 100 steps x 1024 rollouts, reported uncorrected: the guide's x2 FETCH correction is calibrated for "
+                                    "16 B/lane streams; calibrated on the known byte counts of THIS 8 B/lane pattern the counters read at "
+                                    "face value (WRITE_SIZE 608 KB = 512 KiB state written + 12 KiB counters + write-backs; FETCH_SIZE = "
+                                    "512 KiB state read + the 17 KB constant table per XCD + code); algorithmic = 1 MiB (q,qdot in + out)",
                     "kernel": "k_step_bdf1<32,false>", "kernel_ms": round(kernel_ms, 4),
                     "executed_tflops_estimate": round(iters * 1.65e5 / (kernel_ms * 1e-3) / 1e12, 2),
                     "newton_iters_per_step": round(iters / (B * K), 3), "ls_halvings_per_step": round(halv / (B * K), 4),
