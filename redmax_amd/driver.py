@@ -115,3 +115,26 @@ def driverRedMaxAdjointBDF1(nlinks=2, device=0, verbose=True, maxiter=50):
     res = minimize(fun, np.zeros(scene.nr), jac=True, method="BFGS", options={"maxiter": maxiter, "disp": verbose})
     sim.close()
     return scene, res
+
+
+def _main(argv=None):
+    """python -m redmax_amd.driver [--bdf2] [sceneID ...]: driverRedMaxBDF1(sceneID,true) / driverRedMaxBDF2(sceneID,true) for the
+    listed scenes (default: every scene this build covers), printing the reference's '### PASS ###' line per scene."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m redmax_amd.driver", description=_main.__doc__)
+    ap.add_argument("scenes", nargs="*", type=int, default=[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 14])
+    ap.add_argument("--bdf2", action="store_true", help="driverRedMaxBDF2 instead of driverRedMaxBDF1")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    ok = True
+    for sid in a.scenes:
+        scene, H, passed = (driverRedMaxBDF2 if a.bdf2 else driverRedMaxBDF1)(sid, True, a.device, True)
+        print("    H = %.16e  (kernel %.3f ms, %d Newton iterations, status %d)" % (
+            H, scene.solverInfo["kernel_ms"], scene.solverInfo["newton_iters"], scene.solverInfo["status"]))
+        ok = ok and passed is not False
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(_main())
