@@ -815,30 +815,31 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             for (int c = 0; c < NS; ++c) A[c] = S[c];
         }
         __syncthreads();
-        if constexpr (NP == 32) {
-            // n <= 32 leaves lanes 32..63 idle: component c is scanned by two lanes, lane c over nodes 16..31 and lane 32+c over
-            // nodes 0..15, which then adds the lower lane's total (v_permlane32_swap): half the serial chain, half the LDS
-            // operations per lane
+        if constexpr (NP == 32 || NP == 64) {
+            // the scan needs NS <= 28 lanes, one per component: every component gets TWO lanes instead, lane c over the upper
+            // half of the nodes and lane 32+c over the lower half, which then adds the upper half's total
+            // (v_permlane32_swap): half the serial chain, half the LDS operations per lane
+            constexpr int HALF = NP / 2;
             const int comp = lane & 31;
-            const int base = lane >= 32 ? 0 : 16;
+            const int base = lane >= 32 ? 0 : HALF;
             const bool on = comp < NS;
-            double a[16];
+            double a[HALF];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
+            for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
             double acc = 0.0;
 #pragma unroll
-            for (int t = 15; t >= 0; --t) {
+            for (int t = HALF - 1; t >= 0; --t) {
                 acc += a[t];
                 a[t] = acc;
             }
-            const double tail = dup_lo(acc);           // lanes >= 32: the sum over nodes 16..31 of their component
+            const double tail = dup_lo(acc);           // lanes >= 32: the sum over the upper half of the nodes
             if (lane >= 32) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) a[t] += tail;
+                for (int t = 0; t < HALF; ++t) a[t] += tail;
             }
             if (on) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
+                for (int t = 0; t < HALF; ++t)
                     if (base + t < n) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
             }
         } else if (lane < NS) {
