@@ -465,23 +465,44 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
 }
 
 // ============================================================================ launchers (declared in rmx_host.h)
+//
+// RMX_PART 0: the plain kernels (every scene without ForceGroundCuboid / JointSpherical) plus Euler, adjoint, phase timing.
+// RMX_PART 1: the extended (CT) instantiations of eval / step / energy.  Two objects per size, so the builds run in parallel.
+#ifndef RMX_PART
+#define RMX_PART 0
+#endif
+
+#if RMX_PART == 1
+
+void RMX_CAT(launch_eval_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
+    const dim3 grid(b->B), block(64);
+    if (wantH) k_eval<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
+    else k_eval<RMX_NP, false, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
+}
+void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else k_step_bdf2<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+}
+void RMX_CAT(launch_energy_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
+    const dim3 grid(b->B), block(64);
+    k_energy<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, b->chart);
+}
+
+#else
 
 void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
     const dim3 grid(b->B), block(64);
     // scenes with ForceGroundCuboid or JointSpherical run the extended instantiations (CT), everything else the plain ones
-    const bool ct = m->dm.con != nullptr || m->dm.nsph > 0;
-    if (wantH && ct) k_eval<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
-    else if (wantH) k_eval<RMX_NP, true, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
-    else if (ct) k_eval<RMX_NP, false, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
+    if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_eval_ct_, RMX_NP)(m, b, wantH, eta, dg, dH);
+    if (wantH) k_eval<RMX_NP, true, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
     else k_eval<RMX_NP, false, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
 }
 
 void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
-    const bool ct = m->dm.con != nullptr || m->dm.nsph > 0;
-    if (integ == INTEG_BDF1 && ct) k_step_bdf1<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
-    else if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
-    else if (ct) k_step_bdf2<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_step_ct_, RMX_NP)(m, b, integ, o, a);
+    if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
     else k_step_bdf2<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
 }
 
@@ -492,8 +513,8 @@ void RMX_CAT(launch_euler_, RMX_NP)(const rmx_model* m, const rmx_batch* b, doub
 
 void RMX_CAT(launch_energy_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);
-    if (m->dm.con || m->dm.nsph) k_energy<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, b->chart);
-    else k_energy<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, nullptr);
+    if (m->dm.con || m->dm.nsph) return RMX_CAT(launch_energy_ct_, RMX_NP)(m, b, dT, dV);
+    k_energy<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, nullptr);
 }
 
 void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a) {
@@ -506,3 +527,5 @@ void RMX_CAT(launch_phase_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int 
     const dim3 grid(b->B), block(64);
     k_phase_time<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, reps, b->q, b->qd, h, d);
 }
+
+#endif
