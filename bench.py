@@ -41,7 +41,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="rollouts per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="rollouts per GPU (default: 1024; 512 for --workload tree64)")
+    ap.add_argument("--workload", choices=("chain", "tree64", "ground"), default="chain",
+                    help="chain: BASELINE.json configs[1], the headline metric (default).  tree64: configs[2], 64-joint "
+                         "revolute/prismatic tree, BDF1.  ground: configs[4], 32-link chain over frictional ground, BDF2.  The last "
+                         "two are extra measurements of the 'next' rows; no roofline / cpu_baseline is attached to them")
     ap.add_argument("--links", type=int, default=32)
     ap.add_argument("--tol", type=float, default=1e-8, help="Newton |g| tolerance (reference hard-codes 1e-9, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -64,13 +68,35 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from redmax_amd import BatchSim, sceneChain, syntheticStates
+    from redmax_amd import BatchSim, sceneChain, sceneChainGround, sceneTree, syntheticStates
 
+    wl = args.workload
+    if args.batch <= 0:
+        args.batch = 512 if wl == "tree64" else 1024
     n, B, K, W, h = args.links, args.batch, args.steps, args.warmup, 1e-2
-    scene = sceneChain(n)
-    scene.init()
-    q0, qd0 = syntheticStates(scene.nr, B, first=rank * B)      # global trajectory index => shard-invariant inputs
+    if wl == "chain":
+        scene = sceneChain(n)
+        scene.init()
+        q0, qd0 = syntheticStates(scene.nr, B, first=rank * B)      # global trajectory index => shard-invariant inputs
+    elif wl == "tree64":
+        scene = sceneTree(64)
+        scene.init()
+        n = scene.nr
+        qs, _ = scene.getQ()
+        q0, qd0 = np.empty((B, n)), np.empty((B, n))
+        for i in range(B):
+            rng = np.random.default_rng(20240 + rank * B + i)
+            q0[i] = qs + rng.uniform(-0.05, 0.05, n)
+            qd0[i] = rng.uniform(-0.1, 0.1, n)
+    else:
+        scene = sceneChainGround(32)
+        scene.init()
+        n, h = scene.nr, scene.h
+        q0, qd0 = syntheticStates(scene.nr, B, first=rank * B, sq=5e-4, sv=0.1)   # every chain starts above the ground
+        if rank == 0:
+            q0[0], qd0[0] = scene.getQ()
     sim = BatchSim(scene, batch=B, device=local_rank)
+    step_sync = sim.step_bdf2 if wl == "ground" else sim.step_bdf1
     sim.opts.h = h
     sim.opts.tol = args.tol
     sim.set_state(q0, qd0)
@@ -88,7 +114,7 @@ def main():
 
     # ---- warmup (untimed)
     if W > 0:
-        sim.step_bdf1(W)
+        step_sync(W)
     if world > 1:   # warm the collective too
         sim.get_state_device(q_loc.data_ptr(), qd_loc.data_ptr())
         dist.all_gather_into_tensor(q_all, q_loc)
@@ -98,8 +124,12 @@ def main():
     # ---- timed region: exactly K steps
     barrier()
     t0 = time.perf_counter()
-    sim.step_bdf1_async(K)            # all K steps of all B rollouts: one kernel launch
-    kernel_ms = sim.sync()            # HIP events around the kernel, on the kernel's own stream
+    if wl == "ground":                # BDF2 has no async entry point: the synchronous call returns after the kernel
+        out_step = step_sync(K, stats=True)
+        kernel_ms = out_step["ms"]
+    else:
+        sim.step_bdf1_async(K)        # all K steps of all B rollouts: one kernel launch
+        kernel_ms = sim.sync()        # HIP events around the kernel, on the kernel's own stream
     if world > 1:                     # the single collective of the path: final gather of (q, qdot)
         sim.get_state_device(q_loc.data_ptr(), qd_loc.data_ptr())
         dist.all_gather_into_tensor(q_all, q_loc)
@@ -111,7 +141,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    st = sim.stats_read()
+    st = out_step if wl == "ground" else sim.stats_read()
     iters = int(st["newton_iters"].sum())
     halv = int(st["ls_halvings"].sum())
     bad = int(((st["status"] & 15) != 0).sum())
@@ -125,7 +155,7 @@ def main():
         # algorithmic flops of THIS launch on this rank: per Newton iteration one (g,H) evaluation and one LU,
         # plus one residual evaluation per line-search trial (iterations + halvings)
         flops = iters * (F_H + F_LU) + (iters + halv) * F_G
-        if n != 32:
+        if n != 32 or wl != "chain":
             flops = None
         roof = None
         if flops is not None and kernel_ms > 0:
@@ -152,15 +182,24 @@ def main():
             "ms_per_step": round(1e3 * elapsed / K, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d-link serial revolute chain, BDF1 fp64, batch=%d per GPU (BASELINE.json configs[1])" % (n, B),
+            "config": {"workload": {"chain": "%d-link serial revolute chain, BDF1 fp64, batch=%d per GPU (BASELINE.json configs[1])" % (n, B),
+                                    "tree64": "64-joint revolute/prismatic branching tree, BDF1 fp64, batch=%d per GPU (BASELINE.json configs[2])" % B,
+                                    "ground": "32-link chain over frictional ground (ForceGroundCuboid on every body), BDF2 fp64, h=5e-4, "
+                                              "batch=%d per GPU (BASELINE.json configs[4])" % B}[wl],
                        "batch_per_gpu": B, "links": n, "h": h, "newton_tol": args.tol, "reference_newton_tol": 1e-9,
-                       "init": "q,qdot~U(-0.1,0.1), rng(20240+global_index); traj 0: q=0.1,qdot=0",
+                       "init": {"chain": "q,qdot~U(-0.1,0.1), rng(20240+global_index); traj 0: q=0.1,qdot=0",
+                                "tree64": "scene state + U(-0.05,0.05), qdot~U(-0.1,0.1), rng(20240+global_index)",
+                                "ground": "q~U(-5e-4,5e-4), qdot~U(-0.1,0.1), rng(20240+global_index); traj 0: the scene's state"}[wl],
                        "parallelism": "batch-sharded x%d, one RCCL all-gather of final (q,qdot)" % world,
                        "steps_per_launch": K, "not_converged_trajectories": bad, "trajectories_with_pivoted_fallback": pivoted,
                        "all_finite": finite},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if wl != "chain":
+            out["metric"] = "sim steps/sec (whole node), " + {"tree64": "64-joint tree BDF1", "ground": "32-link chain + ground contact BDF2"}[wl]
+            out["config"]["newton_iters_per_step"] = round(iters / (B * K), 3)
+            out["config"]["kernel_ms"] = round(kernel_ms, 4)
+        if world == 1 and not args.no_cpu_baseline and wl == "chain":
             out["cpu_baseline"], out["q_l2_relerr_vs_oracle_max"] = cpu_baseline(scene, args, h)
         print(json.dumps(out), flush=True)
     if dist is not None:
