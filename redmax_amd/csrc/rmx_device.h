@@ -511,12 +511,44 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
         for (int c = 0; c < NC; ++c) A[c] = v[c];
     }
     __syncthreads();
-    if (lane < NC) {
+    if constexpr (NP >= 32) {
+        // two lanes per component (see eval_front_e2): lane c scans the upper half of the nodes, lane 32+c the lower half
+        constexpr int HALF = NP / 2;
+        const int comp = lane & 31;
+        const int base = lane >= 32 ? 0 : HALF;
+        const bool on = comp < NC;
+        double a[HALF];
+#pragma unroll
+        for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
         double acc = 0.0;
-        for (int jn = n - 1; jn >= 0; --jn) {
-            acc += sAcc[jn * ACC_STRIDE + lane];
-            sAcc[jn * ACC_STRIDE + lane] = acc;
+#pragma unroll
+        for (int t = HALF - 1; t >= 0; --t) {
+            acc += a[t];
+            a[t] = acc;
         }
+        const double tail = dup_lo(acc);
+        if (lane >= 32) {
+#pragma unroll
+            for (int t = 0; t < HALF; ++t) a[t] += tail;
+        }
+        if (on) {
+#pragma unroll
+            for (int t = 0; t < HALF; ++t)
+                if (base + t < n) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+        }
+    } else if (lane < NC) {
+        double a[NP];
+#pragma unroll
+        for (int jn = 0; jn < NP; ++jn) a[jn] = (jn < n) ? sAcc[jn * ACC_STRIDE + lane] : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int jn = NP - 1; jn >= 0; --jn) {
+            acc += a[jn];
+            a[jn] = acc;
+        }
+#pragma unroll
+        for (int jn = 0; jn < NP; ++jn)
+            if (jn < n) sAcc[jn * ACC_STRIDE + lane] = a[jn];
     }
     __syncthreads();
     {
