@@ -1067,12 +1067,13 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             const double* cCon = cEnd + NP;
             const bool con = act && cCon[jj] != 0.0;
             const double sd[3] = {cCon[NP + jj], cCon[2 * NP + jj], cCon[3 * NP + jj]};
-            double Fc[6], Kx[36], Dx[36], eVc;
+            double Fc[6], KD[72], eVc;            // Kx and Dx back to back: 72 numbers = three passes of the 28-wide scan
+            double (&Kx)[36] = *reinterpret_cast<double (*)[36]>(&KD[0]);
+            double (&Dx)[36] = *reinterpret_cast<double (*)[36]>(&KD[36]);
             contact_body<true>(M, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Kx, Dx, eVc);
-            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Kx[0]);
-            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Kx[28]);
-            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Dx[0]);
-            lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Dx[28]);
+            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &KD[0]);
+            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &KD[28]);
+            lds_subtree_sum<NP, 16>(M, sAcc, cEnd, lane, act, jj, &KD[56]);
             const double s6[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
             double m26[6];
 #pragma unroll
