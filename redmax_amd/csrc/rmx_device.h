@@ -1683,7 +1683,7 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     for (int k = 0; k < NP; ++k) {
         rinv_own = (lane == k) ? rinv : rinv_own;
         const double l = (lane > k) ? Hrow[k] * rinv : 0.0;
-        bad = bad | !(l * l * piv <= lim) | !(piv > 0.0);   // bitwise: no branches in the elimination loop
+        bad = bad | !(Hrow[k] * l <= lim) | !(piv > 0.0);   // l^2 u_kk = a_ik l ; bitwise: no branches in the elimination loop
         if (k + 1 < NP) {
             Hrow[k + 1] -= l * readlane_d(Hrow[k + 1], k);
             piv = readlane_d(Hrow[k + 1], k + 1);
