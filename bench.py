@@ -176,7 +176,8 @@ def main():
                             "J/dJdq contraction; ~1.65e5 per Newton iteration = executed_tflops_estimate); one wave per SIMD: the "
                             "kernel is issue/latency-bound, see DESIGN.md §4 and §6"}
         out = {
-            "metric": "sim steps/sec (whole node), 1024-batch 32-DOF chain BDF1",
+            # BASELINE.json's metric string, verbatim; its second half (q L2 err vs ref) is q_l2_relerr_vs_oracle_max below
+            "metric": "sim steps/sec (whole node), 1024-batch 32-DOF chain BDF1; q L2 err vs ref",
             "value": round(value, 1), "unit": "rollout-steps/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 5),
