@@ -64,6 +64,38 @@ __global__ void __launch_bounds__(64) k(double* out, unsigned long long* cyc, in
                 rr = fma(fma(-x, rr, 1.0), rr, rr);
                 a[i] = rr + 1.0;
             }
+        } else if (MODE == 10) {  // 16 x (ds_swizzle broadcast of lane 5 within each 32-lane half, double) + FMA: 2D-split LU pattern
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(a[i]), 5 << 5);
+                const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(a[i]), 5 << 5);
+                a[i] -= l * __hiloint2double(hi, lo);
+            }
+        } else if (MODE == 11) {  // 16 x ds_swizzle broadcast (double) only, accumulate
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(a[i]), 5 << 5);
+                const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(a[i]), 5 << 5);
+                acc += __hiloint2double(hi, lo);
+            }
+            l += acc;
+        } else if (MODE == 12) {  // 16 x v_permlane32_swap pair (double) + add
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int lo = __double2loint(a[i]), hi = __double2hiint(a[i]);
+                const auto x = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+                const auto y = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+                a[i] += __hiloint2double(y[0], x[0]);
+            }
+        } else if (MODE == 13) {  // mixed: 8 x (readlane_d + fma) on the VALU, 8 x (ds_swizzle bcast + fma) on the LDS pipe
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(a[i]), 5 << 5);
+                const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(a[i]), 5 << 5);
+                a[i + 1] -= l * readlane_d(a[i + 1], 5);
+                a[i] -= l * __hiloint2double(hi, lo);
+            }
         } else if (MODE == 9) {   // sincos fp64
             double s_, c_;
             sincos(a[0], &s_, &c_);
@@ -109,6 +141,10 @@ int main() {
         run<7>("16 dependent __shfl double + add", 16, nblk);
         run<8>("4 x recip (rcp + 2 newton)", 4, nblk);
         run<9>("sincos fp64", 1, nblk);
+        run<10>("16 x (ds_swizzle bcast32 double + fma)", 16, nblk);
+        run<11>("16 x ds_swizzle bcast32 double", 16, nblk);
+        run<12>("16 x permlane32_swap double + add", 16, nblk);
+        run<13>("8 x (readlane+fma) + 8 x (swizzle+fma)", 16, nblk);
     }
     return 0;
 }
