@@ -166,6 +166,13 @@ __device__ __forceinline__ double dpp_shr0(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + K, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// row_shr:K with a caller-chosen value for the lanes without a source
+template <int K>
+__device__ __forceinline__ double dpp_shr_old(double v, const double old) {
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x110 + K, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x110 + K, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 // row_shl:K inside each 16-lane row (lane l receives lane l+K); lanes without a source receive 0
 template <int K>
 __device__ __forceinline__ double dpp_shl0(double v) {
@@ -254,24 +261,25 @@ __device__ __forceinline__ void chain_scan_sum6(const int lane, double (&a)[3], 
 
 template <int K>
 __device__ __forceinline__ void chain_compose_step(const int lane, double (&R)[9], double (&p)[3]) {
+    // lanes without a predecessor K lanes down the row receive the identity transform, so the composition below needs no
+    // lane condition (1*x + 0*y + 0*z reproduces x exactly)
+    (void)lane;
     double Ra[9], pa[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) Ra[c] = dpp_shr0<K>(R[c]);
+    for (int c = 0; c < 9; ++c) Ra[c] = dpp_shr_old<K>(R[c], (c % 4 == 0) ? 1.0 : 0.0);
 #pragma unroll
     for (int c = 0; c < 3; ++c) pa[c] = dpp_shr0<K>(p[c]);
-    if ((lane & 15) >= K) {
-        double Rn[9], pn[3];
+    double Rn[9], pn[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
-            pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
-        }
-#pragma unroll
-        for (int c = 0; c < 9; ++c) R[c] = Rn[c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) p[c] = pn[c];
+        for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
+        pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
     }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = pn[c];
 }
 template <int NP>
 __device__ __forceinline__ void chain_scan_transform(const int lane, double (&R)[9], double (&p)[3]) {
