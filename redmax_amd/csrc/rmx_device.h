@@ -526,8 +526,14 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
         const int base = lane >= 32 ? 0 : HALF;
         const bool on = comp < NC;
         double a[HALF];
+        const bool full = n == NP;             // wave-uniform: no per-row bounds needed
+        if (full) {
 #pragma unroll
-        for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
+            for (int t = 0; t < HALF; ++t) a[t] = sAcc[(base + t) * ACC_STRIDE + comp];
+        } else {
+#pragma unroll
+            for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
+        }
         double acc = 0.0;
 #pragma unroll
         for (int t = HALF - 1; t >= 0; --t) {
@@ -540,9 +546,14 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
             for (int t = 0; t < HALF; ++t) a[t] += tail;
         }
         if (on) {
+            if (full) {
 #pragma unroll
-            for (int t = 0; t < HALF; ++t)
-                if (base + t < n) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+                for (int t = 0; t < HALF; ++t) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < HALF; ++t)
+                    if (base + t < n) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+            }
         }
     } else if (lane < NC) {
         double a[NP];
@@ -855,6 +866,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             for (int c = 0; c < NS; ++c) A[c] = S[c];
         }
         __syncthreads();
+        RMX_STAMP(5)
         if constexpr (NP == 32 || NP == 64) {
             // the scan needs NS <= 28 lanes, one per component: every component gets TWO lanes instead, lane c over the upper
             // half of the nodes and lane 32+c over the lower half, which then adds the upper half's total
@@ -864,8 +876,14 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             const int base = lane >= 32 ? 0 : HALF;
             const bool on = comp < NS;
             double a[HALF];
+            const bool full = n == NP;             // wave-uniform: every node slot in use, no per-row bounds needed
+            if (full) {
 #pragma unroll
-            for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
+                for (int t = 0; t < HALF; ++t) a[t] = sAcc[(base + t) * ACC_STRIDE + comp];   // lanes >= NS read finite junk, never stored
+            } else {
+#pragma unroll
+                for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
+            }
             double acc = 0.0;
 #pragma unroll
             for (int t = HALF - 1; t >= 0; --t) {
@@ -878,9 +896,14 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
                 for (int t = 0; t < HALF; ++t) a[t] += tail;
             }
             if (on) {
+                if (full) {
 #pragma unroll
-                for (int t = 0; t < HALF; ++t)
-                    if (base + t < n) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+                    for (int t = 0; t < HALF; ++t) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HALF; ++t)
+                        if (base + t < n) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+                }
             }
         } else if (lane < NS) {
             double a[NP];
