@@ -35,6 +35,10 @@ __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
     return a > b ? a : b;
 }
 constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matrix cores (false: half-wave split of the column loop)
+// Column stride of the per-node constants in LDS.  Trees padded to fewer than 64 lanes get one extra "idle" column (index NP):
+// identity joint transform, zero everything else.  Lanes beyond the padded size read it, idle node slots n..NP-1 hold the same
+// defaults in their own columns, so the evaluation loads constants without any per-lane selects.
+__host__ __device__ constexpr int cstride(const int NP) { return NP < 64 ? NP + 1 : NP; }
 constexpr int NCOLX = 24;         // with ground contact the column side also needs m2v(3) and sv(3)
 
 // Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
@@ -593,19 +597,21 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     const int jj = act ? lane : 0;
     // per-node constants staged in LDS by smem_setup (stride NP): reading them from L2 at every evaluation left the single
     // resident wave parked at s_waitcnt (SQ_WAIT_ANY 31 % of wave cycles)
+    constexpr int CS = cstride(NP);
+    const int jc = (CS > NP && lane >= NP) ? NP : lane;      // this lane's column of constants (idle column beyond NP)
     const double* cK = sAcc + acc_doubles(n, NP);
-    const double* cSb = cK + 36 * NP;
-    const double* cI4 = cSb + 6 * NP;
-    const double* cPrm = cI4 + 4 * NP;
-    const double* cTyp = cPrm + 8 * NP;     // joint type, stored as a double
-    const double* cRel = cTyp + NP;         // 2 rows: ancestor / descendant bit masks (bit patterns)
-    const double* cAnc = cRel + 2 * NP;     // MAXROUNDS rows: ancestor 2^r levels up (as doubles), trees only
-    const double* cEnd = cAnc + MAXROUNDS * NP;
-    const double* cCon = cEnd + NP;         // 4 rows: contact flag, cuboid sides
-    const int type = act ? (int)cTyp[jj] : 0;
+    const double* cSb = cK + 36 * CS;
+    const double* cI4 = cSb + 6 * CS;
+    const double* cPrm = cI4 + 4 * CS;
+    const double* cTyp = cPrm + 8 * CS;     // joint type, stored as a double
+    const double* cRel = cTyp + CS;         // 2 rows: ancestor / descendant bit masks (bit patterns)
+    const double* cAnc = cRel + 2 * CS;     // MAXROUNDS rows: ancestor 2^r levels up (as doubles), trees only
+    const double* cEnd = cAnc + MAXROUNDS * CS;
+    const double* cCon = cEnd + CS;         // 4 rows: contact flag, cuboid sides
+    const int type = (int)cTyp[jc];
     const bool dof = type != 0;
-    fs.anc_m = act ? (unsigned long long)__double_as_longlong(cRel[jj]) : 0ull;
-    fs.desc_m = act ? (unsigned long long)__double_as_longlong(cRel[NP + jj]) : 0ull;
+    fs.anc_m = (unsigned long long)__double_as_longlong(cRel[jc]);
+    fs.desc_m = (unsigned long long)__double_as_longlong(cRel[CS + jc]);
 
     const double q = dof ? xq : 0.0;
     const double qd = dof ? xqd : 0.0;
@@ -621,15 +627,10 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     }
     double R[9], p[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) R[c] = cK[c * NP + jj] + u * cK[(12 + c) * NP + jj] + w * cK[(24 + c) * NP + jj];
+    for (int c = 0; c < 9; ++c) R[c] = cK[c * CS + jc] + u * cK[(12 + c) * CS + jc] + w * cK[(24 + c) * CS + jc];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) p[c] = cK[(9 + c) * NP + jj] + u * cK[(21 + c) * NP + jj] + w * cK[(33 + c) * NP + jj];
-    if (!act) {   // idle lanes carry the identity so that they are neutral in the chain scans
-#pragma unroll
-        for (int c = 0; c < 9; ++c) R[c] = (c % 4 == 0) ? 1.0 : 0.0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) p[c] = 0.0;
-    }
+    for (int c = 0; c < 3; ++c) p[c] = cK[(9 + c) * CS + jc] + u * cK[(21 + c) * CS + jc] + w * cK[(33 + c) * CS + jc];
+    // idle lanes read the identity transform from their constants, so they are neutral in the chain scans
 
     RMX_STAMP(0)
     // ---- world transforms E_w,j = E_w,parent T_j
@@ -637,7 +638,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         chain_scan_transform<NP>(lane, R, p);
     } else {   // general tree: pointer jumping over ancestors (log2(depth) rounds of cross-lane permutes)
         for (int r = 0; r < M.rounds; ++r) {
-            const int a = act ? (int)cAnc[r * NP + jj] : -1;
+            const int a = (int)cAnc[r * CS + jc];
             const int src = a >= 0 ? a : lane;
             double Ra[9], pa[3];
 #pragma unroll
@@ -667,8 +668,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     double (&sv)[3] = fs.sv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        sbw[c] = act ? cSb[c * NP + jj] : 0.0;
-        sbv[c] = act ? cSb[(3 + c) * NP + jj] : 0.0;
+        sbw[c] = cSb[c * CS + jc];
+        sbv[c] = cSb[(3 + c) * CS + jc];
     }
     mat3v(R, sbw, sw);
     mat3v(R, sbv, sv);
@@ -688,7 +689,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         chain_scan_sum6<NP>(lane, phw, phv);
     } else {
         for (int r = 0; r < M.rounds; ++r) {
-            const int a = act ? (int)cAnc[r * NP + jj] : -1;
+            const int a = (int)cAnc[r * CS + jc];
             const int src = a >= 0 ? a : lane;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -720,7 +721,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         chain_scan_sum6<NP>(lane, bw, bv);
     } else {
         for (int r = 0; r < M.rounds; ++r) {
-            const int a = act ? (int)cAnc[r * NP + jj] : -1;
+            const int a = (int)cAnc[r * CS + jc];
             const int src = a >= 0 ? a : lane;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -735,8 +736,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
 
     RMX_STAMP(3)
     // ---- world-frame spatial inertia of body j (Body.computeMassGrav :99-101): m, mc, Ibar = R diag(I) R' + m [c][c]'
-    const double I1 = act ? cI4[0 * NP + jj] : 0.0, I2 = act ? cI4[1 * NP + jj] : 0.0;
-    const double I3 = act ? cI4[2 * NP + jj] : 0.0, ms = act ? cI4[3 * NP + jj] : 0.0;
+    const double I1 = cI4[0 * CS + jc], I2 = cI4[1 * CS + jc];
+    const double I3 = cI4[2 * CS + jc], ms = cI4[3 * CS + jc];
     double mc[3], Ib[6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) mc[c] = ms * p[c];
@@ -784,8 +785,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     double eVc = 0.0;
     fs.touched = false;
     if constexpr (CT) {
-        const bool con = act && cCon[jj] != 0.0;
-        const double sd[3] = {cCon[NP + jj], cCon[2 * NP + jj], cCon[3 * NP + jj]};
+        const bool con = cCon[jc] != 0.0;
+        const double sd[3] = {cCon[CS + jc], cCon[2 * CS + jc], cCon[3 * CS + jc]};
         double Fc[6], k1[36], d1[36];
         fs.touched = contact_body<false>(M, con, sd, R, p, phw, phv, Fc, k1, d1, eVc);
 #pragma unroll
@@ -796,10 +797,10 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     }
 
     // energies (Body.computeEnergies Body.m:167-173, Joint.computeEnergies Joint.m:616-637)
-    const double stiff = act ? cPrm[1 * NP + jj] : 0.0, damp = act ? cPrm[2 * NP + jj] : 0.0;
-    const double tau = act ? cPrm[0 * NP + jj] : 0.0, qRest = act ? cPrm[3 * NP + jj] : 0.0;
-    const double qLimL = act ? cPrm[4 * NP + jj] : 0.0, qLimU = act ? cPrm[5 * NP + jj] : 0.0;
-    const double qLimK = act ? cPrm[6 * NP + jj] : 0.0, qLimD = act ? cPrm[7 * NP + jj] : 0.0;
+    const double stiff = cPrm[1 * CS + jc], damp = cPrm[2 * CS + jc];
+    const double tau = cPrm[0 * CS + jc], qRest = cPrm[3 * CS + jc];
+    const double qLimL = cPrm[4 * CS + jc], qLimU = cPrm[5 * CS + jc];
+    const double qLimK = cPrm[6 * CS + jc], qLimD = cPrm[7 * CS + jc];
     const double hitL = (dof && q < qLimL) ? 1.0 : 0.0, hitU = (dof && q > qLimU) ? 1.0 : 0.0;
     {
         double eT = 0.5 * (dot3(phw, ht) + dot3(phv, hf));
@@ -926,7 +927,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
 #pragma unroll
             for (int c = 0; c < NS; ++c) S[c] = A[c];
             if (!M.is_chain) {
-                const int en = act ? (int)cEnd[jj] : n;
+                const int en = (int)cEnd[jc];
                 const double* E = sAcc + en * ACC_STRIDE;
 #pragma unroll
                 for (int c = 0; c < NS; ++c) S[c] -= E[c];
@@ -1076,6 +1077,7 @@ template <int NP, bool TIMED = false, bool CT = false>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
+    constexpr int CS = cstride(NP);
     const double eta = fs.eta, e2 = eta * eta;
     const bool act = fs.act, dof = fs.dof;
     const int jj = act ? lane : 0;
@@ -1094,10 +1096,10 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
         for (int c = 0; c < 6; ++c) cxy[c] = cxr2[c] = cxr3[c] = 0.0;
         if (fs.touched) {
-            const double* cEnd = sAcc + acc_doubles(M.n, NP) + (NCONST - 5) * NP;
-            const double* cCon = cEnd + NP;
+            const double* cEnd = sAcc + acc_doubles(M.n, NP) + (NCONST - 5) * CS;
+            const double* cCon = cEnd + CS;
             const bool con = act && cCon[jj] != 0.0;
-            const double sd[3] = {cCon[NP + jj], cCon[2 * NP + jj], cCon[3 * NP + jj]};
+            const double sd[3] = {cCon[CS + jj], cCon[2 * CS + jj], cCon[3 * CS + jj]};
             double Fc[6], KD[72], eVc;            // Kx and Dx back to back: 72 numbers = three passes of the 28-wide scan
             double (&Kx)[36] = *reinterpret_cast<double (*)[36]>(&KD[0]);
             double (&Dx)[36] = *reinterpret_cast<double (*)[36]>(&KD[36]);
@@ -1281,7 +1283,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         __syncthreads();
         typedef double v4d __attribute__((ext_vector_type(4)));
         const int g = lane >> 4, j = lane & 15;
-        const double* cRel = sAcc + acc_doubles(M.n, NP) + (36 + 6 + 4 + 8 + 1) * NP;   // relation bit masks of the nodes (as doubles)
+        const double* cRel = sAcc + acc_doubles(M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;   // relation bit masks of the nodes (as doubles)
         v4d up[2][2], lw[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -1325,7 +1327,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             am[nb] = (unsigned long long)__double_as_longlong(cRel[16 * nb + j]) >> g;
-            dm[nb] = (unsigned long long)__double_as_longlong(cRel[NP + 16 * nb + j]) >> g;
+            dm[nb] = (unsigned long long)__double_as_longlong(cRel[CS + 16 * nb + j]) >> g;
             hd[nb] = sOp[R_HD * HM_OP_STRIDE + 16 * nb + j];
         }
         double hv[2][2][4];
@@ -1594,7 +1596,7 @@ __device__ __forceinline__ void sph_apply_chart(const DevModel& M, double* __res
         chart_axes(chart, a1, a2, a3);
         const int a = k == 0 ? a1 : (k == 1 ? a2 : a3);
         const double* src = M.sphV + ((size_t)(g * 3 + k) * 3 + a) * SPH_ROWS;
-        for (int r = 0; r < SPH_ROWS; ++r) sCol[r * NP + lane] = src[r];
+        for (int r = 0; r < SPH_ROWS; ++r) sCol[r * cstride(NP) + lane] = src[r];
     }
 }
 // kernel prologue: bring the LDS constants in line with the stored charts (smem_setup staged CHART_XYZ)

@@ -16,28 +16,29 @@ __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, dou
     sAcc = smem;
     sCol = smem + acc_doubles(M.n, NP);       // per-node constants, [NCONST][NP] (see eval_front_e2)
     if (threadIdx.x < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + threadIdx.x] = 0.0;   // zero row n (end-of-tree suffix)
-    if (threadIdx.x < NP) {
+    constexpr int CS = cstride(NP);
+    if (threadIdx.x < CS) {       // column NP (trees padded to < 64 lanes) and the unused node slots n..NP-1: idle defaults
         const int j = threadIdx.x;
         const bool in = j < M.n;
         double* c = sCol;
-        for (int r = 0; r < 36; ++r) c[r * NP + j] = in ? M.K[r * MAXN + j] : 0.0;
-        c += 36 * NP;
-        for (int r = 0; r < 6; ++r) c[r * NP + j] = in ? M.sb[r * MAXN + j] : 0.0;
-        c += 6 * NP;
-        for (int r = 0; r < 4; ++r) c[r * NP + j] = in ? M.I4[r * MAXN + j] : 0.0;
-        c += 4 * NP;
-        for (int r = 0; r < 8; ++r) c[r * NP + j] = in ? M.prm[r * MAXN + j] : 0.0;
-        c += 8 * NP;
+        for (int r = 0; r < 36; ++r) c[r * CS + j] = in ? M.K[r * MAXN + j] : ((r == 0 || r == 4 || r == 8) ? 1.0 : 0.0);   // identity
+        c += 36 * CS;
+        for (int r = 0; r < 6; ++r) c[r * CS + j] = in ? M.sb[r * MAXN + j] : 0.0;
+        c += 6 * CS;
+        for (int r = 0; r < 4; ++r) c[r * CS + j] = in ? M.I4[r * MAXN + j] : 0.0;
+        c += 4 * CS;
+        for (int r = 0; r < 8; ++r) c[r * CS + j] = in ? M.prm[r * MAXN + j] : 0.0;
+        c += 8 * CS;
         c[j] = in ? (double)M.type[j] : 0.0;
-        c += NP;
+        c += CS;
         c[j] = in ? __longlong_as_double((long long)M.rel[j]) : 0.0;
-        c[NP + j] = in ? __longlong_as_double((long long)M.rel[MAXN + j]) : 0.0;
-        c += 2 * NP;
-        for (int r = 0; r < MAXROUNDS; ++r) c[r * NP + j] = in ? (double)M.anc[r * MAXN + j] : -1.0;
-        c += MAXROUNDS * NP;
+        c[CS + j] = in ? __longlong_as_double((long long)M.rel[MAXN + j]) : 0.0;
+        c += 2 * CS;
+        for (int r = 0; r < MAXROUNDS; ++r) c[r * CS + j] = in ? (double)M.anc[r * MAXN + j] : -1.0;
+        c += MAXROUNDS * CS;
         c[j] = in ? (double)M.end[j] : (double)M.n;
-        c += NP;
-        for (int r = 0; r < 4; ++r) c[r * NP + j] = (in && M.con) ? M.con[r * MAXN + j] : 0.0;
+        c += CS;
+        for (int r = 0; r < 4; ++r) c[r * CS + j] = (in && M.con) ? M.con[r * MAXN + j] : 0.0;
     }
     __syncthreads();
 }
