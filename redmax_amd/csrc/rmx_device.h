@@ -613,9 +613,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     fs.anc_m = (unsigned long long)__double_as_longlong(cRel[jc]);
     fs.desc_m = (unsigned long long)__double_as_longlong(cRel[CS + jc]);
 
-    const double q = dof ? xq : 0.0;
-    const double qd = dof ? xqd : 0.0;
-    const double v = dof ? xv : 0.0;
+    // callers pass zeros on lanes without a DOF (fixed joints, idle lanes): no selects needed here
+    const double q = xq, qd = xqd, v = xv;
 
     // ---- joint transform T_j(q) = K0 + u K1 + w K2  (JointRevolute/Prismatic.update_, Joint.update :401-408,
     //      Body.update :70-72, folded with the constant offsets E0_ij(parent) E0_pj and E0_ji)
@@ -810,8 +809,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             const double dqL = hitL * (qLimL - q), dqU = hitU * (qLimU - q);
             eV += 0.5 * stiff * (dq * dq) + 0.5 * qLimK * (dqL * dqL + dqU * dqU);
         }
-        out.eT = act ? eT : 0.0;
-        out.eV = act ? eV + eVc : 0.0;
+        out.eT = eT;              // idle lanes: zero mass, zero twist, no joint -> exact zeros
+        out.eV = eV + eVc;
     }
 
     RMX_STAMP(4)
@@ -1073,7 +1072,7 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 }
 
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle lanes are the identity.
-template <int NP, bool TIMED = false, bool CT = false>
+template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1220,19 +1219,22 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
     // column-side vectors of this node (zero on idle lanes).  NP != 32: column i is broadcast out of lane i with v_readlane
     // into scalar registers, which the FMAs consume directly.  NP == 32: see below.
     constexpr int NCV = CT ? NCOLX : NCOL;
+    // idle node slots have s = 0, hence all-zero column vectors by arithmetic; the explicit selects are kept only where the
+    // vectors of lanes >= NP could be read (the v_readlane loops), not for the n <= 32 MFMA path, which stages lanes < NP only
+    const bool keep = (NP == 32 && HESS_MFMA) ? true : act;
     double cv[NCV];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         if (CT) {
-            cv[18 + c] = act ? eta * sv[c] + e2 * xiv[c] : 0.0;   // m2v
-            cv[21 + c] = act ? sv[c] : 0.0;
+            cv[18 + c] = keep ? eta * sv[c] + e2 * xiv[c] : 0.0;   // m2v
+            cv[21 + c] = keep ? sv[c] : 0.0;
         }
-        cv[c] = act ? yt[c] - zt[c] : 0.0;
-        cv[3 + c] = act ? yf[c] - zf[c] : 0.0;
-        cv[6 + c] = act ? m1w[c] : 0.0;
-        cv[9 + c] = act ? m1v[c] : 0.0;
-        cv[12 + c] = act ? m2w[c] : 0.0;
-        cv[15 + c] = act ? sw[c] : 0.0;
+        cv[c] = keep ? yt[c] - zt[c] : 0.0;
+        cv[3 + c] = keep ? yf[c] - zf[c] : 0.0;
+        cv[6 + c] = keep ? m1w[c] : 0.0;
+        cv[9 + c] = keep ? m1v[c] : 0.0;
+        cv[12 + c] = keep ? m2w[c] : 0.0;
+        cv[15 + c] = keep ? sw[c] : 0.0;
     }
     RMX_STAMP(10)
     const unsigned long long anc_m = fs.anc_m, desc_m = fs.desc_m;
@@ -1322,12 +1324,12 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         }
         // relation bits of this lane's two column nodes c = 16 nb + j: bit a of the ancestor mask -> UP applies, of the
         // descendant mask -> LO applies; shifted by g so that the row a = 16 mb + 4 r + g needs a constant shift
-        unsigned long long am[2], dm[2];
+        unsigned am[2], dm[2];        // rows 16 mb + 4 r + g <= 31: the low words of the shifted masks are enough
         double hd[2];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            am[nb] = (unsigned long long)__double_as_longlong(cRel[16 * nb + j]) >> g;
-            dm[nb] = (unsigned long long)__double_as_longlong(cRel[CS + 16 * nb + j]) >> g;
+            am[nb] = (unsigned)((unsigned long long)__double_as_longlong(cRel[16 * nb + j]) >> g);
+            dm[nb] = (unsigned)((unsigned long long)__double_as_longlong(cRel[CS + 16 * nb + j]) >> g);
             hd[nb] = sOp[R_HD * HM_OP_STRIDE + 16 * nb + j];
         }
         double hv[2][2][4];
@@ -1339,8 +1341,8 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                 for (int r = 0; r < 4; ++r) {
                     const int sh = 16 * mb + 4 * r;
                     double v = 0.0;
-                    if (nb >= mb) v = (double)(unsigned)((am[nb] >> sh) & 1ull) * up[mb][nb][r];
-                    if (nb <= mb) v += (double)(unsigned)((dm[nb] >> sh) & 1ull) * lw[mb][nb][r];
+                    if (nb >= mb) v = (double)((am[nb] >> sh) & 1u) * up[mb][nb][r];
+                    if (nb <= mb) v += (double)((dm[nb] >> sh) & 1u) * lw[mb][nb][r];
                     hv[mb][nb][r] = (mb == nb && 4 * r + g == j) ? hd[nb] : v;
                 }
         __syncthreads();             // every lane is done with the operands: the same LDS now takes H, row-major
@@ -1358,8 +1360,10 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
             for (int c = 0; c < NP / 2; ++c) {
                 const v2d t = hr[c];
-                Hrow[2 * c] = lo_half ? t[0] : 0.0;
-                Hrow[2 * c + 1] = lo_half ? t[1] : 0.0;
+                // ZERO_IDLE: lanes >= 32 hold all-zero rows (the pivot search of lu_solve_neg looks at every lane).  The guarded
+                // diagonal solve never reads them and ignores their guard bits, so there they keep the mirrored row.
+                Hrow[2 * c] = (ZERO_IDLE && !lo_half) ? 0.0 : t[0];
+                Hrow[2 * c + 1] = (ZERO_IDLE && !lo_half) ? 0.0 : t[1];
             }
         }
         __syncthreads();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
@@ -1706,7 +1710,11 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
                                                     bool& ok) {
     double b = -g;
     bool bad = false;
-    double rinv_own = 0.0;    // 1/U(lane,lane), kept for the back substitution
+    // 1/U(k,k) for the back substitution: n <= 32 keeps all of them (wave-uniform values, no per-lane select per step);
+    // 64 rows would cost 128 more registers, so there every lane keeps its own
+    constexpr bool KEEP_ALL = NP <= 32;
+    double rinv_own = 0.0;
+    double rinvs[KEEP_ALL ? NP : 1];
     const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
     // the reciprocal of pivot k+1 is started as soon as column k+1 has seen step k, ahead of the other trailing columns, so
     // that its latency chain (readlane -> rcp -> 2 Newton steps) overlaps their updates
@@ -1714,7 +1722,8 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     double rinv = recip(piv);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        rinv_own = (lane == k) ? rinv : rinv_own;
+        if constexpr (KEEP_ALL) rinvs[k] = rinv;
+        else rinv_own = (lane == k) ? rinv : rinv_own;
         const double l = (lane > k) ? Hrow[k] * rinv : 0.0;
         bad = bad | !(Hrow[k] * l <= lim) | !(piv > 0.0);   // l^2 u_kk = a_ik l ; bitwise: no branches in the elimination loop
         if (k + 1 < NP) {
@@ -1729,11 +1738,13 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     double dx = 0.0;
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
-        const double xk = readlane_d(b * rinv_own, k);
+        double xk;
+        if constexpr (KEEP_ALL) xk = readlane_d(b, k) * rinvs[k];
+        else xk = readlane_d(b * rinv_own, k);
         if (lane == k) dx = xk;
         if (lane < k) b -= Hrow[k] * xk;
     }
-    ok = !__any(bad);
+    ok = !__any(bad && lane < NP);   // lanes beyond the padded size may carry mirrored rows (eval_hess ZERO_IDLE = false)
     return dx;
 }
 
@@ -1817,8 +1828,9 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     NodeOut e;
     eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     int iter = 1;
+    double gcarry = -1.0;
     while (true) {
-        const double hdiag = eval_hess<NP, false, CT>(M, lane, fs, Hrow, nullptr, sAcc);
+        const double hdiag = eval_hess<NP, false, CT, PIVOT_ONLY>(M, lane, fs, Hrow, nullptr, sAcc);
         const NodeOut e0 = e;
         last = e;
         ++iters;
@@ -1851,7 +1863,9 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
             break;
         }
         double alpha = 1.0;
-        const double g0n2 = wave_sum(e.g * e.g);
+        // |g(x0)|^2: from the second iteration on it is the |g|^2 the previous line search ended with (same vector, same
+        // deterministic reduction), so it is carried over instead of being reduced again
+        const double g0n2 = gcarry >= 0.0 ? gcarry : wave_sum(e.g * e.g);
         const double f0 = 0.5 * g0n2;
         const double x0 = x;
         int iterLs = 1;
@@ -1883,6 +1897,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
             if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
             break;
         }
+        gcarry = gn2;
         if (sqrt(gn2) < o.tol) break;
         if (iter >= o.iterMax) {
             status |= 2;         // "Newton did not converge" (:150-153)
