@@ -166,8 +166,10 @@ __device__ __forceinline__ unsigned wave_umax32(unsigned v) {
 // row_shr:K inside each 16-lane row; lanes without a source (lane&15 < K) receive 0
 template <int K>
 __device__ __forceinline__ double dpp_shr0(double v) {
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + K, 0xF, 0xF, false);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + K, 0xF, 0xF, false);
+    // bound_ctrl: lanes without a source read 0 from the DPP itself; with bound_ctrl off the destination would have to be
+    // pre-loaded with the fill value (two v_mov + a hazard s_nop per use)
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + K, 0xF, 0xF, true);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + K, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 // row_shr:K with a caller-chosen value for the lanes without a source
@@ -180,8 +182,8 @@ __device__ __forceinline__ double dpp_shr_old(double v, const double old) {
 // row_shl:K inside each 16-lane row (lane l receives lane l+K); lanes without a source receive 0
 template <int K>
 __device__ __forceinline__ double dpp_shl0(double v) {
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + K, 0xF, 0xF, false);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + K, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + K, 0xF, 0xF, true);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + K, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 // 1/x to full double precision: hardware estimate + two Newton steps (error <= 1 ulp; LAPACK's dgetf2 also scales
@@ -270,7 +272,7 @@ __device__ __forceinline__ void chain_compose_step(const int lane, double (&R)[9
     (void)lane;
     double Ra[9], pa[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) Ra[c] = dpp_shr_old<K>(R[c], (c % 4 == 0) ? 1.0 : 0.0);
+    for (int c = 0; c < 9; ++c) Ra[c] = (c % 4 == 0) ? dpp_shr_old<K>(R[c], 1.0) : dpp_shr0<K>(R[c]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) pa[c] = dpp_shr0<K>(p[c]);
     double Rn[9], pn[3];
