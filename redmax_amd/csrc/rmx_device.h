@@ -1707,11 +1707,21 @@ __device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restric
 // the caller redoes the solve with full partial pivoting (lu_solve_neg) on a re-assembled H: pivoting semantics are kept,
 // its cost is paid only when needed.
 constexpr double LU_GROWTH_MAX = 8.0;
+constexpr int LU_BATCH = 8;
+__device__ __forceinline__ void lu_pin(double (&pv)[LU_BATCH]) {
+    asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]), "+s"(pv[4]), "+s"(pv[5]), "+s"(pv[6]), "+s"(pv[7]));
+}
 template <int NP>
 __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, const double diag_own,
                                                     bool& ok) {
     double b = -g;
     bool bad = false;
+    // The lane comparisons below (lane > k, lane == k, lane < k for 32..64 values of k) are invariant across Newton iterations;
+    // hoisted out of the loops they would be ~100 64-bit masks held in SGPRs, spilled to VGPR lanes and fetched back with
+    // v_readlane inside the elimination, and the starved allocator would serialise the pivot-row broadcasts.  An opaque copy
+    // of the lane id keeps the compares (one VALU instruction each) where they are used.
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
     // 1/U(k,k) for the back substitution: n <= 32 keeps all of them (wave-uniform values, no per-lane select per step);
     // 64 rows would cost 128 more registers, so there every lane keeps its own
     constexpr bool KEEP_ALL = NP <= 32;
@@ -1725,16 +1735,31 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         if constexpr (KEEP_ALL) rinvs[k] = rinv;
-        else rinv_own = (lane == k) ? rinv : rinv_own;
-        const double l = (lane > k) ? Hrow[k] * rinv : 0.0;
+        else rinv_own = (lv == k) ? rinv : rinv_own;
+        const double l = (lv > k) ? Hrow[k] * rinv : 0.0;
         bad = bad | !(Hrow[k] * l <= lim) | !(piv > 0.0);   // l^2 u_kk = a_ik l ; bitwise: no branches in the elimination loop
         if (k + 1 < NP) {
             Hrow[k + 1] -= l * readlane_d(Hrow[k + 1], k);
             piv = readlane_d(Hrow[k + 1], k + 1);
             rinv = recip(piv);
         }
+        // The pivot row is broadcast LU_BATCH entries at a time, all of a batch before its first FMA: an FMA that reads the scalar
+        // registers a v_readlane has just written needs hazard wait states, and the element-by-element order costs 22 cycles
+        // per element against 15 for batches of 8 (tools/ubench.hip).  The "+s" pin keeps the scheduler from re-interleaving.
+        if constexpr (NP > 32) {    // 64 rows: the pinned batches push the register allocator over the edge (10x slower); plain order
 #pragma unroll
-        for (int c = k + 2; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], k);
+            for (int c = k + 2; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], k);
+        } else
+#pragma unroll
+        for (int c0 = k + 2; c0 < NP; c0 += LU_BATCH) {
+            double pv[LU_BATCH];
+#pragma unroll
+            for (int i = 0; i < LU_BATCH; ++i) pv[i] = (c0 + i < NP) ? readlane_d(Hrow[c0 + i < NP ? c0 + i : NP - 1], k) : 0.0;
+            lu_pin(pv);
+#pragma unroll
+            for (int i = 0; i < LU_BATCH; ++i)
+                if (c0 + i < NP) Hrow[c0 + i] -= l * pv[i];
+        }
         b -= l * readlane_d(b, k);
     }
     double dx = 0.0;
@@ -1743,8 +1768,8 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         double xk;
         if constexpr (KEEP_ALL) xk = readlane_d(b, k) * rinvs[k];
         else xk = readlane_d(b * rinv_own, k);
-        if (lane == k) dx = xk;
-        if (lane < k) b -= Hrow[k] * xk;
+        if (lv == k) dx = xk;
+        if (lv < k) b -= Hrow[k] * xk;
     }
     ok = !__any(bad && lane < NP);   // lanes beyond the padded size may carry mirrored rows (eval_hess ZERO_IDLE = false)
     return dx;

@@ -96,6 +96,16 @@ __global__ void __launch_bounds__(64) k(double* out, unsigned long long* cyc, in
                 a[i + 1] -= l * readlane_d(a[i + 1], 5);
                 a[i] -= l * __hiloint2double(hi, lo);
             }
+        } else if (MODE == 14) {  // 16 x (readlane_d imm + fma), broadcasts batched 8 at a time ahead of their FMAs
+#pragma unroll
+            for (int h = 0; h < 16; h += 8) {
+                double pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = readlane_d(a[h + i], 5);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[h + i] -= l * pv[i];
+            }
         } else if (MODE == 9) {   // sincos fp64
             double s_, c_;
             sincos(a[0], &s_, &c_);
@@ -145,6 +155,7 @@ int main() {
         run<11>("16 x ds_swizzle bcast32 double", 16, nblk);
         run<12>("16 x permlane32_swap double + add", 16, nblk);
         run<13>("8 x (readlane+fma) + 8 x (swizzle+fma)", 16, nblk);
+        run<14>("16 x (readlane_d imm + fma), batches of 8", 16, nblk);
     }
     return 0;
 }
