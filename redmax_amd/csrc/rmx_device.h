@@ -1746,9 +1746,17 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         // The pivot row is broadcast LU_BATCH entries at a time, all of a batch before its first FMA: an FMA that reads the scalar
         // registers a v_readlane has just written needs hazard wait states, and the element-by-element order costs 22 cycles
         // per element against 15 for batches of 8 (tools/ubench.hip).  The "+s" pin keeps the scheduler from re-interleaving.
-        if constexpr (NP > 32) {    // 64 rows: the pinned batches push the register allocator over the edge (10x slower); plain order
+        if constexpr (NP > 32) {    // 64 rows: batches of 8 push the register allocator over the edge (10x slower); batches of 4
 #pragma unroll
-            for (int c = k + 2; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], k);
+            for (int c0 = k + 2; c0 < NP; c0 += 4) {
+                double pv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pv[i] = (c0 + i < NP) ? readlane_d(Hrow[c0 + i < NP ? c0 + i : NP - 1], k) : 0.0;
+                asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c0 + i < NP) Hrow[c0 + i] -= l * pv[i];
+            }
         } else
 #pragma unroll
         for (int c0 = k + 2; c0 < NP; c0 += LU_BATCH) {
