@@ -1715,7 +1715,10 @@ template <int NP>
 __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, const double diag_own,
                                                     bool& ok) {
     double b = -g;
-    bool bad = false;
+    // guard state: the largest scaled multiplier seen by this lane and the smallest pivot (wave-uniform), compared once at the
+    // end (v_max / v_min per step instead of two compares and two mask updates; a NaN passes through v_max but shows up in dx,
+    // which the caller checks)
+    double gmax = 0.0, pmin = 1.0;
     // The lane comparisons below (lane > k, lane == k, lane < k for 32..64 values of k) are invariant across Newton iterations;
     // hoisted out of the loops they would be ~100 64-bit masks held in SGPRs, spilled to VGPR lanes and fetched back with
     // v_readlane inside the elimination, and the starved allocator would serialise the pivot-row broadcasts.  An opaque copy
@@ -1737,7 +1740,8 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         if constexpr (KEEP_ALL) rinvs[k] = rinv;
         else rinv_own = (lv == k) ? rinv : rinv_own;
         const double l = (lv > k) ? Hrow[k] * rinv : 0.0;
-        bad = bad | !(Hrow[k] * l <= lim) | !(piv > 0.0);   // l^2 u_kk = a_ik l ; bitwise: no branches in the elimination loop
+        gmax = fmax(gmax, Hrow[k] * l);          // l^2 u_kk = a_ik l
+        pmin = fmin(pmin, piv);
         if (k + 1 < NP) {
             Hrow[k + 1] -= l * readlane_d(Hrow[k + 1], k);
             piv = readlane_d(Hrow[k + 1], k + 1);
@@ -1779,7 +1783,8 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         if (lv == k) dx = xk;
         if (lv < k) b -= Hrow[k] * xk;
     }
-    ok = !__any(bad && lane < NP);   // lanes beyond the padded size may carry mirrored rows (eval_hess ZERO_IDLE = false)
+    // lanes beyond the padded size may carry mirrored rows (eval_hess ZERO_IDLE = false): their guard is ignored
+    ok = !__any(lane < NP && !(gmax <= lim)) && (pmin > 0.0);
     return dx;
 }
 
