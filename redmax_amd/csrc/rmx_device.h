@@ -1788,7 +1788,10 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     return dx;
 }
 
-template <int NP>
+// BATCHED: pivot-row broadcasts in batches ahead of their FMAs (see lu_solve_neg_diag).  The Euler and adjoint kernels use
+// it (-31 % on the solve); inside the Newton loop of the step kernels the same change costs the guarded path 2 % through
+// register allocation, so the rare fallback there keeps the plain order.
+template <int NP, bool BATCHED = false>
 __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, double (&Hrow)[NP], const double g) {
     // Rows/columns >= n are the identity (eval_node pads them), so all NP steps run unguarded: straight-line code lets
     // the scheduler overlap the pivot search of step k+1 with the trailing updates of step k.
@@ -1812,8 +1815,23 @@ __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, doub
             rinv_own = rinv;
         }
         const double l = elim ? Hrow[k] * rinv : 0.0;
+        // l == 0 on rows not being eliminated; the pivot row is broadcast in batches ahead of the FMAs (see lu_solve_neg_diag)
+        constexpr int BT = NP > 32 ? 4 : LU_BATCH;
+        if constexpr (!BATCHED) {
 #pragma unroll
-        for (int c = k + 1; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], pl);   // l == 0 on rows not being eliminated
+            for (int c = k + 1; c < NP; ++c) Hrow[c] -= l * readlane_d(Hrow[c], pl);
+        } else
+#pragma unroll
+        for (int c0 = k + 1; c0 < NP; c0 += BT) {
+            double pv[LU_BATCH];
+#pragma unroll
+            for (int i = 0; i < BT; ++i) pv[i] = (c0 + i < NP) ? readlane_d(Hrow[c0 + i < NP ? c0 + i : NP - 1], pl) : 0.0;
+            if constexpr (BT == LU_BATCH) lu_pin(pv);
+            else asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]));
+#pragma unroll
+            for (int i = 0; i < BT; ++i)
+                if (c0 + i < NP) Hrow[c0 + i] -= l * pv[i];
+        }
         b -= l * readlane_d(b, pl);
     }
     // back substitution on the implicitly permuted upper triangle

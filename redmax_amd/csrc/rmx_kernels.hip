@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) k_step_euler(const DevModel M, const doubl
 #pragma unroll
         for (int i = 0; i < NP; ++i)
             if (i == lane && fs.dof) Mrow[i] += h * fs.dd + h * h * fs.kd;
-        const double qd1 = lu_solve_neg<NP>(M.n, lane, Mrow, -rhs);
+        const double qd1 = lu_solve_neg<NP, true>(M.n, lane, Mrow, -rhs);
         q = q + h * qd1;
         qd = qd1;
         if (a.histT) {
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
                 }
             }
             ++iters;
-            const double dx = lu_solve_neg<NP>(n, lane, Hrow, e.g);      // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128
+            const double dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);      // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128
             const double dxn2 = wave_sum(dx * dx);
             if (!(dxn2 == dxn2)) { status |= 4; break; }
             if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }            // :129-132
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevO
         const double* Hc = a.Hs + ((size_t)traj * a.nsteps + (k - 1)) * nn + (size_t)col * n;
 #pragma unroll
         for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? Hc[i] : ((i == lane) ? 1.0 : 0.0);
-        const double z = lu_solve_neg<NP>(n, lane, Hrow, -y);
+        const double z = lu_solve_neg<NP, true>(n, lane, Hrow, -y);
         zs += z;
         z2 = z1;
         z1 = z;
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
         eval_node<NP, true, true>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow, stamps);
         unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        const double dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        const double dx = lu_solve_neg<NP, true>(M.n, lane, Hrow, e.g);
         unsigned long long t3 = __builtin_amdgcn_s_memtime();
         const double s1 = wave_sum(dx * dx) + wave_sum(e.g * e.g);
         unsigned long long t4 = __builtin_amdgcn_s_memtime();
