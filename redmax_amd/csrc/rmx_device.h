@@ -255,12 +255,19 @@ __device__ __forceinline__ void chain_scan_sum6(const int lane, double (&a)[3], 
     constexpr int NROWS = (NP + 15) / 16;
 #pragma unroll
     for (int r = 1; r < NROWS; ++r) {   // row r adds the (already complete) total of lane 16r-1
-        const bool in = (lane >> 4) == r;
+        // a 0/1 weight per lane and one FMA with the scalar broadcast as operand (exact: 1*t + a, 0*t + a) instead of moving
+        // the broadcast into a vector register and selecting; all six broadcasts first, then the FMAs (readlane -> use hazard)
+        const double w = ((lane >> 4) == r) ? 1.0 : 0.0;
+        double ta[3], tb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double ta = readlane_d(a[c], 16 * r - 1), tb = readlane_d(b[c], 16 * r - 1);
-            a[c] += in ? ta : 0.0;
-            b[c] += in ? tb : 0.0;
+            ta[c] = readlane_d(a[c], 16 * r - 1);
+            tb[c] = readlane_d(b[c], 16 * r - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[c] = fma(w, ta[c], a[c]);
+            b[c] = fma(w, tb[c], b[c]);
         }
     }
 }
