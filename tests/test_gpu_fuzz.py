@@ -17,17 +17,18 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def _random_scene(seed, contact=False):
+def _random_scene(seed, contact=False, big=False):
     rng = np.random.default_rng(seed)
     sc = Scene()
     sc.h = 5e-3
-    njoints = int(rng.integers(3, 12))
+    njoints = int(rng.integers(20, 30)) if big else int(rng.integers(3, 12))
+    max_nodes = 62 if big else 30
     kinds = ["rev", "rev", "rev", "pri", "fix", "planar", "universal", "trans", "free2d", "sph", "free3d"]
     nodes = 0
     for i in range(njoints):
         kind = kinds[int(rng.integers(len(kinds)))] if i else kinds[int(rng.integers(3))]
         cost = {"planar": 2, "universal": 2, "trans": 3, "free2d": 3, "sph": 3, "free3d": 6}.get(kind, 1)
-        if nodes + cost > 30:
+        if nodes + cost > max_nodes:
             kind, cost = "rev", 1
         nodes += cost
         body = BodyCuboid(float(rng.uniform(0.5, 2.0)), rng.uniform(0.5, 4.0, 3))
@@ -89,10 +90,11 @@ def _random_scene(seed, contact=False):
     return sc
 
 
-@pytest.mark.parametrize("seed", list(range(100, 116)))
+@pytest.mark.parametrize("seed", list(range(100, 116)) + [200, 201, 202, 203])
 def test_random_tree_matches_oracle(oracle_lib, seed):
+    """seeds >= 200: 20-30 joints / 33-62 nodes (the 64-lane code paths, 201 and 203 with ground contact)."""
     from redmax_amd import BatchSim
-    sc = _random_scene(seed, contact=(seed % 4 == 3))
+    sc = _random_scene(seed, contact=(seed % 4 == 3) or seed == 201, big=seed >= 200)
     nr, h = sc.nr, sc.h
     rng = np.random.default_rng(seed + 1000)
     B = 2
