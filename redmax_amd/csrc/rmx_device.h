@@ -4,10 +4,12 @@
 // kinematic tree (depth-first order), so every per-node quantity lives in registers and the tree
 // recursions of the reference (Joint.update / Joint.computeJacobian / Body.computeMassGrav,
 // matlab-diff/+redmax/Joint.m:382-613, Body.m:70-135) become
-//   * root->node path products/sums   : pointer jumping over ancestors with cross-lane permutes
-//   * node->leaves subtree sums       : transpose through LDS, one lane per component scans the nodes
-//   * the nr x nr Hessian             : lane = row, broadcast column vectors from LDS
-//   * the dense solve  dx = -H\g      : lane = row, row held in registers, pivot row via readlane
+//   * root->node path products/sums   : serial chains: DPP row scans + row hand-over; trees: pointer jumping (ds_bpermute)
+//   * node->leaves subtree sums       : transpose through LDS, two lanes per component scan the nodes
+//   * the nr x nr Hessian             : n <= 32: two 32x32 products on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), masked
+//                                       by the ancestor/descendant relation; larger trees: lane = row, v_readlane columns
+//   * the dense solve  dx = -H\g      : lane = row, row held in registers, pivot row by batched v_readlane broadcasts
+// One wave per SIMD means the kernel time is the instruction count on the path: see DESIGN.md "The instruction-count pass".
 // The algebra (world-frame recursive Newton-Euler with analytic derivatives, no J / dJdq tensors)
 // is derived in DESIGN.md and restated executable in tests/proto_worldframe.py.
 #pragma once
@@ -1080,7 +1082,8 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
     }
 }
 
-// Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle lanes are the identity.
+// Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle node slots are the identity.
+// Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
 template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr) {
