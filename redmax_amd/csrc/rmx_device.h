@@ -107,6 +107,19 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+// acc += m * (value of src in lane N of the caller's own 16-lane row): v_fmac_f64 with the DPP row_newbcast control, the one
+// DPP control gfx90a+ allows on 64-bit VALU operations.  The broadcast rides on the FMA: 7.3 cycles per element for a lone
+// wavefront against 15.4 for two v_readlane plus an FMA (tools/ubench.hip modes 14, 16, 17).  The compiler emits
+// v_mov_b64_dpp + v_fmac for the builtin form (13.1 cycles) and does not fold them, hence the assembly.  A DPP read of a
+// VGPR the previous instruction wrote needs two wait states the assembler does not add: NOPS puts an s_nop 1 in front.
+template <int N, bool NOPS>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, const double src, const double m) {
+    static_assert(N >= 0 && N < 16, "row_newbcast lane");
+    if constexpr (NOPS)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
+}
 // v_permlane32_swap (gfx950): swaps lanes 32..63 of its first operand with lanes 0..31 of the second.
 // dup_lo: every lane l >= 32 receives the value of lane l-32 (lanes < 32 keep theirs); take_hi: every lane l < 32 receives
 // the value of lane l+32.
@@ -1718,9 +1731,36 @@ __device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restric
 // its cost is paid only when needed.
 constexpr double LU_GROWTH_MAX = 8.0;
 constexpr int LU_BATCH = 8;
+constexpr bool LU_DPP_TAIL = true;
 __device__ __forceinline__ void lu_pin(double (&pv)[LU_BATCH]) {
     asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]), "+s"(pv[4]), "+s"(pv[5]), "+s"(pv[6]), "+s"(pv[7]));
 }
+// The last 16 pivots of lu_solve_neg_diag (K is a template constant: the DPP lane is an immediate).  Every row still being
+// eliminated sits in the pivot row's own 16-lane DPP row, so the pivot-row broadcast rides on the FMA (fmac_rowbcast).  Rows
+// in the other DPP rows are finished (l == 0: they add 0 x a finite entry of one of their own finished rows) or idle mirrors.
+template <int NP, int K, int NR>
+__device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, double& gmax, double& pmin, double& piv, double& rinv,
+                                             double (&rinvs)[NR], double& rinv_own, const int lv) {
+    if constexpr (K < NP) {
+        constexpr int N = K - (NP - 16);
+        if constexpr (NR == NP) rinvs[K] = rinv;
+        else rinv_own = (lv == K) ? rinv : rinv_own;
+        const double l = (lv > K) ? Hrow[K] * rinv : 0.0;
+        gmax = fmax(gmax, Hrow[K] * l);
+        pmin = fmin(pmin, piv);
+        const double nl = -l;
+        if constexpr (K + 1 < NP) {
+            fmac_rowbcast<N, true>(Hrow[K + 1], Hrow[K + 1], nl);
+            piv = readlane_d(Hrow[K + 1], K + 1);
+            rinv = recip(piv);
+        }
+#pragma unroll
+        for (int c = K + 2; c < NP; ++c) fmac_rowbcast<N, false>(Hrow[c], Hrow[c], nl);
+        fmac_rowbcast<N, false>(b, b, nl);
+        lu_diag_tail<NP, K + 1, NR>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
+    }
+}
+
 template <int NP>
 __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, const double diag_own,
                                                     bool& ok) {
@@ -1745,8 +1785,9 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     // that its latency chain (readlane -> rcp -> 2 Newton steps) overlaps their updates
     double piv = readlane_d(Hrow[0], 0);
     double rinv = recip(piv);
+    constexpr int KTAIL = (NP >= 16 && LU_DPP_TAIL) ? NP - 16 : NP;   // pivots from KTAIL on: lu_diag_tail
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
+    for (int k = 0; k < KTAIL; ++k) {
         if constexpr (KEEP_ALL) rinvs[k] = rinv;
         else rinv_own = (lv == k) ? rinv : rinv_own;
         const double l = (lv > k) ? Hrow[k] * rinv : 0.0;
@@ -1784,6 +1825,7 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         }
         b -= l * readlane_d(b, k);
     }
+    if constexpr (KTAIL < NP) lu_diag_tail<NP, KTAIL>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
     double dx = 0.0;
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {

@@ -106,6 +106,22 @@ __global__ void __launch_bounds__(64) k(double* out, unsigned long long* cyc, in
 #pragma unroll
                 for (int i = 0; i < 8; ++i) a[h + i] -= l * pv[i];
             }
+        } else if (MODE == 15) {   // 16 x (v_mov_b64_dpp row_newbcast + fma): 64-bit DPP broadcast inside each 16-lane row
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] -= l * __builtin_amdgcn_update_dpp(0.0, a[i], 0x150 + 5, 0xF, 0xF, true);
+        } else if (MODE == 16) {   // 16 x v_fmac_f64_dpp row_newbcast (broadcast fused into the FMA, inline asm)
+            asm volatile("s_nop 1");
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[i]), "v"(l));
+        } else if (MODE == 17) {   // same, source row distinct from the accumulator (the LU pattern: acc[c] += bcast(piv[c]) * l)
+            asm volatile("s_nop 1");
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[8 + i]), "v"(l));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:6 row_mask:0xf bank_mask:0xf" : "+v"(a[8 + i]) : "v"(a[i]), "v"(l));
         } else if (MODE == 9) {   // sincos fp64
             double s_, c_;
             sincos(a[0], &s_, &c_);
@@ -139,7 +155,27 @@ void run(const char* name, int per, int nblk) {
     hipFree(out); hipFree(cyc);
 }
 
+__global__ void __launch_bounds__(64) dpp_check(double* out) {
+    const int lane = threadIdx.x;
+    double src = 100.0 + lane, l = 0.5 + lane, acc = 1000.0 * lane;
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(l));
+    out[lane] = acc;   // expect 1000*lane + (100 + 16*(lane/16) + 5) * (0.5 + lane)
+    out[64 + lane] = __builtin_amdgcn_update_dpp(0.0, src, 0x150 + 9, 0xF, 0xF, true);   // expect 100 + 16*(lane/16) + 9
+}
+
 int main() {
+    {
+        double* d; hipMalloc(&d, sizeof(double) * 128);
+        dpp_check<<<1, 64>>>(d);
+        double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int l = 0; l < 64; ++l) {
+            bad += h[l] != 1000.0 * l + (100.0 + 16 * (l / 16) + 5) * (0.5 + l);
+            bad += h[64 + l] != 100.0 + 16 * (l / 16) + 9;
+        }
+        printf("v_fmac_f64_dpp / v_mov_b64_dpp row_newbcast check: %s (%d mismatches)\n", bad ? "FAIL" : "ok", bad);
+        hipFree(d);
+    }
     for (int nblk : {1024, 4096}) {
         run<0>("16 indep v_fma_f64", 16, nblk);
         run<1>("16 dependent v_fma_f64", 16, nblk);
@@ -156,6 +192,9 @@ int main() {
         run<12>("16 x permlane32_swap double + add", 16, nblk);
         run<13>("8 x (readlane+fma) + 8 x (swizzle+fma)", 16, nblk);
         run<14>("16 x (readlane_d imm + fma), batches of 8", 16, nblk);
+        run<15>("16 x (v_mov_b64_dpp row_newbcast + fma)", 16, nblk);
+        run<16>("16 x v_fmac_f64_dpp row_newbcast (asm)", 16, nblk);
+        run<17>("16 x v_fmac_f64_dpp, src != acc (asm)", 16, nblk);
     }
     return 0;
 }
