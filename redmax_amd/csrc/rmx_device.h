@@ -37,6 +37,8 @@ __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
     return a > b ? a : b;
 }
 constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matrix cores (false: half-wave split of the column loop)
+constexpr bool LU_DPP_TAIL = true;                      // guarded LU: last 16 pivots with the broadcast fused into the FMA (DPP)
+constexpr bool LU_SPLIT32 = HESS_MFMA && LU_DPP_TAIL;   // n <= 32: pivots 0..15 in the column-split layout of lu_solve_neg_diag32
 // Column stride of the per-node constants in LDS.  Trees padded to fewer than 64 lanes get one extra "idle" column (index NP):
 // identity joint transform, zero everything else.  Lanes beyond the padded size read it, idle node slots n..NP-1 hold the same
 // defaults in their own columns, so the evaluation loads constants without any per-lane selects.
@@ -1378,6 +1380,9 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sOp[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
         __syncthreads();
+        // guarded diagonal solve of n <= 32 (lu_solve_neg_diag32): it reads H out of the staging area in its own layout and
+        // hands sAcc back to the front itself
+        if constexpr (!ZERO_IDLE && LU_SPLIT32) return Hdiag;
         {
             typedef double v2d __attribute__((ext_vector_type(2)));
             const v2d* hr = reinterpret_cast<const v2d*>(sOp + (lane & 31) * HM_H_STRIDE);   // rows are 16-byte aligned
@@ -1731,7 +1736,6 @@ __device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restric
 // its cost is paid only when needed.
 constexpr double LU_GROWTH_MAX = 8.0;
 constexpr int LU_BATCH = 8;
-constexpr bool LU_DPP_TAIL = true;
 __device__ __forceinline__ void lu_pin(double (&pv)[LU_BATCH]) {
     asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]), "+s"(pv[4]), "+s"(pv[5]), "+s"(pv[6]), "+s"(pv[7]));
 }
@@ -1837,6 +1841,133 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     }
     // lanes beyond the padded size may carry mirrored rows (eval_hess ZERO_IDLE = false): their guard is ignored
     ok = !__any(lane < NP && !(gmax <= lim)) && (pmin > 0.0);
+    return dx;
+}
+
+// ---- n <= 32, H staged row-major in LDS by the MFMA Hessian: pivots 0..15 without a single v_readlane broadcast.
+// Every 16-lane DPP row r = lane >> 4 works on ALL 32 matrix rows, two per lane (set A: row j = lane & 15, set B: row 16 + j),
+// and holds columns 0..15 (replicated in the four DPP rows: they are the pivot columns of this phase, so every DPP row can
+// form the multipliers itself) plus its own four of the columns 16..31 (16 + 4 r ...).  The pivot row k < 16 is set A of lane k
+// of the SAME DPP row, so every update is one v_fmac_f64_dpp (fmac_rowbcast): 2 (15 - k) + 8 + 2 of them per pivot, 400 in
+// all, against 376 x (2 v_readlane + FMA) plus the right-hand side in the row-per-lane layout.  The four column quarters then
+// return through LDS to row-per-lane (lane = row), which is exactly the state lu_solve_neg_diag has after 16 pivots: the last
+// 16 pivots (lu_diag_tail) and the back substitution are shared.  Same operations on the same values in the same order
+// per matrix entry: the results are bit-identical to lu_solve_neg_diag.
+template <int K>
+__device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], double (&B)[16], double (&BX)[4], double& bA,
+                                            double& bB, double& gmaxA, double& gmaxB, double& pmin, double& piv, double& rinv,
+                                            double (&rinvs)[32], const int jv) {
+    if constexpr (K < 16) {
+        rinvs[K] = rinv;
+        const double lA = (jv > K) ? A[K] * rinv : 0.0;
+        const double lB = B[K] * rinv;
+        gmaxA = fmax(gmaxA, A[K] * lA);
+        gmaxB = fmax(gmaxB, B[K] * lB);
+        pmin = fmin(pmin, piv);
+        const double nA = -lA, nB = -lB;
+        if constexpr (K + 1 < 16) {
+            fmac_rowbcast<K, true>(A[K + 1], A[K + 1], nA);
+            piv = readlane_d(A[K + 1], K + 1);
+            rinv = recip(piv);
+        } else {                       // pivot 16 is row 16 (set B of lane 0), column 16 (first extra column of DPP row 0)
+            fmac_rowbcast<K, true>(BX[0], AX[0], nB);
+            piv = readlane_d(BX[0], 0);
+            rinv = recip(piv);
+        }
+#pragma unroll
+        for (int c = K + 2; c < 16; ++c) fmac_rowbcast<K, false>(A[c], A[c], nA);
+#pragma unroll
+        for (int c = K + 1; c < 16; ++c) fmac_rowbcast<K, false>(B[c], A[c], nB);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            fmac_rowbcast<K, false>(AX[c], AX[c], nA);
+            if (K + 1 < 16 || c > 0) fmac_rowbcast<K, false>(BX[c], AX[c], nB);
+        }
+        fmac_rowbcast<K, false>(bB, bA, nB);      // before bA: lane K's bA is the broadcast value (l = 0 there, it stays anyway)
+        fmac_rowbcast<K, false>(bA, bA, nA);
+        lu32_phase1<K + 1>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pmin, piv, rinv, rinvs, jv);
+    }
+}
+
+__device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lane, double* sAcc, const double g, bool& ok) {
+    constexpr int NP = 32;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    double* sH = sAcc;                                   // H, row-major [32][HM_H_STRIDE]; columns 32, 33 of a row are spare
+    const int r4 = lane >> 4, j = lane & 15;
+    if (lane < NP) sH[lane * HM_H_STRIDE + 32] = -g;
+    __syncthreads();
+    double A[16], AX[4], B[16], BX[4];
+    const double* rowA = sH + j * HM_H_STRIDE;
+    const double* rowB = sH + (16 + j) * HM_H_STRIDE;
+    {
+        const v2d* ra = reinterpret_cast<const v2d*>(rowA);
+        const v2d* rb = reinterpret_cast<const v2d*>(rowB);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v2d ta = ra[c], tb = rb[c];
+            A[2 * c] = ta[0];
+            A[2 * c + 1] = ta[1];
+            B[2 * c] = tb[0];
+            B[2 * c + 1] = tb[1];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const v2d ta = ra[8 + 2 * r4 + c], tb = rb[8 + 2 * r4 + c];
+            AX[2 * c] = ta[0];
+            AX[2 * c + 1] = ta[1];
+            BX[2 * c] = tb[0];
+            BX[2 * c + 1] = tb[1];
+        }
+    }
+    double bA = rowA[32], bB = rowB[32];
+    const double limA = (LU_GROWTH_MAX * LU_GROWTH_MAX) * rowA[j], limB = (LU_GROWTH_MAX * LU_GROWTH_MAX) * rowB[16 + j];
+    int jv = j, lv = lane;                               // opaque copies: see lu_solve_neg_diag
+    asm volatile("" : "+v"(jv), "+v"(lv));
+    double gmaxA = 0.0, gmaxB = 0.0, pmin = 1.0;
+    double rinvs[NP];
+    double piv = readlane_d(A[0], 0);
+    double rinv = recip(piv);
+    lu32_phase1<0>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pmin, piv, rinv, rinvs, jv);
+    // the column quarters 16 + 4 r .. of both row sets go back to their rows; lane = row reads columns 16..31
+    __syncthreads();
+    {
+        v2d* wa = reinterpret_cast<v2d*>(sH + j * HM_H_STRIDE + 16 + 4 * r4);
+        v2d* wb = reinterpret_cast<v2d*>(sH + (16 + j) * HM_H_STRIDE + 16 + 4 * r4);
+        wa[0] = v2d{AX[0], AX[1]};
+        wa[1] = v2d{AX[2], AX[3]};
+        wb[0] = v2d{BX[0], BX[1]};
+        wb[1] = v2d{BX[2], BX[3]};
+    }
+    __syncthreads();
+    double Hrow[NP];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Hrow[c] = A[c];         // rows 0..15 (lanes 0..15); never read on the other lanes
+    {
+        const v2d* hr = reinterpret_cast<const v2d*>(sH + (lane & 31) * HM_H_STRIDE + 16);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v2d t = hr[c];
+            Hrow[16 + 2 * c] = t[0];
+            Hrow[16 + 2 * c + 1] = t[1];
+        }
+    }
+    const bool rowsA = (lane & 16) == 0;                 // lanes 0..15 (and their idle mirrors 32..47) carry set A
+    double b = rowsA ? bA : bB;
+    double gmax = rowsA ? gmaxA : gmaxB;
+    const double lim = rowsA ? limA : limB;
+    double rinv_own = 0.0;
+    lu_diag_tail<NP, 16>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
+    double dx = 0.0;
+#pragma unroll
+    for (int k = NP - 1; k >= 0; --k) {
+        const double xk = readlane_d(b, k) * rinvs[k];
+        if (lv == k) dx = xk;
+        if (lv < k) b -= Hrow[k] * xk;
+    }
+    ok = !__any(lane < NP && !(gmax <= lim)) && (pmin > 0.0);
+    __syncthreads();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
+    if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
+    __syncthreads();
     return dx;
 }
 
@@ -1949,7 +2080,8 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
             dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
         } else {
             bool lu_ok;
-            dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
+            if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
+            else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
             if (lu_ok) {
                 piv.streak = 0;
             } else {             // growth guard tripped: redo this solve with partial pivoting
