@@ -109,19 +109,19 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// acc += m * (value of src in lane N of the caller's own 16-lane row): v_fmac_f64 with the DPP row_newbcast control, the one
+// acc -= m * (value of src in lane N of the caller's own 16-lane row): v_fmac_f64 with the DPP row_newbcast control, the one
 // DPP control gfx90a+ allows on 64-bit VALU operations.  The broadcast rides on the FMA: 7.3 cycles per element for a lone
 // wavefront against 15.4 for two v_readlane plus an FMA (tools/ubench.hip modes 14, 16, 17).  The compiler emits
-// v_mov_b64_dpp + v_fmac for the builtin form (13.1 cycles) and does not fold them, hence the assembly.  A DPP read of a
-// VGPR the previous instruction wrote needs two wait states the assembler does not add: NOPS puts an s_nop 1 in front.
-template <int N, bool NOPS>
-__device__ __forceinline__ void fmac_rowbcast(double& acc, const double src, const double m) {
+// v_mov_b64_dpp + v_fmac for the builtin form (13.1 cycles) and does not fold them, hence the assembly.
+// Hazard: a DPP read of a VGPR written by one of the two preceding VALU instructions returns the OLD value, and the
+// assembler adds no wait states.  Every use below reads lane N of a register that the interfering write leaves unchanged IN
+// LANE N (the pivot lane's multiplier is 0, so its rows are rewritten with the same values), so old and new agree.
+template <int N>
+__device__ __forceinline__ void fmsub_rowbcast(double& acc, const double src, const double m) {
     static_assert(N >= 0 && N < 16, "row_newbcast lane");
-    if constexpr (NOPS)
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
-    else
-        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
 }
+
 // v_permlane32_swap (gfx950): swaps lanes 32..63 of its first operand with lanes 0..31 of the second.
 // dup_lo: every lane l >= 32 receives the value of lane l-32 (lanes < 32 keep theirs); take_hi: every lane l < 32 receives
 // the value of lane l+32.
@@ -1360,6 +1360,20 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             hd[nb] = sOp[R_HD * HM_OP_STRIDE + 16 * nb + j];
         }
         double hv[2][2][4];
+        if (M.is_chain) {
+            // a chain in depth-first order: a is an ancestor of i iff a < i.  The off-diagonal tiles need no mask at all and
+            // the diagonal tiles one comparison of the row 4 r + g with the column j (same values: the masks are 0 / 1)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (nb > mb) hv[mb][nb][r] = up[mb][nb][r];
+                        else if (nb < mb) hv[mb][nb][r] = lw[mb][nb][r];
+                        else hv[mb][nb][r] = (4 * r + g < j) ? up[mb][nb][r] : ((4 * r + g == j) ? hd[nb] : lw[mb][nb][r]);
+                    }
+        } else {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -1372,6 +1386,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                     if (nb <= mb) v += (double)((dm[nb] >> sh) & 1u) * lw[mb][nb][r];
                     hv[mb][nb][r] = (mb == nb && 4 * r + g == j) ? hd[nb] : v;
                 }
+        }
         __syncthreads();             // every lane is done with the operands: the same LDS now takes H, row-major
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -1740,7 +1755,7 @@ __device__ __forceinline__ void lu_pin(double (&pv)[LU_BATCH]) {
     asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]), "+s"(pv[4]), "+s"(pv[5]), "+s"(pv[6]), "+s"(pv[7]));
 }
 // The last 16 pivots of lu_solve_neg_diag (K is a template constant: the DPP lane is an immediate).  Every row still being
-// eliminated sits in the pivot row's own 16-lane DPP row, so the pivot-row broadcast rides on the FMA (fmac_rowbcast).  Rows
+// eliminated sits in the pivot row's own 16-lane DPP row, so the pivot-row broadcast rides on the FMA (fmsub_rowbcast).  Rows
 // in the other DPP rows are finished (l == 0: they add 0 x a finite entry of one of their own finished rows) or idle mirrors.
 template <int NP, int K, int NR>
 __device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, double& gmax, double& pmin, double& piv, double& rinv,
@@ -1752,15 +1767,14 @@ __device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, doub
         const double l = (lv > K) ? Hrow[K] * rinv : 0.0;
         gmax = fmax(gmax, Hrow[K] * l);
         pmin = fmin(pmin, piv);
-        const double nl = -l;
         if constexpr (K + 1 < NP) {
-            fmac_rowbcast<N, true>(Hrow[K + 1], Hrow[K + 1], nl);
+            fmsub_rowbcast<N>(Hrow[K + 1], Hrow[K + 1], l);
             piv = readlane_d(Hrow[K + 1], K + 1);
             rinv = recip(piv);
         }
 #pragma unroll
-        for (int c = K + 2; c < NP; ++c) fmac_rowbcast<N, false>(Hrow[c], Hrow[c], nl);
-        fmac_rowbcast<N, false>(b, b, nl);
+        for (int c = K + 2; c < NP; ++c) fmsub_rowbcast<N>(Hrow[c], Hrow[c], l);
+        fmsub_rowbcast<N>(b, b, l);
         lu_diag_tail<NP, K + 1, NR>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
     }
 }
@@ -1848,7 +1862,7 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
 // Every 16-lane DPP row r = lane >> 4 works on ALL 32 matrix rows, two per lane (set A: row j = lane & 15, set B: row 16 + j),
 // and holds columns 0..15 (replicated in the four DPP rows: they are the pivot columns of this phase, so every DPP row can
 // form the multipliers itself) plus its own four of the columns 16..31 (16 + 4 r ...).  The pivot row k < 16 is set A of lane k
-// of the SAME DPP row, so every update is one v_fmac_f64_dpp (fmac_rowbcast): 2 (15 - k) + 8 + 2 of them per pivot, 400 in
+// of the SAME DPP row, so every update is one v_fmac_f64_dpp (fmsub_rowbcast): 2 (15 - k) + 8 + 2 of them per pivot, 400 in
 // all, against 376 x (2 v_readlane + FMA) plus the right-hand side in the row-per-lane layout.  The four column quarters then
 // return through LDS to row-per-lane (lane = row), which is exactly the state lu_solve_neg_diag has after 16 pivots: the last
 // 16 pivots (lu_diag_tail) and the back substitution are shared.  Same operations on the same values in the same order
@@ -1864,27 +1878,26 @@ __device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], do
         gmaxA = fmax(gmaxA, A[K] * lA);
         gmaxB = fmax(gmaxB, B[K] * lB);
         pmin = fmin(pmin, piv);
-        const double nA = -lA, nB = -lB;
         if constexpr (K + 1 < 16) {
-            fmac_rowbcast<K, true>(A[K + 1], A[K + 1], nA);
+            fmsub_rowbcast<K>(A[K + 1], A[K + 1], lA);
             piv = readlane_d(A[K + 1], K + 1);
             rinv = recip(piv);
         } else {                       // pivot 16 is row 16 (set B of lane 0), column 16 (first extra column of DPP row 0)
-            fmac_rowbcast<K, true>(BX[0], AX[0], nB);
+            fmsub_rowbcast<K>(BX[0], AX[0], lB);
             piv = readlane_d(BX[0], 0);
             rinv = recip(piv);
         }
 #pragma unroll
-        for (int c = K + 2; c < 16; ++c) fmac_rowbcast<K, false>(A[c], A[c], nA);
+        for (int c = K + 2; c < 16; ++c) fmsub_rowbcast<K>(A[c], A[c], lA);
 #pragma unroll
-        for (int c = K + 1; c < 16; ++c) fmac_rowbcast<K, false>(B[c], A[c], nB);
+        for (int c = K + 1; c < 16; ++c) fmsub_rowbcast<K>(B[c], A[c], lB);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            fmac_rowbcast<K, false>(AX[c], AX[c], nA);
-            if (K + 1 < 16 || c > 0) fmac_rowbcast<K, false>(BX[c], AX[c], nB);
+            fmsub_rowbcast<K>(AX[c], AX[c], lA);
+            if (K + 1 < 16 || c > 0) fmsub_rowbcast<K>(BX[c], AX[c], lB);
         }
-        fmac_rowbcast<K, false>(bB, bA, nB);      // before bA: lane K's bA is the broadcast value (l = 0 there, it stays anyway)
-        fmac_rowbcast<K, false>(bA, bA, nA);
+        fmsub_rowbcast<K>(bB, bA, lB);
+        fmsub_rowbcast<K>(bA, bA, lA);
         lu32_phase1<K + 1>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pmin, piv, rinv, rinvs, jv);
     }
 }
