@@ -31,7 +31,7 @@ import numpy as np
 F_G = 363712        # one residual evaluation
 F_H = 1418432       # one residual + Hessian evaluation
 F_LU = 23893        # one 32x32 LU solve
-HBM_TRAFFIC_BYTES = int((920.375 + 608.0) * 1024)   # measured with PMC counters, see roofline.traffic_note
+HBM_TRAFFIC_BYTES = int((875.9375 + 608.0) * 1024)   # measured with PMC counters, see roofline.traffic_note
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the
                           # microarch guide lists no fp64 row, so the datasheet value is used and stated)
 
@@ -162,7 +162,7 @@ def main():
             ach = flops / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP64_PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_BYTES if (B == 1024 and K == 100 and n == 32) else None,
-                    "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01g_pmc_*.csv): 920.4 KB + 608 KB per "
+                    "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01h_pmc_*.csv): 875.9 KB + 608 KB per "
                                     "launch of 100 steps x 1024 rollouts, reported uncorrected: the guide's x2 FETCH correction is calibrated for "
                                     "16 B/lane streams; calibrated on the known byte counts of THIS 8 B/lane pattern the counters read at "
                                     "face value (WRITE_SIZE 608 KB = 512 KiB state written + 12 KiB counters + write-backs; FETCH_SIZE = "
