@@ -1102,7 +1102,7 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 // Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
 template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
-                                          unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr) {
+                                          unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0) {
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr int CS = cstride(NP);
     const double eta = fs.eta, e2 = eta * eta;
@@ -1395,6 +1395,9 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sOp[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
+        // the right-hand side of the solve travels with its row (column 32 of the staging rows is spare)
+        if constexpr (!ZERO_IDLE && LU_SPLIT32)
+            if (lane < NP) sOp[lane * HM_H_STRIDE + 32] = -g_stage;
         __syncthreads();
         // guarded diagonal solve of n <= 32 (lu_solve_neg_diag32): it reads H out of the staging area in its own layout and
         // hands sAcc back to the front itself
@@ -1908,8 +1911,7 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
     typedef double v2d __attribute__((ext_vector_type(2)));
     double* sH = sAcc;                                   // H, row-major [32][HM_H_STRIDE]; columns 32, 33 of a row are spare
     const int r4 = lane >> 4, j = lane & 15;
-    if (lane < NP) sH[lane * HM_H_STRIDE + 32] = -g;
-    __syncthreads();
+    (void)g;                                             // eval_hess has staged -g in column 32 of the rows
     double A[16], AX[4], B[16], BX[4];
     const double* rowA = sH + j * HM_H_STRIDE;
     const double* rowB = sH + (16 + j) * HM_H_STRIDE;
@@ -2085,7 +2087,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     int iter = 1;
     double gcarry = -1.0;
     while (true) {
-        const double hdiag = eval_hess<NP, false, CT, PIVOT_ONLY>(M, lane, fs, Hrow, nullptr, sAcc);
+        const double hdiag = eval_hess<NP, false, CT, PIVOT_ONLY>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
         const NodeOut e0 = e;
         last = e;
         ++iters;
