@@ -116,10 +116,15 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // Hazard: a DPP read of a VGPR written by one of the two preceding VALU instructions returns the OLD value, and the
 // assembler adds no wait states.  Every use below reads lane N of a register that the interfering write leaves unchanged IN
 // LANE N (the pivot lane's multiplier is 0, so its rows are rewritten with the same values), so old and new agree.
-template <int N>
+// Where a broadcast does read a value that the previous step changed (the look-ahead column and the right-hand side in
+// lu_diag_tail), a whole step's instructions lie in between, except in the last two steps, which take NOPS (s_nop 1 first).
+template <int N, bool NOPS = false>
 __device__ __forceinline__ void fmsub_rowbcast(double& acc, const double src, const double m) {
     static_assert(N >= 0 && N < 16, "row_newbcast lane");
-    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
+    if constexpr (NOPS)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
 }
 
 // v_permlane32_swap (gfx950): swaps lanes 32..63 of its first operand with lanes 0..31 of the second.
@@ -1771,14 +1776,15 @@ __device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, doub
         const double l = (lv > K) ? Hrow[K] * rinv : 0.0;
         gmax = fmax(gmax, Hrow[K] * l);
         pmin = fmin(pmin, piv);
+        constexpr bool LAST = K + 2 >= NP;      // too few instructions left in a step to separate dependent broadcasts
         if constexpr (K + 1 < NP) {
-            fmsub_rowbcast<N>(Hrow[K + 1], Hrow[K + 1], l);
+            fmsub_rowbcast<N, LAST>(Hrow[K + 1], Hrow[K + 1], l);
             piv = readlane_d(Hrow[K + 1], K + 1);
             rinv = recip(piv);
         }
 #pragma unroll
         for (int c = K + 2; c < NP; ++c) fmsub_rowbcast<N>(Hrow[c], Hrow[c], l);
-        fmsub_rowbcast<N>(b, b, l);
+        fmsub_rowbcast<N, LAST>(b, b, l);
         lu_diag_tail<NP, K + 1, NR>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
     }
 }
