@@ -101,7 +101,10 @@ typedef struct rmx_opts {
     int lu_mode;           /* dx = -H\g (driverRedMaxBDF1.m:117, LU with partial pivoting in MATLAB):
                               0 (default) eliminate on the diagonal under a growth guard (|multiplier| <= 8, i.e. threshold
                                 pivoting with tau = 1/8) and redo the solve with full partial pivoting when the guard trips;
-                              1 always full partial pivoting (the literal reference behaviour, ~2x slower solve)  */
+                              1 always full partial pivoting (the reference behaviour, ~2x slower solve).  The pivot search compares
+                                the top 26 bits of |H(a,k)| (exponent + 14 mantissa bits), lowest row first among equals: exact
+                                ties resolve as LAPACK's first maximum, candidates within 2^-14 relative of each other may be
+                                taken in another order, so results agree with dgetrf to roundoff, not bit for bit  */
 } rmx_opts;
 
 typedef struct rmx_model rmx_model;

@@ -1,0 +1,85 @@
+classdef HipSim < handle
+	%HipSim  B independent rollouts of one redmax.Scene on one MI355X (libredmax_hip.so through redmax_hip_mex).
+	%
+	%   sim = redmax.HipSim(scene, batch, device)   scene: an initialised redmax.Scene (or a desc struct)
+	%   sim.setState(q, qdot)                       nr x batch, the DOF order of Joint.getQ
+	%   [T,V,stats,Q,Qdot] = sim.step(itype, h, nsteps, opts)   itype 1: BDF1, 2: SDIRK2 + BDF2
+	%   [q, qdot] = sim.getState()
+	%   delete(sim)
+	%
+	% Replaces the interpreter-side simLoop / newton / evalBDF1 / computeValues of matlab-diff/driverRedMaxBDF1.m:57-243
+	% (and driverRedMaxBDF2.m) for a whole batch of trajectories; the Scene/Joint/Body classes are the reference's.
+
+	properties (SetAccess = private)
+		h      % uint64 handle of the gateway
+		nr     % reduced DOFs
+		nm     % maximal DOFs
+		nsph   % spherical joints (Euler charts live on the device, see getCharts)
+		batch  % trajectories
+		idxR   % 0-based reduced index of every listed joint's first DOF (-1: fixed)
+	end
+
+	methods
+		function this = HipSim(scene, batch, device)
+			if nargin < 2, batch = 1; end
+			if nargin < 3, device = 0; end
+			if isstruct(scene)
+				desc = scene;
+			else
+				desc = redmax.flattenScene(scene);
+			end
+			this.h = redmax_hip_mex('create', desc, batch, device);
+			info = redmax_hip_mex('info', this.h);
+			this.nr = info.nr; this.nm = info.nm; this.nsph = info.nsph; this.batch = info.batch; this.idxR = info.idxR;
+		end
+
+		function delete(this)
+			if ~isempty(this.h)
+				redmax_hip_mex('destroy', this.h);
+				this.h = [];
+			end
+		end
+
+		function setState(this, q, qdot)
+			% Joint.setQ for the batch; a single column is replicated over the batch
+			if size(q,2) == 1 && this.batch > 1
+				q = repmat(q, 1, this.batch); qdot = repmat(qdot, 1, this.batch);
+			end
+			redmax_hip_mex('set', this.h, q, qdot);
+		end
+
+		function [q, qdot] = getState(this)
+			[q, qdot] = redmax_hip_mex('get', this.h);
+		end
+
+		function varargout = step(this, itype, hstep, nsteps, opts)
+			if nargin < 5, opts = struct(); end
+			[varargout{1:max(nargout,1)}] = redmax_hip_mex('step', this.h, itype, hstep, nsteps, opts);
+		end
+
+		function [T, V] = euler(this, hstep, nsteps)
+			[T, V] = redmax_hip_mex('euler', this.h, hstep, nsteps);
+		end
+
+		function varargout = evalResidual(this, q, qA, qB, eta)
+			% g (and H when two outputs are requested): evalBDF1 is evalResidual(q1, q0, q0 + h*qdot0, h)
+			[varargout{1:max(nargout,1)}] = redmax_hip_mex('eval', this.h, q, qA, qB, eta);
+		end
+
+		function [T, V] = energy(this)
+			[T, V] = redmax_hip_mex('energy', this.h);
+		end
+
+		function c = getCharts(this)
+			c = redmax_hip_mex('getcharts', this.h);
+		end
+
+		function setCharts(this, c)
+			redmax_hip_mex('setcharts', this.h, int32(c));
+		end
+
+		function [P, dPdp, stats] = adjoint(this, hstep, nsteps, task, p)
+			[P, dPdp, stats] = redmax_hip_mex('adjoint', this.h, hstep, nsteps, task, p);
+		end
+	end
+end

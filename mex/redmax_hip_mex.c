@@ -1,0 +1,385 @@
+/*
+ * redmax_hip_mex.c -- MATLAB MEX gateway onto the C ABI of include/redmax_hip.h.
+ *
+ * The reference (sueda/redmax, matlab-diff) runs simLoop / newton / evalBDF1 / computeValues inside the MATLAB
+ * interpreter (driverRedMaxBDF1.m:57-243).  This gateway is the thin layer BASELINE.json's north_star names: MATLAB keeps the
+ * +redmax Scene/Joint/Body classes and the driverRedMaxBDF1(sceneID,batch) entry point, and the body of simLoop becomes
+ * calls into libredmax_hip.so.  The MATLAB callers are matlab/+redmax/HipSim.m (handle wrapper), matlab/+redmax/flattenScene.m
+ * (Scene -> rmx_model_desc arrays) and matlab/driverRedMaxBDF1.m / driverRedMaxBDF2.m.
+ *
+ *   mex -I../include redmax_hip_mex.c -L../redmax_amd -lredmax_hip          (inside MATLAB, R2018a+ for the C matrix API used)
+ *
+ * MATLAB is not available in the build environment: the file is compiled and EXECUTED against mex/stub/ (a minimal
+ * implementation of the mx and mex functions used here) by tests/test_mex_gateway.py.
+ *
+ * Commands (first argument is the command string).  Array shapes are MATLAB's; the ABI's row-major [batch][nr] is the
+ * column-major nr x batch MATLAB matrix, [nsteps][batch] is batch x nsteps, [nsteps][batch][nr] is nr x batch x nsteps, 4x4
+ * transforms are column-major on both sides, so no transposition happens anywhere.
+ *
+ *   v            = redmax_hip_mex('version')
+ *   n            = redmax_hip_mex('devices')
+ *   h            = redmax_hip_mex('create', desc, batch [, device])     desc: struct, see read_desc() below
+ *                  redmax_hip_mex('destroy', h)
+ *   info         = redmax_hip_mex('info', h)                            struct nr, nm, nsph, batch, idxR (0-based, -1 fixed)
+ *                  redmax_hip_mex('set', h, q, qdot)                     nr x B each          Joint.setQ   (Joint.m:231-292)
+ *   [q, qdot]    = redmax_hip_mex('get', h)                                                   Joint.getQ   (Joint.m:173-229)
+ *   [T,V,st,Q,Qd]= redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])
+ *                  itype 1: simLoop of driverRedMaxBDF1.m:57-91, 2: of driverRedMaxBDF2.m:57-125.  T, V: B x nsteps
+ *                  (Scene.saveHistory energies); st: B x 3 int32 [newton iterations, line-search halvings, RMX_ST_* bits];
+ *                  Q, Qd (only when requested): nr x B x nsteps, the full Scene.saveHistory record (Scene.m:134-161).
+ *                  opts: struct with any of tol, dxMax, iterMaxPerDof, iterLsMax, lu_mode (driverRedMaxBDF1.m:95-98).
+ *   [T, V]       = redmax_hip_mex('euler', h, hstep, nsteps)             matlab-simple/testRedMax.m:67-109
+ *   [g, H]       = redmax_hip_mex('eval', h, q, qA, qB, eta)             evalBDF1 & co (driverRedMaxBDF1.m:160-187); H: nr x nr x B
+ *   [T, V]       = redmax_hip_mex('energy', h)                           Joint/Body.computeEnergies
+ *   c            = redmax_hip_mex('getcharts', h)                        nsph x B int32, JointSpherical.chart
+ *                  redmax_hip_mex('setcharts', h, c)
+ *   [P,dPdp,st]  = redmax_hip_mex('adjoint', h, hstep, nsteps, task, p)  taskObjective, driverRedMaxAdjointBDF1.m:39-62;
+ *                  task: struct body (1-based listing index), xlocal, xtarget, step, pscale, wreg, wpos; p: nr x B;
+ *                  st: B x 2 int32 [newton iterations, status]
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mex.h"
+#include "redmax_hip.h"
+
+typedef struct {
+    uint64_t magic;
+    rmx_model* m;
+    rmx_batch* b;
+    int nr, nm, nsph, B, njoints;
+} handle_t;
+
+#define HANDLE_MAGIC 0x726d78686970ull /* "rmxhip" */
+/* live handles: a handle value that MATLAB passes back is only dereferenced when it is in this table, so a stale or
+ * made-up uint64 is an error message, not a crash */
+#define MAX_LIVE 256
+static handle_t* g_live[MAX_LIVE];
+static int live_slot(const handle_t* h) {
+    for (int i = 0; i < MAX_LIVE; ++i)
+        if (g_live[i] == h) return i;
+    return -1;
+}
+
+static void die_rmx(const char* what) { mexErrMsgIdAndTxt("redmax:hip", "%s: %s", what, rmx_last_error()); }
+static void die(const char* msg) { mexErrMsgIdAndTxt("redmax:hip", "%s", msg); }
+
+static const mxArray* field(const mxArray* s, const char* k, int required) {
+    const mxArray* f = mxIsStruct(s) ? mxGetField(s, 0, k) : NULL;
+    if ((!f || mxIsEmpty(f)) && required) mexErrMsgIdAndTxt("redmax:hip", "desc.%s is required", k);
+    return (f && !mxIsEmpty(f)) ? f : NULL;
+}
+/* double array field with exactly `count` elements (NULL when optional and absent) */
+static const double* f64(const mxArray* s, const char* k, size_t count, int required) {
+    const mxArray* f = field(s, k, required);
+    if (!f) return NULL;
+    if (!mxIsDouble(f) || mxIsComplex(f)) mexErrMsgIdAndTxt("redmax:hip", "desc.%s must be a real double array", k);
+    if (mxGetNumberOfElements(f) != count) mexErrMsgIdAndTxt("redmax:hip", "desc.%s must have %d elements", k, (int)count);
+    return mxGetPr(f);
+}
+static const int* i32(const mxArray* s, const char* k, size_t count, int required) {
+    const mxArray* f = field(s, k, required);
+    if (!f) return NULL;
+    if (!mxIsInt32(f)) mexErrMsgIdAndTxt("redmax:hip", "desc.%s must be an int32 array", k);
+    if (mxGetNumberOfElements(f) != count) mexErrMsgIdAndTxt("redmax:hip", "desc.%s must have %d elements", k, (int)count);
+    return (const int*)mxGetData(f);
+}
+static double scalar_field(const mxArray* s, const char* k, double dflt) {
+    const mxArray* f = field(s, k, 0);
+    return f ? mxGetScalar(f) : dflt;
+}
+
+static handle_t* get_handle(int nrhs, const mxArray* prhs[]) {
+    if (nrhs < 2 || !mxIsUint64(prhs[1]) || mxGetNumberOfElements(prhs[1]) != 1) die("second argument must be the uint64 handle");
+    handle_t* h = (handle_t*)(uintptr_t)(*(const uint64_t*)mxGetData(prhs[1]));
+    if (!h || live_slot(h) < 0 || h->magic != HANDLE_MAGIC) die("stale or invalid handle");
+    return h;
+}
+static const double* state_arg(const mxArray* a, const handle_t* h, const char* name) {
+    if (!mxIsDouble(a) || mxIsComplex(a) || mxGetNumberOfElements(a) != (size_t)h->nr * (size_t)h->B)
+        mexErrMsgIdAndTxt("redmax:hip", "%s must be a real double nr x batch (%d x %d) array", name, h->nr, h->B);
+    return mxGetPr(a);
+}
+static mxArray* new_i32(size_t r, size_t c) { return mxCreateNumericMatrix(r, c, mxINT32_CLASS, mxREAL); }
+
+/* Scene.init() (Scene.m:59-119) -> rmx_model_create.  desc fields, joints in the scene's listing order (N = njoints):
+ *   njoints; parent int32 1xN (0-based, -1 root); type int32 1xN (RMX_JOINT_*); axis 3xN; E0_pj, E0_ji 4x4xN; I_i 6xN;
+ *   qRest, tau, stiffness, damping, qLimL, qLimU, qLimK, qLimD 1xN (optional: the Joint.m:77-83 defaults apply); grav 3x1;
+ *   plane 6xN ([b1;b2] of JointPlanar, optional); qRestR nr x 1 (rest position of every DOF, optional);
+ *   ground contact (optional, ForceGroundCuboid): contact int32 1xN, sides 3xN, groundE 4x4, kn, kt, mu, kd */
+static void cmd_create(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    (void)nlhs;
+    if (nrhs < 3) die("usage: h = redmax_hip_mex('create', desc, batch [, device])");
+    const mxArray* s = prhs[1];
+    if (!mxIsStruct(s)) die("desc must be a struct (redmax.flattenScene)");
+    const int batch = (int)mxGetScalar(prhs[2]);
+    const int device = nrhs > 3 ? (int)mxGetScalar(prhs[3]) : 0;
+    rmx_model_desc d;
+    memset(&d, 0, sizeof d);
+    d.njoints = (int)scalar_field(s, "njoints", 0);
+    if (d.njoints < 1) die("desc.njoints must be >= 1");
+    const size_t n = (size_t)d.njoints;
+    d.parent = i32(s, "parent", n, 1);
+    d.type = i32(s, "type", n, 1);
+    d.axis = f64(s, "axis", 3 * n, 1);
+    d.E0_pj = f64(s, "E0_pj", 16 * n, 1);
+    d.E0_ji = f64(s, "E0_ji", 16 * n, 1);
+    d.I_i = f64(s, "I_i", 6 * n, 1);
+    d.qRest = f64(s, "qRest", n, 0);
+    d.tau = f64(s, "tau", n, 0);
+    d.stiffness = f64(s, "stiffness", n, 0);
+    d.damping = f64(s, "damping", n, 0);
+    d.qLimL = f64(s, "qLimL", n, 0);
+    d.qLimU = f64(s, "qLimU", n, 0);
+    d.qLimK = f64(s, "qLimK", n, 0);
+    d.qLimD = f64(s, "qLimD", n, 0);
+    d.plane = f64(s, "plane", 6 * n, 0);
+    memcpy(d.grav, f64(s, "grav", 3, 1), 3 * sizeof(double));
+    {   /* qRestR has nr entries; nr is only known after lowering, so its length is checked against the DOF counts here */
+        const mxArray* f = field(s, "qRestR", 0);
+        if (f) {
+            static const int ndof_of[] = {0, 1, 1, 2, 3, 2, 3, 3, 6};
+            size_t nr = 0;
+            for (size_t i = 0; i < n; ++i) {
+                if (d.type[i] < 0 || d.type[i] > RMX_JOINT_FREE3D) die("desc.type holds an unknown joint type");
+                nr += (size_t)ndof_of[d.type[i]];
+            }
+            d.qRestR = f64(s, "qRestR", nr, 1);
+        }
+    }
+    const int slot = live_slot(NULL);
+    if (slot < 0) die("too many live handles (destroy some first)");
+    handle_t* h = (handle_t*)mxCalloc(1, sizeof *h);
+    mexMakeMemoryPersistent(h);
+    if (rmx_model_create(&d, device, &h->m)) { mxFree(h); die_rmx("rmx_model_create"); }
+    if (field(s, "contact", 0)) {   /* scene.forces holds ForceGroundCuboid objects (scenesRedMax.m:303-309) */
+        rmx_ground_contact gc;
+        memset(&gc, 0, sizeof gc);
+        gc.flags = i32(s, "contact", n, 1);
+        gc.sides = f64(s, "sides", 3 * n, 1);
+        memcpy(gc.E, f64(s, "groundE", 16, 1), 16 * sizeof(double));
+        gc.kn = scalar_field(s, "kn", 1.0);   /* ForceGroundCuboid.m:22-26 defaults */
+        gc.kt = scalar_field(s, "kt", 0.0);
+        gc.mu = scalar_field(s, "mu", 0.0);
+        gc.kd = scalar_field(s, "kd", 0.0);
+        if (rmx_model_set_ground_contact(h->m, &gc)) { rmx_model_destroy(h->m); mxFree(h); die_rmx("rmx_model_set_ground_contact"); }
+    }
+    h->nr = rmx_model_nr(h->m);
+    h->nm = rmx_model_nm(h->m);
+    h->nsph = rmx_model_nsph(h->m);
+    h->B = batch;
+    h->njoints = d.njoints;
+    if (rmx_batch_create(h->m, batch, &h->b)) { rmx_model_destroy(h->m); mxFree(h); die_rmx("rmx_batch_create"); }
+    h->magic = HANDLE_MAGIC;
+    g_live[slot] = h;
+    plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+    *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+}
+
+static void cmd_destroy(int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    g_live[live_slot(h)] = NULL;
+    rmx_batch_destroy(h->b);
+    rmx_model_destroy(h->m);
+    h->magic = 0;
+    mxFree(h);
+}
+
+static void cmd_info(mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    static const char* names[] = {"nr", "nm", "nsph", "batch", "idxR"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 5, names);
+    mxSetField(plhs[0], 0, "nr", mxCreateDoubleScalar(h->nr));
+    mxSetField(plhs[0], 0, "nm", mxCreateDoubleScalar(h->nm));
+    mxSetField(plhs[0], 0, "nsph", mxCreateDoubleScalar(h->nsph));
+    mxSetField(plhs[0], 0, "batch", mxCreateDoubleScalar(h->B));
+    mxArray* idx = new_i32(1, (size_t)h->njoints);
+    if (rmx_model_idxR(h->m, (int*)mxGetData(idx))) die_rmx("rmx_model_idxR");
+    mxSetField(plhs[0], 0, "idxR", idx);
+}
+
+static void read_opts(const mxArray* s, rmx_opts* o) {
+    if (!s || mxIsEmpty(s)) return;
+    if (!mxIsStruct(s)) die("opts must be a struct");
+    o->tol = scalar_field(s, "tol", o->tol);
+    o->dxMax = scalar_field(s, "dxMax", o->dxMax);
+    o->iterMaxPerDof = (int)scalar_field(s, "iterMaxPerDof", o->iterMaxPerDof);
+    o->iterLsMax = (int)scalar_field(s, "iterLsMax", o->iterLsMax);
+    o->lu_mode = (int)scalar_field(s, "lu_mode", o->lu_mode);
+}
+
+static void cmd_step(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    if (nrhs < 5) die("usage: [T,V,stats,Q,Qdot] = redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])");
+    const int itype = (int)mxGetScalar(prhs[2]);
+    const int nsteps = (int)mxGetScalar(prhs[4]);
+    if (itype != 1 && itype != 2) die("itype must be 1 (BDF1) or 2 (BDF2)");
+    if (nsteps < 0) die("nsteps < 0");
+    rmx_opts o;
+    rmx_opts_default(&o);
+    o.h = mxGetScalar(prhs[3]);
+    if (nrhs > 5) read_opts(prhs[5], &o);
+    const size_t B = (size_t)h->B, K = (size_t)nsteps;
+    mxArray* T = mxCreateDoubleMatrix(B, K, mxREAL);
+    mxArray* V = mxCreateDoubleMatrix(B, K, mxREAL);
+    mxArray* st = new_i32(B, 3);
+    int* sp = (int*)mxGetData(st);
+    rmx_stats stats;
+    stats.newton_iters = sp;
+    stats.ls_halvings = sp + B;
+    stats.status = sp + 2 * B;
+    mxArray *Q = NULL, *Qd = NULL;
+    rmx_history hist;
+    hist.T = K ? mxGetPr(T) : NULL;
+    hist.V = K ? mxGetPr(V) : NULL;
+    hist.q = hist.qdot = NULL;
+    if (nlhs > 3) {   /* the full Scene.saveHistory record */
+        const mwSize dims[3] = {(mwSize)h->nr, (mwSize)B, (mwSize)K};
+        Q = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+        Qd = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+        if (K && h->nr) { hist.q = mxGetPr(Q); hist.qdot = mxGetPr(Qd); }
+    }
+    if (rmx_step_history(h->b, &o, nsteps, itype, &stats, &hist)) die_rmx("rmx_step_history");
+    plhs[0] = T;
+    if (nlhs > 1) plhs[1] = V;
+    if (nlhs > 2) plhs[2] = st;
+    if (nlhs > 3) plhs[3] = Q;
+    if (nlhs > 4) plhs[4] = Qd;
+}
+
+static void cmd_euler(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    if (nrhs < 4) die("usage: [T,V] = redmax_hip_mex('euler', h, hstep, nsteps)");
+    const int nsteps = (int)mxGetScalar(prhs[3]);
+    if (nsteps < 0) die("nsteps < 0");
+    mxArray* T = mxCreateDoubleMatrix((size_t)h->B, (size_t)nsteps, mxREAL);
+    mxArray* V = mxCreateDoubleMatrix((size_t)h->B, (size_t)nsteps, mxREAL);
+    if (rmx_step_euler(h->b, mxGetScalar(prhs[2]), nsteps, nsteps ? mxGetPr(T) : NULL, nsteps ? mxGetPr(V) : NULL)) die_rmx("rmx_step_euler");
+    plhs[0] = T;
+    if (nlhs > 1) plhs[1] = V;
+}
+
+static void cmd_eval(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    if (nrhs < 6) die("usage: [g,H] = redmax_hip_mex('eval', h, q, qA, qB, eta)");
+    const double* q = state_arg(prhs[2], h, "q");
+    const double* qA = state_arg(prhs[3], h, "qA");
+    const double* qB = state_arg(prhs[4], h, "qB");
+    mxArray* g = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
+    mxArray* H = NULL;
+    if (nlhs > 1) {   /* nargout == 1 selects the residual-only path, as in evalBDF1 (driverRedMaxBDF1.m:165) */
+        const mwSize dims[3] = {(mwSize)h->nr, (mwSize)h->nr, (mwSize)h->B};
+        H = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+    }
+    if (rmx_eval(h->b, q, qA, qB, mxGetScalar(prhs[5]), mxGetPr(g), H ? mxGetPr(H) : NULL)) die_rmx("rmx_eval");
+    plhs[0] = g;
+    if (nlhs > 1) plhs[1] = H;
+}
+
+static void cmd_adjoint(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    if (nrhs < 6) die("usage: [P,dPdp,stats] = redmax_hip_mex('adjoint', h, hstep, nsteps, task, p)");
+    const mxArray* t = prhs[4];
+    if (!mxIsStruct(t)) die("task must be a struct");
+    rmx_task_pointpos task;
+    memset(&task, 0, sizeof task);
+    task.body = (int)scalar_field(t, "body", 1) - 1;   /* MATLAB listing index -> 0-based */
+    const mxArray* xl = field(t, "xlocal", 1);
+    const mxArray* xt = field(t, "xtarget", 1);
+    if (mxGetNumberOfElements(xl) != 3 || mxGetNumberOfElements(xt) != 3) die("task.xlocal / task.xtarget must have 3 elements");
+    memcpy(task.xlocal, mxGetPr(xl), 3 * sizeof(double));
+    memcpy(task.xtarget, mxGetPr(xt), 3 * sizeof(double));
+    task.step = (int)scalar_field(t, "step", 0);
+    task.pscale = scalar_field(t, "pscale", 1.0);
+    task.wreg = scalar_field(t, "wreg", 0.0);
+    task.wpos = scalar_field(t, "wpos", 1.0);
+    rmx_opts o;
+    rmx_opts_default(&o);
+    o.h = mxGetScalar(prhs[2]);
+    o.iterMaxPerDof = 5;                               /* driverRedMaxAdjointBDF1.m:108 */
+    const int nsteps = (int)mxGetScalar(prhs[3]);
+    const double* p = state_arg(prhs[5], h, "p");
+    mxArray* P = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);
+    mxArray* dPdp = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
+    mxArray* st = new_i32((size_t)h->B, 2);
+    int* sp = (int*)mxGetData(st);
+    rmx_stats stats;
+    stats.newton_iters = sp;
+    stats.ls_halvings = NULL;
+    stats.status = sp + h->B;
+    if (rmx_adjoint_bdf1(h->b, &o, nsteps, &task, p, mxGetPr(P), mxGetPr(dPdp), &stats)) die_rmx("rmx_adjoint_bdf1");
+    plhs[0] = P;
+    if (nlhs > 1) plhs[1] = dPdp;
+    if (nlhs > 2) plhs[2] = st;
+}
+
+/* `clear mex` / MATLAB exit: free what is still alive on the device */
+static void at_exit(void) {
+    for (int i = 0; i < MAX_LIVE; ++i)
+        if (g_live[i]) {
+            rmx_batch_destroy(g_live[i]->b);
+            rmx_model_destroy(g_live[i]->m);
+            mxFree(g_live[i]);
+            g_live[i] = NULL;
+        }
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    static int registered = 0;
+    if (!registered) {
+        mexAtExit(at_exit);
+        registered = 1;
+    }
+    char cmd[24];
+    if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) die("first argument must be a command string");
+    if (!strcmp(cmd, "version")) {
+        plhs[0] = mxCreateDoubleScalar((double)rmx_version());
+    } else if (!strcmp(cmd, "devices")) {
+        plhs[0] = mxCreateDoubleScalar((double)rmx_device_count());
+    } else if (!strcmp(cmd, "create")) {
+        cmd_create(nlhs, plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "destroy")) {
+        cmd_destroy(nrhs, prhs);
+    } else if (!strcmp(cmd, "info")) {
+        cmd_info(plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "set")) {
+        handle_t* h = get_handle(nrhs, prhs);
+        if (nrhs < 4) die("usage: redmax_hip_mex('set', h, q, qdot)");
+        if (rmx_set_state(h->b, state_arg(prhs[2], h, "q"), state_arg(prhs[3], h, "qdot"))) die_rmx("rmx_set_state");
+    } else if (!strcmp(cmd, "get")) {
+        handle_t* h = get_handle(nrhs, prhs);
+        mxArray* q = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
+        mxArray* qd = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
+        if (rmx_get_state(h->b, mxGetPr(q), mxGetPr(qd))) die_rmx("rmx_get_state");
+        plhs[0] = q;
+        if (nlhs > 1) plhs[1] = qd;
+    } else if (!strcmp(cmd, "step")) {
+        cmd_step(nlhs, plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "euler")) {
+        cmd_euler(nlhs, plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "eval")) {
+        cmd_eval(nlhs, plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "energy")) {
+        handle_t* h = get_handle(nrhs, prhs);
+        mxArray* T = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);
+        mxArray* V = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);
+        if (rmx_energy(h->b, mxGetPr(T), mxGetPr(V))) die_rmx("rmx_energy");
+        plhs[0] = T;
+        if (nlhs > 1) plhs[1] = V;
+    } else if (!strcmp(cmd, "getcharts")) {
+        handle_t* h = get_handle(nrhs, prhs);
+        mxArray* c = new_i32((size_t)h->nsph, (size_t)h->B);
+        if (h->nsph && rmx_get_charts(h->b, (int*)mxGetData(c))) die_rmx("rmx_get_charts");
+        plhs[0] = c;
+    } else if (!strcmp(cmd, "setcharts")) {
+        handle_t* h = get_handle(nrhs, prhs);
+        if (nrhs < 3 || !mxIsInt32(prhs[2]) || mxGetNumberOfElements(prhs[2]) != (size_t)h->nsph * (size_t)h->B)
+            die("charts must be an int32 nsph x batch array");
+        if (h->nsph && rmx_set_charts(h->b, (const int*)mxGetData(prhs[2]))) die_rmx("rmx_set_charts");
+    } else if (!strcmp(cmd, "adjoint")) {
+        cmd_adjoint(nlhs, plhs, nrhs, prhs);
+    } else {
+        mexErrMsgIdAndTxt("redmax:hip", "unknown command '%s'", cmd);
+    }
+}

@@ -476,11 +476,19 @@ extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_conta
         any = any || gc->flags[L];
         for (int c = 0; c < 3; ++c) con[(1 + c) * MAXN + k] = gc->sides[3 * L + c];
     }
-    if (m->dcon) { (void)hipFree(m->dcon); m->dcon = nullptr; m->dm.con = nullptr; }
+    // the new table is uploaded first and swapped in only on success; kernels of existing batches that may still read the
+    // old one (rmx_step_bdf1_async) are drained before it is freed
+    void* fresh = nullptr;
+    if (any) {
+        HIPCHK(hipMalloc(&fresh, con.size() * sizeof(double)));
+        const hipError_t e = hipMemcpy(fresh, con.data(), con.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(fresh); return fail(RMX_E_HIP, std::string("hipMemcpy(contact): ") + hipGetErrorString(e)); }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    if (m->dcon) (void)hipFree(m->dcon);
+    m->dcon = fresh;
+    m->dm.con = (const double*)fresh;
     if (!any) return RMX_OK;
-    HIPCHK(hipMalloc(&m->dcon, con.size() * sizeof(double)));
-    HIPCHK(hipMemcpy(m->dcon, con.data(), con.size() * sizeof(double), hipMemcpyHostToDevice));
-    m->dm.con = (const double*)m->dcon;
     const M4 E = from_cm(gc->E);
     for (int c = 0; c < 3; ++c) {
         m->dm.gn[c] = E.a[c][2];      // ng = E(1:3,3)   ForceGroundCuboid.m:70
@@ -659,7 +667,10 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.chart = b->chart;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
-    if (integ == INTEG_BDF2) HIPCHK(hipMemsetAsync(b->started, 1, sizeof(int), b->stream));   // any non-zero value
+    // BDF2 keeps (q, qdot) of step k-1 in qp/qdp.  BDF1 steps do not maintain them (and, with JointSpherical, may leave q in
+    // another Euler chart than qp), so a BDF1 call invalidates the multistep history: the next rmx_step_bdf2 restarts with
+    // SDIRK2, as a fresh driverRedMaxBDF2 run from that state would (driverRedMaxBDF2.m:64-88).
+    HIPCHK(hipMemsetAsync(b->started, integ == INTEG_BDF2 ? 1 : 0, sizeof(int), b->stream));   // BDF2: any non-zero value
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     return RMX_OK;

@@ -2008,11 +2008,15 @@ __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, doub
     for (int k = 0; k < NP; ++k) {
         // every lane inverts its own candidate while the search runs (off the critical path)
         const double rinv_mine = recip(Hrow[k]);
-        // pivot search: max |H(a,k)| over unused rows; 26-bit key (exponent + 14 mantissa bits) + lane id
+        // pivot search: max |H(a,k)| over unused rows.  The key is the top 26 bits of |H(a,k)| (exponent + 14 mantissa bits)
+        // with 63 - lane below it: candidates that agree to ~2^-14 relative count as equal and the LOWEST row wins, which is
+        // LAPACK's first-maximum rule for exact ties (dgetf2/idamax behind MATLAB's mldivide, driverRedMaxBDF1.m:117); rows
+        // whose magnitudes differ by less than 2^-14 may be taken in another order than LAPACK would (same growth bound up to
+        // that factor; stated in redmax_hip.h and DESIGN.md)
         unsigned key = 0u;
-        if (pivstep < 0) key = ((unsigned)(__double2hiint(Hrow[k]) & 0x7fffffff) & ~63u) + 64u + (unsigned)lane;
+        if (pivstep < 0) key = ((unsigned)(__double2hiint(Hrow[k]) & 0x7fffffff) & ~63u) + 64u + (63u - (unsigned)lane);
         key = (NP <= 32) ? wave_umax32(key) : wave_umax(key);
-        const int pl = (int)(key & 63u);
+        const int pl = 63 - (int)(key & 63u);
         const double rinv = readlane_d(rinv_mine, pl);
         const bool elim = pivstep < 0 && lane != pl;
         if (lane == pl) {

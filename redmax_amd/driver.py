@@ -23,6 +23,15 @@ def simLoop(scene, itype=1, device=0):
     out = step(scene.nsteps, h=scene.h, stats=True, history="full")
     q, qd = sim.get_state()
     scene.setQ(q[0], qd[0])
+    # JointSpherical / JointFree3D keep chart and q together (JointSpherical.m:28-34, 63-102): the final q is expressed in
+    # the charts the device ended in, so they go back onto the joints with it.  The per-step history q is in the chart
+    # that was current at that step (the reference's history has the same property); status bit RMX_ST_CHART says whether
+    # any switch happened at all.
+    if sim.nsph:
+        charts = sim.charts()[0]
+        sph = [j for j in scene.joints if hasattr(j, "chart")]
+        for j, c in zip(sph, charts):
+            j.chart = int(c)
     scene.history = []
     for k in range(scene.nsteps):              # Scene.saveHistory (Scene.m:134-161): the record of every step
         scene.t = (k + 1) * scene.h

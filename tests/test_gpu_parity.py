@@ -348,3 +348,30 @@ def test_per_step_trajectory_matches_oracle(oracle_lib, name, integ):
             assert abs(out["T"][k, b] - T[0]) <= 1e-7 * max(abs(T[0]), 1.0)
             assert abs(out["V"][k, b] - V[0]) <= 1e-7 * max(abs(V[0]), 1.0)
     sim.close()
+
+
+def test_bdf1_steps_restart_the_bdf2_history(oracle_lib):
+    """BDF2 keeps (q, qdot) of step k-1; BDF1 steps do not maintain it, so a BDF1 call must invalidate it: the next BDF2 call
+    restarts with SDIRK2, exactly as a fresh driverRedMaxBDF2 run from that state (driverRedMaxBDF2.m:64-88).  bdf2 x5 ->
+    bdf1 x3 -> bdf2 x5 on the device vs the oracle doing the same with a restarted multistep history (step0 = 0)."""
+    from redmax_amd import BatchSim
+    sc = _scene("3")
+    sc.init()
+    B = 2
+    q0, qd0 = syntheticStates(sc.nr, B, first=3)
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q0, qd0)
+    sim.step_bdf2(5, h=sc.h)
+    sim.step_bdf1(3, h=sc.h)
+    sim.step_bdf2(5, h=sc.h)
+    qg, qdg = sim.get_state()
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q0[b], qd0[b])
+        o.step_bdf2(sc.h, 5, step0=0)
+        o.step_bdf1(sc.h, 3)
+        o.step_bdf2(sc.h, 5, step0=0)          # SDIRK2 start again
+        qo, qdo = o.get_state()
+        assert _close(qg[b], qo, 1e-9, 1e-10), (b, _rel(qg[b], qo))
+        assert _close(qdg[b], qdo, 1e-7, 1e-8), (b, _rel(qdg[b], qdo))
+    sim.close()
