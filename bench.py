@@ -1,23 +1,34 @@
 #!/usr/bin/env python
 """bench.py -- sim steps/s of the batched RedMax BDF1 step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): 32-link serial revolute chain (scenesRedMax.m:52-79 pattern), BDF1, fp64,
-1024 independent rollouts PER GPU (weak scaling: the batch axis shards, no data-path collective; one RCCL
-all-gather of the final (q, qdot) per rollout).  A "step" is one BDF1 step of the rank's 1024-rollout batch;
-`value` = rollout-steps per second summed over all ranks.  Inputs are resident in HBM before the timed region.
+Workload (BASELINE.json configs[1]): 32-link serial revolute chain (scenesRedMax.m:52-79 pattern), BDF1, fp64, 1024
+independent rollouts.  A "step" is one BDF1 step of a rank's batch; `value` = rollout-steps per second summed over all
+ranks, inputs resident in HBM before the timed region, the K steps of a rank are ONE kernel launch, and the only
+collective is the final all-gather of (q, qdot) (redmax_amd/sharding.py; RCCL when every rank has its own GPU).
 
-Extra objects on the JSON line: `roofline` (algorithmic flops of SURVEY.md §8(d) with the MEASURED Newton
-iteration / line-search counts, divided by the kernel duration measured with HIP events on the kernel's own
-stream) and `cpu_baseline` (the oracle = literal CPU restatement of the reference, timed on the host cores on a
-bounded sample of the same workload; rank 0, N=1 only).
+`value` / `scaling`: weak scaling - 1024 rollouts PER GPU (the batch axis shards, per-GPU work fixed).  The same run also
+measures the strong-scaling reading of BASELINE.json's north_star (1024 rollouts IN TOTAL, 1024/N per GPU) and reports it
+as `strong_scaling`; at N = 1 the two coincide.
+
+Objects on the JSON line besides the driver's contract:
+  roofline                 executed fp64 work of the dominant kernel against the fp64 peak (frac <= 1), its issue-bound
+                           ceiling, the SURVEY §8(d) "algorithmic" figure for reference, HBM traffic per launch
+  repeat                   the K-step launch repeated from the same state: median / min / max kernel time
+  value_at_reference_tol   the same measurement with the reference's hard-coded Newton tol = 1e-9 (driverRedMaxBDF1.m:95)
+  strong_scaling           1024 rollouts in total over the N ranks
+  cpu_baseline             the literal CPU restatement of the reference (oracle) on the host cores, bounded sample
+  cpu_baseline_tensor_free the tensor-free CPU implementation (the algorithm the GPU executes), same sample protocol
+  newton_count_agreement   per-rollout Newton iteration counts, GPU vs oracle, on the in-run sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,199 +38,411 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-# SURVEY.md §8(d) algorithmic flop counts for the n=32 serial chain (1 per add/mul, FMA = 2)
-F_G = 363712        # one residual evaluation
-F_H = 1418432       # one residual + Hessian evaluation
-F_LU = 23893        # one 32x32 LU solve
-HBM_TRAFFIC_BYTES = int((875.9375 + 608.0) * 1024)   # measured with PMC counters, see roofline.traffic_note
-FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the
-                          # microarch guide lists no fp64 row, so the datasheet value is used and stated)
+METRIC = "sim steps/sec (whole node), 1024-batch 32-DOF chain BDF1; q L2 err vs ref"     # BASELINE.json, verbatim
+
+# SURVEY.md §8(d) "algorithmic" flop counts for the n=32 serial chain (1 per add/mul, FMA = 2): what a sparsity-exploiting
+# evaluation of the reference's J / dJdq formulation would cost.  The kernels execute ~10x less (O(n^2) world-frame
+# recursion), so this figure is reported as `algorithmic_equiv_tflops`, NOT as the roofline fraction.
+F_G, F_H, F_LU = 363712, 1418432, 23893
+
+# EXECUTED work of k_step_bdf1<32,false>, per wavefront (= per rollout), split by stage.  Calibrated from the SQ instruction
+# counters of the profiled bench command (separate rocprofv3 --pmc passes, profiles/r02a_pmc_*.csv) by
+# tools/roofline_from_pmc.py: counts(launch) = front_evals * FRONT + newton_iters * NEWTON, fitted on two launches with
+# different iterations-per-step mixes.  flops = 64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 512 x MFMA_MOPS_F64: what the
+# SIMD spent, idle lanes included (a wave-wide instruction costs its issue slots whatever the EXEC mask says).
+EXEC = {
+    "profile": "profiles/r02a (see profiles/README.md)",
+    "flops_front": 5.51e4,      # one eval_front (residual + subtree sums), per wave
+    "flops_newton": 1.10e5,     # eval_hess + LU solve + back substitution + norms, per wave
+    "valu_front": 1250.0,       # VALU wave-instructions (all kinds, MFMA included)
+    "valu_newton": 2350.0,
+}
+FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the microarch guide has no fp64 row)
+SHADER_CLOCK_GHZ = 2.4    # max clock (guide); the effective clock under load is lower, so cycle counts below are upper bounds
+N_SIMD = 1024             # 256 CUs x 4 SIMDs
+# HBM bytes per launch from the TCC counters (separate FETCH_SIZE / WRITE_SIZE passes, profiles/r02a_pmc_fetch_size.csv,
+# ..._write_size.csv, KB as rocprofv3 reports them).  The state is read once and written once per LAUNCH whatever K is.
+HBM_FETCH_KB, HBM_WRITE_KB = 875.9, 608.0
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=0, help="steps in the timed region (default: 100; adjoint: a 20-step horizon, the longest "
+                                                          "round horizon over which the reference's line-search-free Newton converges on every step)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=0, help="rollouts per GPU (default: 1024; 512 for --workload tree64)")
-    ap.add_argument("--workload", choices=("chain", "tree64", "ground"), default="chain",
+    ap.add_argument("--batch", type=int, default=0, help="rollouts per GPU (default: 1024; 512 for tree64 and adjoint)")
+    ap.add_argument("--workload", choices=("chain", "tree64", "ground", "adjoint"), default="chain",
                     help="chain: BASELINE.json configs[1], the headline metric (default).  tree64: configs[2], 64-joint "
-                         "revolute/prismatic tree, BDF1.  ground: configs[4], 32-link chain over frictional ground, BDF2.  The last "
-                         "two are extra measurements of the 'next' rows; no roofline / cpu_baseline is attached to them")
+                         "revolute/prismatic tree, BDF1.  ground: configs[4], 32-link chain over frictional ground, BDF2.  adjoint: "
+                         "configs[3], 16-DOF chain, forward + backward adjoint sweep (HBM roofline).  Only chain carries cpu baselines")
     ap.add_argument("--links", type=int, default=32)
-    ap.add_argument("--tol", type=float, default=1e-8, help="Newton |g| tolerance (reference hard-codes 1e-9, see DESIGN.md)")
+    ap.add_argument("--tol", type=float, default=1e-8, help="Newton |g| tolerance of the headline line (the reference hard-codes 1e-9: "
+                                                             "that measurement is reported next to it as value_at_reference_tol; DESIGN.md §5)")
+    ap.add_argument("--repeats", type=int, default=5, help="extra timed launches of the same K steps from the same state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-traj", type=int, default=0, help="rollouts in the CPU sample (default: 4 per host core, <= batch)")
+    ap.add_argument("--no-reference-tol", action="store_true")
+    ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--cpu-traj", type=int, default=0, help="rollouts in the CPU sample (default: one per host thread, <= 256)")
     ap.add_argument("--cpu-steps", type=int, default=40)
-    args = ap.parse_args()
+    ap.add_argument("--json-out", default="", help="also write the JSON line to this file (tests)")
+    args = ap.parse_args(argv)
+    if args.steps <= 0:
+        args.steps = 20 if args.workload == "adjoint" else 100
+    return args
 
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the measured path)")
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from redmax_amd import BatchSim, sceneChain, sceneChainGround, sceneTree, syntheticStates
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: run the N ranks under torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
-    wl = args.workload
-    if args.batch <= 0:
-        args.batch = 512 if wl == "tree64" else 1024
-    n, B, K, W, h = args.links, args.batch, args.steps, args.warmup, 1e-2
+
+# ---------------------------------------------------------------------------------------------- the stepper a rank drives
+class GpuStepper:
+    """One rank's batch on one MI355X (redmax_amd.BatchSim = the C ABI).  tests/test_bench_ranks_gloo.py substitutes an
+    oracle-backed object with the same methods to drive this file's rank code on CPU."""
+
+    def __init__(self, scene, batch, device, integ="bdf1"):
+        from redmax_amd import BatchSim
+        self.sim = BatchSim(scene, batch=batch, device=device)
+        self.integ = integ
+        self.device = device
+        self.B, self.nr = batch, scene.nr
+        self._out = None
+
+    def set_opts(self, h, tol):
+        self.sim.opts.h = h
+        self.sim.opts.tol = tol
+
+    def set_state(self, q, qd):
+        self.sim.set_state(q, qd)
+
+    def get_state(self):
+        return self.sim.get_state()
+
+    def warmup(self, W):
+        if W > 0:
+            (self.sim.step_bdf2 if self.integ == "bdf2" else self.sim.step_bdf1)(W)
+
+    def stats_reset(self):
+        self.sim.stats_reset()
+        self.sim.sync()
+
+    def launch(self, K):
+        if self.integ == "bdf2":      # BDF2 has no async entry point: the synchronous call returns after the kernel
+            self._out = self.sim.step_bdf2(K, stats=True)
+        else:
+            self.sim.step_bdf1_async(K)      # all K steps of all rollouts: one kernel launch
+            self._out = None
+
+    def wait(self):
+        """kernel milliseconds of the launch (HIP events on the kernel's own stream)."""
+        return self._out["ms"] if self._out is not None else self.sim.sync()
+
+    def stats(self):
+        return self._out if self._out is not None else self.sim.stats_read()
+
+    def state_tensors(self, torch, on_device):
+        """(q, qdot) of this rank as torch tensors for the gather: device tensors (RCCL) or host tensors (gloo)."""
+        if on_device:
+            dev = torch.device("cuda", self.device)
+            q = torch.empty((self.B, self.nr), dtype=torch.float64, device=dev)
+            qd = torch.empty_like(q)
+            self.sim.get_state_device(q.data_ptr(), qd.data_ptr())
+            return q, qd
+        q, qd = self.sim.get_state()
+        return torch.from_numpy(q), torch.from_numpy(qd)
+
+    def close(self):
+        self.sim.close()
+
+
+def build_workload(wl, links):
+    from redmax_amd import sceneChain, sceneChainGround, sceneTree, syntheticStates
     if wl == "chain":
-        scene = sceneChain(n)
+        scene = sceneChain(links)
         scene.init()
-        q0, qd0 = syntheticStates(scene.nr, B, first=rank * B)      # global trajectory index => shard-invariant inputs
-    elif wl == "tree64":
+        return scene, 1e-2, "bdf1", (lambda first, count: syntheticStates(scene.nr, count, first=first))
+    if wl == "tree64":
         scene = sceneTree(64)
         scene.init()
-        n = scene.nr
         qs, _ = scene.getQ()
-        q0, qd0 = np.empty((B, n)), np.empty((B, n))
-        for i in range(B):
-            rng = np.random.default_rng(20240 + rank * B + i)
-            q0[i] = qs + rng.uniform(-0.05, 0.05, n)
-            qd0[i] = rng.uniform(-0.1, 0.1, n)
-    else:
-        scene = sceneChainGround(32)
-        scene.init()
-        n, h = scene.nr, scene.h
-        q0, qd0 = syntheticStates(scene.nr, B, first=rank * B, sq=5e-4, sv=0.1)   # every chain starts above the ground
-        if rank == 0:
+
+        def gen(first, count):
+            q0, qd0 = np.empty((count, scene.nr)), np.empty((count, scene.nr))
+            for i in range(count):
+                rng = np.random.default_rng(20240 + first + i)
+                q0[i] = qs + rng.uniform(-0.05, 0.05, scene.nr)
+                qd0[i] = rng.uniform(-0.1, 0.1, scene.nr)
+            return q0, qd0
+        return scene, 1e-2, "bdf1", gen
+    scene = sceneChainGround(32)
+    scene.init()
+
+    def geng(first, count):
+        q0, qd0 = syntheticStates(scene.nr, count, first=first, sq=5e-4, sv=0.1)     # every chain starts above the ground
+        if first == 0 and count:
             q0[0], qd0[0] = scene.getQ()
-    sim = BatchSim(scene, batch=B, device=local_rank)
-    step_sync = sim.step_bdf2 if wl == "ground" else sim.step_bdf1
-    sim.opts.h = h
-    sim.opts.tol = args.tol
-    sim.set_state(q0, qd0)
-    dev = torch.device("cuda", local_rank)
-    q_loc = torch.empty((B, scene.nr), dtype=torch.float64, device=dev)
-    qd_loc = torch.empty_like(q_loc)
-    if world > 1:
-        q_all = torch.empty((world * B, scene.nr), dtype=torch.float64, device=dev)
-        qd_all = torch.empty_like(q_all)
+        return q0, qd0
+    return scene, scene.h, "bdf2", geng
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    # ---- warmup (untimed)
-    if W > 0:
-        step_sync(W)
-    if world > 1:   # warm the collective too
-        sim.get_state_device(q_loc.data_ptr(), qd_loc.data_ptr())
-        dist.all_gather_into_tensor(q_all, q_loc)
-    sim.stats_reset()
-    sim.sync()
+class RankContext:
+    """Process-group plumbing of one rank: barrier, gather, max-reduction, on RCCL (one GPU per rank) or gloo."""
 
-    # ---- timed region: exactly K steps
-    barrier()
+    def __init__(self, rank, world, torch, dist, on_device, device, sync_cuda):
+        self.rank, self.world, self.torch, self.dist, self.device = rank, world, torch, dist, device
+        self.on_device = on_device      # collectives run on device tensors (RCCL); False: host tensors (gloo)
+        self.sync_cuda = sync_cuda      # the barrier also waits for the device
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.sync_cuda:
+            self.torch.cuda.synchronize()
+
+    def gather(self, stepper, shard):
+        if self.dist is None:
+            return None
+        from redmax_amd import sharding
+        q, qd = stepper.state_tensors(self.torch, self.on_device)
+        return sharding.gather_states(q, qd, shard)
+
+    def max(self, x):
+        from redmax_amd import sharding
+        dev = self.torch.device("cuda", self.device) if (self.on_device and self.dist is not None) else None
+        return sharding.max_over_ranks(x, dev) if self.dist is not None else float(x)
+
+    def sum_int(self, x):
+        if self.dist is None:
+            return int(x)
+        t = self.torch.tensor([int(x)], dtype=self.torch.int64, device=self.torch.device("cuda", self.device) if self.on_device else "cpu")
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+
+def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats):
+    """The contract's timed region for one shard plan: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier +
+    device sync on both sides, MAX over ranks; then `repeats` more launches of the same K steps from the same (post-warm-up)
+    state for the spread.  Returns a dict (identical on every rank where it matters)."""
+    if shard.count < 1:
+        raise SystemExit("rank %d owns no rollout (batch %d over %d ranks)" % (shard.rank, shard.global_batch, shard.world))
+    if integ == "bdf2":
+        repeats = 0                    # a restored state restarts BDF2 with its SDIRK2 step: not the same work as the timed launch
+    st = make_stepper(scene, shard.count, ctx.device, integ)
+    st.set_opts(h, tol)
+    q0, qd0 = gen(shard.first, shard.count)
+    st.set_state(q0, qd0)
+    st.warmup(W)
+    ctx.gather(st, shard)              # warm the collective too
+    qw, qdw = st.get_state()           # the state every timed launch starts from
+    st.stats_reset()
+    ctx.barrier()
     t0 = time.perf_counter()
-    if wl == "ground":                # BDF2 has no async entry point: the synchronous call returns after the kernel
-        out_step = step_sync(K, stats=True)
-        kernel_ms = out_step["ms"]
-    else:
-        sim.step_bdf1_async(K)        # all K steps of all B rollouts: one kernel launch
-        kernel_ms = sim.sync()        # HIP events around the kernel, on the kernel's own stream
-    if world > 1:                     # the single collective of the path: final gather of (q, qdot)
-        sim.get_state_device(q_loc.data_ptr(), qd_loc.data_ptr())
-        dist.all_gather_into_tensor(q_all, q_loc)
-        dist.all_gather_into_tensor(qd_all, qd_loc)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    st.launch(K)
+    kernel_ms = st.wait()
+    gathered = ctx.gather(st, shard)   # the single collective of the path: final gather of (q, qdot)
+    ctx.barrier()
+    elapsed = ctx.max(time.perf_counter() - t0)
+    s = st.stats()
+    qf, qdf = st.get_state()
+    out = {
+        "elapsed": elapsed, "kernel_ms": ctx.max(kernel_ms),
+        "iters": ctx.sum_int(s["newton_iters"].sum()), "halvings": ctx.sum_int(s["ls_halvings"].sum()),
+        "bad": ctx.sum_int(((s["status"] & 15) != 0).sum()), "pivoted": ctx.sum_int(((s["status"] & 16) != 0).sum()),
+        "finite": bool(np.isfinite(qf).all() and np.isfinite(qdf).all()), "rollouts": shard.global_batch,
+        "gathered_rows": int(gathered[0].shape[0]) if gathered is not None else shard.count,
+        "local_iters": s["newton_iters"].copy(),
+    }
+    rep_k, rep_w = [], []
+    for _ in range(max(repeats, 0)):
+        st.set_state(qw, qdw)
+        ctx.barrier()
+        t0 = time.perf_counter()
+        st.launch(K)
+        rep_k.append(ctx.max(st.wait()))
+        ctx.gather(st, shard)
+        ctx.barrier()
+        rep_w.append(ctx.max(time.perf_counter() - t0))
+    if rep_k:
+        allk = sorted(rep_k + [out["kernel_ms"]])
+        allw = sorted(rep_w + [elapsed])
+        out["repeat"] = {"launches": len(allk), "kernel_ms_median": round(float(np.median(allk)), 4), "kernel_ms_min": round(allk[0], 4),
+                         "kernel_ms_max": round(allk[-1], 4), "wall_ms_median": round(1e3 * float(np.median(allw)), 4),
+                         "value_median": round(shard.global_batch * K / float(np.median(allw)), 1),
+                         "note": "the timed K-step launch repeated from the same post-warm-up state (same work every time); "
+                                 "`value` is the first launch, as the contract defines the timed region"}
+    st.close()
+    return out
 
-    st = out_step if wl == "ground" else sim.stats_read()
-    iters = int(st["newton_iters"].sum())
-    halv = int(st["ls_halvings"].sum())
-    bad = int(((st["status"] & 15) != 0).sum())
-    pivoted = int(((st["status"] & 16) != 0).sum())
-    qf, qdf = sim.get_state()
-    finite = bool(np.isfinite(qf).all() and np.isfinite(qdf).all())
+
+def roofline(m, K, B_local, world, n, wl):
+    """Executed-work roofline of k_step_bdf1<32,false> for one rank's launch (rank 0's counters stand for all: identical work
+    distribution by construction)."""
+    if wl != "chain" or n != 32 or m["kernel_ms"] <= 0:
+        return None
+    iters_rank, halv_rank = m["iters"] / world, m["halvings"] / world
+    steps_rank = B_local * K
+    fronts = steps_rank + iters_rank + halv_rank          # one per step (initial guess) + one per line-search trial
+    sec = m["kernel_ms"] * 1e-3
+    flops = fronts * EXEC["flops_front"] + iters_rank * EXEC["flops_newton"]
+    ach = flops / sec / 1e12
+    alg = (iters_rank * (F_H + F_LU) + (iters_rank + halv_rank) * F_G) / sec / 1e12
+    # issue-bound ceiling: a lone wavefront per SIMD issues at most one VALU instruction per 4 cycles (fp64: 16 lanes/clk/SIMD)
+    valu_wave = (fronts * EXEC["valu_front"] + iters_rank * EXEC["valu_newton"]) / B_local      # per wave (mean)
+    slowest = float(m["local_iters"].max()) / max(float(m["local_iters"].mean()), 1.0)          # the launch ends with its slowest wave
+    cycles = sec * SHADER_CLOCK_GHZ * 1e9
+    return {
+        "bound": "mfma", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 4),
+        "traffic": int((HBM_FETCH_KB + HBM_WRITE_KB) * 1024),
+        "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): %.1f KB + %.1f KB for "
+                        "1024 rollouts; the state is read once and written once per LAUNCH, so the figure holds for any --steps "
+                        "(profiled at K=100 and K=20); algorithmic = 1 MiB (q, qdot in + out).  Reported at face value: the guide's "
+                        "x2 FETCH correction is calibrated for 16 B/lane streams, this kernel reads 8 B/lane once" % (HBM_FETCH_KB, HBM_WRITE_KB),
+        "kernel": "k_step_bdf1<32,false>", "kernel_ms": round(m["kernel_ms"], 4),
+        "executed_flops_per_front_eval": EXEC["flops_front"], "executed_flops_per_newton_iter": EXEC["flops_newton"],
+        "calibration": EXEC["profile"],
+        "issue_bound": {"valu_insts_per_wave": round(valu_wave, 1), "cycles_at_4_per_inst": round(4.0 * valu_wave * slowest, 1),
+                        "kernel_cycles_at_%.1fGHz" % SHADER_CLOCK_GHZ: round(cycles, 1),
+                        "frac": round(4.0 * valu_wave * slowest / cycles, 4),
+                        "note": "one wavefront per SIMD (490 VGPRs, 1024 rollouts on 1024 SIMDs): the kernel is bound by the issue "
+                                "rate of a single wave (<= 1 VALU instruction / 4 cycles for fp64), not by fp64 throughput; "
+                                "frac = (VALU instructions of the slowest wave x 4 cycles) / kernel cycles"},
+        "algorithmic_equiv_tflops": round(alg, 2),
+        "newton_iters_per_step": round(iters_rank / steps_rank, 3), "ls_halvings_per_step": round(halv_rank / steps_rank, 4),
+        "note": "achieved = EXECUTED fp64 flops (per-stage counts calibrated on the SQ_INSTS_VALU_*_F64 / MFMA_MOPS_F64 counters x the "
+                "measured front-evaluation and Newton-iteration counts of THIS launch) / kernel time measured with HIP events on "
+                "the kernel's stream; peak = 78.6 TF (fp64 vector = fp64 matrix on MI355X).  algorithmic_equiv_tflops is the "
+                "SURVEY.md §8(d) contract figure (flops a J/dJdq-based evaluation would need x measured counts / time): it exceeds "
+                "the peak because the kernel executes ~10x fewer flops than that formulation, and is not a utilisation",
+    }
+
+
+def rank_main(args, make_stepper=None, backend=None):
+    import torch
+    from redmax_amd import sharding
+    rank, local_rank, world = sharding.env_rank()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    on_gpu = make_stepper is None
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the measured path)")
+        make_stepper = GpuStepper
+        ndev = torch.cuda.device_count()
+        device = local_rank % ndev
+        shared = world > ndev            # several ranks on one device: RCCL refuses duplicate GPUs, the gather goes through gloo
+        torch.cuda.set_device(device)
+        backend = backend or ("gloo" if shared else "nccl")
+    else:
+        device, shared, backend = 0, False, backend or "gloo"
+    dist = sharding.init_process_group(rank, world, backend, device if backend == "nccl" else None) if world > 1 else None
+    ctx = RankContext(rank, world, torch, dist, on_device=on_gpu and backend == "nccl", device=device, sync_cuda=on_gpu)
+
+    wl = args.workload
+    if wl == "adjoint":
+        return adjoint_main(args, ctx)
+    if args.batch <= 0:
+        args.batch = 512 if wl == "tree64" else 1024
+    B, K, W = args.batch, args.steps, args.warmup
+    scene, h, integ, gen = build_workload(wl, args.links)
+    n = scene.nr
+    weak = sharding.plan(rank, world, B, "weak")
+    m = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, K, W, args.repeats)
+    ref = strong = None
+    if wl == "chain" and not args.no_reference_tol and args.tol != 1e-9:
+        ref = measure(ctx, make_stepper, scene, gen, weak, h, 1e-9, integ, K, W, 0)
+    if world > 1 and not args.no_strong:
+        strong = measure(ctx, make_stepper, scene, gen, sharding.plan(rank, world, B, "strong"), h, args.tol, integ, K, W, args.repeats)
 
     if rank == 0:
-        total_steps = world * B * K
-        value = total_steps / elapsed
-        # algorithmic flops of THIS launch on this rank: per Newton iteration one (g,H) evaluation and one LU,
-        # plus one residual evaluation per line-search trial (iterations + halvings)
-        flops = iters * (F_H + F_LU) + (iters + halv) * F_G
-        if n != 32 or wl != "chain":
-            flops = None
-        roof = None
-        if flops is not None and kernel_ms > 0:
-            ach = flops / (kernel_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP64_PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_BYTES if (B == 1024 and K == 100 and n == 32) else None,
-                    "traffic_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01h_pmc_*.csv): 875.9 KB + 608 KB per "
-                                    "launch of 100 steps x 1024 rollouts, reported uncorrected: the guide's x2 FETCH correction is calibrated for "
-                                    "16 B/lane streams; calibrated on the known byte counts of THIS 8 B/lane pattern the counters read at "
-                                    "face value (WRITE_SIZE 608 KB = 512 KiB state written + 12 KiB counters + write-backs; FETCH_SIZE = "
-                                    "512 KiB state read + the 17 KB constant table per XCD + code); algorithmic = 1 MiB (q,qdot in + out)",
-                    "kernel": "k_step_bdf1<32,false>", "kernel_ms": round(kernel_ms, 4),
-                    "executed_tflops_estimate": round(iters * 1.65e5 / (kernel_ms * 1e-3) / 1e12, 2),
-                    "newton_iters_per_step": round(iters / (B * K), 3), "ls_halvings_per_step": round(halv / (B * K), 4),
-                    "note": "fp64 path: FP64 vector == FP64 matrix peak on MI355X (78.6 TF, datasheet); achieved = ALGORITHMIC flops "
-                            "(SURVEY.md §8(d) figures x measured iteration counts) / kernel time, as the contract asks - it can exceed "
-                            "the peak because the kernel EXECUTES ~10x fewer flops (O(n^2) world-frame recursion instead of the "
-                            "J/dJdq contraction; ~1.65e5 per Newton iteration = executed_tflops_estimate); one wave per SIMD: the "
-                            "kernel is issue/latency-bound, see DESIGN.md §4 and §6"}
+        value = m["rollouts"] * K / m["elapsed"]
+        workload = {"chain": "%d-link serial revolute chain, BDF1 fp64, batch=%d per GPU (BASELINE.json configs[1])" % (n, B),
+                    "tree64": "64-joint revolute/prismatic branching tree, BDF1 fp64, batch=%d per GPU (BASELINE.json configs[2])" % B,
+                    "ground": "32-link chain over frictional ground (ForceGroundCuboid on every body), BDF2 fp64, h=5e-4, "
+                              "batch=%d per GPU (BASELINE.json configs[4])" % B}[wl]
         out = {
-            # BASELINE.json's metric string, verbatim; its second half (q L2 err vs ref) is q_l2_relerr_vs_oracle_max below
-            "metric": "sim steps/sec (whole node), 1024-batch 32-DOF chain BDF1; q L2 err vs ref",
-            "value": round(value, 1), "unit": "rollout-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(1e3 * elapsed / K, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": {"chain": "%d-link serial revolute chain, BDF1 fp64, batch=%d per GPU (BASELINE.json configs[1])" % (n, B),
-                                    "tree64": "64-joint revolute/prismatic branching tree, BDF1 fp64, batch=%d per GPU (BASELINE.json configs[2])" % B,
-                                    "ground": "32-link chain over frictional ground (ForceGroundCuboid on every body), BDF2 fp64, h=5e-4, "
-                                              "batch=%d per GPU (BASELINE.json configs[4])" % B}[wl],
-                       "batch_per_gpu": B, "links": n, "h": h, "newton_tol": args.tol, "reference_newton_tol": 1e-9,
+            "metric": METRIC, "value": round(value, 1), "unit": "rollout-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * m["elapsed"] / K, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "batch_per_gpu": B, "global_batch": m["rollouts"], "links": n, "h": h,
+                       "newton_tol": args.tol, "reference_newton_tol": 1e-9,
                        "init": {"chain": "q,qdot~U(-0.1,0.1), rng(20240+global_index); traj 0: q=0.1,qdot=0",
                                 "tree64": "scene state + U(-0.05,0.05), qdot~U(-0.1,0.1), rng(20240+global_index)",
                                 "ground": "q~U(-5e-4,5e-4), qdot~U(-0.1,0.1), rng(20240+global_index); traj 0: the scene's state"}[wl],
-                       "parallelism": "batch-sharded x%d, one RCCL all-gather of final (q,qdot)" % world,
-                       "steps_per_launch": K, "not_converged_trajectories": bad, "trajectories_with_pivoted_fallback": pivoted,
-                       "all_finite": finite},
-            "roofline": roof,
+                       "parallelism": "batch-sharded x%d (redmax_amd.sharding), one %s all-gather of the final (q,qdot)%s" % (
+                           world, "RCCL" if backend == "nccl" else backend,
+                           "; ranks share a device, so the gather runs on gloo with host tensors" if (on_gpu and shared) else ""),
+                       "steps_per_launch": K, "not_converged_trajectories": m["bad"], "trajectories_with_pivoted_fallback": m["pivoted"],
+                       "all_finite": m["finite"], "gathered_rows": m["gathered_rows"]},
+            "roofline": roofline(m, K, B, world, n, wl) if on_gpu else None,
         }
+        if "repeat" in m:
+            out["repeat"] = m["repeat"]
         if wl != "chain":
             out["metric"] = "sim steps/sec (whole node), " + {"tree64": "64-joint tree BDF1", "ground": "32-link chain + ground contact BDF2"}[wl]
-            out["config"]["newton_iters_per_step"] = round(iters / (B * K), 3)
-            out["config"]["kernel_ms"] = round(kernel_ms, 4)
-        if world == 1 and not args.no_cpu_baseline and wl == "chain":
-            out["cpu_baseline"], out["q_l2_relerr_vs_oracle_max"] = cpu_baseline(scene, args, h)
-        print(json.dumps(out), flush=True)
+            out["config"]["newton_iters_per_step"] = round(m["iters"] / (m["rollouts"] * K), 3)
+            out["config"]["kernel_ms"] = round(m["kernel_ms"], 4)
+        if ref is not None:
+            out["value_at_reference_tol"] = {
+                "newton_tol": 1e-9, "value": round(ref["rollouts"] * K / ref["elapsed"], 1), "unit": "rollout-steps/s",
+                "ms_per_step": round(1e3 * ref["elapsed"] / K, 5), "kernel_ms": round(ref["kernel_ms"], 4),
+                "newton_iters_per_step": round(ref["iters"] / (ref["rollouts"] * K), 3),
+                "ls_halvings_per_step": round(ref["halvings"] / (ref["rollouts"] * K), 3),
+                "not_converged_trajectories": ref["bad"], "all_finite": ref["finite"],
+                "note": "same launch with the reference's hard-coded tol = 1e-9 (driverRedMaxBDF1.m:95).  |g| of this 320 cm cgs chain "
+                        "has an fp64 roundoff floor of ~1e-9, so whether |g| < 1e-9 is reached is decided by roundoff: iterations that "
+                        "cannot pass run the full 20-halving line search, rollouts at a floating-point fixed point report MAXITER "
+                        "(the reference prints 'Newton did not converge' and keeps x).  The final states of the two tolerances agree to "
+                        "<= 6e-13 relative (DESIGN.md §5); the launch ends with its slowest rollout"}
+        if strong is not None:
+            out["strong_scaling"] = {
+                "global_batch": strong["rollouts"], "batch_per_gpu": strong["rollouts"] / world,
+                "value": round(strong["rollouts"] * K / strong["elapsed"], 1), "unit": "rollout-steps/s",
+                "ms_per_step": round(1e3 * strong["elapsed"] / K, 5), "kernel_ms": round(strong["kernel_ms"], 4),
+                "repeat": strong.get("repeat"),
+                "note": "BASELINE.json north_star reading: %d rollouts in TOTAL over the %d ranks.  One rollout is one wavefront and a "
+                        "Newton step is a sequential chain, so below 1024 rollouts per GPU the kernel time does not shrink with the "
+                        "batch (SIMDs idle): expect a flat curve (SURVEY.md §8(e))" % (strong["rollouts"], world)}
+        if on_gpu and world == 1 and not args.no_cpu_baseline and wl == "chain":
+            out.update(cpu_baselines(scene, args, h))
+        line = json.dumps(out)
+        print(line, flush=True)
+        if args.json_out:
+            with open(args.json_out, "w") as f:
+                f.write(line + "\n")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def cpu_baseline(scene, args, h):
-    """The oracle (literal CPU restatement of the reference path, kind="port") on the host cores, OpenMP over
-    trajectories, on a bounded sample of the same workload: the first --cpu-traj rollouts x --cpu-steps steps, same
-    Newton constants as the GPU run.  Also returns max_b |q_gpu - q_oracle| / |q_oracle| on that sample."""
+def cpu_baselines(scene, args, h):
+    """The two CPU baselines on the host cores (OpenMP over rollouts, one rollout per thread) on a bounded sample of the same
+    workload - the first `nb` rollouts x `ks` steps, same Newton constants as the GPU run - plus the in-run parity numbers:
+    max_b |q_gpu - q_oracle| / |q_oracle| and the per-rollout Newton iteration counts of GPU vs oracle.
+      cpu_baseline             kind "port": oracle/redmax_oracle.c, the literal restatement of the reference (O(n^3) tensor path)
+      cpu_baseline_tensor_free oracle/redmax_tensorfree.c: the algorithm the GPU executes, scalar C"""
     from oracle import oracle as orc
     from redmax_amd import BatchSim, syntheticStates
     cores = os.cpu_count() or 1
-    nb = args.cpu_traj if args.cpu_traj > 0 else min(cores, args.batch)     # one rollout per host thread
+    nb = args.cpu_traj if args.cpu_traj > 0 else min(cores, 256, args.batch)     # one rollout per host thread
     cores = min(cores, nb)                  # threads actually used (OpenMP over rollouts)
     q, qd = syntheticStates(scene.nr, nb)
     orc.set_newton(tol=args.tol)
-    # size the sample to ~15 s of wall time: time 2 steps first, then pick the step count (bounded by --cpu-steps)
+    # literal port: size the sample to ~15 s of wall time (time 2 steps first), bounded by --cpu-steps
     qc, qdc = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
     t0 = time.perf_counter()
     orc.batch_step_bdf1(scene.desc(), qc, qdc, h, 2, nthreads=cores)
@@ -227,20 +450,128 @@ def cpu_baseline(scene, args, h):
     ks = int(max(4, min(args.cpu_steps, 15.0 / max(per_step, 1e-6))))
     qc, qdc = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
     t0 = time.perf_counter()
-    orc.batch_step_bdf1(scene.desc(), qc, qdc, h, ks, nthreads=cores)
+    cnt = orc.batch_step_bdf1(scene.desc(), qc, qdc, h, ks, nthreads=cores, counters=True)
     dt = time.perf_counter() - t0
     orc.set_newton()
+    # tensor-free: the same rollouts for the full 100 steps, repeated until ~5 s have passed
+    kt = 100
+    reps, dtt = 0, 0.0
+    while dtt < 5.0 and reps < 50:
+        qt, qdt = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
+        t0 = time.perf_counter()
+        cntt = orc.tensorfree_batch_step_bdf1(scene.desc(), qt, qdt, h, kt, nthreads=cores, tol=args.tol)
+        dtt += time.perf_counter() - t0
+        reps += 1
+    # the GPU on the same sample
     sim = BatchSim(scene, batch=nb)
     sim.opts.tol = args.tol
     sim.set_state(q, qd)
-    sim.step_bdf1(ks, h=h)
+    og = sim.step_bdf1(ks, h=h, stats=True)
     qg, _ = sim.get_state()
+    sim.set_state(q, qd)
+    og100 = sim.step_bdf1(kt, h=h, stats=True)
+    qg100, _ = sim.get_state()
+    sim.close()
     err = float(np.max(np.linalg.norm(qg - qc, axis=1) / np.linalg.norm(qc, axis=1)))
-    base = {"value": round(nb * ks / dt, 2), "unit": "rollout-steps/s", "cores": cores, "kind": "port",
-            "sample": "first %d rollouts x %d steps of the same workload (oracle/redmax_oracle.c, OpenMP over rollouts, %.1f s); "
-                      "MATLAB is not available, the reference publishes no timing" % (nb, ks, dt)}
-    return base, err
+    errt = float(np.max(np.linalg.norm(qg100 - qt, axis=1) / np.linalg.norm(qt, axis=1)))
+    same = int((og["newton_iters"] == cnt["newton_iters"]).sum())
+    samet = int((og100["newton_iters"] == cntt["newton_iters"]).sum())
+    return {
+        "cpu_baseline": {"value": round(nb * ks / dt, 2), "unit": "rollout-steps/s", "cores": cores, "kind": "port",
+                         "sample": "first %d rollouts x %d steps of the same workload (oracle/redmax_oracle.c: literal restatement of the "
+                                   "reference incl. its O(n^3) dJ/dq tensor path, OpenMP over rollouts, %.1f s); MATLAB is not available, "
+                                   "the reference publishes no timing" % (nb, ks, dt)},
+        "cpu_baseline_tensor_free": {"value": round(nb * kt * reps / dtt, 1), "unit": "rollout-steps/s", "cores": cores, "kind": "port",
+                                     "sample": "first %d rollouts x %d steps x %d repetitions (oracle/redmax_tensorfree.c: the O(n^2) world-frame "
+                                               "algorithm the GPU executes, scalar C -O2, same Newton, OpenMP over rollouts, %.1f s)" % (nb, kt, reps, dtt),
+                                     "q_l2_relerr_gpu_vs_this_max": errt},
+        "q_l2_relerr_vs_oracle_max": err,
+        "newton_count_agreement": {
+            "vs_oracle": {"rollouts": nb, "steps": ks, "rollouts_with_equal_count": same, "frac": round(same / nb, 4),
+                          "gpu_iters": int(og["newton_iters"].sum()), "oracle_iters": int(cnt["newton_iters"].sum()),
+                          "max_abs_diff_per_rollout": int(np.abs(og["newton_iters"] - cnt["newton_iters"]).max())},
+            "vs_tensor_free": {"rollouts": nb, "steps": kt, "rollouts_with_equal_count": samet, "frac": round(samet / nb, 4),
+                               "gpu_iters": int(og100["newton_iters"].sum()), "cpu_iters": int(cntt["newton_iters"].sum()),
+                               "max_abs_diff_per_rollout": int(np.abs(og100["newton_iters"] - cntt["newton_iters"]).max())},
+            "note": "Newton iterations per rollout summed over the sample's steps, GPU vs CPU at the same tol; counts differ only where "
+                    "|g| lands within roundoff of tol at an iteration's convergence test"},
+    }
+
+
+def adjoint_main(args, ctx):
+    """BASELINE.json configs[3]: adjoint BDF1 (forward + backward sweep) of the 16-DOF chain of scene 100's pattern, B rollouts
+    with their own parameter vectors.  The one path of this library whose HBM traffic matters: the forward kernel stores
+    H, M, D (3 n^2 doubles) per step and rollout, the backward kernel reads them back."""
+    import torch
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneAdjointChain
+    n = 16
+    sc = sceneAdjointChain(n)
+    sc.init()
+    B = args.batch if args.batch > 0 else 512
+    K = args.steps
+    rng = np.random.default_rng(20240 + ctx.rank)
+    p = 1e-1 * rng.standard_normal((B, sc.nr))       # p ~ N(0, 1e-2)  (SURVEY.md §8(d) config 4)
+    task = dict(sc.task, t=K * sc.h)
+    sim = BatchSim(sc, batch=B, device=ctx.device)
+    q0, qd0 = sc.getQ()
+
+    def run():
+        sim.set_state(q0[None, :], qd0[None, :])
+        return sim.adjoint_bdf1(K, sc.h, task, p, stats=True)
+    for _ in range(max(1, min(args.warmup, 2))):
+        run()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    P, dPdp, info = run()
+    ctx.barrier()
+    elapsed = ctx.max(time.perf_counter() - t0)
+    ms = [info["ms"]]
+    for _ in range(max(args.repeats, 0)):
+        ms.append(run()[2]["ms"])
+    sim.close()
+    if ctx.rank == 0:
+        kernel_ms = float(np.median(ms))
+        iters = int(info["newton_iters"].sum())
+        # algorithmic HBM bytes: forward writes H, M, D of the LAST iterate of every step (3 n^2 doubles; earlier iterates of a
+        # step are overwritten in L2/HBM: counted once), backward reads H once, M twice (blocks k+1 and k+2), D once
+        nn8 = n * n * 8
+        alg = B * K * nn8 * (3 + 4)
+        bad = int((info["status"] != 0).sum())
+        out = {"metric": "sim steps/sec (whole node), 16-DOF chain adjoint BDF1 forward+backward", "value": round(ctx.world * B * K / elapsed, 1),
+               "unit": "rollout-steps/s", "n_gpus": ctx.world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 5),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "adjoint BDF1 forward+backward (rmx_adjoint_bdf1), %d-DOF chain of scene 100's pattern, batch=%d per GPU, "
+                                      "horizon %d steps (BASELINE.json configs[3])" % (n, B, K),
+                          "batch_per_gpu": B, "links": n, "h": sc.h, "params": "p~N(0,1e-2), rng(20240+rank)",
+                          "newton_iters_per_step": round(iters / (B * K), 3), "not_converged_trajectories": bad,
+                          "all_finite": bool(np.isfinite(P).all() and np.isfinite(dPdp).all()),
+                          "timed_region": "set_state + forward kernel + backward kernel + copy-out of P, dPdp (host buffers at the ABI)"},
+               "roofline": {"bound": "hbm", "achieved": round(alg / (kernel_ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(alg / (kernel_ms * 1e-3) / 8e12, 5), "traffic": None,
+                            "kernel": "k_adjoint_fwd<16> + k_adjoint_bwd<16>", "kernel_ms": round(kernel_ms, 4),
+                            "kernel_ms_all": [round(x, 4) for x in ms],
+                            "note": "algorithmic bytes = B x K x n^2 x 8 x (3 written: H, M, D of each step + 4 read back: H, D once, M "
+                                    "twice) = %d B per launch pair; the forward kernel rewrites a step's H, M, D once per Newton "
+                                    "iteration (%.2f per step), so its store traffic is that multiple of the 3 written" % (alg, iters / (B * K))}}
+        line = json.dumps(out)
+        print(line, flush=True)
+        if args.json_out:
+            with open(args.json_out, "w") as f:
+                f.write(line + "\n")
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    return rank_main(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

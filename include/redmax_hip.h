@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 101
+#define RMX_VERSION 102
 
 enum {
     RMX_OK = 0,
@@ -170,6 +170,13 @@ int rmx_get_state_device(rmx_batch* b, double* d_q, double* d_qdot);
  * (NULL selects the cheap residual-only path, nargout==1 in the reference).  Does not change state. */
 int rmx_eval(rmx_batch* b, const double* q, const double* qA, const double* qB, double eta,
              double* g, double* H);
+
+/* Parity hook = computeValues (driverRedMaxBDF1.m:190-243) at (q, qdot) for every trajectory: the reduced mass matrix
+ * M = J'MmJ (:212), the force vector f = fr + J'(fm - Mm Jdot qdot) (:215-216) and D = df/dqdot (:227-237).  q, qdot, f: host
+ * [batch][nr]; M, D: host [batch][nr*nr] column-major.  K = df/dq is not returned on its own: it only exists folded into H
+ * (rmx_eval gives H = M - eta D - eta^2 K + dMdq dqtmp).  Models with ground contact or spherical joints are refused.
+ * Does not change state. */
+int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, double* M, double* f, double* D);
 
 /* Per-trajectory counters of one rmx_step_* call (host arrays [batch], any may be NULL). */
 typedef struct rmx_stats {

@@ -136,7 +136,9 @@ int mxIsEmpty(const mxArray* a) { return mxGetNumberOfElements(a) == 0; }
 void* mxCalloc(size_t n, size_t size) { return calloc(n, size); }
 void mxFree(void* p) { free(p); }
 void mexMakeMemoryPersistent(void* p) { (void)p; }
-int mexAtExit(void (*f)(void)) { return atexit(f); }
+static void (*g_exit_fcn)(void) = NULL;
+int mexAtExit(void (*f)(void)) { g_exit_fcn = f; return 0; }   /* MATLAB calls it on `clear mex`; the harness on request */
+void rmxstub_clear_mex(void) { if (g_exit_fcn) g_exit_fcn(); }
 
 static jmp_buf g_jmp;
 static int g_armed = 0;

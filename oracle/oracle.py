@@ -41,8 +41,8 @@ class TaskPointPos(C.Structure):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "redmax_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("redmax_oracle.c", "redmax_tensorfree.c", "redmax_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -83,6 +83,13 @@ def lib():
         L.orc_step_euler_simple.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp]
         L.orc_batch_step_bdf1.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int]
         L.orc_batch_step_bdf1.restype = C.c_long
+        L.orc_batch_step_bdf1_ex.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, _ip, _ip, _ip]
+        L.orc_batch_step_bdf1_ex.restype = C.c_long
+        L.otf_nr.argtypes = [C.POINTER(_Desc)]
+        L.otf_eval.argtypes = [C.POINTER(_Desc), _dp, _dp, _dp, C.c_double, _dp, _dp]
+        L.otf_batch_step_bdf1.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double,
+                                          C.c_int, C.c_int, _ip, _ip, _ip]
+        L.otf_batch_step_bdf1.restype = C.c_long
         L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
         L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
@@ -377,14 +384,44 @@ def set_newton(tol=1e-9, dxMax=1e3, iterMaxPerDof=10, iterLsMax=20):
     lib().orc_set_newton(float(tol), float(dxMax), int(iterMaxPerDof), int(iterLsMax))
 
 
-def batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0):
+def batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0, counters=False):
     """B independent rollouts on the host cores (OpenMP over trajectories): the cpu_baseline leg.
-    q, qdot: [B][nr] arrays, updated in place.  Returns total Newton iterations."""
+    q, qdot: [B][nr] arrays, updated in place.  Returns total Newton iterations; with counters=True a dict of per-rollout
+    arrays (newton_iters, ls_halvings, bad = steps that diverged or did not converge) instead."""
     L = lib()
     d, keep = make_desc(desc_dict)
     assert q.flags.c_contiguous and qdot.flags.c_contiguous and q.dtype == np.float64
     # qRest: the batch helper takes it from the descriptor's q (model constant)
-    return int(L.orc_batch_step_bdf1(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads)))
+    if not counters:
+        return int(L.orc_batch_step_bdf1(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads)))
+    out = {k: np.zeros(q.shape[0], dtype=np.int32) for k in ("newton_iters", "ls_halvings", "bad")}
+    L.orc_batch_step_bdf1_ex(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads),
+                             *[out[k].ctypes.data_as(_ip) for k in ("newton_iters", "ls_halvings", "bad")])
+    return out
+
+
+# ---- redmax_tensorfree.c: "Baseline B", the tensor-free CPU implementation (same algorithm as the HIP kernels) ----
+def tensorfree_eval(desc_dict, q, qA, qB, eta, want_H=True):
+    """g (and H [row][col]) of the generic implicit residual from the tensor-free CPU code."""
+    L = lib()
+    d, keep = make_desc(desc_dict)
+    nr = L.otf_nr(C.byref(d))
+    q, qA, qB = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, qA, qB))
+    g = np.zeros(nr)
+    H = np.zeros(nr * nr) if want_H else None
+    L.otf_eval(C.byref(d), _p(q), _p(qA), _p(qB), float(eta), _p(g), _p(H))
+    return (g, H.reshape(nr, nr).T.copy()) if want_H else g
+
+
+def tensorfree_batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0, tol=1e-9, dxMax=1e3, iterMaxPerDof=10, iterLsMax=20):
+    """simLoop for B rollouts (q, qdot [B][nr], in place), OpenMP over rollouts.  Returns per-rollout counters."""
+    L = lib()
+    d, keep = make_desc(desc_dict)
+    assert q.flags.c_contiguous and qdot.flags.c_contiguous and q.dtype == np.float64
+    out = {k: np.zeros(q.shape[0], dtype=np.int32) for k in ("newton_iters", "ls_halvings", "status")}
+    L.otf_batch_step_bdf1(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads), float(tol), float(dxMax),
+                          int(iterMaxPerDof), int(iterLsMax), *[out[k].ctypes.data_as(_ip) for k in ("newton_iters", "ls_halvings", "status")])
+    return out
 
 
 def euler(chart, q):

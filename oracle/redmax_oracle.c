@@ -1417,7 +1417,12 @@ double orc_adjoint_bdf1(orc_scene* s, double h, int nsteps, const orc_task_point
 
 /* -------------------------------------------------- batch CPU baseline */
 
+long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad);
 long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads) {
+    return orc_batch_step_bdf1_ex(d, B, q, qdot, h, nsteps, nthreads, NULL, NULL, NULL);
+}
+/* the same with per-rollout counters: Newton iterations, line-search halvings, diverged + not-converged steps ([B] or NULL) */
+long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad) {
     long total = 0;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -1438,6 +1443,9 @@ long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, doub
             orc_step_bdf1(s, h, nsteps, &st, NULL, NULL);
             orc_get_state(s, q + (size_t)b * nr, qdot + (size_t)b * nr);
             total += st.newton_iters;
+            if (iters) iters[b] = st.newton_iters;
+            if (halvings) halvings[b] = st.ls_halvings;
+            if (bad) bad[b] = st.diverged + st.not_converged;
         }
         free(qrest);
         orc_destroy(s);

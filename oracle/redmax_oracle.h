@@ -134,6 +134,18 @@ double orc_adjoint_bdf1(orc_scene* s, double h, int nsteps, const orc_task_point
 /* Batch helper for the timed CPU baseline: B independent trajectories of the same scene,
  * OpenMP over trajectories (nthreads), q/qdot [B][nr] in/out. Returns total Newton iterations. */
 long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads);
+/* the same, also returning per-rollout counters ([B] each, any may be NULL): Newton iterations, line-search halvings,
+ * number of steps that ended in "Newton diverged" / "did not converge" */
+long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads,
+                            int* iters, int* halvings, int* bad);
+
+/* ---- redmax_tensorfree.c: the tensor-free CPU baseline ("Baseline B"): the algorithm the HIP kernels
+ * execute (world-frame recursive Newton-Euler + analytic derivatives), scalar C, same Newton, OpenMP over rollouts.
+ * Trees of fixed / revolute / prismatic joints, no contact.  Checked against the literal restatement above. */
+int  otf_nr(const orc_desc* d);
+void otf_eval(const orc_desc* d, const double* q, const double* qA, const double* qB, double eta, double* g, double* H);
+long otf_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, double tol,
+                         double dxMax, int iterMaxPerDof, int iterLsMax, int* iters, int* halvings, int* status);
 
 #ifdef __cplusplus
 }

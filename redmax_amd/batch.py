@@ -109,6 +109,16 @@ class BatchSim:
         q0 = self._arr(q0)
         return self.eval_residual(q1, q0, q0 + h * self._arr(qdot0), h, want_H)
 
+    def eval_mfd(self, q, qdot):
+        """computeValues (driverRedMaxBDF1.m:190-243) at (q, qdot): M [B][nr][nr], f [B][nr], D = df/dqdot [B][nr][nr]."""
+        q, qdot = self._arr(q), self._arr(qdot)
+        M = np.empty((self.B, self.nr * self.nr))
+        D = np.empty((self.B, self.nr * self.nr))
+        f = np.empty((self.B, self.nr))
+        _abi.check(self._L.rmx_eval_mfd(self._batch, _abi.dptr(q), _abi.dptr(qdot), _abi.dptr(M), _abi.dptr(f), _abi.dptr(D)), "rmx_eval_mfd")
+        sh = (self.B, self.nr, self.nr)
+        return M.reshape(sh).transpose(0, 2, 1), f, D.reshape(sh).transpose(0, 2, 1)      # column-major -> [b][row][col]
+
     # ---- stepping ----
     def _step(self, fn, nsteps, h, stats, history):
         if h is not None:

@@ -637,6 +637,33 @@ extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const d
     return RMX_OK;
 }
 
+extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, double* M, double* f, double* D) {
+    if (!b || !q || !qdot || !M || !f || !D) return fail(RMX_E_INVALID, "null argument");
+    rmx_model* m = b->m;
+    if (m->dm.con) return fail(RMX_E_INVALID, "rmx_eval_mfd: models with ground contact are outside this hook (the contact K/D blocks only exist inside H)");
+    if (m->dm.nsph) return fail(RMX_E_INVALID, "rmx_eval_mfd: models with spherical joints are outside this hook");
+    HIPCHK(hipSetDevice(m->device));
+    const size_t nv = (size_t)b->B * m->nr, nn = nv * m->nr;
+    if (nv == 0) return RMX_OK;
+    double* buf = nullptr;
+    HIPCHK(hipMalloc((void**)&buf, (2 * nn + nv) * sizeof(double)));
+    double *dM = buf, *dD = buf + nn, *df = buf + 2 * nn;
+    hipError_t e = hipMemsetAsync(buf, 0, (2 * nn + nv) * sizeof(double), b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->tmpA, q, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->tmpB, qdot, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) {
+        DISPATCH_NP(m->NP, launch_mfd, m, b, dM, df, dD);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(M, dM, nn * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(D, dD, nn * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(f, df, nv * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_eval_mfd: ") + hipGetErrorString(e));
+    return RMX_OK;
+}
+
 static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
     rmx_opts def;
     rmx_opts_default(&def);

@@ -403,6 +403,37 @@ __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, cons
     }
 }
 
+// Parity hook for computeValues itself (driverRedMaxBDF1.m:190-243): M = J'MmJ (:212), f = fr + J'(fm - Mm Jdot qdot) (:215-216)
+// and D = df/dqdot (:227-237) at (q, qdot), results to HBM (column-major per trajectory).  f is the residual with v = 0 and
+// e2 = 1 (g = M v - e2 f = -f); M and D rows come from the subtree sums the same front pass leaves behind (eval_MD).
+template <int NP>
+__global__ void __launch_bounds__(64) k_eval_mfd(const DevModel M, const int B, const double* __restrict__ q, const double* __restrict__ qd,
+                                                 double* __restrict__ Mo, double* __restrict__ fo, double* __restrict__ Do) {
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    FrontState fs;
+    NodeOut e;
+    eval_front_e2<NP, true>(M, sAcc, lane, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, 1.0, e, fs);
+    double Mrow[NP], Drow[NP];
+    eval_MD<NP>(M, lane, fs, Mrow, Drow);
+    if (id >= 0) fo[off] = -e.g;
+    double* Mt = Mo + (size_t)traj * M.nr * M.nr;
+    double* Dt = Do + (size_t)traj * M.nr * M.nr;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < M.n) {
+            const int ci = M.idx[i];
+            if (id >= 0 && ci >= 0) {
+                Mt[(size_t)ci * M.nr + id] = Mrow[i];
+                Dt[(size_t)ci * M.nr + id] = Drow[i];
+            }
+        }
+    }
+}
+
 // Joint.computeEnergies / Body.computeEnergies at the stored state.
 template <int NP, bool CT>
 __global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, const double* __restrict__ q,
@@ -522,6 +553,11 @@ void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, co
     const dim3 grid(b->B), block(64);
     k_adjoint_fwd<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
     k_adjoint_bwd<RMX_NP><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+}
+
+void RMX_CAT(launch_mfd_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD) {
+    const dim3 grid(b->B), block(64);
+    k_eval_mfd<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD);
 }
 
 void RMX_CAT(launch_phase_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d) {

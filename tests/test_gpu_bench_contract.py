@@ -35,6 +35,29 @@ def test_default_workload_line():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert d["q_l2_relerr_vs_oracle_max"] < 1e-8
     assert d["config"]["all_finite"] and d["config"]["not_converged_trajectories"] == 0
+    # round-2 measurement contract: a utilisation (<= 1) from executed flops, traffic for ANY --steps, an issue-bound ceiling,
+    # the reference-tolerance line, the tensor-free CPU baseline, Newton-count agreement and the repeated launches
+    assert 0 < r["frac"] <= 1 and r["traffic"] > 0 and 0 < r["issue_bound"]["frac"] <= 1.05
+    assert r["algorithmic_equiv_tflops"] > r["achieved"]
+    t = d["value_at_reference_tol"]
+    assert t["newton_tol"] == 1e-9 and t["value"] > 0 and t["all_finite"] and t["newton_iters_per_step"] >= r["newton_iters_per_step"]
+    tf = d["cpu_baseline_tensor_free"]
+    assert tf["value"] > c["value"] and tf["q_l2_relerr_gpu_vs_this_max"] < 1e-8
+    n = d["newton_count_agreement"]
+    assert n["vs_oracle"]["frac"] >= 0.9 and n["vs_tensor_free"]["frac"] >= 0.9
+    assert d["repeat"]["launches"] >= 6 and d["repeat"]["kernel_ms_min"] <= d["repeat"]["kernel_ms_median"]
+    assert "strong_scaling" not in d          # one rank: weak and strong coincide
+
+
+def test_two_ranks_on_one_gpu_self_launch():
+    """`python bench.py --gpus 2` bare (no torchrun): bench.py re-executes itself under torch.distributed.run.  On a 1-GPU box
+    both ranks share device 0, where RCCL refuses duplicate GPUs, so the gather goes through gloo with host tensors - the rank
+    code, shard plans, barriers and both scaling modes are the ones an 8-GPU RCCL run uses."""
+    d = _run("--gpus", "2", "--steps", "10", "--warmup", "2", "--batch", "256", "--repeats", "1", "--no-reference-tol")
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["config"]["gathered_rows"] == 512
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["config"]["all_finite"]
+    s = d["strong_scaling"]
+    assert s["global_batch"] == 256 and s["batch_per_gpu"] == 128 and s["value"] > 0
 
 
 @pytest.mark.parametrize("wl", ["tree64", "ground"])
@@ -42,3 +65,12 @@ def test_extra_workload_lines(wl):
     d = _run("--workload", wl, "--steps", "10", "--warmup", "2", "--batch", "64")
     assert d["value"] > 0 and d["roofline"] is None and "cpu_baseline" not in d
     assert d["config"]["batch_per_gpu"] == 64 and d["config"]["all_finite"]
+
+
+def test_adjoint_workload_line():
+    """BASELINE.json configs[3] at config size: 16-DOF chain, 512 rollouts, forward + backward sweep, HBM roofline."""
+    d = _run("--workload", "adjoint", "--repeats", "2")
+    assert d["steps"] == 20 and d["config"]["batch_per_gpu"] == 512 and d["value"] > 0
+    assert d["config"]["all_finite"] and d["config"]["not_converged_trajectories"] == 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] <= 1 and r["kernel_ms"] > 0

@@ -375,3 +375,26 @@ def test_bdf1_steps_restart_the_bdf2_history(oracle_lib):
         assert _close(qg[b], qo, 1e-9, 1e-10), (b, _rel(qg[b], qo))
         assert _close(qdg[b], qdo, 1e-7, 1e-8), (b, _rel(qdg[b], qdo))
     sim.close()
+
+
+@pytest.mark.parametrize("name", ["0", "2", "3", "14", "chain8skew", "tree15", "chain32"])
+def test_compute_values_hook_matches_oracle(oracle_lib, name):
+    """rmx_eval_mfd = computeValues (driverRedMaxBDF1.m:190-243): M = J'MmJ, f = fr + J'(fm - Mm Jdot qdot), D = df/dqdot vs the
+    oracle's literal dense restatement (J, Jdot, the dJ/dq tensors), 1e-11 relative."""
+    from redmax_amd import BatchSim
+    sc = _scene(name)
+    sc.init()
+    B = 3
+    q, qd = syntheticStates(sc.nr, B, first=7)
+    s0, sd0 = sc.getQ()
+    q, qd = q + s0, qd + sd0
+    sim = BatchSim(sc, batch=B)
+    M, f, D = sim.eval_mfd(q, qd)
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        Mo, fo, _, _, Do = o.compute_values(deriv=True)
+        assert _rel(M[b], Mo) <= 1e-11, (name, b, _rel(M[b], Mo))
+        assert _rel(f[b], fo) <= 1e-11, (name, b, _rel(f[b], fo))
+        assert _rel(D[b], Do) <= 1e-11 or np.linalg.norm(D[b] - Do) <= 1e-11 * np.linalg.norm(Mo), (name, b, _rel(D[b], Do))
+    sim.close()

@@ -1,0 +1,61 @@
+"""Reduced slices of the two long-running checks that used to be scripts only (tests/soak_parity.py, tests/fuzz_more.py):
+
+* soak: 256 of the 1024 benchmark rollouts (every 4th global index, incl. the deterministic rollout 0) x 25 BDF1 steps at the
+  benchmark's Newton tolerance against the CPU oracle (OpenMP over the host cores), with the PER-ROLLOUT NEWTON ITERATION COUNTS
+  compared - SURVEY.md §8(d) expects identical counts on >= 99 % of trajectory-steps.  tol = 1e-8 is above the fp64 noise floor of
+  |g| on this chain, so the counts are reproducible, which they are not at the reference's 1e-9.
+* fuzz: 36 more random trees (30 small, 6 with 33..62 nodes) through test_gpu_fuzz's parity check; besides parity this keeps the
+  DPP-fused elimination (fmsub_rowbcast: a DPP read right after a VALU write of the same register sees the old value) exercised
+  on many matrix sizes and pivot patterns.
+The full-size versions remain runnable: python tests/soak_parity.py, python tests/fuzz_more.py."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_chain32_soak_slice_with_newton_counts(oracle_lib):
+    from redmax_amd import BatchSim, sceneChain, syntheticStates
+    sc = sceneChain(32)
+    sc.init()
+    B, K, h, tol = 256, 25, 1e-2, 1e-8
+    q = np.empty((B, 32))
+    qd = np.empty((B, 32))
+    for i in range(B):
+        q[i], qd[i] = (a[0] for a in syntheticStates(32, 1, first=4 * i))
+    sim = BatchSim(sc, batch=B)
+    sim.opts.tol = tol
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(K, h=h, stats=True)
+    qg, qdg = sim.get_state()
+    sim.close()
+    oracle_lib.set_newton(tol=tol)
+    qc, qdc = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
+    cnt = oracle_lib.batch_step_bdf1(sc.desc(), qc, qdc, h, K, nthreads=os.cpu_count(), counters=True)
+    oracle_lib.set_newton()
+    eq = np.linalg.norm(qg - qc, axis=1) / np.linalg.norm(qc, axis=1)
+    ed = np.linalg.norm(qdg - qdc, axis=1) / np.maximum(np.linalg.norm(qdc, axis=1), 1e-30)
+    assert (out["status"] & 15 == 0).all() and (cnt["bad"] == 0).all()
+    assert eq.max() <= 1e-10 and ed.max() <= 1e-8, (eq.max(), ed.max())
+    same = out["newton_iters"] == cnt["newton_iters"]
+    print("newton counts: %d/%d rollouts identical over %d steps; gpu %d vs oracle %d iterations; halvings gpu %d oracle %d" % (
+        same.sum(), B, K, out["newton_iters"].sum(), cnt["newton_iters"].sum(), out["ls_halvings"].sum(), cnt["ls_halvings"].sum()))
+    assert same.mean() >= 0.99, list(zip(np.nonzero(~same)[0], out["newton_iters"][~same], cnt["newton_iters"][~same]))
+    assert abs(int(out["newton_iters"].sum()) - int(cnt["newton_iters"].sum())) <= 0.002 * cnt["newton_iters"].sum()
+
+
+@pytest.mark.parametrize("seed", list(range(300, 330)) + list(range(600, 606)))
+def test_random_tree_matches_oracle_extended(oracle_lib, seed, monkeypatch):
+    import test_gpu_fuzz as tf
+    from redmax_amd._abi import RedMaxHipError
+    if seed >= 600:       # the suite's convention for the 33..62-node trees
+        orig = tf._random_scene
+        monkeypatch.setattr(tf, "_random_scene", lambda s, contact=False, big=False: orig(s, contact=contact, big=True))
+    try:
+        tf.test_random_tree_matches_oracle(oracle_lib, seed)
+    except RedMaxHipError as e:      # the generator's node estimate can overshoot the 64-node limit of one wavefront
+        if "the limit is 64" not in str(e):
+            raise
+        pytest.skip("random scene needs more than 64 nodes")
