@@ -44,7 +44,7 @@ def test_default_workload_line():
     tf = d["cpu_baseline_tensor_free"]
     assert tf["value"] > c["value"] and tf["q_l2_relerr_gpu_vs_this_max"] < 1e-8
     n = d["newton_count_agreement"]
-    assert n["vs_oracle"]["frac"] >= 0.9 and n["vs_tensor_free"]["frac"] >= 0.9
+    assert n["vs_oracle"]["frac"] >= 0.99 and n["vs_tensor_free"]["frac"] >= 0.99          # per trajectory-step
     assert d["repeat"]["launches"] >= 6 and d["repeat"]["kernel_ms_min"] <= d["repeat"]["kernel_ms_median"]
     assert "strong_scaling" not in d          # one rank: weak and strong coincide
 
