@@ -248,6 +248,11 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
         double* Dk = a.Ds + ((size_t)traj * a.nsteps + (s - 1)) * nn;
         double Jw[3] = {0.0, 0.0, 0.0}, Jv[3] = {0.0, 0.0, 0.0};   // J(idxM_body, this joint) of the last evaluated iterate
         int iter = 1;
+        // Scene.saveHistory keeps H, M, D of the LAST evaluated iterate of the step (driverRedMaxAdjointBDF1.m:100, 127).  Up to 32
+        // nodes the three rows ride in registers and go to HBM once per step, after the Newton loop; larger trees (3 x 64 doubles
+        // per lane) store every iterate and the last store wins.
+        constexpr bool STORE_ONCE = NP <= 32;
+        double Hs[STORE_ONCE ? NP : 1], Ms[STORE_ONCE ? NP : 1], Dsv[STORE_ONCE ? NP : 1];
         while (true) {
             NodeOut e;
             double Hrow[NP];
@@ -256,7 +261,14 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
             {
                 double Mrow[NP], Drow[NP];
                 eval_MD<NP>(M, lane, fs, Mrow, Drow);
-                if (lane < n) {
+                if constexpr (STORE_ONCE) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        Hs[i] = Hrow[i];      // the solve below destroys Hrow
+                        Ms[i] = Mrow[i];
+                        Dsv[i] = Drow[i];
+                    }
+                } else if (lane < n) {
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
                         if (i < n) {
@@ -290,6 +302,17 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
             if (sqrt(wave_sum(e.g * e.g)) < o.tol) break;                 // :135-138
             if (iter >= o.iterMax) { status |= 2; break; }                // :139-142
             ++iter;
+        }
+        if constexpr (STORE_ONCE) {
+            if (lane < n) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    if (i < n) {
+                        Hk[(size_t)i * n + lane] = Hs[i];
+                        Mk[(size_t)i * n + lane] = Ms[i];
+                        Dk[(size_t)i * n + lane] = Dsv[i];
+                    }
+            }
         }
         qd = (x - q0) / h;
         q = x;

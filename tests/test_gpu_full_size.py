@@ -1,0 +1,128 @@
+"""BASELINE.json configs[2], [3] and [4] at their FULL per-GPU sizes through size-independent properties (the oracle cannot follow at
+these sizes in test time), plus an oracle comparison on a small sample of the same batch.
+
+  configs[2]  64-joint revolute/prismatic tree, BDF1, 512 rollouts per GPU (4096 / 8)
+  configs[3]  adjoint BDF1 forward + backward, 16-DOF chain, 512 rollouts
+  configs[4]  32-link chain over frictional ground, BDF2, 1024 rollouts
+Properties: every rollout converges (or fails exactly where the reference algorithm does), finite results, shard invariance (a
+rollout's result does not depend on its batch neighbours: bit-identical when a slice is recomputed alone), determinism, and for
+the adjoint the finite-difference identity of the reference's own testGrad (driverRedMaxAdjointBDF1.m:46-61) on the device."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _tree_states(sc, B):
+    qs, _ = sc.getQ()
+    q0, qd0 = np.empty((B, sc.nr)), np.empty((B, sc.nr))
+    for i in range(B):
+        rng = np.random.default_rng(20240 + i)
+        q0[i] = qs + rng.uniform(-0.05, 0.05, sc.nr)
+        qd0[i] = rng.uniform(-0.1, 0.1, sc.nr)
+    return q0, qd0
+
+
+def test_config3_tree64_full_size(oracle_lib):
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneTree
+    sc = sceneTree(64)
+    sc.init()
+    B, K = 512, 10
+    q, qd = _tree_states(sc, B)
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(K, h=1e-2, stats=True, history=True)          # the reference's own Newton constants (tol = 1e-9)
+    qa, qda = sim.get_state()
+    assert (out["status"] & 15 == 0).all() and np.isfinite(qa).all() and np.isfinite(qda).all()
+    T, V = sim.energy()
+    assert np.allclose(T, out["T"][-1], rtol=1e-12, atol=1e-9) and np.allclose(V, out["V"][-1], rtol=1e-12, atol=1e-9)
+    sub = BatchSim(sc, batch=64)
+    sub.set_state(q[128:192], qd[128:192])
+    sub.step_bdf1(K, h=1e-2)
+    qs, qds = sub.get_state()
+    assert np.array_equal(qs, qa[128:192]) and np.array_equal(qds, qda[128:192])
+    sim.set_state(q, qd)
+    sim.step_bdf1(K, h=1e-2)
+    qb, _ = sim.get_state()
+    assert np.array_equal(qa, qb)
+    for b in (0, 77, 300, 511):                                          # a sample of the same batch against the oracle
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        st = o.step_bdf1(1e-2, K)
+        qo, qdo = o.get_state()
+        assert _rel(qa[b], qo) <= 1e-8 and _rel(qda[b], qdo) <= 1e-6, (b, _rel(qa[b], qo))
+        assert out["newton_iters"][b] == st.newton_iters, (b, out["newton_iters"][b], st.newton_iters)
+
+
+def test_config4_adjoint_full_size(oracle_lib):
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneAdjointChain
+    sc = sceneAdjointChain(16)
+    sc.init()
+    B, K = 512, 20          # the longest round horizon on which the reference's line-search-free Newton converges on every step
+    rng = np.random.default_rng(20240)
+    p = 1e-1 * rng.standard_normal((B, sc.nr))
+    p[1] = p[0]             # two rollouts with the same parameters
+    task = dict(sc.task, t=K * sc.h)
+    q0, qd0 = sc.getQ()
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q0[None, :], qd0[None, :])
+    P, dPdp, info = sim.adjoint_bdf1(K, sc.h, task, p, stats=True)
+    assert (info["status"] == 0).all() and np.isfinite(P).all() and np.isfinite(dPdp).all()
+    assert P[0] == P[1] and np.array_equal(dPdp[0], dPdp[1])             # no cross-talk between rollouts
+    sub = BatchSim(sc, batch=32)
+    sub.set_state(q0[None, :], qd0[None, :])
+    Ps, dPs, _ = sub.adjoint_bdf1(K, sc.h, task, p[200:232])
+    assert np.array_equal(Ps, P[200:232]) and np.array_equal(dPs, dPdp[200:232])      # shard invariance
+    for b in (0, 123, 511):                                              # sample vs the oracle's literal restatement
+        o = oracle_lib.Oracle(sc.desc())
+        Po, dPo, st = o.adjoint_bdf1(sc.h, K, task, p[b])
+        assert abs(P[b] - Po) <= 1e-9 * abs(Po) and _rel(dPdp[b], dPo) <= 1e-7, (b, P[b], Po)
+        assert info["newton_iters"][b] == st.newton_iters
+    # testGrad (driverRedMaxAdjointBDF1.m:46-61) on the device: central differences of P along 8 random directions, one per
+    # pair of rollouts of a single launch, against dPdp . direction
+    nd, eps = 8, 1e-5
+    d = rng.standard_normal((nd, sc.nr))
+    pp = np.repeat(p[:1], 2 * nd, axis=0)
+    pp[0::2] += eps * d
+    pp[1::2] -= eps * d
+    fd = BatchSim(sc, batch=2 * nd)
+    fd.set_state(q0[None, :], qd0[None, :])
+    Pf, _, _ = fd.adjoint_bdf1(K, sc.h, task, pp)
+    num = (Pf[0::2] - Pf[1::2]) / (2 * eps)
+    ana = d @ dPdp[0]
+    assert np.allclose(num, ana, rtol=2e-5, atol=1e-6 * np.abs(ana).max()), (num, ana)
+
+
+def test_config5_chain_ground_full_size(oracle_lib):
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainGround, syntheticStates
+    sc = sceneChainGround(32)
+    sc.init()
+    B, K = 1024, 40
+    q, qd = syntheticStates(sc.nr, B, sq=5e-4, sv=0.1)
+    q[0], qd[0] = sc.getQ()
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = sim.step_bdf2(K, h=sc.h, stats=True)
+    qa, qda = sim.get_state()
+    assert np.isfinite(qa).all() and np.isfinite(qda).all() and not (out["status"] & 5).any()      # nothing diverged, no NaN
+    sub = BatchSim(sc, batch=64)
+    sub.set_state(q[512:576], qd[512:576])
+    sub.step_bdf2(K, h=sc.h)
+    qs, qds = sub.get_state()
+    assert np.array_equal(qs, qa[512:576]) and np.array_equal(qds, qda[512:576])
+    for b in (1, 700):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        st = o.step_bdf2(sc.h, K)
+        qo, qdo = o.get_state()
+        if st.not_converged or st.diverged:
+            assert out["status"][b] & 3          # the reference algorithm fails on this rollout: so must we
+            continue
+        assert _rel(qa[b], qo) <= 1e-7, (b, _rel(qa[b], qo))
