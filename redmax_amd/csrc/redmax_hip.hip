@@ -308,6 +308,10 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     m->node_of_listing = pos;
     m->NP = n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64;
     m->smem_bytes = sizeof(double) * ((size_t)acc_doubles(n, m->NP) + (size_t)NCONST * cstride(m->NP));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_simd = 4 * prop.multiProcessorCount;
+    }
     if (hipSetDevice(device) != hipSuccess) { delete m; return fail(RMX_E_HIP, "hipSetDevice failed"); }
     const size_t nd = K.size() + sb.size() + I4.size() + prm.size();
     const size_t ni = type.size() + idx.size() + endd.size() + anc.size();

@@ -15,6 +15,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Synchronisation and LDS layout hooks.  The single-wave kernels (one 64-lane workgroup per trajectory) use the defaults: a
+// workgroup barrier (which the compiler reduces to the LDS wait for a one-wave workgroup) and the per-node constants right behind
+// the wave's scratch.  The two-wave step kernel (rmx_kernels_w2.hip) redefines both before including this header: its waves run
+// the evaluation stages independently on private scratch (wave-local ordering only) and share one copy of the constants.
+#ifndef RMX_SYNC
+#define RMX_SYNC() __syncthreads()
+#endif
+#ifndef RMX_CONSTS
+#define RMX_CONSTS(sAcc, n, NP) ((sAcc) + acc_doubles((n), (NP)))
+#endif
+
 namespace rmx {
 
 constexpr int MAXN = 64;          // nodes per tree handled by one wavefront
@@ -554,7 +565,7 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
 #pragma unroll
         for (int c = 0; c < NC; ++c) A[c] = v[c];
     }
-    __syncthreads();
+    RMX_SYNC();
     if constexpr (NP >= 32) {
         // two lanes per component (see eval_front_e2): lane c scans the upper half of the nodes, lane 32+c the lower half
         constexpr int HALF = NP / 2;
@@ -605,7 +616,7 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
         for (int jn = 0; jn < NP; ++jn)
             if (jn < n) sAcc[jn * ACC_STRIDE + lane] = a[jn];
     }
-    __syncthreads();
+    RMX_SYNC();
     {
         const double* A = sAcc + jj * ACC_STRIDE;
         const int en = (act && !M.is_chain) ? (int)cEnd[jj] : n;
@@ -613,7 +624,7 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
 #pragma unroll
         for (int c = 0; c < NC; ++c) v[c] = A[c] - E[c];
     }
-    __syncthreads();
+    RMX_SYNC();
 }
 
 // FULL: accumulate the Hessian's subtree sums as well (28 numbers per body instead of 6).
@@ -631,7 +642,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     // resident wave parked at s_waitcnt (SQ_WAIT_ANY 31 % of wave cycles)
     constexpr int CS = cstride(NP);
     const int jc = (CS > NP && lane >= NP) ? NP : lane;      // this lane's column of constants (idle column beyond NP)
-    const double* cK = sAcc + acc_doubles(n, NP);
+    const double* cK = RMX_CONSTS(sAcc, n, NP);
     const double* cSb = cK + 36 * CS;
     const double* cI4 = cSb + 6 * CS;
     const double* cPrm = cI4 + 4 * CS;
@@ -897,7 +908,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
 #pragma unroll
             for (int c = 0; c < NS; ++c) A[c] = S[c];
         }
-        __syncthreads();
+        RMX_SYNC();
         RMX_STAMP(5)
         if constexpr (NP == 32 || NP == 64) {
             // the scan needs NS <= 28 lanes, one per component: every component gets TWO lanes instead, lane c over the upper
@@ -952,7 +963,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
                 if (jn < n) sAcc[jn * ACC_STRIDE + lane] = a[jn];
         }
         RMX_STAMP(6)
-        __syncthreads();
+        RMX_SYNC();
         {
             const double* A = sAcc + jj * ACC_STRIDE;
 #pragma unroll
@@ -964,7 +975,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
                 for (int c = 0; c < NS; ++c) S[c] -= E[c];
             }
         }
-        __syncthreads();   // sAcc is rewritten by the next evaluation
+        RMX_SYNC();   // sAcc is rewritten by the next evaluation
     }
     RMX_STAMP(7)
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j   (Joint.computeForce Joint.m:437-456, evalBDF1 :180)
@@ -1105,9 +1116,12 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle node slots are the identity.
 // Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
-template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true>
-__device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
+// NW / W (trees of more than 32 nodes only): the columns are dealt out to NW wavefronts of the workgroup, this one computes
+// columns i = NW t + W into Hrow[t] (the two-wave step kernel, k_step_bdf1_w2); NW = 1 is the whole row.
+template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true, int NW = 1, int W = 0>
+__device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP / NW],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0) {
+    static_assert(NW == 1 || NP > 32, "column split: 64-lane trees only");
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr int CS = cstride(NP);
     const double eta = fs.eta, e2 = eta * eta;
@@ -1128,7 +1142,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
         for (int c = 0; c < 6; ++c) cxy[c] = cxr2[c] = cxr3[c] = 0.0;
         if (fs.touched) {
-            const double* cEnd = sAcc + acc_doubles(M.n, NP) + (NCONST - 5) * CS;
+            const double* cEnd = RMX_CONSTS(sAcc, M.n, NP) + (NCONST - 5) * CS;
             const double* cCon = cEnd + CS;
             const bool con = act && cCon[jj] != 0.0;
             const double sd[3] = {cCon[CS + jj], cCon[2 * CS + jj], cCon[3 * CS + jj]};
@@ -1315,10 +1329,10 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             for (int c = 6; c < NCV; ++c) o[(R_CL + c - 6) * HM_OP_STRIDE] = cv[c];
             o[R_HD * HM_OP_STRIDE] = Hdiag;
         }
-        __syncthreads();
+        RMX_SYNC();
         typedef double v4d __attribute__((ext_vector_type(4)));
         const int g = lane >> 4, j = lane & 15;
-        const double* cRel = sAcc + acc_doubles(M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;   // relation bit masks of the nodes (as doubles)
+        const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;   // relation bit masks of the nodes (as doubles)
         v4d up[2][2], lw[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -1393,7 +1407,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                     hv[mb][nb][r] = (mb == nb && 4 * r + g == j) ? hd[nb] : v;
                 }
         }
-        __syncthreads();             // every lane is done with the operands: the same LDS now takes H, row-major
+        RMX_SYNC();             // every lane is done with the operands: the same LDS now takes H, row-major
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -1403,7 +1417,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         // the right-hand side of the solve travels with its row (column 32 of the staging rows is spare)
         if constexpr (!ZERO_IDLE && LU_SPLIT32)
             if (lane < NP) sOp[lane * HM_H_STRIDE + 32] = -g_stage;
-        __syncthreads();
+        RMX_SYNC();
         // guarded diagonal solve of n <= 32 (lu_solve_neg_diag32): it reads H out of the staging area in its own layout and
         // hands sAcc back to the front itself
         if constexpr (!ZERO_IDLE && LU_SPLIT32) return Hdiag;
@@ -1420,9 +1434,9 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                 Hrow[2 * c + 1] = (ZERO_IDLE && !lo_half) ? 0.0 : t[1];
             }
         }
-        __syncthreads();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+        RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
-        __syncthreads();
+        RMX_SYNC();
     } else if constexpr (NP == 32) {
         // Trees of at most 32 nodes leave lanes 32..63 idle: they mirror the row-side state of lanes 0..31 and take columns
         // 16..31 while lanes 0..31 take columns 0..15, so the column loop runs 16 times instead of 32.  The column vectors go
@@ -1432,7 +1446,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
             for (int c = 0; c < NCV; ++c) sAcc[lane * NCV + c] = cv[c];
         }
-        __syncthreads();
+        RMX_SYNC();
         const bool hi = lane >= 32;
         double rsw[3], rsv[3], q1t[3], q1f[3], q2w[3], q3w[3], x2v[3], x3v[3];
 #pragma unroll
@@ -1485,12 +1499,38 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             Hrow[i] = hi ? 0.0 : Hh[i];
             Hrow[16 + i] = hi ? 0.0 : t;
         }
-        __syncthreads();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+        RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
-        __syncthreads();
+        RMX_SYNC();
     } else {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
+        for (int t = 0; t < NP / NW; ++t) {
+            const int i = NW * t + W;
+            if constexpr (NW > 1) {
+                // two-wave kernel: the column in three batches of 6 broadcasts, one column at a time.  Left to itself the scheduler
+                // requests several columns' broadcasts at once, and beside the scalars that live across the Newton loop they no
+                // longer fit in the scalar registers: they would be parked in VGPR lanes (v_writelane / v_readlane + s_nop each)
+                static_assert(NW == 1 || !CT, "column split: plain models");
+                double Ca[6], Cb[6], Cc[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Ca[c] = readlane_d(cv[c], i);
+                const double up = sw[0] * Ca[0] + sw[1] * Ca[1] + sw[2] * Ca[2] + sv[0] * Ca[3] + sv[1] * Ca[4] + sv[2] * Ca[5];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Cb[c] = readlane_d(cv[6 + c], i);
+                double lo = r1t[0] * Cb[0] + r1t[1] * Cb[1] + r1t[2] * Cb[2] + r1f[0] * Cb[3] + r1f[1] * Cb[4] + r1f[2] * Cb[5];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Cc[c] = readlane_d(cv[12 + c], i);
+                lo = lo - (r2w[0] * Cc[0] + r2w[1] * Cc[1] + r2w[2] * Cc[2]) - (r3w[0] * Cc[3] + r3w[1] * Cc[4] + r3w[2] * Cc[5]);
+                const double mu = (double)(unsigned)((desc_m >> i) & 1ull);
+                const double ml = (double)(unsigned)((anc_m >> i) & 1ull);
+                const double hv = mu * up + ml * lo;
+                Hrow[t] = (i == lane) ? Hdiag : hv;
+                asm volatile("" : "+v"(Hrow[t]));      // the column's arithmetic stays here (it would otherwise sink to its first use in the solve, broadcasts and all)
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             double Ci[NCV];
 #pragma unroll
             for (int c = 0; c < NCV; ++c) Ci[c] = readlane_d(cv[c], i);
@@ -1503,7 +1543,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             const double mu = (double)(unsigned)((desc_m >> i) & 1ull);   // column node i is a strict descendant of this row's node
             const double ml = (double)(unsigned)((anc_m >> i) & 1ull);    // column node i is a strict ancestor
             const double hv = mu * up + ml * lo;
-            Hrow[i] = (i == lane) ? Hdiag : hv;
+            Hrow[t] = (i == lane) ? Hdiag : hv;
         }
     }
     RMX_STAMP(11)
@@ -1668,7 +1708,7 @@ __device__ __forceinline__ void sph_setup(const DevModel& M, double* __restrict_
             any = true;
         }
     }
-    if (any) __syncthreads();
+    if (any) RMX_SYNC();
 }
 // Joint.reparam -> JointSpherical.reparam_ (:63-102) for every spherical group of this trajectory, after setQ at the end of a step
 // (driverRedMaxBDF1.m:78, driverRedMaxBDF2.m:112).  q, qd: this lane's DOF of the new state; qp, qdp: of the previous step
@@ -1740,7 +1780,7 @@ __device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restric
             switched = true;
         }
     }
-    if (switched) __syncthreads();
+    if (switched) RMX_SYNC();
     return switched;
 }
 
@@ -1951,7 +1991,7 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
     double rinv = recip(piv);
     lu32_phase1<0>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pmin, piv, rinv, rinvs, jv);
     // the column quarters 16 + 4 r .. of both row sets go back to their rows; lane = row reads columns 16..31
-    __syncthreads();
+    RMX_SYNC();
     {
         v2d* wa = reinterpret_cast<v2d*>(sH + j * HM_H_STRIDE + 16 + 4 * r4);
         v2d* wb = reinterpret_cast<v2d*>(sH + (16 + j) * HM_H_STRIDE + 16 + 4 * r4);
@@ -1960,7 +2000,7 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
         wb[0] = v2d{BX[0], BX[1]};
         wb[1] = v2d{BX[2], BX[3]};
     }
-    __syncthreads();
+    RMX_SYNC();
     double Hrow[NP];
 #pragma unroll
     for (int c = 0; c < 16; ++c) Hrow[c] = A[c];         // rows 0..15 (lanes 0..15); never read on the other lanes
@@ -1987,9 +2027,9 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
         if (lv < k) b -= Hrow[k] * xk;
     }
     ok = !__any(lane < NP && !(gmax <= lim)) && (pmin > 0.0);
-    __syncthreads();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
+    RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
     if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
-    __syncthreads();
+    RMX_SYNC();
     return dx;
 }
 
@@ -2187,6 +2227,210 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
     const double r = newton_impl<NP, false, CT>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
     pivot_policy_update(piv);
     return r;
+}
+
+// ----------------------------------------------------------------------------- two wavefronts per trajectory (trees of 33..64 nodes)
+//
+// One wavefront per trajectory leaves SIMDs idle whenever a GPU holds fewer rollouts than it has SIMDs (BASELINE.json
+// configs[2]: 4096 rollouts over 8 GPUs = 512 per GPU on 1024 SIMDs), and for 64-row systems the instruction stream of one
+// Newton iteration is dominated by two loops over COLUMNS - the Hessian assembly (per column 36 v_readlane + 30 FMA) and the
+// elimination (per remaining column 2 v_readlane + 1 FMA) - whose columns are independent of each other.  The two-wave step
+// kernel (k_step_bdf1_w2) gives a trajectory a workgroup of two wavefronts, wave W owning the columns c = 2 t + W:
+//   * both waves run the front (kinematics, path / subtree sums, residual) REDUNDANTLY on private LDS scratch: same
+//     instructions on the same data, bit-identical results, so all Newton control flow agrees without any exchange;
+//   * each wave assembles its 32 columns of H (eval_hess<.., NW = 2, W>);
+//   * elimination: at pivot k the owner of column k forms the multipliers l = H(:,k) / H(k,k) and publishes them through LDS
+//     (one ds_write, one s_barrier, one ds_read for the other wave; double-buffered), then both waves update their own columns
+//     > k - the pivot row's entries of a wave's columns sit in lane k of that wave's own registers.  The right-hand side is
+//     carried by both waves (3 instructions a step).  The elimination is Gauss-Jordan (rows above the pivot are eliminated too,
+//     which costs no instruction in a lane = row layout: the FMAs run for all 64 lanes anyway), so there is no back substitution
+//     with its per-step hand-over between the waves: dx = b / pivot at the end, the reciprocals travel through LDS as well.
+// Pivots are taken on the diagonal under the same growth guard as lu_solve_neg_diag (multipliers of rows below the pivot on the
+// equilibrated matrix, positive pivots); when it trips, wave 0 alone redoes the solve with full partial pivoting (the
+// single-wave code) and hands dx to wave 1.  Steps that the pivot policy assigns to the pivot-only Newton run on wave 0 alone.
+constexpr int W2_XCH = 3 * MAXN + 8;      // LDS doubles of the exchange area: multipliers [2][MAXN], reciprocals [MAXN], flags / dx hand-over
+
+// Apply pivot P's multipliers l to this wave's columns t >= T0 (and to the right-hand side): the pivot row's entries are
+// broadcast out of lane P in batches ahead of their FMAs (see lu_solve_neg_diag); sched_barriers keep the scheduler from hoisting
+// later batches' broadcasts above earlier FMAs (it would run out of scalar registers and park them in VGPR lanes).
+template <int NP, int P, int T0>
+__device__ __forceinline__ void w2_apply_pivot(double (&Hh)[NP / 2], double& b, const double l) {
+    constexpr int BT = 4;
+#pragma unroll
+    for (int c0 = T0; c0 < NP / 2; c0 += BT) {
+        double pv[BT];
+#pragma unroll
+        for (int i = 0; i < BT; ++i) pv[i] = (c0 + i < NP / 2) ? readlane_d(Hh[c0 + i < NP / 2 ? c0 + i : NP / 2 - 1], P) : 0.0;
+        asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]));
+#pragma unroll
+        for (int i = 0; i < BT; ++i)
+            if (c0 + i < NP / 2) Hh[c0 + i] -= l * pv[i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    b -= l * readlane_d(b, P);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One pivot step of lu_gj_w2 with one step of look-ahead.  `lp` = multipliers of pivot K-1 when this wave received them from the
+// other one and has not applied them yet (it owns column K): it first brings column K alone up to date, forms and publishes the
+// multipliers of pivot K, and only then applies both pivots to its other columns - the other wave meanwhile does the same one step
+// later, so each wave's serial chain (LDS read, pivot broadcast, reciprocal, publish, barrier) runs under the other's bulk updates.
+// The steps are chained by template recursion (a 64-trip loop of this size is beyond what "#pragma unroll" unrolls completely,
+// and a rolled loop would turn the register array into a scratch array).
+template <int NP, int W, int K>
+__device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, double (&Hh)[NP / 2], double& b, double& gmax, double& pmin,
+                                              double lp, double* __restrict__ sL, double* __restrict__ sR) {
+    if constexpr (K < NP) {
+        constexpr int T = K >> 1;
+        if constexpr ((K & 1) == W) {    // this wave owns column K
+            if constexpr (K >= 1) {      // pivot K-1 (received) on column K only
+                Hh[T] -= lp * readlane_d(Hh[T], K - 1);
+            }
+            const double piv = readlane_d(Hh[T], K);
+            const double rinv = recip(piv);
+            const double lm = Hh[T] * rinv;
+            const double l = (lv != K) ? lm : 0.0;
+            gmax = fmax(gmax, (lv > K) ? Hh[T] * lm : 0.0);      // l^2 u_kk of the rows below the pivot
+            pmin = fmin(pmin, piv);
+            sL[(K & 1) * NP + lane] = l;
+            if (lv == K) sR[K] = rinv;
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            // bulk: pivot K-1, then pivot K, on the own columns right of K (the first one is t = T + 1) and on the right-hand side
+            if constexpr (K >= 1) w2_apply_pivot<NP, K - 1, T + 1>(Hh, b, lp);
+            w2_apply_pivot<NP, K, T + 1>(Hh, b, l);
+            lu_gj_w2_step<NP, W, K + 1>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
+        } else {                         // the other wave's column: take its multipliers; they are applied in the next step
+            __syncthreads();
+            const double l = sL[(K & 1) * NP + lane];
+            if constexpr (K + 1 == NP) {
+                b -= l * readlane_d(b, K);          // last pivot: no column of this wave is left, only the right-hand side
+            }
+            lu_gj_w2_step<NP, W, K + 1>(lane, lv, Hh, b, gmax, pmin, l, sL, sR);
+        }
+    }
+}
+
+template <int NP, int W>
+__device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2], const double g, const double diag_own,
+                                           double* __restrict__ sX, bool& ok) {
+    static_assert(NP == 64, "two-wave elimination: 64-lane trees");
+    double* sL = sX;                 // [2][NP] multipliers, buffer = pivot parity
+    double* sR = sX + 2 * NP;        // [NP] reciprocal pivots
+    double* sF = sX + 3 * NP;        // [2] guard verdict of each wave
+    double b = -g;
+    double gmax = 0.0, pmin = 1.0;
+    const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));     // keeps the lane compares local (see lu_solve_neg_diag)
+    lu_gj_w2_step<NP, W, 0>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
+    const bool mine = !__any(!(gmax <= lim)) && (pmin > 0.0);
+    if (lane == 0) sF[W] = mine ? 1.0 : 0.0;
+    __syncthreads();
+    ok = sF[0] != 0.0 && sF[1] != 0.0;
+    const double dx = b * sR[lane];
+    __syncthreads();                 // the exchange area is rewritten by the next solve
+    return dx;
+}
+
+// The rare single-wave detours of the two-wave kernel are real function calls (not inlined): inlined, their uniform values
+// (model constants, masks) stay resident in scalar registers across the whole Newton loop of wave 0 and the Hessian's column
+// broadcasts no longer fit beside them.
+template <int NP>
+__device__ __attribute__((noinline)) double w2_pivoted_solve(const DevModel& M, double* sAcc, const int lane, const double x, const double qA,
+                                                             const double qB, const double eta, const double g) {
+    double Hrow[NP];
+    FrontState fs;
+    NodeOut e2;
+    eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
+    eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
+    return lu_solve_neg<NP>(M.n, lane, Hrow, g);
+}
+
+// newton_impl<NP, false> for wave W of a two-wave workgroup.  sAcc: this wave's private front scratch; sX: the exchange area.
+template <int NP, int W, bool PROF = false>
+__device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o, double* sAcc, double* sX, const int lane, double x,
+                                            const double qA, const double qB, const double eta, NodeOut& last, int& iters, int& halvings,
+                                            int& status, PivotPolicy& piv, unsigned long long* prof = nullptr) {
+    double Hh[NP / 2];
+    FrontState fs;
+    NodeOut e;
+    unsigned long long t0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+    if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
+    int iter = 1;
+    double gcarry = -1.0;
+    while (true) {
+        const double hdiag = eval_hess<NP, false, false, true, 2, W>(M, lane, fs, Hh, nullptr, sAcc);
+        if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[1] += t1 - t0; t0 = t1; }
+        const NodeOut e0 = e;
+        last = e;
+        ++iters;
+        bool lu_ok;
+        double dx = lu_gj_w2<NP, W>(lane, Hh, e.g, hdiag, sX, lu_ok);
+        if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
+        if (lu_ok) {
+            piv.streak = 0;
+        } else {                     // growth guard tripped: wave 0 redoes this solve with partial pivoting, wave 1 takes its dx
+            ++piv.streak;
+            status |= 16;
+            if (W == 0) {
+                dx = w2_pivoted_solve<NP>(M, sAcc, lane, x, qA, qB, eta, e.g);
+                sX[lane] = dx;
+            }
+            __syncthreads();
+            if (W != 0) dx = sX[lane];
+            __syncthreads();
+        }
+        const double dxn2 = wave_sum(dx * dx);
+        if (!(dxn2 == dxn2)) {
+            status |= 4;
+            break;
+        }
+        if (sqrt(dxn2) > o.dxMax) {
+            status |= 1;
+            break;
+        }
+        double alpha = 1.0;
+        const double g0n2 = gcarry >= 0.0 ? gcarry : wave_sum(e.g * e.g);
+        const double f0 = 0.5 * g0n2;
+        const double x0 = x;
+        int iterLs = 1;
+        double gn2 = g0n2;
+        bool stalled = false;
+        while (true) {
+            x = x0 + alpha * dx;
+            if (__all(x == x0)) {
+                stalled = true;
+                iterLs = o.iterLsMax;
+                e = e0;
+                break;
+            }
+            if (PROF) t0 = __builtin_amdgcn_s_memtime();
+            eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+            if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
+            gn2 = wave_sum(e.g * e.g);
+            if (0.5 * gn2 < f0) break;
+            if (iterLs >= o.iterLsMax) break;
+            alpha *= 0.5;
+            ++iterLs;
+        }
+        last = e;
+        halvings += iterLs - 1;
+        if (stalled) {
+            if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+            break;
+        }
+        gcarry = gn2;
+        if (sqrt(gn2) < o.tol) break;
+        if (iter >= o.iterMax) {
+            status |= 2;
+            break;
+        }
+        ++iter;
+        if (PROF) t0 = __builtin_amdgcn_s_memtime();
+    }
+    return x;
 }
 
 }  // namespace rmx

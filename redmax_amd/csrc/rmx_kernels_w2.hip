@@ -1,0 +1,167 @@
+// rmx_kernels_w2.hip -- the two-wave BDF1 step kernel for trees of 33..64 nodes (rmx_device.h, "two wavefronts per trajectory").
+//
+// A trajectory gets a workgroup of TWO wavefronts; wave W owns the columns c = 2 t + W of the Hessian and of the elimination.
+// Chosen by the launcher when the batch leaves SIMDs idle (2 B <= number of SIMDs: BASELINE.json configs[2] puts 512 rollouts
+// on each GPU's 1024 SIMDs), see launch_step_w2_64 below.  LDS of a workgroup: [per-node constants, one copy][exchange
+// area][front scratch of wave 0][front scratch of wave 1].  Inside the evaluation stages the waves are independent (private
+// scratch), so those stages order their LDS traffic wave-locally; only the elimination's hand-overs use the workgroup barrier.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__device__ __forceinline__ double* rmx_smem_base() {
+    extern __shared__ __attribute__((aligned(16))) double rmx_smem[];
+    return rmx_smem;
+}
+// wave-local ordering of LDS traffic: wait for this wave's outstanding LDS operations (an LDS queue serves one wave in order), no s_barrier
+#define RMX_SYNC()                                                \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+    } while (0)
+#define RMX_CONSTS(sAcc, n, NP) (rmx_smem_base())
+
+#include "rmx_host.h"
+
+// pivot-only Newton of one step on wave 0 alone: a real call, see w2_pivoted_solve
+template <int NP>
+__device__ __attribute__((noinline)) double w2_pivot_only_newton(const DevModel& M, const DevOpts& o, double* sAcc, const int lane, const double xg,
+                                                                 const double q0, NodeOut& last, int& iters, int& halv, int& status, PivotPolicy& piv) {
+    return newton_impl<NP, true, false>(M, o, sAcc, nullptr, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
+}
+
+template <int NP, int W, bool PROF>
+__device__ __forceinline__ void step_bdf1_w2_body(const DevModel& M, const DevOpts& o, const StepArgs& a, double* sAcc, double* sX, unsigned long long* dprof) {
+    unsigned long long prof[3] = {0ull, 0ull, 0ull};
+    const int lane = threadIdx.x & 63, traj = blockIdx.x;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    int iters = 0, halv = 0, status = 0;
+    PivotPolicy piv;
+    for (int s = 0; s < a.nsteps; ++s) {       // simLoop (driverRedMaxBDF1.m:57-91), as k_step_bdf1
+        const double q0 = q, qd0 = qd;
+        const double xg = q0 + o.h * qd0;
+        NodeOut last;
+        double x;
+        if (o.lu_mode != 0 || piv.hold > 0) {  // pivot-only Newton (wave-uniform, same in both waves): wave 0 alone, the single-wave code
+            if (piv.hold > 0) --piv.hold;
+            if (W == 0) {
+                x = w2_pivot_only_newton<NP>(M, o, sAcc, lane, xg, q0, last, iters, halv, status, piv);
+                sX[lane] = x;
+            }
+            __syncthreads();
+            if (W != 0) x = sX[lane];
+            __syncthreads();
+        } else {
+            x = newton_w2<NP, W, PROF>(M, o, sAcc, sX, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, prof);
+            pivot_policy_update(piv);
+        }
+        qd = (x - q0) / o.h;
+        q = x;
+        if (W == 0) {
+            if (a.histT) {
+                const double T = wave_sum(last.eT), V = wave_sum(last.eV);
+                if (lane == 0) {
+                    a.histT[(size_t)s * a.B + traj] = T;
+                    a.histV[(size_t)s * a.B + traj] = V;
+                }
+            }
+            if (a.histQ && id >= 0) {
+                a.histQ[(size_t)s * a.B * M.nr + off] = q;
+                a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+            }
+        }
+    }
+    if (PROF && lane == 0) {
+        for (int c = 0; c < 3; ++c) dprof[(size_t)(2 * traj + W) * 4 + c] = prof[c];
+        dprof[(size_t)(2 * traj + W) * 4 + 3] = (unsigned long long)iters;
+    }
+    if (W == 0) {
+        if (id >= 0) {
+            a.q[off] = q;
+            a.qd[off] = qd;
+        }
+        if (lane == 0 && a.it) {
+            a.it[traj] += iters;
+            a.ls[traj] += halv;
+            a.status[traj] |= status;
+        }
+    }
+}
+
+template <int NP, bool PROF>
+__global__ void __launch_bounds__(128) k_step_bdf1_w2(const DevModel M, const DevOpts o, const StepArgs a, unsigned long long* dprof) {
+    double* smem = rmx_smem_base();
+    constexpr int CS = cstride(NP);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* sX = smem + NCONST * CS;
+    double* sAcc = sX + W2_XCH + w * acc_doubles(M.n, NP);
+    // per-node constants (the layout eval_front_e2 reads; see smem_setup in rmx_kernels.hip), staged by wave 0
+    if (threadIdx.x < CS) {
+        const int j = threadIdx.x;
+        const bool in = j < M.n;
+        double* c = smem;
+        for (int r = 0; r < 36; ++r) c[r * CS + j] = in ? M.K[r * MAXN + j] : ((r == 0 || r == 4 || r == 8) ? 1.0 : 0.0);
+        c += 36 * CS;
+        for (int r = 0; r < 6; ++r) c[r * CS + j] = in ? M.sb[r * MAXN + j] : 0.0;
+        c += 6 * CS;
+        for (int r = 0; r < 4; ++r) c[r * CS + j] = in ? M.I4[r * MAXN + j] : 0.0;
+        c += 4 * CS;
+        for (int r = 0; r < 8; ++r) c[r * CS + j] = in ? M.prm[r * MAXN + j] : 0.0;
+        c += 8 * CS;
+        c[j] = in ? (double)M.type[j] : 0.0;
+        c += CS;
+        c[j] = in ? __longlong_as_double((long long)M.rel[j]) : 0.0;
+        c[CS + j] = in ? __longlong_as_double((long long)M.rel[MAXN + j]) : 0.0;
+        c += 2 * CS;
+        for (int r = 0; r < MAXROUNDS; ++r) c[r * CS + j] = in ? (double)M.anc[r * MAXN + j] : -1.0;
+        c += MAXROUNDS * CS;
+        c[j] = in ? (double)M.end[j] : (double)M.n;
+        c += CS;
+        for (int r = 0; r < 4; ++r) c[r * CS + j] = 0.0;
+    }
+    if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;     // zero row n of this wave's scratch (end-of-tree suffix)
+    __syncthreads();
+    if (w == 0) step_bdf1_w2_body<NP, 0, PROF>(M, o, a, sAcc, sX, dprof);
+    else step_bdf1_w2_body<NP, 1, PROF>(M, o, a, sAcc, sX, dprof);
+}
+
+size_t rmx_w2_smem_bytes(const rmx_model* m) {
+    return sizeof(double) * ((size_t)NCONST * cstride(64) + W2_XCH + 2 * (size_t)acc_doubles(m->n, 64));
+}
+
+void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(128);
+    const size_t bytes = rmx_w2_smem_bytes(m);
+    static bool raised = false;
+    if (!raised) {       // 64 KiB+ of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_bdf1_w2<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_bdf1_w2<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    if (getenv("RMX_W2_PROF")) {   // development aid: shader-clock cycles of (front, Hessian, elimination) per wave, printed to stderr
+        unsigned long long* d = nullptr;
+        const size_t nb = sizeof(unsigned long long) * 8 * (size_t)b->B;
+        if (hipMalloc((void**)&d, nb) != hipSuccess) return;
+        (void)hipMemsetAsync(d, 0, nb, b->stream);
+        k_step_bdf1_w2<64, true><<<grid, block, bytes, b->stream>>>(m->dm, o, a, d);
+        std::vector<unsigned long long> h(8 * (size_t)b->B);
+        (void)hipMemcpyAsync(h.data(), d, nb, hipMemcpyDeviceToHost, b->stream);
+        (void)hipStreamSynchronize(b->stream);
+        (void)hipFree(d);
+        double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int t = 0; t < b->B; ++t)
+            for (int w = 0; w < 2; ++w)
+                for (int c = 0; c < 4; ++c) acc[w][c] += (double)h[(size_t)(2 * t + w) * 4 + c];
+        for (int w = 0; w < 2; ++w)
+            fprintf(stderr, "w2 prof wave %d: per Newton iteration front %.0f  hess %.0f  elimination %.0f cycles (%.0f iterations per rollout)\n", w,
+                    acc[w][0] / acc[w][3], acc[w][1] / acc[w][3], acc[w][2] / acc[w][3], acc[w][3] / b->B);
+        return;
+    }
+    k_step_bdf1_w2<64, false><<<grid, block, bytes, b->stream>>>(m->dm, o, a, nullptr);
+}

@@ -3,13 +3,16 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from redmax_amd import BatchSim, sceneChain, syntheticStates  # noqa: E402
+import numpy as np  # noqa: E402
+from redmax_amd import BatchSim, sceneChain, sceneTree, syntheticStates  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32          # negative: the |n|-joint tree of BASELINE.json configs[2]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-sc = sceneChain(n)
+sc = sceneChain(n) if n > 0 else sceneTree(-n)
 sc.init()
 q, qd = syntheticStates(sc.nr, B)
+if n < 0:
+    q = q * 0.5 + sc.getQ()[0]
 sim = BatchSim(sc, batch=B)
 sim.set_state(q, qd)
 sim.step_bdf1(10, h=1e-2)
