@@ -42,12 +42,27 @@ constexpr int SPH_ROWS = 42;      // per-node constants that depend on a spheric
 constexpr int HM_OP_STRIDE = 33;  // MFMA Hessian (NP = 32): operand rows [k][node], odd stride in doubles
 constexpr int HM_ROWS = 57;       // RU 8, RL 12|20, CU 8, CL 12|20, Hdiag 1 (|: with ground contact)
 constexpr int HM_H_STRIDE = 34;   // H staged row-major [32][34] for the hand-over to row-per-lane (16-byte aligned rows)
+// two-wave kernel (NP = 64): each wave stages the operands of ITS 64 x 32 half of H: rows RU 6, RL 12, CU 6, CL 12, Hdiag 1 of
+// [k][node] with stride 65, then its half of H row-major [64][34]; the front's scratch shares the area
+constexpr int W2_OP_STRIDE = 65, W2_OP_ROWS = 37;
+__host__ __device__ constexpr int w2_acc_doubles(const int n) {
+    const int a = (n + 1) * ACC_STRIDE, b = W2_OP_ROWS * W2_OP_STRIDE, c = MAXN * HM_H_STRIDE;
+    return (a > b ? a : b) > c ? (a > b ? a : b) : c;
+}
 __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
     const int a = (n + 1) * ACC_STRIDE;
     const int b = NP == 32 ? HM_ROWS * HM_OP_STRIDE : 0;     // 1881 doubles; also covers H: 32*34 = 1088
     return a > b ? a : b;
 }
 constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matrix cores (false: half-wave split of the column loop)
+#ifndef RMX_W2_HESS_MFMA
+#define RMX_W2_HESS_MFMA 1
+#endif
+#ifndef RMX_W2_TAIL32
+#define RMX_W2_TAIL32 1
+#endif
+constexpr bool W2_TAIL32 = RMX_W2_TAIL32 != 0;         // two-wave kernel: the trailing 32 x 32 Schur complement through the one-wave DPP-fused solver
+constexpr bool W2_HESS_MFMA = RMX_W2_HESS_MFMA != 0;   // two-wave kernel: each wave's 64 x 32 half of H on the matrix cores (0: v_readlane column loop)
 constexpr bool LU_DPP_TAIL = true;                      // guarded LU: last 16 pivots with the broadcast fused into the FMA (DPP)
 constexpr bool LU_SPLIT32 = HESS_MFMA && LU_DPP_TAIL;   // n <= 32: pivots 0..15 in the column-split layout of lu_solve_neg_diag32
 // Column stride of the per-node constants in LDS.  Trees padded to fewer than 64 lanes get one extra "idle" column (index NP):
@@ -1502,6 +1517,129 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
         RMX_SYNC();
+    } else if constexpr (NW == 2 && W2_HESS_MFMA) {
+        // Two-wave kernel, 64 rows: this wave's half of H (all 64 rows x its 32 columns i = 2 t + W) on the fp64 matrix cores,
+        // as for n <= 32 above: H(a,i) = [a strict ancestor of i] RU_a.CU_i + [a strict descendant of i] RL_a.CL_i with
+        // RU = s (6), CU = y - z (6), RL = (r1, -r2w, -r3w) (12), CL = (m1, m2w, sw) (12).  4 x 2 tiles of 16 x 16; in depth-first
+        // numbering an ancestor has the smaller index, so 2 of the 8 UP tiles and 2 of the 8 LO tiles are empty: 6 x 2 + 6 x 3 = 30
+        // v_mfma_f64_16x16x4_f64 instead of 32 columns x (36 v_readlane + 30 FMA).  Operands through this wave's own LDS scratch
+        // in [k][node] order; results masked per lane with the relation bits of its two column nodes and handed to row-per-lane
+        // (Hrow[t] = H(lane, 2 t + W)) through the same scratch.
+        static_assert(NP == 64 && !CT, "two-wave MFMA Hessian: 64-lane plain models");
+        constexpr int ST = W2_OP_STRIDE;
+        constexpr int R_RU = 0, R_RL = 6, R_CU = 18, R_CL = 24, R_HD = 36;
+        double* sOp = sAcc;
+        {
+            double* o = sOp + lane;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[(R_RU + c) * ST] = sw[c];
+                o[(R_RU + 3 + c) * ST] = sv[c];
+                o[(R_RL + c) * ST] = r1t[c];
+                o[(R_RL + 3 + c) * ST] = r1f[c];
+                o[(R_RL + 6 + c) * ST] = -r2w[c];
+                o[(R_RL + 9 + c) * ST] = -r3w[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[(R_CU + c) * ST] = cv[c];
+#pragma unroll
+            for (int c = 6; c < 18; ++c) o[(R_CL + c - 6) * ST] = cv[c];
+            o[R_HD * ST] = Hdiag;
+        }
+        RMX_SYNC();
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int g = lane >> 4, j = lane & 15;
+        constexpr int CSW = cstride(NP);
+        const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CSW;   // relation bit masks of the nodes (as doubles)
+        v4d up[4][2], lw[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                up[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
+                lw[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
+            }
+        // tile (mb, nb): rows 16 mb .. +15, column nodes 32 nb + W .. 32 nb + 30 + W.  UP needs a row below some column
+        // (16 mb < 32 nb + 31), LO a row above some column (16 mb + 15 > 32 nb)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {       // UP: K = 6, padded to 8 by zero operands on the lanes with k = 6, 7
+            double a[4], b[2];
+            const bool kon = 4 * kk + g < 6;
+            const int kr = kon ? 4 * kk + g : 0;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a[mb] = kon ? sOp[(R_RU + kr) * ST + 16 * mb + j] : 0.0;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) b[nb] = kon ? sOp[(R_CU + kr) * ST + 32 * nb + 2 * j + W] : 0.0;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    if (16 * mb < 32 * nb + 31) up[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], up[mb][nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {       // LO: K = 12
+            double a[4], b[2];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) a[mb] = sOp[(R_RL + 4 * kk + g) * ST + 16 * mb + j];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) b[nb] = sOp[(R_CL + 4 * kk + g) * ST + 32 * nb + 2 * j + W];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    if (16 * mb + 15 > 32 * nb) lw[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], lw[mb][nb], 0, 0, 0);
+        }
+        // relation bits of this lane's two column nodes i = 32 nb + 2 j + W: bit a of its ancestor mask -> UP applies to row a,
+        // of its descendant mask -> LO applies; rows a = 16 mb + 4 r + g: low word for mb < 2, high word otherwise
+        unsigned amlo[2], amhi[2], dmlo[2], dmhi[2];
+        double hd[2];
+        int icol[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            icol[nb] = 32 * nb + 2 * j + W;
+            const unsigned long long am = (unsigned long long)__double_as_longlong(cRel[icol[nb]]) >> g;
+            const unsigned long long dm = (unsigned long long)__double_as_longlong(cRel[CSW + icol[nb]]) >> g;
+            amlo[nb] = (unsigned)am;
+            amhi[nb] = (unsigned)(am >> 32);
+            dmlo[nb] = (unsigned)dm;
+            dmhi[nb] = (unsigned)(dm >> 32);
+            hd[nb] = sOp[R_HD * ST + icol[nb]];
+        }
+        double hv[4][2][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int sh = (16 * mb + 4 * r) & 31;
+                    const unsigned aw = mb < 2 ? amlo[nb] : amhi[nb], dw = mb < 2 ? dmlo[nb] : dmhi[nb];
+                    double v = 0.0;
+                    if (16 * mb < 32 * nb + 31) v = (double)((aw >> sh) & 1u) * up[mb][nb][r];
+                    if (16 * mb + 15 > 32 * nb) v += (double)((dw >> sh) & 1u) * lw[mb][nb][r];
+                    hv[mb][nb][r] = (16 * mb + 4 * r + g == icol[nb]) ? hd[nb] : v;
+                }
+        RMX_SYNC();                  // every lane is done with the operands: the same scratch now takes H, row-major [64][34]
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sOp[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
+        RMX_SYNC();
+        {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d* hr = reinterpret_cast<const v2d*>(sOp + lane * HM_H_STRIDE);   // rows are 16-byte aligned
+#pragma unroll
+            for (int c = 0; c < NP / 4; ++c) {
+                const v2d t = hr[c];
+                Hrow[2 * c] = t[0];
+                Hrow[2 * c + 1] = t[1];
+            }
+        }
+        RMX_SYNC();                  // the scratch goes back to the front, whose subtree scan relies on a zero row n
+        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+        RMX_SYNC();
     } else {
 #pragma unroll
         for (int t = 0; t < NP / NW; ++t) {
@@ -2277,10 +2415,10 @@ __device__ __forceinline__ void w2_apply_pivot(double (&Hh)[NP / 2], double& b, 
 // later, so each wave's serial chain (LDS read, pivot broadcast, reciprocal, publish, barrier) runs under the other's bulk updates.
 // The steps are chained by template recursion (a 64-trip loop of this size is beyond what "#pragma unroll" unrolls completely,
 // and a rolled loop would turn the register array into a scratch array).
-template <int NP, int W, int K>
+template <int NP, int W, int K, int KEND>
 __device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, double (&Hh)[NP / 2], double& b, double& gmax, double& pmin,
                                               double lp, double* __restrict__ sL, double* __restrict__ sR) {
-    if constexpr (K < NP) {
+    if constexpr (K < KEND) {
         constexpr int T = K >> 1;
         if constexpr ((K & 1) == W) {    // this wave owns column K
             if constexpr (K >= 1) {      // pivot K-1 (received) on column K only
@@ -2299,23 +2437,32 @@ __device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, doub
             // bulk: pivot K-1, then pivot K, on the own columns right of K (the first one is t = T + 1) and on the right-hand side
             if constexpr (K >= 1) w2_apply_pivot<NP, K - 1, T + 1>(Hh, b, lp);
             w2_apply_pivot<NP, K, T + 1>(Hh, b, l);
-            lu_gj_w2_step<NP, W, K + 1>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
+            lu_gj_w2_step<NP, W, K + 1, KEND>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
         } else {                         // the other wave's column: take its multipliers; they are applied in the next step
             __syncthreads();
             const double l = sL[(K & 1) * NP + lane];
-            if constexpr (K + 1 == NP) {
-                b -= l * readlane_d(b, K);          // last pivot: no column of this wave is left, only the right-hand side
+            if constexpr (K + 1 == KEND) {      // last two-wave pivot: nobody owns a "next step", apply it now
+                w2_apply_pivot<NP, K, ((K - W + 2) >> 1)>(Hh, b, l);
             }
-            lu_gj_w2_step<NP, W, K + 1>(lane, lv, Hh, b, gmax, pmin, l, sL, sR);
+            lu_gj_w2_step<NP, W, K + 1, KEND>(lane, lv, Hh, b, gmax, pmin, l, sL, sR);
         }
     }
 }
 
+// dx = -H\g for wave W of a two-wave workgroup.  Pivots 0 .. 31 as above (two-wave Gauss-Jordan).  What is left then is
+//     [ D1  U12 ] [x1]   [b1]        D1 diagonal (rows 0..31), S the 32 x 32 Schur complement (rows / columns 32..63):
+//     [ 0   S   ] [x2] = [b2]
+// the late pivots of a two-wave elimination are bound by the hand-over chain (few columns left to update, still one LDS round
+// trip and one reciprocal chain per pivot), and a 32 x 32 system is exactly what the one-wave DPP-fused solver is built for. Both
+// waves copy their 16 columns of S into BOTH waves' scratch, each solves S x2 = b2 redundantly with lu_solve_neg_diag32 (same
+// code, same data, bit-identical x2: 7 k cycles instead of 32 more hand-overs), then x1 = D1^-1 (b1 - U12 x2) with each wave
+// summing over its own 16 columns of U12 and the two partial sums added in a fixed order on both sides.
 template <int NP, int W>
-__device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2], const double g, const double diag_own,
-                                           double* __restrict__ sX, bool& ok) {
+__device__ __forceinline__ double lu_gj_w2(const int n, const int lane, double (&Hh)[NP / 2], const double g, const double diag_own,
+                                           double* __restrict__ sX, double* __restrict__ sAcc, bool& ok) {
     static_assert(NP == 64, "two-wave elimination: 64-lane trees");
-    double* sL = sX;                 // [2][NP] multipliers, buffer = pivot parity
+    constexpr int KEND = W2_TAIL32 ? 32 : NP;
+    double* sL = sX;                 // [2][NP] multipliers, buffer = pivot parity; later the two partial sums of U12 x2
     double* sR = sX + 2 * NP;        // [NP] reciprocal pivots
     double* sF = sX + 3 * NP;        // [2] guard verdict of each wave
     double b = -g;
@@ -2323,12 +2470,48 @@ __device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2],
     const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
     int lv = lane;
     asm volatile("" : "+v"(lv));     // keeps the lane compares local (see lu_solve_neg_diag)
-    lu_gj_w2_step<NP, W, 0>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
+    lu_gj_w2_step<NP, W, 0, KEND>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
     const bool mine = !__any(!(gmax <= lim)) && (pmin > 0.0);
     if (lane == 0) sF[W] = mine ? 1.0 : 0.0;
-    __syncthreads();
-    ok = sF[0] != 0.0 && sF[1] != 0.0;
-    const double dx = b * sR[lane];
+    double dx;
+    if constexpr (W2_TAIL32) {
+        // S and b2 into both private scratch areas, row-major [32][HM_H_STRIDE], right-hand side in column 32 (what the MFMA
+        // Hessian of the 32-lane kernels leaves for lu_solve_neg_diag32)
+        double* sMine = sAcc;
+        double* sOther = (W == 0) ? sAcc + w2_acc_doubles(n) : sAcc - w2_acc_doubles(n);
+        if (lane >= 32) {
+            const int r = lane - 32;
+#pragma unroll
+            for (int t = 16; t < 32; ++t) {
+                sMine[r * HM_H_STRIDE + 2 * t + W - 32] = Hh[t];
+                sOther[r * HM_H_STRIDE + 2 * t + W - 32] = Hh[t];
+            }
+            sMine[r * HM_H_STRIDE + 32] = b;
+        }
+        __syncthreads();
+        bool ok32;
+        const double x2 = lu_solve_neg_diag32(n, lane, sAcc, 0.0, ok32);      // lanes 0..31: x of rows 32 + lane
+        double p = 0.0;
+#pragma unroll
+        for (int t0 = 16; t0 < 32; t0 += 4) {
+            double xv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = readlane_d(x2, 2 * (t0 + i) + W - 32);
+            asm volatile("" : "+s"(xv[0]), "+s"(xv[1]), "+s"(xv[2]), "+s"(xv[3]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p += Hh[t0 + i] * xv[i];
+        }
+        sL[W * NP + lane] = p;
+        __syncthreads();
+        ok = sF[0] != 0.0 && sF[1] != 0.0 && ok32;
+        const double x1 = (b - (sL[lane] + sL[NP + lane])) * sR[lane & 31];
+        const double xhi = dup_lo(x2);      // lanes >= 32 receive lane - 32
+        dx = lane < 32 ? x1 : xhi;
+    } else {
+        __syncthreads();
+        ok = sF[0] != 0.0 && sF[1] != 0.0;
+        dx = b * sR[lane];
+    }
     __syncthreads();                 // the exchange area is rewritten by the next solve
     return dx;
 }
@@ -2367,7 +2550,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
         last = e;
         ++iters;
         bool lu_ok;
-        double dx = lu_gj_w2<NP, W>(lane, Hh, e.g, hdiag, sX, lu_ok);
+        double dx = lu_gj_w2<NP, W>(M.n, lane, Hh, e.g, hdiag, sX, sAcc, lu_ok);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
         if (lu_ok) {
             piv.streak = 0;

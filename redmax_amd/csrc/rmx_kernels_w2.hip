@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(128) k_step_bdf1_w2(const DevModel M, const De
     constexpr int CS = cstride(NP);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* sX = smem + NCONST * CS;
-    double* sAcc = sX + W2_XCH + w * acc_doubles(M.n, NP);
+    double* sAcc = sX + W2_XCH + w * w2_acc_doubles(M.n);
     // per-node constants (the layout eval_front_e2 reads; see smem_setup in rmx_kernels.hip), staged by wave 0
     if (threadIdx.x < CS) {
         const int j = threadIdx.x;
@@ -132,23 +132,21 @@ __global__ void __launch_bounds__(128) k_step_bdf1_w2(const DevModel M, const De
 }
 
 size_t rmx_w2_smem_bytes(const rmx_model* m) {
-    return sizeof(double) * ((size_t)NCONST * cstride(64) + W2_XCH + 2 * (size_t)acc_doubles(m->n, 64));
+    return sizeof(double) * ((size_t)NCONST * cstride(64) + W2_XCH + 2 * (size_t)w2_acc_doubles(m->n));
 }
 
 void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(128);
     const size_t bytes = rmx_w2_smem_bytes(m);
-    static bool raised = false;
-    if (!raised) {       // 64 KiB+ of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_bdf1_w2<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_bdf1_w2<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
-    }
+    // 64 KiB+ of dynamic LDS needs the opt-in; it is a per-device attribute and costs microseconds, so it is set at every launch
+    // rather than cached (a process may drive several devices from several threads)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_bdf1_w2<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (getenv("RMX_W2_PROF")) {   // development aid: shader-clock cycles of (front, Hessian, elimination) per wave, printed to stderr
         unsigned long long* d = nullptr;
         const size_t nb = sizeof(unsigned long long) * 8 * (size_t)b->B;
         if (hipMalloc((void**)&d, nb) != hipSuccess) return;
         (void)hipMemsetAsync(d, 0, nb, b->stream);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_bdf1_w2<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         k_step_bdf1_w2<64, true><<<grid, block, bytes, b->stream>>>(m->dm, o, a, d);
         std::vector<unsigned long long> h(8 * (size_t)b->B);
         (void)hipMemcpyAsync(h.data(), d, nb, hipMemcpyDeviceToHost, b->stream);

@@ -100,6 +100,7 @@ def test_bench_rank_code_world_size_2(tmp_path):
     assert s["global_batch"] == 3 and s["value"] > 0                                   # 2 + 1 rollouts: uneven shards
     r = d["value_at_reference_tol"]
     assert r["newton_tol"] == 1e-9 and r["value"] > 0 and r["all_finite"]
+    assert d["value_at_survey_init"]["value"] > 0
     assert d["roofline"] is None and "cpu_baseline" not in d                            # GPU-only objects
 
 
