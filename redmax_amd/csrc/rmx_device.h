@@ -58,10 +58,6 @@ constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matri
 #ifndef RMX_W2_HESS_MFMA
 #define RMX_W2_HESS_MFMA 1
 #endif
-#ifndef RMX_W2_TAIL32
-#define RMX_W2_TAIL32 1
-#endif
-constexpr bool W2_TAIL32 = RMX_W2_TAIL32 != 0;         // two-wave kernel: the trailing 32 x 32 Schur complement through the one-wave DPP-fused solver
 constexpr bool W2_HESS_MFMA = RMX_W2_HESS_MFMA != 0;   // two-wave kernel: each wave's 64 x 32 half of H on the matrix cores (0: v_readlane column loop)
 constexpr bool LU_DPP_TAIL = true;                      // guarded LU: last 16 pivots with the broadcast fused into the FMA (DPP)
 constexpr bool LU_SPLIT32 = HESS_MFMA && LU_DPP_TAIL;   // n <= 32: pivots 0..15 in the column-split layout of lu_solve_neg_diag32
@@ -2386,7 +2382,25 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
 // Pivots are taken on the diagonal under the same growth guard as lu_solve_neg_diag (multipliers of rows below the pivot on the
 // equilibrated matrix, positive pivots); when it trips, wave 0 alone redoes the solve with full partial pivoting (the
 // single-wave code) and hands dx to wave 1.  Steps that the pivot policy assigns to the pivot-only Newton run on wave 0 alone.
-constexpr int W2_XCH = 3 * MAXN + 8;      // LDS doubles of the exchange area: multipliers [2][MAXN], reciprocals [MAXN], flags / dx hand-over
+constexpr int W2_XCH = 3 * MAXN + 8;      // LDS doubles of the exchange area: multipliers [2][MAXN], reciprocals [MAXN], guard verdicts [2], hand-over counters (2 ints)
+
+// Hand-over of the multipliers between the two waves WITHOUT a workgroup barrier.  A barrier per pivot keeps the waves in lock
+// step: between two barriers one wave applies two pivots to all its columns while the other only runs its pivot chain and then
+// idles, so a pivot costs a full two-pivot update (measured: 910 cycles per early pivot, with or without look-ahead).  With a
+// sequence counter per producer each wave alternates "chain, updates" at its own pace and only ever waits for data it needs:
+// producer: multipliers -> LDS, release (waits for its LDS writes), counter = pivots published; consumer: spin on the other
+// wave's counter (one broadcast ds_read per poll), acquire, read.  LDS serves a wave's operations in order.  The double buffer
+// stays safe without the barrier: a wave rewrites buffer K & 1 at pivot K + 2, after it has consumed pivot K + 1, which the other
+// wave published after reading pivot K.  Counters are reset (under a barrier) at the start of every solve.
+__device__ __forceinline__ int* w2_counters(double* sL) { return reinterpret_cast<int*>(sL + 3 * MAXN + 4); }
+__device__ __forceinline__ void w2_publish(double* sL, const int w, const int count) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (threadIdx.x % 64 == 0) __atomic_store_n(w2_counters(sL) + w, count, __ATOMIC_RELAXED);
+}
+__device__ __forceinline__ void w2_await(double* sL, const int w, const int count) {
+    while (__atomic_load_n(w2_counters(sL) + w, __ATOMIC_RELAXED) < count) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // Apply pivot P's multipliers l to this wave's columns t >= T0 (and to the right-hand side): the pivot row's entries are
 // broadcast out of lane P in batches ahead of their FMAs (see lu_solve_neg_diag); sched_barriers keep the scheduler from hoisting
@@ -2432,14 +2446,14 @@ __device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, doub
             pmin = fmin(pmin, piv);
             sL[(K & 1) * NP + lane] = l;
             if (lv == K) sR[K] = rinv;
-            __syncthreads();
+            w2_publish(sL, W, K + 1);
             __builtin_amdgcn_sched_barrier(0);
             // bulk: pivot K-1, then pivot K, on the own columns right of K (the first one is t = T + 1) and on the right-hand side
             if constexpr (K >= 1) w2_apply_pivot<NP, K - 1, T + 1>(Hh, b, lp);
             w2_apply_pivot<NP, K, T + 1>(Hh, b, l);
             lu_gj_w2_step<NP, W, K + 1, KEND>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
         } else {                         // the other wave's column: take its multipliers; they are applied in the next step
-            __syncthreads();
+            w2_await(sL, 1 - W, K + 1);
             const double l = sL[(K & 1) * NP + lane];
             if constexpr (K + 1 == KEND) {      // last two-wave pivot: nobody owns a "next step", apply it now
                 w2_apply_pivot<NP, K, ((K - W + 2) >> 1)>(Hh, b, l);
@@ -2449,69 +2463,31 @@ __device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, doub
     }
 }
 
-// dx = -H\g for wave W of a two-wave workgroup.  Pivots 0 .. 31 as above (two-wave Gauss-Jordan).  What is left then is
-//     [ D1  U12 ] [x1]   [b1]        D1 diagonal (rows 0..31), S the 32 x 32 Schur complement (rows / columns 32..63):
-//     [ 0   S   ] [x2] = [b2]
-// the late pivots of a two-wave elimination are bound by the hand-over chain (few columns left to update, still one LDS round
-// trip and one reciprocal chain per pivot), and a 32 x 32 system is exactly what the one-wave DPP-fused solver is built for. Both
-// waves copy their 16 columns of S into BOTH waves' scratch, each solves S x2 = b2 redundantly with lu_solve_neg_diag32 (same
-// code, same data, bit-identical x2: 7 k cycles instead of 32 more hand-overs), then x1 = D1^-1 (b1 - U12 x2) with each wave
-// summing over its own 16 columns of U12 and the two partial sums added in a fixed order on both sides.
+// dx = -H\g for wave W of a two-wave workgroup (Gauss-Jordan, all 64 pivots dealt out to the two waves).
+// Measured and not kept: finishing the trailing 32 x 32 Schur complement with the one-wave DPP-fused solver (both waves
+// redundantly, S copied into both scratch areas) after 32 two-wave pivots - 9.18 ms per 100 steps of the 64-joint tree against 8.92:
+// the two-wave pivots are bound by their update instructions (4.6 k per wave and solve), not by the hand-overs, and the detour
+// (staging, 1.6 k instructions of solve, the U12 x2 product) is no shorter than the 1.5 k instructions it replaces.
 template <int NP, int W>
-__device__ __forceinline__ double lu_gj_w2(const int n, const int lane, double (&Hh)[NP / 2], const double g, const double diag_own,
-                                           double* __restrict__ sX, double* __restrict__ sAcc, bool& ok) {
+__device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2], const double g, const double diag_own,
+                                           double* __restrict__ sX, bool& ok) {
     static_assert(NP == 64, "two-wave elimination: 64-lane trees");
-    constexpr int KEND = W2_TAIL32 ? 32 : NP;
-    double* sL = sX;                 // [2][NP] multipliers, buffer = pivot parity; later the two partial sums of U12 x2
+    double* sL = sX;                 // [2][NP] multipliers, buffer = pivot parity
     double* sR = sX + 2 * NP;        // [NP] reciprocal pivots
-    double* sF = sX + 3 * NP;        // [2] guard verdict of each wave
+    double* sF = sX + 3 * NP;        // [2] guard verdict of each wave (the hand-over counters follow)
     double b = -g;
     double gmax = 0.0, pmin = 1.0;
     const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
     int lv = lane;
     asm volatile("" : "+v"(lv));     // keeps the lane compares local (see lu_solve_neg_diag)
-    lu_gj_w2_step<NP, W, 0, KEND>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
+    if (lane == 0) w2_counters(sL)[W] = 0;
+    __syncthreads();
+    lu_gj_w2_step<NP, W, 0, NP>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
     const bool mine = !__any(!(gmax <= lim)) && (pmin > 0.0);
     if (lane == 0) sF[W] = mine ? 1.0 : 0.0;
-    double dx;
-    if constexpr (W2_TAIL32) {
-        // S and b2 into both private scratch areas, row-major [32][HM_H_STRIDE], right-hand side in column 32 (what the MFMA
-        // Hessian of the 32-lane kernels leaves for lu_solve_neg_diag32)
-        double* sMine = sAcc;
-        double* sOther = (W == 0) ? sAcc + w2_acc_doubles(n) : sAcc - w2_acc_doubles(n);
-        if (lane >= 32) {
-            const int r = lane - 32;
-#pragma unroll
-            for (int t = 16; t < 32; ++t) {
-                sMine[r * HM_H_STRIDE + 2 * t + W - 32] = Hh[t];
-                sOther[r * HM_H_STRIDE + 2 * t + W - 32] = Hh[t];
-            }
-            sMine[r * HM_H_STRIDE + 32] = b;
-        }
-        __syncthreads();
-        bool ok32;
-        const double x2 = lu_solve_neg_diag32(n, lane, sAcc, 0.0, ok32);      // lanes 0..31: x of rows 32 + lane
-        double p = 0.0;
-#pragma unroll
-        for (int t0 = 16; t0 < 32; t0 += 4) {
-            double xv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xv[i] = readlane_d(x2, 2 * (t0 + i) + W - 32);
-            asm volatile("" : "+s"(xv[0]), "+s"(xv[1]), "+s"(xv[2]), "+s"(xv[3]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) p += Hh[t0 + i] * xv[i];
-        }
-        sL[W * NP + lane] = p;
-        __syncthreads();
-        ok = sF[0] != 0.0 && sF[1] != 0.0 && ok32;
-        const double x1 = (b - (sL[lane] + sL[NP + lane])) * sR[lane & 31];
-        const double xhi = dup_lo(x2);      // lanes >= 32 receive lane - 32
-        dx = lane < 32 ? x1 : xhi;
-    } else {
-        __syncthreads();
-        ok = sF[0] != 0.0 && sF[1] != 0.0;
-        dx = b * sR[lane];
-    }
+    __syncthreads();
+    ok = sF[0] != 0.0 && sF[1] != 0.0;
+    const double dx = b * sR[lane];
     __syncthreads();                 // the exchange area is rewritten by the next solve
     return dx;
 }
@@ -2550,7 +2526,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
         last = e;
         ++iters;
         bool lu_ok;
-        double dx = lu_gj_w2<NP, W>(M.n, lane, Hh, e.g, hdiag, sX, sAcc, lu_ok);
+        double dx = lu_gj_w2<NP, W>(lane, Hh, e.g, hdiag, sX, lu_ok);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
         if (lu_ok) {
             piv.streak = 0;
