@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 102
+#define RMX_VERSION 103
 
 enum {
     RMX_OK = 0,
@@ -200,6 +200,10 @@ typedef struct rmx_history {
     double* V;       /* [nsteps][batch]      potential energy                */
     double* q;       /* [nsteps][batch][nr]  reduced positions (with qdot)   */
     double* qdot;    /* [nsteps][batch][nr]  reduced velocities              */
+    int* charts;     /* [nsteps][batch][nsph] Euler chart (1..12) of every JointSpherical / JointFree3D after each step, i.e. the
+                        chart the step's q / qdot are expressed in (the reference keeps chart and q together on the joint,
+                        JointSpherical.m:28-34; its own history has a TODO for it, Scene.m:138).  May be NULL; ignored when the
+                        model has no spherical joint */
 } rmx_history;
 int rmx_step_history(rmx_batch* b, const rmx_opts* opts, int nsteps, int integrator, rmx_stats* stats,
                      const rmx_history* hist);

@@ -8,7 +8,7 @@ sim = redmax.HipSim(scene, 1);
 guard = onCleanup(@() delete(sim));
 [q0, qdot0] = jroot.getQ();
 sim.setState(q0, qdot0);
-[T, V, stats, Q, Qdot] = sim.step(itype, scene.h, scene.nsteps);
+[T, V, stats, Q, Qdot, C] = sim.step(itype, scene.h, scene.nsteps);   % C: Euler charts after every step (nsph x 1 x nsteps)
 
 % Newton's messages (driverRedMaxBDF1.m:118-121, 150-153); bits: include/redmax_hip.h RMX_ST_*
 if bitand(stats(1,3), 1), fprintf('Newton diverged\n'); end
@@ -26,7 +26,7 @@ if sim.nsph > 0
 	end
 end
 
-replay = scene.drawHz > 0 && sim.nsph == 0;   % per-step charts are not recorded, so spherical scenes are not replayed
+replay = scene.drawHz > 0;
 for k = 1 : scene.nsteps
 	scene.t = k*scene.h;
 	scene.k = k;
@@ -37,7 +37,17 @@ for k = 1 : scene.nsteps
 		scene.history(k).V = V(1,k);
 		scene.history(k).t = scene.t;
 	end
+	if sim.nsph > 0
+		scene.history(k).charts = double(C(:,1,k));   % the chart q and qdot of this step are expressed in
+	end
 	if replay
+		s = 0;
+		for i = 1 : numel(scene.joints)
+			if isprop(scene.joints{i}, 'chart')
+				s = s + 1;
+				scene.joints{i}.chart = double(C(s,1,k));
+			end
+		end
 		jroot.setQ(Q(:,1,k), Qdot(:,1,k));
 		jroot.update();
 		scene.draw();

@@ -23,10 +23,11 @@
  *   info         = redmax_hip_mex('info', h)                            struct nr, nm, nsph, batch, idxR (0-based, -1 fixed)
  *                  redmax_hip_mex('set', h, q, qdot)                     nr x B each          Joint.setQ   (Joint.m:231-292)
  *   [q, qdot]    = redmax_hip_mex('get', h)                                                   Joint.getQ   (Joint.m:173-229)
- *   [T,V,st,Q,Qd]= redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])
+ *   [T,V,st,Q,Qd,C]= redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])
  *                  itype 1: simLoop of driverRedMaxBDF1.m:57-91, 2: of driverRedMaxBDF2.m:57-125.  T, V: B x nsteps
  *                  (Scene.saveHistory energies); st: B x 3 int32 [newton iterations, line-search halvings, RMX_ST_* bits];
- *                  Q, Qd (only when requested): nr x B x nsteps, the full Scene.saveHistory record (Scene.m:134-161).
+ *                  Q, Qd (only when requested): nr x B x nsteps, the full Scene.saveHistory record (Scene.m:134-161);
+ *                  C (only when requested): nsph x B x nsteps int32, the Euler chart of every spherical joint after each step.
  *                  opts: struct with any of tol, dxMax, iterMaxPerDof, iterLsMax, lu_mode (driverRedMaxBDF1.m:95-98).
  *   [T, V]       = redmax_hip_mex('euler', h, hstep, nsteps)             matlab-simple/testRedMax.m:67-109
  *   [g, H]       = redmax_hip_mex('eval', h, q, qA, qB, eta)             evalBDF1 & co (driverRedMaxBDF1.m:160-187); H: nr x nr x B
@@ -211,7 +212,7 @@ static void read_opts(const mxArray* s, rmx_opts* o) {
 
 static void cmd_step(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     handle_t* h = get_handle(nrhs, prhs);
-    if (nrhs < 5) die("usage: [T,V,stats,Q,Qdot] = redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])");
+    if (nrhs < 5) die("usage: [T,V,stats,Q,Qdot,C] = redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])");
     const int itype = (int)mxGetScalar(prhs[2]);
     const int nsteps = (int)mxGetScalar(prhs[4]);
     if (itype != 1 && itype != 2) die("itype must be 1 (BDF1) or 2 (BDF2)");
@@ -234,11 +235,18 @@ static void cmd_step(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
     hist.T = K ? mxGetPr(T) : NULL;
     hist.V = K ? mxGetPr(V) : NULL;
     hist.q = hist.qdot = NULL;
+    hist.charts = NULL;
+    mxArray* C = NULL;
     if (nlhs > 3) {   /* the full Scene.saveHistory record */
         const mwSize dims[3] = {(mwSize)h->nr, (mwSize)B, (mwSize)K};
         Q = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
         Qd = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
         if (K && h->nr) { hist.q = mxGetPr(Q); hist.qdot = mxGetPr(Qd); }
+    }
+    if (nlhs > 5) {   // JointSpherical.chart after every step: nsph x B x nsteps int32
+        const mwSize dims[3] = {(mwSize)h->nsph, (mwSize)B, (mwSize)K};
+        C = mxCreateNumericArray(3, dims, mxINT32_CLASS, mxREAL);
+        if (K && h->nsph) hist.charts = (int*)mxGetData(C);
     }
     if (rmx_step_history(h->b, &o, nsteps, itype, &stats, &hist)) die_rmx("rmx_step_history");
     plhs[0] = T;
@@ -246,6 +254,7 @@ static void cmd_step(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
     if (nlhs > 2) plhs[2] = st;
     if (nlhs > 3) plhs[3] = Q;
     if (nlhs > 4) plhs[4] = Qd;
+    if (nlhs > 5) plhs[5] = C;
 }
 
 static void cmd_euler(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {

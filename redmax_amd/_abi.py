@@ -61,7 +61,7 @@ class GroundContact(C.Structure):
 
 
 class History(C.Structure):
-    _fields_ = [("T", _dp), ("V", _dp), ("q", _dp), ("qdot", _dp)]
+    _fields_ = [("T", _dp), ("V", _dp), ("q", _dp), ("qdot", _dp), ("charts", _ip)]
 
 
 class Stats(C.Structure):

@@ -139,7 +139,9 @@ class BatchSim:
         if history == "full":                     # Scene.saveHistory: q, qdot of every step as well (Scene.m:134-161)
             out["q"] = np.empty((nsteps, self.B, self.nr))
             out["qdot"] = np.empty((nsteps, self.B, self.nr))
-            hist = _abi.History(_abi.dptr(T), _abi.dptr(V), _abi.dptr(out["q"]), _abi.dptr(out["qdot"]))
+            out["charts"] = np.full((nsteps, self.B, self.nsph), 7, dtype=np.int32)     # JointSpherical.chart after every step
+            hist = _abi.History(_abi.dptr(T), _abi.dptr(V), _abi.dptr(out["q"]), _abi.dptr(out["qdot"]),
+                                _abi.iptr(out["charts"]) if self.nsph else None)
             _abi.check(self._L.rmx_step_history(self._batch, C.byref(self.opts), int(nsteps), 1 if fn == "bdf1" else 2, stp,
                                                 C.byref(hist)), "rmx_step_history")
         else:

@@ -683,7 +683,7 @@ static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
 }
 
 static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ, bool with_stats, double* dT, double* dV,
-                       double* dQ = nullptr, double* dQd = nullptr) {
+                       double* dQ = nullptr, double* dQd = nullptr, int* dC = nullptr) {
     rmx_model* m = b->m;
     DevOpts o;
     int rc = make_opts(b, opts, o);
@@ -694,7 +694,7 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.q = b->q; a.qd = b->qd; a.qp = b->qp; a.qdp = b->qdp; a.started = b->started;
     a.it = with_stats ? b->it : nullptr; a.ls = b->ls; a.status = b->status;
     a.histT = dT; a.histV = dV;
-    a.histQ = dQ; a.histQd = dQd;
+    a.histQ = dQ; a.histQd = dQd; a.histC = dC;
     a.chart = b->chart;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
@@ -708,7 +708,7 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
 }
 
 static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* st, double* hT, double* hV, int integ,
-                     double* hQ = nullptr, double* hQd = nullptr) {
+                     double* hQ = nullptr, double* hQd = nullptr, int* hC = nullptr) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     if (nsteps < 0) return fail(RMX_E_INVALID, "nsteps < 0");
     if ((hT == nullptr) != (hV == nullptr)) return fail(RMX_E_INVALID, "hist_T and hist_V must be given together");
@@ -733,13 +733,23 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
             return fail(RMX_E_NOMEM, "hipMalloc(state history)");
         }
     }
+    int* dC = nullptr;
+    const size_t nc = nh * (size_t)m->dm.nsph;
+    if (hC && nc) {      // models with spherical joints run the extended (CT) step kernels, which record the chart after every step
+        hipError_t e = hipMalloc((void**)&dC, nc * sizeof(int));
+        if (e != hipSuccess) {
+            for (void* p : {(void*)dT, (void*)dV, (void*)dQ, (void*)dQd})
+                if (p) (void)hipFree(p);
+            return fail(RMX_E_NOMEM, "hipMalloc(chart history)");
+        }
+    }
     const bool ws = st != nullptr;
     if (ws) {
         (void)hipMemsetAsync(b->it, 0, sizeof(int) * b->B, b->stream);
         (void)hipMemsetAsync(b->ls, 0, sizeof(int) * b->B, b->stream);
         (void)hipMemsetAsync(b->status, 0, sizeof(int) * b->B, b->stream);
     }
-    int rc = launch_step(b, opts, nsteps, integ, ws, dT, dV, dQ, dQd);
+    int rc = launch_step(b, opts, nsteps, integ, ws, dT, dV, dQ, dQd, dC);
     hipError_t e = hipSuccess;
     if (rc == RMX_OK) {
         if (hT) {
@@ -750,6 +760,7 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
             e = hipMemcpyAsync(hQ, dQ, nq * sizeof(double), hipMemcpyDeviceToHost, b->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(hQd, dQd, nq * sizeof(double), hipMemcpyDeviceToHost, b->stream);
         }
+        if (e == hipSuccess && dC) e = hipMemcpyAsync(hC, dC, nc * sizeof(int), hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess && ws) {
             if (st->newton_iters) e = hipMemcpyAsync(st->newton_iters, b->it, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
             if (e == hipSuccess && st->ls_halvings) e = hipMemcpyAsync(st->ls_halvings, b->ls, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
@@ -765,6 +776,7 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
     if (dV) (void)hipFree(dV);
     if (dQ) (void)hipFree(dQ);
     if (dQd) (void)hipFree(dQd);
+    if (dC) (void)hipFree(dC);
     if (rc) return rc;
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_step: ") + hipGetErrorString(e));
     return RMX_OK;
@@ -774,7 +786,7 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
 extern "C" int rmx_step_history(rmx_batch* b, const rmx_opts* opts, int nsteps, int integrator, rmx_stats* stats, const rmx_history* hist) {
     if (integrator != 1 && integrator != 2) return fail(RMX_E_INVALID, "integrator must be 1 (BDF1) or 2 (BDF2)");
     if (!hist) return fail(RMX_E_INVALID, "null history");
-    return step_sync(b, opts, nsteps, stats, hist->T, hist->V, integrator == 1 ? INTEG_BDF1 : INTEG_BDF2, hist->q, hist->qdot);
+    return step_sync(b, opts, nsteps, stats, hist->T, hist->V, integrator == 1 ? INTEG_BDF1 : INTEG_BDF2, hist->q, hist->qdot, hist->charts);
 }
 
 extern "C" int rmx_step_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* stats, double* hist_T, double* hist_V) {

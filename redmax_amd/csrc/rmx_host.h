@@ -29,6 +29,7 @@ struct StepArgs {
     int* chart;       // [B][nsph] Euler charts of the spherical joints (in/out) or null
     double* histQ;    // [nsteps][B][nr] or null: q, qdot after every step (Scene.saveHistory, Scene.m:134-161)
     double* histQd;
+    int* histC;       // [nsteps][B][nsph] or null: Euler charts after every step
 };
 
 struct AdjArgs {

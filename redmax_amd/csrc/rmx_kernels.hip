@@ -84,6 +84,9 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
             a.histQ[(size_t)s * a.B * M.nr + off] = q;
             a.histQd[(size_t)s * a.B * M.nr + off] = qd;
         }
+        if constexpr (CT) {
+            if (a.histC && lane < M.nsph) a.histC[((size_t)s * a.B + traj) * M.nsph + lane] = chart[lane];
+        }
     }
     if (id >= 0) {
         a.q[off] = q;
@@ -160,6 +163,9 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
         if (a.histQ && id >= 0) {
             a.histQ[(size_t)s * a.B * M.nr + off] = q;
             a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+        }
+        if constexpr (CT) {
+            if (a.histC && lane < M.nsph) a.histC[((size_t)s * a.B + traj) * M.nsph + lane] = chart[lane];
         }
     }
     if (id >= 0) {

@@ -25,8 +25,8 @@ def simLoop(scene, itype=1, device=0):
     scene.setQ(q[0], qd[0])
     # JointSpherical / JointFree3D keep chart and q together (JointSpherical.m:28-34, 63-102): the final q is expressed in
     # the charts the device ended in, so they go back onto the joints with it.  The per-step history q is in the chart
-    # that was current at that step (the reference's history has the same property); status bit RMX_ST_CHART says whether
-    # any switch happened at all.
+    # that was current after that step: recorded per step as history[k]["charts"] (the reference's own history has a TODO
+    # for it, Scene.m:138); status bit RMX_ST_CHART says whether any switch happened at all.
     if sim.nsph:
         charts = sim.charts()[0]
         sph = [j for j in scene.joints if hasattr(j, "chart")]
@@ -37,7 +37,7 @@ def simLoop(scene, itype=1, device=0):
         scene.t = (k + 1) * scene.h
         scene.k = k + 1
         scene.history.append({"t": scene.t, "T": float(out["T"][k, 0]), "V": float(out["V"][k, 0]),
-                              "q": out["q"][k, 0].copy(), "qdot": out["qdot"][k, 0].copy()})
+                              "q": out["q"][k, 0].copy(), "qdot": out["qdot"][k, 0].copy(), "charts": out["charts"][k, 0].copy()})
     scene.solverInfo = {"newton_iters": int(out["newton_iters"][0]), "ls_halvings": int(out["ls_halvings"][0]),
                         "status": int(out["status"][0]), "kernel_ms": out["ms"]}
     sim.close()

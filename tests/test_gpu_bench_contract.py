@@ -41,6 +41,8 @@ def test_default_workload_line():
     assert r["algorithmic_equiv_tflops"] > r["achieved"]
     t = d["value_at_reference_tol"]
     assert t["newton_tol"] == 1e-9 and t["value"] > 0 and t["all_finite"] and t["newton_iters_per_step"] >= r["newton_iters_per_step"]
+    w = d["value_at_survey_init"]
+    assert w["value"] > 0 and w["all_finite"] and w["newton_iters_per_step"] > r["newton_iters_per_step"]
     tf = d["cpu_baseline_tensor_free"]
     assert tf["value"] > c["value"] and tf["q_l2_relerr_gpu_vs_this_max"] < 1e-8
     n = d["newton_count_agreement"]

@@ -119,7 +119,10 @@ def test_spherical_chart_switch_matches_oracle(oracle_lib):
             worst = max(worst, _rel(out["q"][k, b], qo))
             assert _rel(out["q"][k, b], qo) <= 1e-7, (b, k)
             assert _rel(out["qdot"][k, b], qdo) <= 1e-6, (b, k)
+            assert list(out["charts"][k, b]) == list(o.charts()), (b, k)      # rmx_history.charts: the chart of every step
         assert list(charts[b]) == list(o.charts())
+        assert list(out["charts"][-1, b]) == list(charts[b]) and list(out["charts"][0, b]) == [7, 7]
+        assert len({tuple(c) for c in out["charts"][:, b]}) >= 2             # the run does switch charts
     assert list(charts[0]) == [7, 10]                                # XYZ, YXZ
     assert np.all(out["status"] & 32)
     sim.close()

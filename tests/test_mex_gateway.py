@@ -139,7 +139,7 @@ def flatten(scene):
 
 
 def test_gateway_builds_warning_free_and_answers_version(gw):
-    assert gw.call(1, "version") == 102
+    assert gw.call(1, "version") == 103
 
 
 def test_gateway_reports_errors_the_matlab_way(gw):
@@ -198,7 +198,7 @@ def test_scene_through_the_gateway_meets_the_golden(gw, sid, itype):
     assert int(info["nr"][0, 0]) == sc.nr and int(info["nm"][0, 0]) == sc.nm
     gw.call(0, "set", h, q0.reshape(-1, 1), qd0.reshape(-1, 1))
     T0, V0 = gw.call(2, "energy", h)
-    T, V, st, Q, Qd = gw.call(5, "step", h, float(itype), sc.h, float(sc.nsteps))
+    T, V, st, Q, Qd, Ch = gw.call(6, "step", h, float(itype), sc.h, float(sc.nsteps))
     q, qd = gw.call(2, "get", h)
     charts = gw.call(1, "getcharts", h)
     gw.call(0, "destroy", h)
@@ -214,6 +214,7 @@ def test_scene_through_the_gateway_meets_the_golden(gw, sid, itype):
     assert np.array_equal(out["T"][:, 0], T[0]) and st[0, 0] == out["newton_iters"][0]
     if sim.nsph:
         assert np.array_equal(sim.charts()[0], charts[:, 0])
+        assert Ch.shape == (sim.nsph, 1, sc.nsteps) and np.array_equal(Ch[:, 0, :].T, out["charts"][:, 0, :])
     sim.close()
 
 
