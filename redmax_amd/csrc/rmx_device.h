@@ -2382,7 +2382,7 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
 // Pivots are taken on the diagonal under the same growth guard as lu_solve_neg_diag (multipliers of rows below the pivot on the
 // equilibrated matrix, positive pivots); when it trips, wave 0 alone redoes the solve with full partial pivoting (the
 // single-wave code) and hands dx to wave 1.  Steps that the pivot policy assigns to the pivot-only Newton run on wave 0 alone.
-constexpr int W2_XCH = 3 * MAXN + 8;      // LDS doubles of the exchange area: multipliers [2][MAXN], reciprocals [MAXN], guard verdicts [2], hand-over counters (2 ints)
+constexpr int W2_XCH = 3 * MAXN + 8;      // LDS doubles of the exchange area: multipliers [2][MAXN], reciprocals [MAXN], guard verdicts [2], 2 spare, hand-over counters (2 ints at +4), wave-0 value slots [2] at +5, 1 spare
 
 // Hand-over of the multipliers between the two waves WITHOUT a workgroup barrier.  A barrier per pivot keeps the waves in lock
 // step: between two barriers one wave applies two pivots to all its columns while the other only runs its pivot chain and then
@@ -2405,7 +2405,7 @@ __device__ __forceinline__ void w2_await(double* sL, const int w, const int coun
 // Apply pivot P's multipliers l to this wave's columns t >= T0 (and to the right-hand side): the pivot row's entries are
 // broadcast out of lane P in batches ahead of their FMAs (see lu_solve_neg_diag); sched_barriers keep the scheduler from hoisting
 // later batches' broadcasts above earlier FMAs (it would run out of scalar registers and park them in VGPR lanes).
-template <int NP, int P, int T0>
+template <int NP, int W, int P, int T0>
 __device__ __forceinline__ void w2_apply_pivot(double (&Hh)[NP / 2], double& b, const double l) {
     constexpr int BT = 4;
 #pragma unroll
@@ -2419,7 +2419,7 @@ __device__ __forceinline__ void w2_apply_pivot(double (&Hh)[NP / 2], double& b, 
             if (c0 + i < NP / 2) Hh[c0 + i] -= l * pv[i];
         __builtin_amdgcn_sched_barrier(0);
     }
-    b -= l * readlane_d(b, P);
+    if constexpr (W == 0) b -= l * readlane_d(b, P);      // the right-hand side is wave 0's business (see lu_gj_w2)
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -2449,14 +2449,14 @@ __device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, doub
             w2_publish(sL, W, K + 1);
             __builtin_amdgcn_sched_barrier(0);
             // bulk: pivot K-1, then pivot K, on the own columns right of K (the first one is t = T + 1) and on the right-hand side
-            if constexpr (K >= 1) w2_apply_pivot<NP, K - 1, T + 1>(Hh, b, lp);
-            w2_apply_pivot<NP, K, T + 1>(Hh, b, l);
+            if constexpr (K >= 1) w2_apply_pivot<NP, W, K - 1, T + 1>(Hh, b, lp);
+            w2_apply_pivot<NP, W, K, T + 1>(Hh, b, l);
             lu_gj_w2_step<NP, W, K + 1, KEND>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
         } else {                         // the other wave's column: take its multipliers; they are applied in the next step
             w2_await(sL, 1 - W, K + 1);
             const double l = sL[(K & 1) * NP + lane];
             if constexpr (K + 1 == KEND) {      // last two-wave pivot: nobody owns a "next step", apply it now
-                w2_apply_pivot<NP, K, ((K - W + 2) >> 1)>(Hh, b, l);
+                w2_apply_pivot<NP, W, K, ((K - W + 2) >> 1)>(Hh, b, l);
             }
             lu_gj_w2_step<NP, W, K + 1, KEND>(lane, lv, Hh, b, gmax, pmin, l, sL, sR);
         }
@@ -2485,9 +2485,12 @@ __device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2],
     lu_gj_w2_step<NP, W, 0, NP>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
     const bool mine = !__any(!(gmax <= lim)) && (pmin > 0.0);
     if (lane == 0) sF[W] = mine ? 1.0 : 0.0;
+    // the step is wave 0's: it alone carries the right-hand side, and wave 1 takes dx from it - bit for bit, so that the two waves'
+    // Newton states cannot drift apart (their code is compiled separately; nothing guarantees identical FMA contraction)
+    if constexpr (W == 0) sL[lane] = b * sR[lane];
     __syncthreads();
     ok = sF[0] != 0.0 && sF[1] != 0.0;
-    const double dx = b * sR[lane];
+    const double dx = sL[lane];
     __syncthreads();                 // the exchange area is rewritten by the next solve
     return dx;
 }
@@ -2506,6 +2509,19 @@ __device__ __attribute__((noinline)) double w2_pivoted_solve(const DevModel& M, 
     return lu_solve_neg<NP>(M.n, lane, Hrow, g);
 }
 
+// A wave-uniform value of wave 0, for both waves.  Every branch of the two-wave Newton loop is taken on wave 0's numbers: the
+// waves run separately compiled copies of the same evaluation code on the same data, which is bit-identical in practice but is
+// not a guarantee one can rest a barrier protocol on (a one-ulp difference in |g|^2 next to tol would send the waves down
+// different paths and hang the workgroup).  Two slots used alternately: one barrier per call.
+template <int W>
+__device__ __forceinline__ double w2_from_wave0(double* __restrict__ sX, int& par, const double v) {
+    double* slot = sX + 3 * MAXN + 5 + (par & 1);
+    par ^= 1;
+    if (W == 0 && threadIdx.x == 0) *slot = v;
+    __syncthreads();
+    return *slot;
+}
+
 // newton_impl<NP, false> for wave W of a two-wave workgroup.  sAcc: this wave's private front scratch; sX: the exchange area.
 template <int NP, int W, bool PROF = false>
 __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o, double* sAcc, double* sX, const int lane, double x,
@@ -2518,6 +2534,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
     eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
     int iter = 1;
+    int par = 0;
     double gcarry = -1.0;
     while (true) {
         const double hdiag = eval_hess<NP, false, false, true, 2, W>(M, lane, fs, Hh, nullptr, sAcc);
@@ -2541,7 +2558,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
             if (W != 0) dx = sX[lane];
             __syncthreads();
         }
-        const double dxn2 = wave_sum(dx * dx);
+        const double dxn2 = wave_sum(dx * dx);           // dx is wave 0's in both waves, the reduction is a fixed chain of adds
         if (!(dxn2 == dxn2)) {
             status |= 4;
             break;
@@ -2551,7 +2568,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
             break;
         }
         double alpha = 1.0;
-        const double g0n2 = gcarry >= 0.0 ? gcarry : wave_sum(e.g * e.g);
+        const double g0n2 = gcarry >= 0.0 ? gcarry : w2_from_wave0<W>(sX, par, wave_sum(e.g * e.g));
         const double f0 = 0.5 * g0n2;
         const double x0 = x;
         int iterLs = 1;
@@ -2559,7 +2576,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
         bool stalled = false;
         while (true) {
             x = x0 + alpha * dx;
-            if (__all(x == x0)) {
+            if (w2_from_wave0<W>(sX, par, __all(x == x0) ? 1.0 : 0.0) != 0.0) {
                 stalled = true;
                 iterLs = o.iterLsMax;
                 e = e0;
@@ -2568,7 +2585,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
             if (PROF) t0 = __builtin_amdgcn_s_memtime();
             eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
             if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
-            gn2 = wave_sum(e.g * e.g);
+            gn2 = w2_from_wave0<W>(sX, par, wave_sum(e.g * e.g));
             if (0.5 * gn2 < f0) break;
             if (iterLs >= o.iterLsMax) break;
             alpha *= 0.5;

@@ -60,6 +60,12 @@ __device__ __forceinline__ void step_bdf1_w2_body(const DevModel& M, const DevOp
         } else {
             x = newton_w2<NP, W, PROF>(M, o, sAcc, sX, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, prof);
             pivot_policy_update(piv);
+            // the state is wave 0's (it alone is stored): wave 1 re-reads it every step so that a one-ulp difference between the
+            // two separately compiled copies of the update x0 + alpha dx cannot grow over a rollout
+            if (W == 0) sX[lane] = x;
+            __syncthreads();
+            x = sX[lane];
+            __syncthreads();
         }
         qd = (x - q0) / o.h;
         q = x;
