@@ -258,26 +258,23 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
         double Jw[3] = {0.0, 0.0, 0.0}, Jv[3] = {0.0, 0.0, 0.0};   // J(idxM_body, this joint) of the last evaluated iterate
         int iter = 1;
         // Scene.saveHistory keeps H, M, D of the LAST evaluated iterate of the step (driverRedMaxAdjointBDF1.m:100, 127).  Up to 32
-        // nodes the three rows ride in registers and go to HBM once per step, after the Newton loop; larger trees (3 x 64 doubles
-        // per lane) store every iterate and the last store wins.
+        // nodes H rides in registers through the Newton loop (the solve destroys its working copy) and M, D are formed ONCE, after
+        // the loop, from the state the last evaluation left behind (fs) - they do not enter the Newton iteration itself; all three
+        // go to HBM once per step.  Larger trees (3 x 64 doubles per lane) form and store them at every iterate, the last store wins.
         constexpr bool STORE_ONCE = NP <= 32;
-        double Hs[STORE_ONCE ? NP : 1], Ms[STORE_ONCE ? NP : 1], Dsv[STORE_ONCE ? NP : 1];
+        double Hs[STORE_ONCE ? NP : 1];
         while (true) {
             NodeOut e;
             double Hrow[NP];
             eval_front<NP, true>(M, sAcc, lane, x, (x - q0) / h, x - xB, h, e, fs);
             eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
-            {
+            if constexpr (STORE_ONCE) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) Hs[i] = Hrow[i];
+            } else {
                 double Mrow[NP], Drow[NP];
                 eval_MD<NP>(M, lane, fs, Mrow, Drow);
-                if constexpr (STORE_ONCE) {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) {
-                        Hs[i] = Hrow[i];      // the solve below destroys Hrow
-                        Ms[i] = Mrow[i];
-                        Dsv[i] = Drow[i];
-                    }
-                } else if (lane < n) {
+                if (lane < n) {
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
                         if (i < n) {
@@ -313,13 +310,15 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
             ++iter;
         }
         if constexpr (STORE_ONCE) {
+            double Mrow[NP], Drow[NP];
+            eval_MD<NP>(M, lane, fs, Mrow, Drow);       // fs: the state of the last evaluated iterate
             if (lane < n) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
                     if (i < n) {
                         Hk[(size_t)i * n + lane] = Hs[i];
-                        Mk[(size_t)i * n + lane] = Ms[i];
-                        Dk[(size_t)i * n + lane] = Dsv[i];
+                        Mk[(size_t)i * n + lane] = Mrow[i];
+                        Dk[(size_t)i * n + lane] = Drow[i];
                     }
             }
         }
