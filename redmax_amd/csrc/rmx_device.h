@@ -55,10 +55,6 @@ __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
     return a > b ? a : b;
 }
 constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matrix cores (false: half-wave split of the column loop)
-#ifndef RMX_W2_HESS_MFMA
-#define RMX_W2_HESS_MFMA 1
-#endif
-constexpr bool W2_HESS_MFMA = RMX_W2_HESS_MFMA != 0;   // two-wave kernel: each wave's 64 x 32 half of H on the matrix cores (0: v_readlane column loop)
 constexpr bool LU_DPP_TAIL = true;                      // guarded LU: last 16 pivots with the broadcast fused into the FMA (DPP)
 constexpr bool LU_SPLIT32 = HESS_MFMA && LU_DPP_TAIL;   // n <= 32: pivots 0..15 in the column-split layout of lu_solve_neg_diag32
 // Column stride of the per-node constants in LDS.  Trees padded to fewer than 64 lanes get one extra "idle" column (index NP):
@@ -1125,14 +1121,123 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
     }
 }
 
+// Two-wave kernel (k_step_bdf1_w2, trees of 33..64 nodes): wave W's 64 x 32 half of H (all rows x its columns i = 2 t + W) on the
+// fp64 matrix cores, from the operands wave 0 staged in sOp ([k][node], stride W2_OP_STRIDE):
+//     H(a,i) = [a strict ancestor of i] RU_a.CU_i + [a strict descendant of i] RL_a.CL_i ,  Hdiag on the diagonal,
+// RU = s (6), CU = y - z (6), RL = (r1, -r2w, -r3w) (12), CL = (m1, m2w, sw) (12), as for n <= 32 in eval_hess.  4 x 2 tiles of
+// 16 x 16; in depth-first numbering an ancestor has the smaller index, so 2 of the 8 UP tiles and 2 of the 8 LO tiles are empty:
+// 6 x 2 + 6 x 3 = 30 v_mfma_f64_16x16x4_f64.  Results are masked per lane with the relation bits of its two column nodes and go
+// to row-per-lane (Hrow[t] = H(lane, 2 t + W)) through sOut, this wave's own scratch (for wave 0 that is sOp itself, hence the
+// workgroup barrier B2 between the last operand read and the first H write; the helper wave takes part in it).
+constexpr int W2_R_RU = 0, W2_R_RL = 6, W2_R_CU = 18, W2_R_CL = 24, W2_R_HD = 36;
+constexpr int W2_CMD = W2_R_HD * W2_OP_STRIDE + 64;      // the pad element of the Hdiag row: command word for the helper wave
+template <int NP, int W>
+__device__ __forceinline__ void w2_hess_mfma(const DevModel& M, const int lane, const double* __restrict__ sOp, double* __restrict__ sOut,
+                                             double (&Hrow)[NP / 2]) {
+    static_assert(NP == 64, "two-wave Hessian: 64-lane trees");
+    constexpr int ST = W2_OP_STRIDE;
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int g = lane >> 4, j = lane & 15;
+    constexpr int CSW = cstride(NP);
+    const double* cRel = RMX_CONSTS(sOut, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CSW;   // relation bit masks of the nodes (as doubles)
+    v4d up[4][2], lw[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            up[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
+            lw[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
+        }
+    // tile (mb, nb): rows 16 mb .. +15, column nodes 32 nb + W .. 32 nb + 30 + W.  UP needs a row below some column
+    // (16 mb < 32 nb + 31), LO a row above some column (16 mb + 15 > 32 nb)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {       // UP: K = 6, padded to 8 by zero operands on the lanes with k = 6, 7
+        double a[4], b[2];
+        const bool kon = 4 * kk + g < 6;
+        const int kr = kon ? 4 * kk + g : 0;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) a[mb] = kon ? sOp[(W2_R_RU + kr) * ST + 16 * mb + j] : 0.0;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) b[nb] = kon ? sOp[(W2_R_CU + kr) * ST + 32 * nb + 2 * j + W] : 0.0;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                if (16 * mb < 32 * nb + 31) up[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], up[mb][nb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {       // LO: K = 12
+        double a[4], b[2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) a[mb] = sOp[(W2_R_RL + 4 * kk + g) * ST + 16 * mb + j];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) b[nb] = sOp[(W2_R_CL + 4 * kk + g) * ST + 32 * nb + 2 * j + W];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                if (16 * mb + 15 > 32 * nb) lw[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], lw[mb][nb], 0, 0, 0);
+    }
+    // relation bits of this lane's two column nodes i = 32 nb + 2 j + W: bit a of its ancestor mask -> UP applies to row a,
+    // of its descendant mask -> LO applies; rows a = 16 mb + 4 r + g: low word for mb < 2, high word otherwise
+    unsigned amlo[2], amhi[2], dmlo[2], dmhi[2];
+    double hd[2];
+    int icol[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        icol[nb] = 32 * nb + 2 * j + W;
+        const unsigned long long am = (unsigned long long)__double_as_longlong(cRel[icol[nb]]) >> g;
+        const unsigned long long dm = (unsigned long long)__double_as_longlong(cRel[CSW + icol[nb]]) >> g;
+        amlo[nb] = (unsigned)am;
+        amhi[nb] = (unsigned)(am >> 32);
+        dmlo[nb] = (unsigned)dm;
+        dmhi[nb] = (unsigned)(dm >> 32);
+        hd[nb] = sOp[W2_R_HD * ST + icol[nb]];
+    }
+    double hv[4][2][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sh = (16 * mb + 4 * r) & 31;
+                const unsigned aw = mb < 2 ? amlo[nb] : amhi[nb], dw = mb < 2 ? dmlo[nb] : dmhi[nb];
+                double v = 0.0;
+                if (16 * mb < 32 * nb + 31) v = (double)((aw >> sh) & 1u) * up[mb][nb][r];
+                if (16 * mb + 15 > 32 * nb) v += (double)((dw >> sh) & 1u) * lw[mb][nb][r];
+                hv[mb][nb][r] = (16 * mb + 4 * r + g == icol[nb]) ? hd[nb] : v;
+            }
+    __syncthreads();             // B2: both waves are done with the operands; wave 0's scratch now takes its half of H
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sOut[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
+    RMX_SYNC();
+    {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d* hr = reinterpret_cast<const v2d*>(sOut + lane * HM_H_STRIDE);   // rows are 16-byte aligned
+#pragma unroll
+        for (int c = 0; c < NP / 4; ++c) {
+            const v2d t = hr[c];
+            Hrow[2 * c] = t[0];
+            Hrow[2 * c + 1] = t[1];
+        }
+    }
+    RMX_SYNC();
+}
+
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle node slots are the identity.
 // Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
-// NW / W (trees of more than 32 nodes only): the columns are dealt out to NW wavefronts of the workgroup, this one computes
-// columns i = NW t + W into Hrow[t] (the two-wave step kernel, k_step_bdf1_w2); NW = 1 is the whole row.
+// NW = 2 (trees of more than 32 nodes, the two-wave step kernel k_step_bdf1_w2, called by wave 0 only): the columns are dealt out
+// to the two wavefronts of the workgroup; wave 0 stages the operands for both and computes columns i = 2 t into Hrow[t]
+// (w2_hess_mfma).  NW = 1 is the whole row.
 template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true, int NW = 1, int W = 0>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP / NW],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0) {
-    static_assert(NW == 1 || NP > 32, "column split: 64-lane trees only");
+    static_assert(NW == 1 || (NW == 2 && NP > 32 && W == 0), "column split: 64-lane trees, wave 0");
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr int CS = cstride(NP);
     const double eta = fs.eta, e2 = eta * eta;
@@ -1513,158 +1618,38 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
         RMX_SYNC();
-    } else if constexpr (NW == 2 && W2_HESS_MFMA) {
-        // Two-wave kernel, 64 rows: this wave's half of H (all 64 rows x its 32 columns i = 2 t + W) on the fp64 matrix cores,
-        // as for n <= 32 above: H(a,i) = [a strict ancestor of i] RU_a.CU_i + [a strict descendant of i] RL_a.CL_i with
-        // RU = s (6), CU = y - z (6), RL = (r1, -r2w, -r3w) (12), CL = (m1, m2w, sw) (12).  4 x 2 tiles of 16 x 16; in depth-first
-        // numbering an ancestor has the smaller index, so 2 of the 8 UP tiles and 2 of the 8 LO tiles are empty: 6 x 2 + 6 x 3 = 30
-        // v_mfma_f64_16x16x4_f64 instead of 32 columns x (36 v_readlane + 30 FMA).  Operands through this wave's own LDS scratch
-        // in [k][node] order; results masked per lane with the relation bits of its two column nodes and handed to row-per-lane
-        // (Hrow[t] = H(lane, 2 t + W)) through the same scratch.
-        static_assert(NP == 64 && !CT, "two-wave MFMA Hessian: 64-lane plain models");
+    } else if constexpr (NW == 2) {
+        // Two-wave kernel, 64 rows (wave 0 only runs eval_hess): stage the operands of the two matrix products in [k][node] order
+        // in this wave's scratch, post the "solve" command for the helper wave next to them, and compute this wave's half of H.
+        static_assert(NP == 64 && !CT && W == 0, "two-wave Hessian: 64-lane plain models, called by wave 0");
         constexpr int ST = W2_OP_STRIDE;
-        constexpr int R_RU = 0, R_RL = 6, R_CU = 18, R_CL = 24, R_HD = 36;
         double* sOp = sAcc;
         {
             double* o = sOp + lane;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                o[(R_RU + c) * ST] = sw[c];
-                o[(R_RU + 3 + c) * ST] = sv[c];
-                o[(R_RL + c) * ST] = r1t[c];
-                o[(R_RL + 3 + c) * ST] = r1f[c];
-                o[(R_RL + 6 + c) * ST] = -r2w[c];
-                o[(R_RL + 9 + c) * ST] = -r3w[c];
+                o[(W2_R_RU + c) * ST] = sw[c];
+                o[(W2_R_RU + 3 + c) * ST] = sv[c];
+                o[(W2_R_RL + c) * ST] = r1t[c];
+                o[(W2_R_RL + 3 + c) * ST] = r1f[c];
+                o[(W2_R_RL + 6 + c) * ST] = -r2w[c];
+                o[(W2_R_RL + 9 + c) * ST] = -r3w[c];
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) o[(R_CU + c) * ST] = cv[c];
+            for (int c = 0; c < 6; ++c) o[(W2_R_CU + c) * ST] = cv[c];
 #pragma unroll
-            for (int c = 6; c < 18; ++c) o[(R_CL + c - 6) * ST] = cv[c];
-            o[R_HD * ST] = Hdiag;
+            for (int c = 6; c < 18; ++c) o[(W2_R_CL + c - 6) * ST] = cv[c];
+            o[W2_R_HD * ST] = Hdiag;
+            if (lane == 0) sOp[W2_CMD] = 1.0;          // command for the helper wave: 1 = solve, 0 = exit
         }
-        RMX_SYNC();
-        typedef double v4d __attribute__((ext_vector_type(4)));
-        const int g = lane >> 4, j = lane & 15;
-        constexpr int CSW = cstride(NP);
-        const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CSW;   // relation bit masks of the nodes (as doubles)
-        v4d up[4][2], lw[4][2];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                up[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
-                lw[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
-            }
-        // tile (mb, nb): rows 16 mb .. +15, column nodes 32 nb + W .. 32 nb + 30 + W.  UP needs a row below some column
-        // (16 mb < 32 nb + 31), LO a row above some column (16 mb + 15 > 32 nb)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {       // UP: K = 6, padded to 8 by zero operands on the lanes with k = 6, 7
-            double a[4], b[2];
-            const bool kon = 4 * kk + g < 6;
-            const int kr = kon ? 4 * kk + g : 0;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a[mb] = kon ? sOp[(R_RU + kr) * ST + 16 * mb + j] : 0.0;
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) b[nb] = kon ? sOp[(R_CU + kr) * ST + 32 * nb + 2 * j + W] : 0.0;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    if (16 * mb < 32 * nb + 31) up[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], up[mb][nb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {       // LO: K = 12
-            double a[4], b[2];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) a[mb] = sOp[(R_RL + 4 * kk + g) * ST + 16 * mb + j];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) b[nb] = sOp[(R_CL + 4 * kk + g) * ST + 32 * nb + 2 * j + W];
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    if (16 * mb + 15 > 32 * nb) lw[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], lw[mb][nb], 0, 0, 0);
-        }
-        // relation bits of this lane's two column nodes i = 32 nb + 2 j + W: bit a of its ancestor mask -> UP applies to row a,
-        // of its descendant mask -> LO applies; rows a = 16 mb + 4 r + g: low word for mb < 2, high word otherwise
-        unsigned amlo[2], amhi[2], dmlo[2], dmhi[2];
-        double hd[2];
-        int icol[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            icol[nb] = 32 * nb + 2 * j + W;
-            const unsigned long long am = (unsigned long long)__double_as_longlong(cRel[icol[nb]]) >> g;
-            const unsigned long long dm = (unsigned long long)__double_as_longlong(cRel[CSW + icol[nb]]) >> g;
-            amlo[nb] = (unsigned)am;
-            amhi[nb] = (unsigned)(am >> 32);
-            dmlo[nb] = (unsigned)dm;
-            dmhi[nb] = (unsigned)(dm >> 32);
-            hd[nb] = sOp[R_HD * ST + icol[nb]];
-        }
-        double hv[4][2][4];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int sh = (16 * mb + 4 * r) & 31;
-                    const unsigned aw = mb < 2 ? amlo[nb] : amhi[nb], dw = mb < 2 ? dmlo[nb] : dmhi[nb];
-                    double v = 0.0;
-                    if (16 * mb < 32 * nb + 31) v = (double)((aw >> sh) & 1u) * up[mb][nb][r];
-                    if (16 * mb + 15 > 32 * nb) v += (double)((dw >> sh) & 1u) * lw[mb][nb][r];
-                    hv[mb][nb][r] = (16 * mb + 4 * r + g == icol[nb]) ? hd[nb] : v;
-                }
-        RMX_SYNC();                  // every lane is done with the operands: the same scratch now takes H, row-major [64][34]
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sOp[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
-        RMX_SYNC();
-        {
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            const v2d* hr = reinterpret_cast<const v2d*>(sOp + lane * HM_H_STRIDE);   // rows are 16-byte aligned
-#pragma unroll
-            for (int c = 0; c < NP / 4; ++c) {
-                const v2d t = hr[c];
-                Hrow[2 * c] = t[0];
-                Hrow[2 * c + 1] = t[1];
-            }
-        }
-        RMX_SYNC();                  // the scratch goes back to the front, whose subtree scan relies on a zero row n
-        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+        __syncthreads();             // B1: operands and command are in LDS; the helper wave has been waiting here
+        w2_hess_mfma<NP, 0>(M, lane, sOp, sOp, Hrow);
+        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;      // the scratch goes back to the front (zero row n)
         RMX_SYNC();
     } else {
 #pragma unroll
         for (int t = 0; t < NP / NW; ++t) {
             const int i = NW * t + W;
-            if constexpr (NW > 1) {
-                // two-wave kernel: the column in three batches of 6 broadcasts, one column at a time.  Left to itself the scheduler
-                // requests several columns' broadcasts at once, and beside the scalars that live across the Newton loop they no
-                // longer fit in the scalar registers: they would be parked in VGPR lanes (v_writelane / v_readlane + s_nop each)
-                static_assert(NW == 1 || !CT, "column split: plain models");
-                double Ca[6], Cb[6], Cc[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) Ca[c] = readlane_d(cv[c], i);
-                const double up = sw[0] * Ca[0] + sw[1] * Ca[1] + sw[2] * Ca[2] + sv[0] * Ca[3] + sv[1] * Ca[4] + sv[2] * Ca[5];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 6; ++c) Cb[c] = readlane_d(cv[6 + c], i);
-                double lo = r1t[0] * Cb[0] + r1t[1] * Cb[1] + r1t[2] * Cb[2] + r1f[0] * Cb[3] + r1f[1] * Cb[4] + r1f[2] * Cb[5];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 6; ++c) Cc[c] = readlane_d(cv[12 + c], i);
-                lo = lo - (r2w[0] * Cc[0] + r2w[1] * Cc[1] + r2w[2] * Cc[2]) - (r3w[0] * Cc[3] + r3w[1] * Cc[4] + r3w[2] * Cc[5]);
-                const double mu = (double)(unsigned)((desc_m >> i) & 1ull);
-                const double ml = (double)(unsigned)((anc_m >> i) & 1ull);
-                const double hv = mu * up + ml * lo;
-                Hrow[t] = (i == lane) ? Hdiag : hv;
-                asm volatile("" : "+v"(Hrow[t]));      // the column's arithmetic stays here (it would otherwise sink to its first use in the solve, broadcasts and all)
-                __builtin_amdgcn_sched_barrier(0);
-                continue;
-            }
             double Ci[NCV];
 #pragma unroll
             for (int c = 0; c < NCV; ++c) Ci[c] = readlane_d(cv[c], i);
@@ -2367,21 +2352,21 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
 //
 // One wavefront per trajectory leaves SIMDs idle whenever a GPU holds fewer rollouts than it has SIMDs (BASELINE.json
 // configs[2]: 4096 rollouts over 8 GPUs = 512 per GPU on 1024 SIMDs), and for 64-row systems the instruction stream of one
-// Newton iteration is dominated by two loops over COLUMNS - the Hessian assembly (per column 36 v_readlane + 30 FMA) and the
-// elimination (per remaining column 2 v_readlane + 1 FMA) - whose columns are independent of each other.  The two-wave step
-// kernel (k_step_bdf1_w2) gives a trajectory a workgroup of two wavefronts, wave W owning the columns c = 2 t + W:
-//   * both waves run the front (kinematics, path / subtree sums, residual) REDUNDANTLY on private LDS scratch: same
-//     instructions on the same data, bit-identical results, so all Newton control flow agrees without any exchange;
-//   * each wave assembles its 32 columns of H (eval_hess<.., NW = 2, W>);
-//   * elimination: at pivot k the owner of column k forms the multipliers l = H(:,k) / H(k,k) and publishes them through LDS
-//     (one ds_write, one s_barrier, one ds_read for the other wave; double-buffered), then both waves update their own columns
-//     > k - the pivot row's entries of a wave's columns sit in lane k of that wave's own registers.  The right-hand side is
-//     carried by both waves (3 instructions a step).  The elimination is Gauss-Jordan (rows above the pivot are eliminated too,
-//     which costs no instruction in a lane = row layout: the FMAs run for all 64 lanes anyway), so there is no back substitution
-//     with its per-step hand-over between the waves: dx = b / pivot at the end, the reciprocals travel through LDS as well.
+// Newton iteration is dominated by two loops over COLUMNS - the Hessian assembly and the elimination - whose columns are
+// independent of each other.  The two-wave step kernel (k_step_bdf1_w2, rmx_kernels_w2.hip) gives a trajectory a workgroup of
+// two wavefronts:
+//   * wave 0 owns the rollout: state, front, line search, every decision (newton_w2 = the one-wave Newton with shared solves);
+//   * wave 1 is a helper without rollout state (w2_helper_loop): it waits for wave 0's command, computes the half of H whose
+//     columns c = 2 t + 1 it owns from the operands wave 0 staged (w2_hess_mfma, fp64 matrix cores), takes part in the elimination;
+//   * elimination (lu_gj_w2): at pivot k the owner of column k forms the multipliers l = H(:,k) / H(k,k) and publishes them
+//     through LDS (double-buffered, sequence counters instead of a barrier per pivot, one step of look-ahead), both waves update
+//     their own columns > k - the pivot row's entries of a wave's columns sit in lane k of that wave's own registers; wave 0
+//     carries the right-hand side.  Gauss-Jordan: rows above the pivot are eliminated too, which costs no instruction in a
+//     lane = row layout (the FMAs run for all 64 lanes anyway), so there is no back substitution with its per-step hand-over:
+//     dx = b / pivot at the end, the reciprocals travel through LDS as well.
 // Pivots are taken on the diagonal under the same growth guard as lu_solve_neg_diag (multipliers of rows below the pivot on the
 // equilibrated matrix, positive pivots); when it trips, wave 0 alone redoes the solve with full partial pivoting (the
-// single-wave code) and hands dx to wave 1.  Steps that the pivot policy assigns to the pivot-only Newton run on wave 0 alone.
+// single-wave code).  Steps that the pivot policy assigns to the pivot-only Newton run on wave 0 alone.
 constexpr int W2_XCH = 3 * MAXN + 8;      // LDS doubles of the exchange area: multipliers [2][MAXN], reciprocals [MAXN], guard verdicts [2], 2 spare, hand-over counters (2 ints at +4), wave-0 value slots [2] at +5, 1 spare
 
 // Hand-over of the multipliers between the two waves WITHOUT a workgroup barrier.  A barrier per pivot keeps the waves in lock
@@ -2463,19 +2448,21 @@ __device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, doub
     }
 }
 
-// dx = -H\g for wave W of a two-wave workgroup (Gauss-Jordan, all 64 pivots dealt out to the two waves).
+// dx = -H\g on a two-wave workgroup (Gauss-Jordan, all 64 pivots dealt out to the two waves).  Wave 0 owns the rollout: it
+// carries the right-hand side and returns dx; the helper wave (W = 1) eliminates its columns and publishes its multipliers.
+// diag_own: H(lane,lane) before the elimination (the guard's scale), b0: -g (wave 0 only).
 // Measured and not kept: finishing the trailing 32 x 32 Schur complement with the one-wave DPP-fused solver (both waves
 // redundantly, S copied into both scratch areas) after 32 two-wave pivots - 9.18 ms per 100 steps of the 64-joint tree against 8.92:
 // the two-wave pivots are bound by their update instructions (4.6 k per wave and solve), not by the hand-overs, and the detour
 // (staging, 1.6 k instructions of solve, the U12 x2 product) is no shorter than the 1.5 k instructions it replaces.
 template <int NP, int W>
-__device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2], const double g, const double diag_own,
+__device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2], const double b0, const double diag_own,
                                            double* __restrict__ sX, bool& ok) {
     static_assert(NP == 64, "two-wave elimination: 64-lane trees");
     double* sL = sX;                 // [2][NP] multipliers, buffer = pivot parity
     double* sR = sX + 2 * NP;        // [NP] reciprocal pivots
     double* sF = sX + 3 * NP;        // [2] guard verdict of each wave (the hand-over counters follow)
-    double b = -g;
+    double b = b0;
     double gmax = 0.0, pmin = 1.0;
     const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
     int lv = lane;
@@ -2485,19 +2472,34 @@ __device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2],
     lu_gj_w2_step<NP, W, 0, NP>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
     const bool mine = !__any(!(gmax <= lim)) && (pmin > 0.0);
     if (lane == 0) sF[W] = mine ? 1.0 : 0.0;
-    // the step is wave 0's: it alone carries the right-hand side, and wave 1 takes dx from it - bit for bit, so that the two waves'
-    // Newton states cannot drift apart (their code is compiled separately; nothing guarantees identical FMA contraction)
-    if constexpr (W == 0) sL[lane] = b * sR[lane];
     __syncthreads();
     ok = sF[0] != 0.0 && sF[1] != 0.0;
-    const double dx = sL[lane];
+    const double dx = (W == 0) ? b * sR[lane] : 0.0;
     __syncthreads();                 // the exchange area is rewritten by the next solve
     return dx;
 }
 
-// The rare single-wave detours of the two-wave kernel are real function calls (not inlined): inlined, their uniform values
-// (model constants, masks) stay resident in scalar registers across the whole Newton loop of wave 0 and the Hessian's column
-// broadcasts no longer fit beside them.
+// The helper wave (W = 1) of the two-wave kernel: no rollout state at all.  It waits at barrier B1 for wave 0's command; on
+// "solve" it computes its half of H from the operands wave 0 staged, takes part in the elimination, and waits again.
+template <int NP, bool PROF = false>
+__device__ __forceinline__ void w2_helper_loop(const DevModel& M, const double* __restrict__ sOp0, double* __restrict__ sMine,
+                                               double* __restrict__ sX, const int lane, unsigned long long* prof = nullptr) {
+    while (true) {
+        __syncthreads();             // B1
+        if (sOp0[W2_CMD] == 0.0) break;
+        unsigned long long t0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+        double Hh[NP / 2];
+        const double hdiag = sOp0[W2_R_HD * W2_OP_STRIDE + lane];
+        w2_hess_mfma<NP, 1>(M, lane, sOp0, sMine, Hh);
+        if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[1] += t1 - t0; t0 = t1; }
+        bool ok;
+        (void)lu_gj_w2<NP, 1>(lane, Hh, 0.0, hdiag, sX, ok);
+        if (PROF) { prof[2] += __builtin_amdgcn_s_memtime() - t0; prof[3] += 1; }
+    }
+}
+
+// The rare single-wave detour of the two-wave kernel is a real function call (not inlined): inlined, its uniform values (model
+// constants, masks) stay resident in scalar registers across the whole Newton loop of wave 0.
 template <int NP>
 __device__ __attribute__((noinline)) double w2_pivoted_solve(const DevModel& M, double* sAcc, const int lane, const double x, const double qA,
                                                              const double qB, const double eta, const double g) {
@@ -2509,21 +2511,9 @@ __device__ __attribute__((noinline)) double w2_pivoted_solve(const DevModel& M, 
     return lu_solve_neg<NP>(M.n, lane, Hrow, g);
 }
 
-// A wave-uniform value of wave 0, for both waves.  Every branch of the two-wave Newton loop is taken on wave 0's numbers: the
-// waves run separately compiled copies of the same evaluation code on the same data, which is bit-identical in practice but is
-// not a guarantee one can rest a barrier protocol on (a one-ulp difference in |g|^2 next to tol would send the waves down
-// different paths and hang the workgroup).  Two slots used alternately: one barrier per call.
-template <int W>
-__device__ __forceinline__ double w2_from_wave0(double* __restrict__ sX, int& par, const double v) {
-    double* slot = sX + 3 * MAXN + 5 + (par & 1);
-    par ^= 1;
-    if (W == 0 && threadIdx.x == 0) *slot = v;
-    __syncthreads();
-    return *slot;
-}
-
-// newton_impl<NP, false> for wave W of a two-wave workgroup.  sAcc: this wave's private front scratch; sX: the exchange area.
-template <int NP, int W, bool PROF = false>
+// newton_impl<NP, false> on wave 0 of a two-wave workgroup: every (g,H) solve is shared with the helper wave, everything else
+// (the front, the line search, all decisions) is the one-wave algorithm on this wave's own scratch.  sX: the exchange area.
+template <int NP, bool PROF = false>
 __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o, double* sAcc, double* sX, const int lane, double x,
                                             const double qA, const double qB, const double eta, NodeOut& last, int& iters, int& halvings,
                                             int& status, PivotPolicy& piv, unsigned long long* prof = nullptr) {
@@ -2534,31 +2524,24 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
     eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
     int iter = 1;
-    int par = 0;
     double gcarry = -1.0;
     while (true) {
-        const double hdiag = eval_hess<NP, false, false, true, 2, W>(M, lane, fs, Hh, nullptr, sAcc);
+        const double hdiag = eval_hess<NP, false, false, true, 2, 0>(M, lane, fs, Hh, nullptr, sAcc);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[1] += t1 - t0; t0 = t1; }
         const NodeOut e0 = e;
         last = e;
         ++iters;
         bool lu_ok;
-        double dx = lu_gj_w2<NP, W>(lane, Hh, e.g, hdiag, sX, lu_ok);
+        double dx = lu_gj_w2<NP, 0>(lane, Hh, -e.g, hdiag, sX, lu_ok);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
         if (lu_ok) {
             piv.streak = 0;
-        } else {                     // growth guard tripped: wave 0 redoes this solve with partial pivoting, wave 1 takes its dx
+        } else {                     // growth guard tripped: redo this solve with partial pivoting, alone (the helper waits for the next command)
             ++piv.streak;
             status |= 16;
-            if (W == 0) {
-                dx = w2_pivoted_solve<NP>(M, sAcc, lane, x, qA, qB, eta, e.g);
-                sX[lane] = dx;
-            }
-            __syncthreads();
-            if (W != 0) dx = sX[lane];
-            __syncthreads();
+            dx = w2_pivoted_solve<NP>(M, sAcc, lane, x, qA, qB, eta, e.g);
         }
-        const double dxn2 = wave_sum(dx * dx);           // dx is wave 0's in both waves, the reduction is a fixed chain of adds
+        const double dxn2 = wave_sum(dx * dx);
         if (!(dxn2 == dxn2)) {
             status |= 4;
             break;
@@ -2568,7 +2551,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
             break;
         }
         double alpha = 1.0;
-        const double g0n2 = gcarry >= 0.0 ? gcarry : w2_from_wave0<W>(sX, par, wave_sum(e.g * e.g));
+        const double g0n2 = gcarry >= 0.0 ? gcarry : wave_sum(e.g * e.g);
         const double f0 = 0.5 * g0n2;
         const double x0 = x;
         int iterLs = 1;
@@ -2576,7 +2559,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
         bool stalled = false;
         while (true) {
             x = x0 + alpha * dx;
-            if (w2_from_wave0<W>(sX, par, __all(x == x0) ? 1.0 : 0.0) != 0.0) {
+            if (__all(x == x0)) {
                 stalled = true;
                 iterLs = o.iterLsMax;
                 e = e0;
@@ -2585,7 +2568,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
             if (PROF) t0 = __builtin_amdgcn_s_memtime();
             eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
             if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
-            gn2 = w2_from_wave0<W>(sX, par, wave_sum(e.g * e.g));
+            gn2 = wave_sum(e.g * e.g);
             if (0.5 * gn2 < f0) break;
             if (iterLs >= o.iterLsMax) break;
             alpha *= 0.5;

@@ -1,10 +1,12 @@
 // rmx_kernels_w2.hip -- the two-wave BDF1 step kernel for trees of 33..64 nodes (rmx_device.h, "two wavefronts per trajectory").
 //
-// A trajectory gets a workgroup of TWO wavefronts; wave W owns the columns c = 2 t + W of the Hessian and of the elimination.
-// Chosen by the launcher when the batch leaves SIMDs idle (2 B <= number of SIMDs: BASELINE.json configs[2] puts 512 rollouts
-// on each GPU's 1024 SIMDs), see launch_step_w2_64 below.  LDS of a workgroup: [per-node constants, one copy][exchange
-// area][front scratch of wave 0][front scratch of wave 1].  Inside the evaluation stages the waves are independent (private
-// scratch), so those stages order their LDS traffic wave-locally; only the elimination's hand-overs use the workgroup barrier.
+// A trajectory gets a workgroup of TWO wavefronts.  Wave 0 owns the rollout (state, front, line search, every decision); the
+// second wave is a linear-algebra helper: for every (g,H) solve wave 0 stages the operands of H in LDS and posts a command, each
+// wave assembles the half of H whose columns c = 2 t + W it owns on the matrix cores and they eliminate together.
+// Chosen by the launcher when that finishes the batch sooner (BASELINE.json configs[2] puts 512 rollouts on each GPU's 1024
+// SIMDs), see launch_step_np_64.  LDS of a workgroup: [per-node constants][exchange area][wave 0: front scratch / operand
+// staging / its half of H][helper: its half of H].  Wave 0's evaluation stages order their LDS traffic wave-locally (RMX_SYNC);
+// workgroup barriers only at the hand-overs of a solve (B1 command, B2 operands consumed, elimination start / verdict / end).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -26,16 +28,17 @@ __device__ __forceinline__ double* rmx_smem_base() {
 
 #include "rmx_host.h"
 
-// pivot-only Newton of one step on wave 0 alone: a real call, see w2_pivoted_solve
+// pivot-only Newton of one step (the pivot policy's back-off, or lu_mode = 1): the one-wave code, a real call (see w2_pivoted_solve)
 template <int NP>
 __device__ __attribute__((noinline)) double w2_pivot_only_newton(const DevModel& M, const DevOpts& o, double* sAcc, const int lane, const double xg,
                                                                  const double q0, NodeOut& last, int& iters, int& halv, int& status, PivotPolicy& piv) {
     return newton_impl<NP, true, false>(M, o, sAcc, nullptr, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
 }
 
-template <int NP, int W, bool PROF>
-__device__ __forceinline__ void step_bdf1_w2_body(const DevModel& M, const DevOpts& o, const StepArgs& a, double* sAcc, double* sX, unsigned long long* dprof) {
-    unsigned long long prof[3] = {0ull, 0ull, 0ull};
+// Wave 0: simLoop (driverRedMaxBDF1.m:57-91) exactly as k_step_bdf1, with the (g,H) solves of the fast Newton shared with the helper wave.
+template <int NP, bool PROF>
+__device__ __forceinline__ void step_bdf1_w2_owner(const DevModel& M, const DevOpts& o, const StepArgs& a, double* sAcc, double* sX, unsigned long long* dprof) {
+    unsigned long long prof[4] = {0ull, 0ull, 0ull, 0ull};
     const int lane = threadIdx.x & 63, traj = blockIdx.x;
     const int id = (lane < M.n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
@@ -43,60 +46,46 @@ __device__ __forceinline__ void step_bdf1_w2_body(const DevModel& M, const DevOp
     double qd = id >= 0 ? a.qd[off] : 0.0;
     int iters = 0, halv = 0, status = 0;
     PivotPolicy piv;
-    for (int s = 0; s < a.nsteps; ++s) {       // simLoop (driverRedMaxBDF1.m:57-91), as k_step_bdf1
+    for (int s = 0; s < a.nsteps; ++s) {
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;
         NodeOut last;
         double x;
-        if (o.lu_mode != 0 || piv.hold > 0) {  // pivot-only Newton (wave-uniform, same in both waves): wave 0 alone, the single-wave code
+        if (o.lu_mode != 0 || piv.hold > 0) {      // wave-uniform: this step on the pivot-only Newton, alone (the helper keeps waiting)
             if (piv.hold > 0) --piv.hold;
-            if (W == 0) {
-                x = w2_pivot_only_newton<NP>(M, o, sAcc, lane, xg, q0, last, iters, halv, status, piv);
-                sX[lane] = x;
-            }
-            __syncthreads();
-            if (W != 0) x = sX[lane];
-            __syncthreads();
+            x = w2_pivot_only_newton<NP>(M, o, sAcc, lane, xg, q0, last, iters, halv, status, piv);
         } else {
-            x = newton_w2<NP, W, PROF>(M, o, sAcc, sX, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, prof);
+            x = newton_w2<NP, PROF>(M, o, sAcc, sX, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, prof);
             pivot_policy_update(piv);
-            // the state is wave 0's (it alone is stored): wave 1 re-reads it every step so that a one-ulp difference between the
-            // two separately compiled copies of the update x0 + alpha dx cannot grow over a rollout
-            if (W == 0) sX[lane] = x;
-            __syncthreads();
-            x = sX[lane];
-            __syncthreads();
         }
         qd = (x - q0) / o.h;
         q = x;
-        if (W == 0) {
-            if (a.histT) {
-                const double T = wave_sum(last.eT), V = wave_sum(last.eV);
-                if (lane == 0) {
-                    a.histT[(size_t)s * a.B + traj] = T;
-                    a.histV[(size_t)s * a.B + traj] = V;
-                }
-            }
-            if (a.histQ && id >= 0) {
-                a.histQ[(size_t)s * a.B * M.nr + off] = q;
-                a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+        if (a.histT) {
+            const double T = wave_sum(last.eT), V = wave_sum(last.eV);
+            if (lane == 0) {
+                a.histT[(size_t)s * a.B + traj] = T;
+                a.histV[(size_t)s * a.B + traj] = V;
             }
         }
+        if (a.histQ && id >= 0) {
+            a.histQ[(size_t)s * a.B * M.nr + off] = q;
+            a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+        }
     }
+    if (lane == 0) sAcc[W2_CMD] = 0.0;     // command: exit
+    __syncthreads();                       // B1 of the helper's last wait
     if (PROF && lane == 0) {
-        for (int c = 0; c < 3; ++c) dprof[(size_t)(2 * traj + W) * 4 + c] = prof[c];
-        dprof[(size_t)(2 * traj + W) * 4 + 3] = (unsigned long long)iters;
+        for (int c = 0; c < 3; ++c) dprof[(size_t)(2 * traj) * 4 + c] = prof[c];
+        dprof[(size_t)(2 * traj) * 4 + 3] = (unsigned long long)iters;
     }
-    if (W == 0) {
-        if (id >= 0) {
-            a.q[off] = q;
-            a.qd[off] = qd;
-        }
-        if (lane == 0 && a.it) {
-            a.it[traj] += iters;
-            a.ls[traj] += halv;
-            a.status[traj] |= status;
-        }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+    }
+    if (lane == 0 && a.it) {
+        a.it[traj] += iters;
+        a.ls[traj] += halv;
+        a.status[traj] |= status;
     }
 }
 
@@ -106,8 +95,9 @@ __global__ void __launch_bounds__(128) k_step_bdf1_w2(const DevModel M, const De
     constexpr int CS = cstride(NP);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* sX = smem + NCONST * CS;
-    double* sAcc = sX + W2_XCH + w * w2_acc_doubles(M.n);
-    // per-node constants (the layout eval_front_e2 reads; see smem_setup in rmx_kernels.hip), staged by wave 0
+    double* sAcc0 = sX + W2_XCH;                       // wave 0: front scratch, operand staging, its half of H
+    double* sAcc1 = sAcc0 + w2_acc_doubles(M.n);       // helper wave: its half of H on the way to row-per-lane
+    // per-node constants (the layout eval_front_e2 reads; see smem_setup in rmx_kernels.hip)
     if (threadIdx.x < CS) {
         const int j = threadIdx.x;
         const bool in = j < M.n;
@@ -131,10 +121,16 @@ __global__ void __launch_bounds__(128) k_step_bdf1_w2(const DevModel M, const De
         c += CS;
         for (int r = 0; r < 4; ++r) c[r * CS + j] = 0.0;
     }
-    if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;     // zero row n of this wave's scratch (end-of-tree suffix)
+    if (threadIdx.x < ACC_STRIDE) sAcc0[M.n * ACC_STRIDE + threadIdx.x] = 0.0;     // zero row n of the front's scratch (end-of-tree suffix)
     __syncthreads();
-    if (w == 0) step_bdf1_w2_body<NP, 0, PROF>(M, o, a, sAcc, sX, dprof);
-    else step_bdf1_w2_body<NP, 1, PROF>(M, o, a, sAcc, sX, dprof);
+    if (w == 0) {
+        step_bdf1_w2_owner<NP, PROF>(M, o, a, sAcc0, sX, dprof);
+    } else {
+        unsigned long long prof[4] = {0ull, 0ull, 0ull, 0ull};
+        w2_helper_loop<NP, PROF>(M, sAcc0, sAcc1, sX, lane, prof);
+        if (PROF && lane == 0)
+            for (int c = 0; c < 4; ++c) dprof[(size_t)(2 * blockIdx.x + 1) * 4 + c] = prof[c];
+    }
 }
 
 size_t rmx_w2_smem_bytes(const rmx_model* m) {
