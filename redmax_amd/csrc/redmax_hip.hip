@@ -523,6 +523,7 @@ extern "C" int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out) {
     alloc((void**)&b->tmpA, nb); alloc((void**)&b->tmpB, nb); alloc((void**)&b->tmpC, nb);
     alloc((void**)&b->started, sizeof(int));
     alloc((void**)&b->it, sizeof(int) * batch); alloc((void**)&b->ls, sizeof(int) * batch); alloc((void**)&b->status, sizeof(int) * batch);
+    alloc((void**)&b->resume, sizeof(int) * batch);
     if (m->dm.nsph) {   // every JointSpherical starts in CHART_XYZ (JointSpherical.m:33)
         const std::vector<int> c7((size_t)batch * m->dm.nsph, 7);
         if (e == hipSuccess) e = hipMalloc((void**)&b->chart, c7.size() * sizeof(int));
@@ -545,7 +546,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     (void)hipSetDevice(b->m->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->chart})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -696,6 +697,7 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.histT = dT; a.histV = dV;
     a.histQ = dQ; a.histQd = dQd; a.histC = dC;
     a.chart = b->chart;
+    a.resume = b->resume;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
     // BDF2 keeps (q, qdot) of step k-1 in qp/qdp.  BDF1 steps do not maintain them (and, with JointSpherical, may leave q in

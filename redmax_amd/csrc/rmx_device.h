@@ -637,7 +637,7 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
 // FULL: accumulate the Hessian's subtree sums as well (28 numbers per body instead of 6).
 // e2 is the coefficient of f in g = M v - e2 f: eta^2 for the implicit integrators; the linearly-implicit Euler step of
 // matlab-simple uses e2 = -h with v = qdot0 so that g = M qdot0 + h f is its right-hand side.
-template <int NP, bool FULL, bool TIMED = false, bool CT = false>
+template <int NP, bool FULL, bool TIMED = false, bool CT = false, bool NEARCHK = false>
 __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
                                               const double xqd, const double xv, const double eta, const double e2, NodeOut& out,
                                               FrontState& fs, unsigned long long* stamps = nullptr) {
@@ -833,15 +833,29 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     // ground contact wrench of this body, world frame (its K/D blocks are formed by eval_hess, once per Newton iteration)
     double eVc = 0.0;
     fs.touched = false;
-    if constexpr (CT) {
+    if constexpr (CT || NEARCHK) {
+        // The lowest corner of the cuboid sits  n.(p - xg) - 1/2 sum_i |n.R_i| sides_i  above the plane (R_i: column i of the
+        // body's rotation).  While that is positive for every body of the tree (wave-uniform, with a margin far above the
+        // rounding of either form) no corner penetrates: the corner loop would find nothing and leave Fc = 0, eVc = 0,
+        // touched = false, and it is skipped.  NEARCHK (the lean Newton of the contact-capable step kernels, newton_node):
+        // only this test runs and its outcome is reported in fs.touched; the caller leaves the lean path when it is set.
         const bool con = cCon[jc] != 0.0;
         const double sd[3] = {cCon[CS + jc], cCon[2 * CS + jc], cCon[3 * CS + jc]};
-        double Fc[6], k1[36], d1[36];
-        fs.touched = contact_body<false>(M, con, sd, R, p, phw, phv, Fc, k1, d1, eVc);
+        const double dc = M.gn[0] * (p[0] - M.gx[0]) + M.gn[1] * (p[1] - M.gx[1]) + M.gn[2] * (p[2] - M.gx[2]);
+        const double reach = 0.5 * (fabs(M.gn[0] * R[0] + M.gn[1] * R[3] + M.gn[2] * R[6]) * sd[0] +
+                                    fabs(M.gn[0] * R[1] + M.gn[1] * R[4] + M.gn[2] * R[7]) * sd[1] +
+                                    fabs(M.gn[0] * R[2] + M.gn[1] * R[5] + M.gn[2] * R[8]) * sd[2]);
+        const bool near = __any(con && !(dc - reach > 1e-9 * (fabs(dc) + reach)));
+        if constexpr (!CT) {
+            fs.touched = near;
+        } else if (near) {
+            double Fc[6], k1[36], d1[36];
+            fs.touched = contact_body<false>(M, con, sd, R, p, phw, phv, Fc, k1, d1, eVc);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            wt[c] -= e2 * Fc[c];
-            wf[c] -= e2 * Fc[3 + c];
+            for (int c = 0; c < 3; ++c) {
+                wt[c] -= e2 * Fc[c];
+                wf[c] -= e2 * Fc[3 + c];
+            }
         }
     }
 
@@ -1001,11 +1015,11 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
     RMX_STAMP(8)
 }
 
-template <int NP, bool FULL, bool TIMED = false, bool CT = false>
+template <int NP, bool FULL, bool TIMED = false, bool CT = false, bool NEARCHK = false>
 __device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
                                            const double xqd, const double xv, const double eta, NodeOut& out, FrontState& fs,
                                            unsigned long long* stamps = nullptr) {
-    eval_front_e2<NP, FULL, TIMED, CT>(M, sAcc, lane, xq, xqd, xv, eta, eta * eta, out, fs, stamps);
+    eval_front_e2<NP, FULL, TIMED, CT, NEARCHK>(M, sAcc, lane, xq, xqd, xv, eta, eta * eta, out, fs, stamps);
 }
 
 // Reduced mass matrix row M(a,:) = (J' Mm J)(a,:) of this node from the subtree inertias (computeValues :212;
@@ -2244,7 +2258,10 @@ __device__ __forceinline__ void pivot_policy_update(PivotPolicy& piv) {   // aft
 // at most iterLsMax halvings (the last trial is kept), stop on |g|<tol, iter>=iterMax or |dx|>dxMax.
 // The (g,H) evaluation at the top of iteration k+1 is the Hessian stage applied to the state of the line-search
 // evaluation that accepted x_{k+1} (same x, same arithmetic, so the same g the reference recomputes).
-template <int NP, bool PIVOT_ONLY, bool CT = false>
+// LEAN (contact-capable kernels, see newton_node): the evaluations carry no contact terms but test whether any cuboid of the tree
+// comes near the ground; the first one that does ends the solve with status bit 64 and the caller redoes it with CT = true.
+constexpr int ST_LEFT_LEAN = 64;
+template <int NP, bool PIVOT_ONLY, bool CT = false, bool LEAN = false>
 __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
                                               int& iters, int& halvings, int& status, PivotPolicy& piv) {
@@ -2252,7 +2269,11 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     double Hrow[NP];
     FrontState fs;
     NodeOut e;
-    eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+    eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+    if (LEAN && fs.touched) {
+        status |= ST_LEFT_LEAN;
+        return x;
+    }
     int iter = 1;
     double gcarry = -1.0;
     while (true) {
@@ -2275,7 +2296,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 // H was destroyed in place.  The front is re-evaluated too (same x, same arithmetic) so that its state does
                 // not have to stay live in registers across the fast-path LU for the sake of this rare branch.
                 NodeOut e2;
-                eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
+                eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
                 eval_hess<NP, false, CT>(M, lane, fs, Hrow, nullptr, sAcc);
                 dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
             }
@@ -2309,7 +2330,11 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 e = e0;              // the evaluation at x0
                 break;
             }
-            eval_front<NP, true, false, CT>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+            eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+            if (LEAN && fs.touched) {
+                status |= ST_LEFT_LEAN;
+                return x;
+            }
             gn2 = wave_sum(e.g * e.g);
             if (0.5 * gn2 < f0) break;
             if (iterLs >= o.iterLsMax) break;
@@ -2335,17 +2360,45 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     return x;
 }
 
-template <int NP, bool CT = false>
+template <int NP, bool CT, bool LEAN>
+__device__ __forceinline__ double newton_policy(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
+                                                double x, const double qA, const double qB, const double eta, NodeOut& last,
+                                                int& iters, int& halvings, int& status, PivotPolicy& piv) {
+    if (o.lu_mode != 0 || piv.hold > 0) {     // wave-uniform
+        if (piv.hold > 0) --piv.hold;
+        return newton_impl<NP, true, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    }
+    const double r = newton_impl<NP, false, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    pivot_policy_update(piv);
+    return r;
+}
+
+// One implicit solve of a step.  LEAN (the first of the two launches of a contact-capable step, rmx_kernels.hip): the plain
+// evaluation plus a test that every cuboid of the tree is clear of the ground, under which the contact terms vanish
+// identically.  The first evaluation that fails the test ends the solve: status bit ST_LEFT_LEAN comes back set, nothing else
+// is touched, and the caller parks the trajectory at the start of this step for the launch with the contact terms.
+template <int NP, bool CT = false, bool LEAN = false>
 __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
                                               int& iters, int& halvings, int& status, PivotPolicy& piv) {
-    if (o.lu_mode != 0 || piv.hold > 0) {     // wave-uniform
-        if (piv.hold > 0) --piv.hold;
-        return newton_impl<NP, true, CT>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    if constexpr (!LEAN) {
+        return newton_policy<NP, CT, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    } else {
+        int it2 = 0, hv2 = 0, st2 = 0;
+        PivotPolicy pv2 = piv;
+        NodeOut l2;
+        const double r = newton_policy<NP, false, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, l2, it2, hv2, st2, pv2);
+        if (st2 & ST_LEFT_LEAN) {
+            status |= ST_LEFT_LEAN;
+            return x;
+        }
+        iters += it2;
+        halvings += hv2;
+        status |= st2;
+        piv = pv2;
+        last = l2;
+        return r;
     }
-    const double r = newton_impl<NP, false, CT>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
-    pivot_policy_update(piv);
-    return r;
 }
 
 // ----------------------------------------------------------------------------- two wavefronts per trajectory (trees of 33..64 nodes)

@@ -30,6 +30,7 @@ struct StepArgs {
     double* histQ;    // [nsteps][B][nr] or null: q, qdot after every step (Scene.saveHistory, Scene.m:134-161)
     double* histQd;
     int* histC;       // [nsteps][B][nsph] or null: Euler charts after every step
+    int* resume;      // [B] contact-capable kernels: first step the lean launch left to the launch with the contact terms
 };
 
 struct AdjArgs {
@@ -68,6 +69,7 @@ struct rmx_batch {
     int* started = nullptr;
     int* chart = nullptr;           // [B][nsph] current Euler chart of every spherical joint (JointSpherical.chart), 1..12
     int *it = nullptr, *ls = nullptr, *status = nullptr;
+    int* resume = nullptr;          // [B] see StepArgs.resume
     double last_ms = 0.0;
 };
 

@@ -47,8 +47,17 @@ __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, dou
 }
 
 // simLoop (driverRedMaxBDF1.m:57-91): all steps of one trajectory inside one wavefront.
-template <int NP, bool CT>
+// Contact-capable scenes (CT) take two launches per call.  LEAN: the plain evaluation plus the test that every cuboid is clear of
+// the ground; a trajectory that fails it stops at the start of that step and leaves the step index in a.resume.  The second
+// launch (CT, not LEAN: the evaluation with the contact terms) takes every trajectory from its a.resume to the end.  In one
+// kernel the contact terms' registers (72 accumulators for the K/D blocks on top of the Hessian stage's state) put the whole
+// Newton loop into scratch - 34 us per iteration in free flight against 12 us for the plain kernel (tools/ct_overhead.py) -
+// and an out-of-line call of the contact solve tripled ITS cost (the model constants arrive as a pointer into scratch).
+template <int NP, bool CT, bool LEAN = false>
 __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpts o, const StepArgs a) {
+    static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
+    const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
+    if (s0 >= a.nsteps) return;                    // the lean launch took this trajectory all the way
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x, traj = blockIdx.x;
@@ -62,11 +71,17 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
     if constexpr (CT) {
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
     }
-    for (int s = 0; s < a.nsteps; ++s) {
+    int stop = a.nsteps;
+    for (int s = s0; s < a.nsteps; ++s) {
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
         NodeOut last;
-        const double x = newton_node<NP, CT>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
+        const double x = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
+        if (LEAN && (status & ST_LEFT_LEAN)) {
+            status &= ~ST_LEFT_LEAN;
+            stop = s;
+            break;
+        }
         qd = (x - q0) / o.h;                       // (:72)
         q = x;
         if constexpr (CT) {                        // jroot.reparam() (:78)
@@ -92,6 +107,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
         a.q[off] = q;
         a.qd[off] = qd;
     }
+    if (LEAN && lane == 0) a.resume[traj] = stop;
     if (lane == 0 && a.it) {
         a.it[traj] += iters;
         a.ls[traj] += halv;
@@ -99,9 +115,12 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
     }
 }
 
-// simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.
-template <int NP, bool CT>
+// simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.  CT / LEAN: see k_step_bdf1.
+template <int NP, bool CT, bool LEAN = false>
 __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpts o, const StepArgs a) {
+    static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
+    const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
+    if (s0 >= a.nsteps) return;
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x, traj = blockIdx.x;
@@ -111,7 +130,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
     double qd = id >= 0 ? a.qd[off] : 0.0;
     double qp = id >= 0 ? a.qp[off] : 0.0;       // step k-1 (Joint.q1 / qdot1 in the reference)
     double qdp = id >= 0 ? a.qdp[off] : 0.0;
-    const bool started = (*a.started) != 0;
+    const bool started = (*a.started) != 0 || s0 > 0;    // resumed behind the lean launch: its steps are this call's history
     const double h = o.h;
     int iters = 0, halv = 0, status = 0;
     PivotPolicy piv;
@@ -119,20 +138,31 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
     if constexpr (CT) {
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
     }
-    for (int s = 0; s < a.nsteps; ++s) {
+    int stop = a.nsteps;
+    for (int s = s0; s < a.nsteps; ++s) {
         NodeOut last;
         if (s == 0 && !started) {
             const double al = (2.0 - sqrt(2.0)) / 2.0;    // (:74)
             const double q0 = q, qd0 = qd;
             // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
             const double xa0 = q0 + al * h * qd0;
-            const double qa = newton_node<NP, CT>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv);
+            const double qa = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv);
+            if (LEAN && (status & ST_LEFT_LEAN)) {
+                status &= ~ST_LEFT_LEAN;
+                stop = s;
+                break;
+            }
             const double qda = (qa - q0) / (al * h);
             // SDIRK2b (evalSDIRK2b :228-260)
             const double x10 = qa + (1.0 - al) * h * qda;
             const double qA = q0 + (1.0 - al) * h * qda;
             const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-            const double q1 = newton_node<NP, CT>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv);
+            const double q1 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv);
+            if (LEAN && (status & ST_LEFT_LEAN)) {
+                status &= ~ST_LEFT_LEAN;
+                stop = s;
+                break;
+            }
             qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
             q = q1;
             qp = q0;
@@ -143,7 +173,12 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             const double x0 = q1 + h * qd1;
             const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
             const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-            const double q2 = newton_node<NP, CT>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv);
+            const double q2 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv);
+            if (LEAN && (status & ST_LEFT_LEAN)) {
+                status &= ~ST_LEFT_LEAN;
+                stop = s;
+                break;
+            }
             qp = q1;
             qdp = qd1;
             qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
@@ -174,6 +209,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
         a.qp[off] = qp;
         a.qdp[off] = qdp;
     }
+    if (LEAN && lane == 0) a.resume[traj] = stop;
     if (lane == 0 && a.it) {
         a.it[traj] += iters;
         a.ls[traj] += halv;
@@ -544,6 +580,11 @@ void RMX_CAT(launch_eval_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bo
 }
 void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+    // every trajectory as far as it stays clear of the ground (all the way in scenes without ForceGroundCuboid) ...
+    if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    else k_step_bdf2<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    if (!m->dm.con) return;
+    // ... and the rest of its steps with the contact terms
     if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
     else k_step_bdf2<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
 }
