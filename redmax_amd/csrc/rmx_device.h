@@ -423,23 +423,28 @@ __device__ __forceinline__ void acc_GwT(const double x[3], const double CL[9], c
     }
 }
 
-template <bool DERIV>
+// index of entry (r, c), r <= c, of a symmetric 6x6 matrix stored as its 21 upper-triangle entries, rows first
+__host__ __device__ constexpr int sym21(const int r, const int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
+// MODE 0: wrench and energy only (F, V: the front, every evaluation).  MODE 1: the stiffness block Kw (36, row-major).
+// MODE 2: the damping block Dw = sum Gw' Y Gw, symmetric because N, T and AT are: its 21 upper-triangle entries, rows first
+// (00..05, 11..15, 22..25, 33..35, 44, 45, 55).  The two derivative passes each repeat the corner geometry; keeping both blocks
+// (72 accumulators) live at once is what pushed the Hessian stage of the contact kernels into scratch.
+template <int MODE>
 __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, const double sd[3], const double R[9],
                                              const double p[3], const double phw[3], const double phv[3], double (&F)[6],
-                                             double (&Kw)[36], double (&Dw)[36], double& V) {
+                                             double (&KD)[36], double& V) {
     const double n[3] = {M.gn[0], M.gn[1], M.gn[2]};
     const double kn = M.kn, kt = M.kt, mu = M.mu, kdc = M.kdc;
+    if (MODE == 0) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) F[c] = 0.0;
-    if (DERIV) {
+        for (int c = 0; c < 6; ++c) F[c] = 0.0;
+        V = 0.0;
+    } else {
 #pragma unroll
-        for (int c = 0; c < 36; ++c) {
-            Kw[c] = 0.0;
-            Dw[c] = 0.0;
-        }
+        for (int c = 0; c < (MODE == 1 ? 36 : 21); ++c) KD[c] = 0.0;
     }
-    V = 0.0;
     bool touched = false;
+#pragma unroll 1     // unrolled, the scheduler interleaves the eight corners and their temporaries spill
     for (int ic = 0; ic < 8; ++ic) {
         // the 8 corners (+-sides/2, ForceGroundCuboid.m:71-83); their order is irrelevant to the sums
         const double xl[3] = {(ic & 4 ? 0.5 : -0.5) * sd[0], (ic & 2 ? 0.5 : -0.5) * sd[1], (ic & 1 ? 0.5 : -0.5) * sd[2]};
@@ -452,47 +457,44 @@ __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, 
         if (!__any(pen)) continue;                   // wave-uniform skip
         touched = true;
         if (pen) {
-            V += 0.5 * kn * d * d;                   // (:176)
+            if (MODE == 0) V += 0.5 * kn * d * d;    // (:176)
             double vw[3], t3[3];
             cross3(phw, x, t3);
 #pragma unroll
             for (int c = 0; c < 3; ++c) vw[c] = phv[c] + t3[c];
             const double nv = dot3(n, vw);
-            double a[3], f[3];
+            double a[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                a[c] = vw[c] - n[c] * nv;            // T vw
-                f[c] = -kn * d * n[c] - kdc * nv * n[c];
-            }
+            for (int c = 0; c < 3; ++c) a[c] = vw[c] - n[c] * nv;            // T vw
             const double an = sqrt(dot3(a, a));
             const bool fric = mu != 0.0;
             const bool stat = fric && (mu * fabs(kn * d) > kt * an);   // (:112)
             const double mukn = mu * kn;
             double tt[3] = {0.0, 0.0, 0.0};
-            if (fric) {
-                if (stat) {
+            if (fric && !stat) {
+                const double ia = 1.0 / an;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) f[c] -= kt * a[c];
-                } else {
-                    const double ia = 1.0 / an;
+                for (int c = 0; c < 3; ++c) tt[c] = a[c] * ia;
+            }
+            if (MODE == 0) {
+                double f[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        tt[c] = a[c] * ia;
-                        f[c] -= mukn * d * tt[c];
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    f[c] = -kn * d * n[c] - kdc * nv * n[c];
+                    if (fric) f[c] -= stat ? kt * a[c] : mukn * d * tt[c];
+                }
+                cross3(x, f, t3);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    F[c] += t3[c];
+                    F[3 + c] += f[c];
                 }
             }
-            cross3(x, f, t3);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                F[c] += t3[c];
-                F[3 + c] += f[c];
-            }
-            if (DERIV) {
+            if (MODE == 1) {
                 double nx[3], nxv[3];
                 cross3(n, x, nx);
                 cross3(n, vw, nxv);
-                double XL[9], XR[9], Y[9], Sk[9];
+                double XL[9], XR[9], Sk[9];
                 // normal spring + damper
                 const double Nv[3] = {n[0] * nv, n[1] * nv, n[2] * nv};
                 double Sn[9], SNv[9];
@@ -502,10 +504,8 @@ __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, 
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const double nn = n[i] * n[k];
                         XL[3 * i + k] = -kn * (d * Sn[3 * i + k] - n[i] * nx[k]) - kdc * (SNv[3 * i + k] - n[i] * nxv[k]);
-                        XR[3 * i + k] = -kn * nn;
-                        Y[3 * i + k] = -kdc * nn;
+                        XR[3 * i + k] = -kn * (n[i] * n[k]);
                     }
                 if (fric) {
                     double Sv[9];
@@ -515,11 +515,8 @@ __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, 
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                const double Tik = (i == k ? 1.0 : 0.0) - n[i] * n[k];
-                                Y[3 * i + k] -= kt * Tik;
+                            for (int k = 0; k < 3; ++k)
                                 XL[3 * i + k] -= kt * (Sk[3 * i + k] - (Sv[3 * i + k] - n[i] * nxv[k]));
-                            }
                     } else {
                         const double ia = 1.0 / an, ia3 = ia * ia * ia, a2 = an * an;
                         double AT[9], ATS[9];
@@ -538,22 +535,66 @@ __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, 
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
                             for (int k = 0; k < 3; ++k) {
-                                Y[3 * i + k] -= mukn * d * AT[3 * i + k];
                                 XL[3 * i + k] -= mukn * (d * Sk[3 * i + k] - d * ATS[3 * i + k] - tt[i] * nx[k]);
                                 XR[3 * i + k] -= mukn * tt[i] * n[k];
                             }
                     }
                 }
-                acc_GwT(x, XL, XR, Kw);
-                // Y Gw = [-Y[x], Y]
-                double Sx[9], YL[9];
+                acc_GwT(x, XL, XR, KD);
+            }
+            if (MODE == 2) {
+                double Y[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) Y[3 * i + k] = -kdc * (n[i] * n[k]);
+                if (fric) {
+                    if (stat) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) Y[3 * i + k] -= kt * ((i == k ? 1.0 : 0.0) - n[i] * n[k]);
+                    } else {
+                        const double ia = 1.0 / an, ia3 = ia * ia * ia, a2 = an * an;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                Y[3 * i + k] -= mukn * d * (((i == k ? a2 : 0.0) - a[i] * a[k]) * ia3 - n[i] * n[k] * ia);
+                    }
+                }
+                // Gw' Y Gw = [[x] Y [x]' , [x] Y ; Y [x]' , Y]  ([x]' = -[x]); YL = -Y [x]
+                double Sx[9], YL[9], TT[9];
                 skew3(x, Sx);
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
                         YL[3 * i + k] = -(Y[3 * i] * Sx[k] + Y[3 * i + 1] * Sx[3 + k] + Y[3 * i + 2] * Sx[6 + k]);
-                acc_GwT(x, YL, Y, Dw);
+                // top rows: [x] [YL Y]
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double cl[3] = {YL[k], YL[3 + k], YL[6 + k]}, cr[3] = {Y[k], Y[3 + k], Y[6 + k]};
+                    double xl3[3], xr3[3];
+                    cross3(x, cl, xl3);
+                    cross3(x, cr, xr3);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        TT[3 * i + k] = xl3[i];          // ([x] YL)(i,k)
+                        if (true) {
+                            // ([x] Y)(i,k): rows 0..2, columns 3..5
+                            const int r = i, c = 3 + k;
+                            KD[sym21(r, c)] += xr3[i];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = i; k < 3; ++k) {
+                        KD[sym21(i, k)] += TT[3 * i + k];
+                        KD[sym21(3 + i, 3 + k)] += Y[3 * i + k];
+                    }
             }
         }
     }
@@ -849,8 +890,8 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         if constexpr (!CT) {
             fs.touched = near;
         } else if (near) {
-            double Fc[6], k1[36], d1[36];
-            fs.touched = contact_body<false>(M, con, sd, R, p, phw, phv, Fc, k1, d1, eVc);
+            double Fc[6], k1[36];
+            fs.touched = contact_body<0>(M, con, sd, R, p, phw, phv, Fc, k1, eVc);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 wt[c] -= e2 * Fc[c];
@@ -1276,13 +1317,6 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             const double* cCon = cEnd + CS;
             const bool con = act && cCon[jj] != 0.0;
             const double sd[3] = {cCon[CS + jj], cCon[2 * CS + jj], cCon[3 * CS + jj]};
-            double Fc[6], KD[72], eVc;            // Kx and Dx back to back: 72 numbers = three passes of the 28-wide scan
-            double (&Kx)[36] = *reinterpret_cast<double (*)[36]>(&KD[0]);
-            double (&Dx)[36] = *reinterpret_cast<double (*)[36]>(&KD[36]);
-            contact_body<true>(M, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Kx, Dx, eVc);
-            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &KD[0]);
-            lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &KD[28]);
-            lds_subtree_sum<NP, 16>(M, sAcc, cEnd, lane, act, jj, &KD[56]);
             const double s6[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
             double m26[6];
 #pragma unroll
@@ -1290,18 +1324,40 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                 m26[c] = eta * sw[c] + e2 * xiw[c];
                 m26[3 + c] = eta * sv[c] + e2 * xiv[c];
             }
+            double Fc[6], eVc;
+            {   // stiffness block: 36 numbers = two passes of the 28-wide scan
+                double Kx[36];
+                contact_body<1>(M, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Kx, eVc);
+                lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Kx[0]);
+                lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Kx[28]);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double ay = 0.0, a2 = 0.0, a3 = 0.0;
+                for (int r = 0; r < 6; ++r) {
+                    double ay = 0.0, a3 = 0.0;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    ay += Dx[6 * r + c] * m26[c] + e2 * Kx[6 * r + c] * s6[c];
-                    a2 += Dx[6 * c + r] * s6[c];
-                    a3 += Kx[6 * c + r] * s6[c];
+                    for (int c = 0; c < 6; ++c) {
+                        ay += Kx[6 * r + c] * s6[c];
+                        a3 += Kx[6 * c + r] * s6[c];
+                    }
+                    cxy[r] = e2 * ay;
+                    cxr3[r] = e2 * a3;
                 }
-                cxy[r] = ay;
-                cxr2[r] = a2;
-                cxr3[r] = e2 * a3;
+            }
+            {   // damping block, symmetric: 21 numbers, one pass
+                double Dx[36];
+                contact_body<2>(M, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Dx, eVc);
+                lds_subtree_sum<NP, 21>(M, sAcc, cEnd, lane, act, jj, &Dx[0]);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double ay = 0.0, a2 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        const double drc = Dx[r <= c ? sym21(r, c) : sym21(c, r)];
+                        ay += drc * m26[c];
+                        a2 += drc * s6[c];
+                    }
+                    cxy[r] += ay;
+                    cxr2[r] = a2;
+                }
             }
         }
     }
