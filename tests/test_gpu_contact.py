@@ -14,7 +14,7 @@ Tolerances (fp64):
 import numpy as np
 import pytest
 
-from redmax_amd.scenes import sceneChainGround, scenesRedMax, syntheticStates
+from redmax_amd.scenes import sceneChain, sceneChainGround, scenesRedMax, syntheticStates
 
 pytestmark = pytest.mark.gpu
 
@@ -107,6 +107,67 @@ def test_config5_chain_ground_rollout_matches_oracle(oracle_lib, integ):
         Hg, Ho = out["T"][:, b] + out["V"][:, b], To + Vo
         assert np.abs(Hg - Ho).max() <= 1e-6 * (np.abs(Ho).max() + 1)
     sim.close()
+
+
+@pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
+def test_hand_over_from_free_flight_to_contact(oracle_lib, integ):
+    """A call on a contact scene is two launches: the lean kernel (plain evaluation + lowest-corner clearance test) takes every
+    trajectory up to the step where a cuboid comes within reach of the ground, the kernel with the contact terms takes it from
+    there.  An 8-link chain dropped from three heights reaches the ground at three different steps of the same call: the
+    per-step history (q, qdot, T, V) across each hand-over is the oracle's, the BDF2 start step is taken once, and the same
+    rollout cut into two calls at an arbitrary step gives the same states."""
+    from redmax_amd import BatchSim
+    nsteps, cut = 120, 37
+    for gz, lo, hi in ((-0.8, 30, 60), (-1.2, 60, 90), (-30.0, None, None)):      # the last one never gets there
+        sc = sceneChainGround(8, ground_z=gz)
+        sc.init()
+        rng = np.random.default_rng(77)       # near horizontal: the lowest corners start 0.5 below the root
+        q0, qd0 = 1e-3 * rng.normal(size=(2, sc.nr)), 0.05 * rng.normal(size=(2, sc.nr))
+        sim = BatchSim(sc, batch=2)
+        sim.set_state(q0, qd0)
+        step = sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2
+        out = step(nsteps, h=sc.h, stats=True, history="full")
+        q, qd = sim.get_state()
+        assert np.all(out["status"] & 5 == 0)
+        scf = sceneChain(8)
+        scf.init()
+        simf = BatchSim(scf, batch=2)
+        simf.set_state(q0, qd0)
+        free = (simf.step_bdf1 if integ == "bdf1" else simf.step_bdf2)(nsteps, h=sc.h, history="full")
+        simf.close()
+        for b in range(2):
+            o = oracle_lib.Oracle(sc.desc())
+            o.set_state(q0[b], qd0[b])
+            st, To, Vo = (o.step_bdf1 if integ == "bdf1" else o.step_bdf2)(sc.h, nsteps, history=True)
+            qo, qdo = o.get_state()
+            assert st.diverged == 0
+            # "Newton did not converge" (a line search stalled at the reference's tol = 1e-9 on a contact kink) is the
+            # reference's behaviour too: the oracle and the GPU must agree on it; such a rollout is compared more loosely
+            stalled = st.not_converged > 0
+            assert bool(out["status"][b] & 2) == stalled
+            # the first step at which the trajectory leaves the one of the same chain without a ground: the hand-over step
+            first = np.flatnonzero(np.abs(out["q"][:, b] - free["q"][:, b]).max(axis=1) > 1e-9)
+            if lo is None:
+                assert first.size == 0
+            else:
+                assert lo <= first[0] <= hi, first[:3]
+            tolq = 1e-5 if stalled else 1e-7
+            assert _rel(q[b], qo) <= tolq and _rel(qd[b], qdo) <= 10 * tolq
+            Hg, Ho = out["T"][:, b] + out["V"][:, b], To + Vo
+            assert np.abs(Hg - Ho).max() <= tolq * (np.abs(Ho).max() + 1)
+            if not stalled:
+                assert abs(int(out["newton_iters"][b]) - st.newton_iters) <= 2
+        # the same rollout in two calls
+        sim2 = BatchSim(sc, batch=2)
+        sim2.set_state(q0, qd0)
+        step2 = sim2.step_bdf1 if integ == "bdf1" else sim2.step_bdf2
+        o1 = step2(cut, h=sc.h, history="full")
+        o2 = step2(nsteps - cut, h=sc.h, history="full")
+        qq, qqd = sim2.get_state()
+        assert _rel(qq, q) <= 1e-10 and _rel(qqd, qd) <= 1e-9
+        assert np.abs(np.concatenate([o1["q"], o2["q"]]) - out["q"]).max() <= 1e-10 * (np.abs(out["q"]).max() + 1)
+        sim.close()
+        sim2.close()
 
 
 def test_contact_is_refused_by_euler_and_adjoint():
