@@ -52,11 +52,14 @@ __host__ __device__ constexpr int w2_acc_doubles(const int n) {
 __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
     const int a = (n + 1) * ACC_STRIDE;
     const int b = NP == 32 ? HM_ROWS * HM_OP_STRIDE : 0;     // 1881 doubles; also covers H: 32*34 = 1088
-    return a > b ? a : b;
+    const int c = NP == 64 ? 64 * 66 : 0;                    // lu_solve_neg_diag64's staging of H (H64_STRIDE)
+    return (a > b ? a : b) > c ? (a > b ? a : b) : c;
 }
 constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matrix cores (false: half-wave split of the column loop)
 constexpr bool LU_DPP_TAIL = true;                      // guarded LU: last 16 pivots with the broadcast fused into the FMA (DPP)
 constexpr bool LU_SPLIT32 = HESS_MFMA && LU_DPP_TAIL;   // n <= 32: pivots 0..15 in the column-split layout of lu_solve_neg_diag32
+constexpr bool LU_SPLIT64 = LU_DPP_TAIL;                // 33..64 rows: the block-column layout of lu_solve_neg_diag64
+constexpr int H64_STRIDE = 66;    // lu_solve_neg_diag64: H staged row-major [64][66] (column 64: right-hand side; 16-byte aligned rows)
 // Column stride of the per-node constants in LDS.  Trees padded to fewer than 64 lanes get one extra "idle" column (index NP):
 // identity joint transform, zero everything else.  Lanes beyond the padded size read it, idle node slots n..NP-1 hold the same
 // defaults in their own columns, so the evaluation loads constants without any per-lane selects.
@@ -2222,6 +2225,203 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
     return dx;
 }
 
+// ---- 33..64 rows, one wavefront: the whole guarded solve without a single v_readlane broadcast of a pivot row.
+// H lives row-major in LDS (sH, the front's scratch) and is eliminated in four phases of 16 pivots.  In phase P every 16-lane
+// DPP row works on ALL rows still being eliminated, one row per lane and row set (set s: row 16 s + j, j = lane & 15; sets < P
+// are finished), so the pivot row 16 P + K is set P of lane K of the lane's OWN DPP row and every update is one v_fmac_f64_dpp
+// (fmsub_rowbcast).  Pass A eliminates inside the 16 pivot columns of the phase (S, replicated in the four DPP rows, so each forms
+// the multipliers itself) and leaves the multipliers in place; pass B applies them, pivot by pivot in the same order, to the
+// later column blocks, each DPP row taking its quarter of a block's columns through registers and back to LDS.  The back
+// substitution runs in the same layout, block by block (the value x_k rides on the DPP broadcast).  Every matrix entry sees the
+// same operations on the same values in the same order as in lu_solve_neg_diag<64>: the results are bit-identical.
+template <int P, int K>
+__device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], double (&gm)[4], double (&rown)[4], double& pmin,
+                                            double& piv, double& rinv, const int jv) {
+    if constexpr (K < 16) {
+        rown[P] = (jv == K) ? rinv : rown[P];
+        double l[4] = {0.0, 0.0, 0.0, 0.0};
+        l[P] = (jv > K) ? S[P][K] * rinv : 0.0;
+#pragma unroll
+        for (int s = P + 1; s < 4; ++s) l[s] = S[s][K] * rinv;
+#pragma unroll
+        for (int s = P; s < 4; ++s) {
+            gm[s] = fmax(gm[s], S[s][K] * l[s]);
+            // pinned here: left alone, the compiler sinks all 230 guard updates of a solve to its end and keeps their operands
+            // alive (in scratch) until then
+            asm volatile("" : "+v"(gm[s]));
+        }
+        pmin = fmin(pmin, piv);
+        if constexpr (K + 1 < 16) {
+            fmsub_rowbcast<K>(S[P][K + 1], S[P][K + 1], l[P]);
+            piv = readlane_d(S[P][K + 1], K + 1);
+            rinv = recip(piv);
+        }
+        // the multipliers stay where the column was (rows at or above the pivot keep their U entries)
+        S[P][K] = (jv > K) ? l[P] : S[P][K];
+#pragma unroll
+        for (int s = P + 1; s < 4; ++s) S[s][K] = l[s];
+        // the later sets first, the pivot set's own rows last: a broadcast then never reads a register that one of the two
+        // preceding instructions wrote (lane K of the pivot set's rows is not changed by its own update - its multiplier is 0 -
+        // so the order does not change a bit, but the hazard costs a wait state each time)
+#pragma unroll
+        for (int s = P + 1; s < 4; ++s)
+#pragma unroll
+            for (int c = K + 1; c < 16; ++c) fmsub_rowbcast<K>(S[s][c], S[P][c], l[s]);
+#pragma unroll
+        for (int c = K + 2; c < 16; ++c) fmsub_rowbcast<K>(S[P][c], S[P][c], l[P]);
+#pragma unroll
+        for (int s = P + 1; s < 4; ++s) fmsub_rowbcast<K>(b[s], b[P], l[s]);
+        fmsub_rowbcast<K>(b[P], b[P], l[P]);
+        lu64_pass_a<P, K + 1>(S, b, gm, rown, pmin, piv, rinv, jv);
+    }
+}
+template <int P, int K>
+__device__ __forceinline__ void lu64_pass_b(const double (&S)[4][16], double (&X)[4][4], const int jv) {
+    if constexpr (K < 16) {
+        const double lP = (jv > K) ? S[P][K] : 0.0;
+#pragma unroll
+        for (int s = P + 1; s < 4; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) fmsub_rowbcast<K>(X[s][c], X[P][c], S[s][K]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fmsub_rowbcast<K>(X[P][c], X[P][c], lP);
+        lu64_pass_b<P, K + 1>(S, X, jv);
+    }
+}
+template <int P>
+__device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&b)[4], double (&gm)[4], double (&rown)[4],
+                                           double& pmin, const int jv) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int r4 = lane >> 4, j = lane & 15;
+    double S[4][16];
+#pragma unroll
+    for (int s = P; s < 4; ++s) {
+        const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * s + j) * H64_STRIDE + 16 * P);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v2d t = rd[c];
+            S[s][2 * c] = t[0];
+            S[s][2 * c + 1] = t[1];
+        }
+    }
+    double piv = readlane_d(S[P][0], 0);
+    double rinv = recip(piv);
+    lu64_pass_a<P, 0>(S, b, gm, rown, pmin, piv, rinv, jv);
+    if (lane < 16) {            // the finished rows of this phase: their part of U (the back substitution reads it)
+        v2d* w = reinterpret_cast<v2d*>(sH + (16 * P + j) * H64_STRIDE + 16 * P);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c] = v2d{S[P][2 * c], S[P][2 * c + 1]};
+    }
+#pragma unroll
+    for (int B = P + 1; B < 4; ++B) {
+        __builtin_amdgcn_sched_barrier(0);      // one block in registers at a time (hoisted loads of all blocks spill)
+        double X[4][4];
+#pragma unroll
+        for (int s = P; s < 4; ++s) {
+            const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * s + j) * H64_STRIDE + 16 * B + 4 * r4);
+            const v2d t0 = rd[0], t1 = rd[1];
+            X[s][0] = t0[0];
+            X[s][1] = t0[1];
+            X[s][2] = t1[0];
+            X[s][3] = t1[1];
+        }
+        lu64_pass_b<P, 0>(S, X, jv);
+#pragma unroll
+        for (int s = P; s < 4; ++s) {
+            v2d* w = reinterpret_cast<v2d*>(sH + (16 * s + j) * H64_STRIDE + 16 * B + 4 * r4);
+            w[0] = v2d{X[s][0], X[s][1]};
+            w[1] = v2d{X[s][2], X[s][3]};
+        }
+    }
+    RMX_SYNC();                 // the next phase (or the back substitution) reads what the four DPP rows have written
+}
+// back substitution inside the diagonal block of set P: x_k = b_k / U(k,k), rows above take U(j,k) x_k off (k = 15 .. 0)
+template <int K>
+__device__ __forceinline__ void lu64_back_diag(double& bP, const double rP, const double (&U)[16], const int jv) {
+    if constexpr (K >= 0) {
+        const double xk = bP * rP;                     // lane K: x_K (its updates from the larger k are complete)
+        const double m = (jv < K) ? U[K] : 0.0;
+        fmsub_rowbcast<K, true>(bP, xk, m);
+        lu64_back_diag<K - 1>(bP, rP, U, jv);
+    }
+}
+
+// rows of an earlier set take the finished block's x off: b(row) -= U(row, 16 P + k) x_k, k = 15 .. 0 (the order of the
+// row-per-lane back substitution)
+template <int K>
+__device__ __forceinline__ void lu64_back_off(double& bs, const double xP, const double (&T)[16]) {
+    if constexpr (K >= 0) {
+        fmsub_rowbcast<K>(bs, xP, T[K]);
+        lu64_back_off<K - 1>(bs, xP, T);
+    }
+}
+
+__device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lane, double* sAcc, const double (&Hrow)[64], const double g,
+                                                      bool& ok) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    double* sH = sAcc;                                   // the front's scratch is free during the solve
+    const int r4 = lane >> 4, j = lane & 15;
+    {
+        v2d* w = reinterpret_cast<v2d*>(sH + lane * H64_STRIDE);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) w[c] = v2d{Hrow[2 * c], Hrow[2 * c + 1]};
+        sH[lane * H64_STRIDE + 64] = -g;
+    }
+    RMX_SYNC();
+    int jv = j;                                          // opaque copy: see lu_solve_neg_diag
+    asm volatile("" : "+v"(jv));
+    double b[4], lim[4], gm[4] = {0.0, 0.0, 0.0, 0.0}, rown[4] = {0.0, 0.0, 0.0, 0.0}, pmin = 1.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double* row = sH + (16 * s + j) * H64_STRIDE;
+        b[s] = row[64];
+        lim[s] = (LU_GROWTH_MAX * LU_GROWTH_MAX) * row[16 * s + j];
+    }
+    lu64_phase<0>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<1>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<2>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<3>(sH, lane, b, gm, rown, pmin, jv);
+    // back substitution, block column by block column from the right
+    double x[4];
+#pragma unroll
+    for (int P = 3; P >= 0; --P) {
+        double U[16];
+        {
+            const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * P + j) * H64_STRIDE + 16 * P);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const v2d t = rd[c];
+                U[2 * c] = t[0];
+                U[2 * c + 1] = t[1];
+            }
+        }
+        lu64_back_diag<15>(b[P], rown[P], U, jv);
+        x[P] = b[P] * rown[P];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s < P) {
+                const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * s + j) * H64_STRIDE + 16 * P);
+                double T[16];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const v2d t = rd[c];
+                    T[2 * c] = t[0];
+                    T[2 * c + 1] = t[1];
+                }
+                lu64_back_off<15>(b[s], x[P], T);
+            }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bad = bad || !(gm[s] <= lim[s]);
+    ok = !__any(bad) && (pmin > 0.0);
+    const double dx = r4 == 0 ? x[0] : (r4 == 1 ? x[1] : (r4 == 2 ? x[2] : x[3]));
+    RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
+    if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
+    RMX_SYNC();
+    return dx;
+}
+
 // BATCHED: pivot-row broadcasts in batches ahead of their FMAs (see lu_solve_neg_diag).  The Euler and adjoint kernels use
 // it (-31 % on the solve); inside the Newton loop of the step kernels the same change costs the guarded path 2 % through
 // register allocation, so the rare fallback there keeps the plain order.
@@ -2343,6 +2543,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         } else {
             bool lu_ok;
             if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
+            else if constexpr (NP == 64 && LU_SPLIT64) dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
             else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
             if (lu_ok) {
                 piv.streak = 0;

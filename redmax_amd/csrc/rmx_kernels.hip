@@ -548,7 +548,14 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
         eval_node<NP, true, true>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow, stamps);
         unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        const double dx = lu_solve_neg<NP, true>(M.n, lane, Hrow, e.g);
+        double dx;
+        if constexpr (NP == 64 && LU_SPLIT64) {      // the guarded solve the step kernels run (33..64 rows)
+            bool lu_ok;
+            dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
+            sink += lu_ok ? 0.0 : 1.0;
+        } else {
+            dx = lu_solve_neg<NP, true>(M.n, lane, Hrow, e.g);
+        }
         unsigned long long t3 = __builtin_amdgcn_s_memtime();
         const double s1 = wave_sum(dx * dx) + wave_sum(e.g * e.g);
         unsigned long long t4 = __builtin_amdgcn_s_memtime();
