@@ -59,6 +59,7 @@ constexpr bool HESS_MFMA = true;  // n <= 32: Hessian assembly on the fp64 matri
 constexpr bool LU_DPP_TAIL = true;                      // guarded LU: last 16 pivots with the broadcast fused into the FMA (DPP)
 constexpr bool LU_SPLIT32 = HESS_MFMA && LU_DPP_TAIL;   // n <= 32: pivots 0..15 in the column-split layout of lu_solve_neg_diag32
 constexpr bool LU_SPLIT64 = LU_DPP_TAIL;                // 33..64 rows: the block-column layout of lu_solve_neg_diag64
+constexpr bool HESS_MFMA64 = LU_SPLIT64;                // 33..64 nodes, plain models, one wavefront: Hessian on the matrix cores, H left in LDS
 constexpr int H64_STRIDE = 66;    // lu_solve_neg_diag64: H staged row-major [64][66] (column 64: right-hand side; 16-byte aligned rows)
 // Column stride of the per-node constants in LDS.  Trees padded to fewer than 64 lanes get one extra "idle" column (index NP):
 // identity joint transform, zero everything else.  Lanes beyond the padded size read it, idle node slots n..NP-1 hold the same
@@ -1189,15 +1190,16 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 // workgroup barrier B2 between the last operand read and the first H write; the helper wave takes part in it).
 constexpr int W2_R_RU = 0, W2_R_RL = 6, W2_R_CU = 18, W2_R_CL = 24, W2_R_HD = 36;
 constexpr int W2_CMD = W2_R_HD * W2_OP_STRIDE + 64;      // the pad element of the Hdiag row: command word for the helper wave
+// Wave W's 64 x 32 half of H on the matrix cores (columns i = 2 t + W), masked: hv[mb][nb][r] = H(16 mb + 4 r + g, 32 nb + 2 j + W)
+// for g = lane >> 4, j = lane & 15 (the C/D layout of the f64 MFMA).  cRel: the relation-mask rows of the per-node constants.
 template <int NP, int W>
-__device__ __forceinline__ void w2_hess_mfma(const DevModel& M, const int lane, const double* __restrict__ sOp, double* __restrict__ sOut,
-                                             double (&Hrow)[NP / 2]) {
-    static_assert(NP == 64, "two-wave Hessian: 64-lane trees");
+__device__ __forceinline__ void w2_hess_tiles(const int lane, const double* __restrict__ sOp, const double* __restrict__ cRel,
+                                              double (&hv)[4][2][4]) {
+    static_assert(NP == 64, "64-lane trees");
     constexpr int ST = W2_OP_STRIDE;
     typedef double v4d __attribute__((ext_vector_type(4)));
     const int g = lane >> 4, j = lane & 15;
     constexpr int CSW = cstride(NP);
-    const double* cRel = RMX_CONSTS(sOut, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CSW;   // relation bit masks of the nodes (as doubles)
     v4d up[4][2], lw[4][2];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -1252,7 +1254,6 @@ __device__ __forceinline__ void w2_hess_mfma(const DevModel& M, const int lane, 
         dmhi[nb] = (unsigned)(dm >> 32);
         hd[nb] = sOp[W2_R_HD * ST + icol[nb]];
     }
-    double hv[4][2][4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -1266,6 +1267,15 @@ __device__ __forceinline__ void w2_hess_mfma(const DevModel& M, const int lane, 
                 if (16 * mb + 15 > 32 * nb) v += (double)((dw >> sh) & 1u) * lw[mb][nb][r];
                 hv[mb][nb][r] = (16 * mb + 4 * r + g == icol[nb]) ? hd[nb] : v;
             }
+}
+
+template <int NP, int W>
+__device__ __forceinline__ void w2_hess_mfma(const DevModel& M, const int lane, const double* __restrict__ sOp, double* __restrict__ sOut,
+                                             double (&Hrow)[NP / 2]) {
+    static_assert(NP == 64, "two-wave Hessian: 64-lane trees");
+    const int g = lane >> 4, j = lane & 15;
+    double hv[4][2][4];
+    w2_hess_tiles<NP, W>(lane, sOp, RMX_CONSTS(sOut, M.n, NP) + (36 + 6 + 4 + 8 + 1) * cstride(NP), hv);
     __syncthreads();             // B2: both waves are done with the operands; wave 0's scratch now takes its half of H
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -1687,6 +1697,63 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             const double t = take_hi(Hh[i]);
             Hrow[i] = hi ? 0.0 : Hh[i];
             Hrow[16 + i] = hi ? 0.0 : t;
+        }
+        RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+        RMX_SYNC();
+    } else if constexpr (NP == 64 && !CT && NW == 1 && HESS_MFMA64) {
+        // 33..64 nodes, one wavefront: the two matrix products of the two-wave kernel, both column halves by this wave.  Operands
+        // in [k][node] order in the scratch, 2 x 30 v_mfma_f64_16x16x4_f64, then H row-major [64][H64_STRIDE] in the same scratch
+        // (the layout lu_solve_neg_diag64 eliminates in; its right-hand side -g travels in column 64).
+        constexpr int ST = W2_OP_STRIDE;
+        double* sOp = sAcc;
+        {
+            double* o = sOp + lane;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[(W2_R_RU + c) * ST] = sw[c];
+                o[(W2_R_RU + 3 + c) * ST] = sv[c];
+                o[(W2_R_RL + c) * ST] = r1t[c];
+                o[(W2_R_RL + 3 + c) * ST] = r1f[c];
+                o[(W2_R_RL + 6 + c) * ST] = -r2w[c];
+                o[(W2_R_RL + 9 + c) * ST] = -r3w[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[(W2_R_CU + c) * ST] = cv[c];
+#pragma unroll
+            for (int c = 6; c < 18; ++c) o[(W2_R_CL + c - 6) * ST] = cv[c];
+            o[W2_R_HD * ST] = Hdiag;
+        }
+        RMX_SYNC();
+        const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;
+        double h0[4][2][4], h1[4][2][4];
+        w2_hess_tiles<NP, 0>(lane, sOp, cRel, h0);
+        __builtin_amdgcn_sched_barrier(0);      // one half's accumulators at a time
+        w2_hess_tiles<NP, 1>(lane, sOp, cRel, h1);
+        RMX_SYNC();             // every lane is done with the operands: the same LDS now takes H
+        {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        *reinterpret_cast<v2d*>(sAcc + (16 * mb + 4 * r + g) * H64_STRIDE + 32 * nb + 2 * j) = v2d{h0[mb][nb][r], h1[mb][nb][r]};
+            sAcc[lane * H64_STRIDE + 64] = -g_stage;
+        }
+        RMX_SYNC();
+        if constexpr (!ZERO_IDLE) return Hdiag;         // the guarded solve takes H where it is (and hands the scratch back)
+        {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d* hr = reinterpret_cast<const v2d*>(sAcc + lane * H64_STRIDE);
+#pragma unroll
+            for (int c = 0; c < NP / 2; ++c) {
+                const v2d t = hr[c];
+                Hrow[2 * c] = t[0];
+                Hrow[2 * c + 1] = t[1];
+            }
         }
         RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
@@ -2356,18 +2423,11 @@ __device__ __forceinline__ void lu64_back_off(double& bs, const double xP, const
     }
 }
 
-__device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lane, double* sAcc, const double (&Hrow)[64], const double g,
-                                                      bool& ok) {
+// H and the right-hand side are in place: sAcc = [64][H64_STRIDE], row-major, column 64 = -g
+__device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const int lane, double* sAcc, bool& ok) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     double* sH = sAcc;                                   // the front's scratch is free during the solve
     const int r4 = lane >> 4, j = lane & 15;
-    {
-        v2d* w = reinterpret_cast<v2d*>(sH + lane * H64_STRIDE);
-#pragma unroll
-        for (int c = 0; c < 32; ++c) w[c] = v2d{Hrow[2 * c], Hrow[2 * c + 1]};
-        sH[lane * H64_STRIDE + 64] = -g;
-    }
-    RMX_SYNC();
     int jv = j;                                          // opaque copy: see lu_solve_neg_diag
     asm volatile("" : "+v"(jv));
     double b[4], lim[4], gm[4] = {0.0, 0.0, 0.0, 0.0}, rown[4] = {0.0, 0.0, 0.0, 0.0}, pmin = 1.0;
@@ -2420,6 +2480,20 @@ __device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lan
     if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
     RMX_SYNC();
     return dx;
+}
+
+// the row-per-lane form of the interface (callers whose Hessian stage leaves H in registers)
+__device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lane, double* sAcc, const double (&Hrow)[64], const double g,
+                                                      bool& ok) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    {
+        v2d* w = reinterpret_cast<v2d*>(sAcc + lane * H64_STRIDE);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) w[c] = v2d{Hrow[2 * c], Hrow[2 * c + 1]};
+        sAcc[lane * H64_STRIDE + 64] = -g;
+    }
+    RMX_SYNC();
+    return lu_solve_neg_diag64_staged(n, lane, sAcc, ok);
 }
 
 // BATCHED: pivot-row broadcasts in batches ahead of their FMAs (see lu_solve_neg_diag).  The Euler and adjoint kernels use
@@ -2543,7 +2617,12 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         } else {
             bool lu_ok;
             if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
-            else if constexpr (NP == 64 && LU_SPLIT64) dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
+            else if constexpr (NP == 64 && LU_SPLIT64) {
+                // the matrix-core Hessian stage (plain models, and contact-capable ones while nothing touches the ground) has left
+                // H and -g in the scratch; the v_readlane stage (contact terms) hands the rows over in registers
+                if (HESS_MFMA64 && (!CT || !fs.touched)) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
+                else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
+            }
             else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
             if (lu_ok) {
                 piv.streak = 0;
