@@ -42,11 +42,11 @@ constexpr int SPH_ROWS = 42;      // per-node constants that depend on a spheric
 constexpr int HM_OP_STRIDE = 33;  // MFMA Hessian (NP = 32): operand rows [k][node], odd stride in doubles
 constexpr int HM_ROWS = 57;       // RU 8, RL 12|20, CU 8, CL 12|20, Hdiag 1 (|: with ground contact)
 constexpr int HM_H_STRIDE = 34;   // H staged row-major [32][34] for the hand-over to row-per-lane (16-byte aligned rows)
-// two-wave kernel (NP = 64): each wave stages the operands of ITS 64 x 32 half of H: rows RU 6, RL 12, CU 6, CL 12, Hdiag 1 of
-// [k][node] with stride 65, then its half of H row-major [64][34]; the front's scratch shares the area
+// trees of 33..64 nodes (NP = 64): operand rows RU 6, RL 12, CU 6, CL 12, Hdiag 1 of [k][node] with stride 65, then H row-major
+// [64][66] (H64_STRIDE; column 64: the right-hand side); the front's scratch shares the area
 constexpr int W2_OP_STRIDE = 65, W2_OP_ROWS = 37;
 __host__ __device__ constexpr int w2_acc_doubles(const int n) {
-    const int a = (n + 1) * ACC_STRIDE, b = W2_OP_ROWS * W2_OP_STRIDE, c = MAXN * HM_H_STRIDE;
+    const int a = (n + 1) * ACC_STRIDE, b = W2_OP_ROWS * W2_OP_STRIDE, c = MAXN * 66;
     return (a > b ? a : b) > c ? (a > b ? a : b) : c;
 }
 __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
@@ -1180,16 +1180,14 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
     }
 }
 
-// Two-wave kernel (k_step_bdf1_w2, trees of 33..64 nodes): wave W's 64 x 32 half of H (all rows x its columns i = 2 t + W) on the
-// fp64 matrix cores, from the operands wave 0 staged in sOp ([k][node], stride W2_OP_STRIDE):
+// Trees of 33..64 nodes: a 64 x 32 half of H (all rows x the columns i = 2 t + W) on the fp64 matrix cores, from operands staged
+// in LDS ([k][node], stride W2_OP_STRIDE):
 //     H(a,i) = [a strict ancestor of i] RU_a.CU_i + [a strict descendant of i] RL_a.CL_i ,  Hdiag on the diagonal,
 // RU = s (6), CU = y - z (6), RL = (r1, -r2w, -r3w) (12), CL = (m1, m2w, sw) (12), as for n <= 32 in eval_hess.  4 x 2 tiles of
 // 16 x 16; in depth-first numbering an ancestor has the smaller index, so 2 of the 8 UP tiles and 2 of the 8 LO tiles are empty:
-// 6 x 2 + 6 x 3 = 30 v_mfma_f64_16x16x4_f64.  Results are masked per lane with the relation bits of its two column nodes and go
-// to row-per-lane (Hrow[t] = H(lane, 2 t + W)) through sOut, this wave's own scratch (for wave 0 that is sOp itself, hence the
-// workgroup barrier B2 between the last operand read and the first H write; the helper wave takes part in it).
+// 6 x 2 + 6 x 3 = 30 v_mfma_f64_16x16x4_f64 per half.  The one-wave kernels compute both halves (eval_hess), the two-wave step
+// kernel one per wave (w2_hess_to_lds).
 constexpr int W2_R_RU = 0, W2_R_RL = 6, W2_R_CU = 18, W2_R_CL = 24, W2_R_HD = 36;
-constexpr int W2_CMD = W2_R_HD * W2_OP_STRIDE + 64;      // the pad element of the Hdiag row: command word for the helper wave
 // Wave W's 64 x 32 half of H on the matrix cores (columns i = 2 t + W), masked: hv[mb][nb][r] = H(16 mb + 4 r + g, 32 nb + 2 j + W)
 // for g = lane >> 4, j = lane & 15 (the C/D layout of the f64 MFMA).  cRel: the relation-mask rows of the per-node constants.
 template <int NP, int W>
@@ -1270,38 +1268,13 @@ __device__ __forceinline__ void w2_hess_tiles(const int lane, const double* __re
 }
 
 template <int NP, int W>
-__device__ __forceinline__ void w2_hess_mfma(const DevModel& M, const int lane, const double* __restrict__ sOp, double* __restrict__ sOut,
-                                             double (&Hrow)[NP / 2]) {
-    static_assert(NP == 64, "two-wave Hessian: 64-lane trees");
-    const int g = lane >> 4, j = lane & 15;
-    double hv[4][2][4];
-    w2_hess_tiles<NP, W>(lane, sOp, RMX_CONSTS(sOut, M.n, NP) + (36 + 6 + 4 + 8 + 1) * cstride(NP), hv);
-    __syncthreads();             // B2: both waves are done with the operands; wave 0's scratch now takes its half of H
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sOut[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
-    RMX_SYNC();
-    {
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        const v2d* hr = reinterpret_cast<const v2d*>(sOut + lane * HM_H_STRIDE);   // rows are 16-byte aligned
-#pragma unroll
-        for (int c = 0; c < NP / 4; ++c) {
-            const v2d t = hr[c];
-            Hrow[2 * c] = t[0];
-            Hrow[2 * c + 1] = t[1];
-        }
-    }
-    RMX_SYNC();
-}
+__device__ __forceinline__ void w2_hess_to_lds(const DevModel& M, const int lane, double* __restrict__ sH, const double g_stage);   // two-wave section below
 
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle node slots are the identity.
 // Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
 // NW = 2 (trees of more than 32 nodes, the two-wave step kernel k_step_bdf1_w2, called by wave 0 only): the columns are dealt out
 // to the two wavefronts of the workgroup; wave 0 stages the operands for both and computes columns i = 2 t into Hrow[t]
-// (w2_hess_mfma).  NW = 1 is the whole row.
+// into the shared staging rows (w2_hess_to_lds).  NW = 1 is the whole row.
 template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true, int NW = 1, int W = 0>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP / NW],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0) {
@@ -1760,7 +1733,8 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         RMX_SYNC();
     } else if constexpr (NW == 2) {
         // Two-wave kernel, 64 rows (wave 0 only runs eval_hess): stage the operands of the two matrix products in [k][node] order
-        // in this wave's scratch, post the "solve" command for the helper wave next to them, and compute this wave's half of H.
+        // in the shared scratch, post the "solve" command for the helper wave, and compute this wave's half of H into the
+        // staging rows (w2_hess_to_lds).  Hrow is not written: the solve (lu_solve_neg_diag64_staged<2>) takes H from LDS.
         static_assert(NP == 64 && !CT && W == 0, "two-wave Hessian: 64-lane plain models, called by wave 0");
         constexpr int ST = W2_OP_STRIDE;
         double* sOp = sAcc;
@@ -1780,12 +1754,10 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
 #pragma unroll
             for (int c = 6; c < 18; ++c) o[(W2_R_CL + c - 6) * ST] = cv[c];
             o[W2_R_HD * ST] = Hdiag;
-            if (lane == 0) sOp[W2_CMD] = 1.0;          // command for the helper wave: 1 = solve, 0 = exit
+            if (lane == 0) const_cast<double*>(RMX_CONSTS(sAcc, M.n, NP))[NCONST * CS] = 1.0;   // exchange area, behind the constants: 1 = solve
         }
         __syncthreads();             // B1: operands and command are in LDS; the helper wave has been waiting here
-        w2_hess_mfma<NP, 0>(M, lane, sOp, sOp, Hrow);
-        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;      // the scratch goes back to the front (zero row n)
-        RMX_SYNC();
+        w2_hess_to_lds<NP, 0>(M, lane, sAcc, g_stage);
     } else {
 #pragma unroll
         for (int t = 0; t < NP / NW; ++t) {
@@ -2342,23 +2314,28 @@ __device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], 
         lu64_pass_a<P, K + 1>(S, b, gm, rown, pmin, piv, rinv, jv);
     }
 }
-template <int P, int K>
-__device__ __forceinline__ void lu64_pass_b(const double (&S)[4][16], double (&X)[4][4], const int jv) {
+template <int P, int K, int CW>
+__device__ __forceinline__ void lu64_pass_b(const double (&S)[4][16], double (&X)[4][CW], const int jv) {
     if constexpr (K < 16) {
         const double lP = (jv > K) ? S[P][K] : 0.0;
 #pragma unroll
         for (int s = P + 1; s < 4; ++s)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) fmsub_rowbcast<K>(X[s][c], X[P][c], S[s][K]);
+            for (int c = 0; c < CW; ++c) fmsub_rowbcast<K>(X[s][c], X[P][c], S[s][K]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) fmsub_rowbcast<K>(X[P][c], X[P][c], lP);
-        lu64_pass_b<P, K + 1>(S, X, jv);
+        for (int c = 0; c < CW; ++c) fmsub_rowbcast<K>(X[P][c], X[P][c], lP);
+        lu64_pass_b<P, K + 1, CW>(S, X, jv);
     }
 }
-template <int P>
+// One phase.  NW = 2 (the two-wave step kernel): both wavefronts run pass A (it is replicated per DPP row anyway, and so every
+// DPP row of either wave holds the multipliers) and share pass B - eight DPP rows, two columns of every later block each - with a
+// workgroup barrier where the next phase collects its pivot columns; the helper wave (W = 1) sits out phase 3, which has no pass
+// B, so that phase ends wave-locally.
+template <int P, int NW = 1, int W = 0>
 __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&b)[4], double (&gm)[4], double (&rown)[4],
                                            double& pmin, const int jv) {
     typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int CW = 4 / NW;                 // columns of a later block per DPP row
     const int r4 = lane >> 4, j = lane & 15;
     double S[4][16];
 #pragma unroll
@@ -2374,33 +2351,38 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
     double piv = readlane_d(S[P][0], 0);
     double rinv = recip(piv);
     lu64_pass_a<P, 0>(S, b, gm, rown, pmin, piv, rinv, jv);
-    if (lane < 16) {            // the finished rows of this phase: their part of U (the back substitution reads it)
+#pragma unroll
+    for (int B = P + 1; B < 4; ++B) {
+        __builtin_amdgcn_sched_barrier(0);      // one block in registers at a time (hoisted loads of all blocks spill)
+        double X[4][CW];
+        const int col = 16 * B + CW * (4 * W + r4);
+#pragma unroll
+        for (int s = P; s < 4; ++s) {
+            const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * s + j) * H64_STRIDE + col);
+#pragma unroll
+            for (int c = 0; c < CW / 2; ++c) {
+                const v2d t = rd[c];
+                X[s][2 * c] = t[0];
+                X[s][2 * c + 1] = t[1];
+            }
+        }
+        lu64_pass_b<P, 0, CW>(S, X, jv);
+#pragma unroll
+        for (int s = P; s < 4; ++s) {
+            v2d* w = reinterpret_cast<v2d*>(sH + (16 * s + j) * H64_STRIDE + col);
+#pragma unroll
+            for (int c = 0; c < CW / 2; ++c) w[c] = v2d{X[s][2 * c], X[s][2 * c + 1]};
+        }
+    }
+    if (NW == 2 && P < 3) __syncthreads();     // the next phase reads what all the DPP rows (of both waves) have written
+    else RMX_SYNC();
+    // the finished rows of this phase: their part of U, for the back substitution.  Written behind the hand-over: until then the
+    // other wave may still be collecting these very entries (as they were before the phase) for its own pass A.
+    if (W == 0 && lane < 16) {
         v2d* w = reinterpret_cast<v2d*>(sH + (16 * P + j) * H64_STRIDE + 16 * P);
 #pragma unroll
         for (int c = 0; c < 8; ++c) w[c] = v2d{S[P][2 * c], S[P][2 * c + 1]};
     }
-#pragma unroll
-    for (int B = P + 1; B < 4; ++B) {
-        __builtin_amdgcn_sched_barrier(0);      // one block in registers at a time (hoisted loads of all blocks spill)
-        double X[4][4];
-#pragma unroll
-        for (int s = P; s < 4; ++s) {
-            const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * s + j) * H64_STRIDE + 16 * B + 4 * r4);
-            const v2d t0 = rd[0], t1 = rd[1];
-            X[s][0] = t0[0];
-            X[s][1] = t0[1];
-            X[s][2] = t1[0];
-            X[s][3] = t1[1];
-        }
-        lu64_pass_b<P, 0>(S, X, jv);
-#pragma unroll
-        for (int s = P; s < 4; ++s) {
-            v2d* w = reinterpret_cast<v2d*>(sH + (16 * s + j) * H64_STRIDE + 16 * B + 4 * r4);
-            w[0] = v2d{X[s][0], X[s][1]};
-            w[1] = v2d{X[s][2], X[s][3]};
-        }
-    }
-    RMX_SYNC();                 // the next phase (or the back substitution) reads what the four DPP rows have written
 }
 // back substitution inside the diagonal block of set P: x_k = b_k / U(k,k), rows above take U(j,k) x_k off (k = 15 .. 0)
 template <int K>
@@ -2424,6 +2406,7 @@ __device__ __forceinline__ void lu64_back_off(double& bs, const double xP, const
 }
 
 // H and the right-hand side are in place: sAcc = [64][H64_STRIDE], row-major, column 64 = -g
+template <int NW = 1>
 __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const int lane, double* sAcc, bool& ok) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     double* sH = sAcc;                                   // the front's scratch is free during the solve
@@ -2437,10 +2420,11 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
         b[s] = row[64];
         lim[s] = (LU_GROWTH_MAX * LU_GROWTH_MAX) * row[16 * s + j];
     }
-    lu64_phase<0>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<1>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<2>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<3>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<0, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<1, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<2, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<3, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
+    RMX_SYNC();                 // (the finished rows of phase 3)
     // back substitution, block column by block column from the right
     double x[4];
 #pragma unroll
@@ -2482,6 +2466,17 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     return dx;
 }
 
+// The helper wave's part of a two-wave solve: phases 0..2 next to wave 0 (pass A for the multipliers, its share of pass B); the
+// right-hand side, the guard and the back substitution are wave 0's.
+__device__ __forceinline__ void lu64_helper(double* sH, const int lane) {
+    int jv = lane & 15;
+    asm volatile("" : "+v"(jv));
+    double b[4] = {0.0, 0.0, 0.0, 0.0}, gm[4] = {0.0, 0.0, 0.0, 0.0}, rown[4] = {0.0, 0.0, 0.0, 0.0}, pmin = 1.0;
+    lu64_phase<0, 2, 1>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<1, 2, 1>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<2, 2, 1>(sH, lane, b, gm, rown, pmin, jv);
+}
+
 // the row-per-lane form of the interface (callers whose Hessian stage leaves H in registers)
 __device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lane, double* sAcc, const double (&Hrow)[64], const double g,
                                                       bool& ok) {
@@ -2493,7 +2488,7 @@ __device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lan
         sAcc[lane * H64_STRIDE + 64] = -g;
     }
     RMX_SYNC();
-    return lu_solve_neg_diag64_staged(n, lane, sAcc, ok);
+    return lu_solve_neg_diag64_staged<1>(n, lane, sAcc, ok);
 }
 
 // BATCHED: pivot-row broadcasts in batches ahead of their FMAs (see lu_solve_neg_diag).  The Euler and adjoint kernels use
@@ -2620,7 +2615,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
             else if constexpr (NP == 64 && LU_SPLIT64) {
                 // the matrix-core Hessian stage (plain models, and contact-capable ones while nothing touches the ground) has left
                 // H and -g in the scratch; the v_readlane stage (contact terms) hands the rows over in registers
-                if (HESS_MFMA64 && (!CT || !fs.touched)) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
+                if (HESS_MFMA64 && (!CT || !fs.touched)) dx = lu_solve_neg_diag64_staged<1>(M.n, lane, sAcc, lu_ok);
                 else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
             }
             else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
@@ -2741,148 +2736,50 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
 //
 // One wavefront per trajectory leaves SIMDs idle whenever a GPU holds fewer rollouts than it has SIMDs (BASELINE.json
 // configs[2]: 4096 rollouts over 8 GPUs = 512 per GPU on 1024 SIMDs), and for 64-row systems the instruction stream of one
-// Newton iteration is dominated by two loops over COLUMNS - the Hessian assembly and the elimination - whose columns are
-// independent of each other.  The two-wave step kernel (k_step_bdf1_w2, rmx_kernels_w2.hip) gives a trajectory a workgroup of
-// two wavefronts:
+// Newton iteration is dominated by the Hessian assembly and the elimination, both of which split by COLUMNS.  The two-wave step
+// kernel (k_step_bdf1_w2, rmx_kernels_w2.hip) gives a trajectory a workgroup of two wavefronts that share one scratch area:
 //   * wave 0 owns the rollout: state, front, line search, every decision (newton_w2 = the one-wave Newton with shared solves);
 //   * wave 1 is a helper without rollout state (w2_helper_loop): it waits for wave 0's command, computes the half of H whose
-//     columns c = 2 t + 1 it owns from the operands wave 0 staged (w2_hess_mfma, fp64 matrix cores), takes part in the elimination;
-//   * elimination (lu_gj_w2): at pivot k the owner of column k forms the multipliers l = H(:,k) / H(k,k) and publishes them
-//     through LDS (double-buffered, sequence counters instead of a barrier per pivot, one step of look-ahead), both waves update
-//     their own columns > k - the pivot row's entries of a wave's columns sit in lane k of that wave's own registers; wave 0
-//     carries the right-hand side.  Gauss-Jordan: rows above the pivot are eliminated too, which costs no instruction in a
-//     lane = row layout (the FMAs run for all 64 lanes anyway), so there is no back substitution with its per-step hand-over:
-//     dx = b / pivot at the end, the reciprocals travel through LDS as well.
-// Pivots are taken on the diagonal under the same growth guard as lu_solve_neg_diag (multipliers of rows below the pivot on the
-// equilibrated matrix, positive pivots); when it trips, wave 0 alone redoes the solve with full partial pivoting (the
-// single-wave code).  Steps that the pivot policy assigns to the pivot-only Newton run on wave 0 alone.
-constexpr int W2_XCH = 3 * MAXN + 8;      // LDS doubles of the exchange area: multipliers [2][MAXN], reciprocals [MAXN], guard verdicts [2], 2 spare, hand-over counters (2 ints at +4), wave-0 value slots [2] at +5, 1 spare
+//     columns c = 2 t + 1 it owns from the operands wave 0 staged (w2_hess_tiles, fp64 matrix cores; wave 0 takes c = 2 t), and
+//     takes its share of the elimination;
+//   * elimination: lu_solve_neg_diag64's block-column layout with eight DPP rows instead of four (lu64_phase<P, 2, W>).  Pass A
+//     of a phase (inside the 16 pivot columns) is replicated per DPP row anyway, so both waves run it and neither waits for
+//     multipliers; pass B (the later column blocks) is shared, two columns of a block per DPP row; a workgroup barrier per
+//     phase where the next pivot columns are collected.  Right-hand side, guard and back substitution stay with wave 0.
+// Workgroup barriers of one solve: command (B1), operands consumed (B2), H complete (B3), phases 0, 1, 2.  When the guard trips,
+// wave 0 alone redoes the solve with full partial pivoting (the single-wave code); steps that the pivot policy assigns to the
+// pivot-only Newton run on wave 0 alone.  The helper waits at B1 meanwhile.
+constexpr int W2_XCH = 8;      // LDS doubles of the exchange area: [0] the command word for the helper wave (1 solve, 0 exit)
 
-// Hand-over of the multipliers between the two waves WITHOUT a workgroup barrier.  A barrier per pivot keeps the waves in lock
-// step: between two barriers one wave applies two pivots to all its columns while the other only runs its pivot chain and then
-// idles, so a pivot costs a full two-pivot update (measured: 910 cycles per early pivot, with or without look-ahead).  With a
-// sequence counter per producer each wave alternates "chain, updates" at its own pace and only ever waits for data it needs:
-// producer: multipliers -> LDS, release (waits for its LDS writes), counter = pivots published; consumer: spin on the other
-// wave's counter (one broadcast ds_read per poll), acquire, read.  LDS serves a wave's operations in order.  The double buffer
-// stays safe without the barrier: a wave rewrites buffer K & 1 at pivot K + 2, after it has consumed pivot K + 1, which the other
-// wave published after reading pivot K.  Counters are reset (under a barrier) at the start of every solve.
-__device__ __forceinline__ int* w2_counters(double* sL) { return reinterpret_cast<int*>(sL + 3 * MAXN + 4); }
-__device__ __forceinline__ void w2_publish(double* sL, const int w, const int count) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (threadIdx.x % 64 == 0) __atomic_store_n(w2_counters(sL) + w, count, __ATOMIC_RELAXED);
-}
-__device__ __forceinline__ void w2_await(double* sL, const int w, const int count) {
-    while (__atomic_load_n(w2_counters(sL) + w, __ATOMIC_RELAXED) < count) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// Apply pivot P's multipliers l to this wave's columns t >= T0 (and to the right-hand side): the pivot row's entries are
-// broadcast out of lane P in batches ahead of their FMAs (see lu_solve_neg_diag); sched_barriers keep the scheduler from hoisting
-// later batches' broadcasts above earlier FMAs (it would run out of scalar registers and park them in VGPR lanes).
-template <int NP, int W, int P, int T0>
-__device__ __forceinline__ void w2_apply_pivot(double (&Hh)[NP / 2], double& b, const double l) {
-    constexpr int BT = 4;
-#pragma unroll
-    for (int c0 = T0; c0 < NP / 2; c0 += BT) {
-        double pv[BT];
-#pragma unroll
-        for (int i = 0; i < BT; ++i) pv[i] = (c0 + i < NP / 2) ? readlane_d(Hh[c0 + i < NP / 2 ? c0 + i : NP / 2 - 1], P) : 0.0;
-        asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]));
-#pragma unroll
-        for (int i = 0; i < BT; ++i)
-            if (c0 + i < NP / 2) Hh[c0 + i] -= l * pv[i];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (W == 0) b -= l * readlane_d(b, P);      // the right-hand side is wave 0's business (see lu_gj_w2)
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// One pivot step of lu_gj_w2 with one step of look-ahead.  `lp` = multipliers of pivot K-1 when this wave received them from the
-// other one and has not applied them yet (it owns column K): it first brings column K alone up to date, forms and publishes the
-// multipliers of pivot K, and only then applies both pivots to its other columns - the other wave meanwhile does the same one step
-// later, so each wave's serial chain (LDS read, pivot broadcast, reciprocal, publish, barrier) runs under the other's bulk updates.
-// The steps are chained by template recursion (a 64-trip loop of this size is beyond what "#pragma unroll" unrolls completely,
-// and a rolled loop would turn the register array into a scratch array).
-template <int NP, int W, int K, int KEND>
-__device__ __forceinline__ void lu_gj_w2_step(const int lane, const int lv, double (&Hh)[NP / 2], double& b, double& gmax, double& pmin,
-                                              double lp, double* __restrict__ sL, double* __restrict__ sR) {
-    if constexpr (K < KEND) {
-        constexpr int T = K >> 1;
-        if constexpr ((K & 1) == W) {    // this wave owns column K
-            if constexpr (K >= 1) {      // pivot K-1 (received) on column K only
-                Hh[T] -= lp * readlane_d(Hh[T], K - 1);
-            }
-            const double piv = readlane_d(Hh[T], K);
-            const double rinv = recip(piv);
-            const double lm = Hh[T] * rinv;
-            const double l = (lv != K) ? lm : 0.0;
-            gmax = fmax(gmax, (lv > K) ? Hh[T] * lm : 0.0);      // l^2 u_kk of the rows below the pivot
-            pmin = fmin(pmin, piv);
-            sL[(K & 1) * NP + lane] = l;
-            if (lv == K) sR[K] = rinv;
-            w2_publish(sL, W, K + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // bulk: pivot K-1, then pivot K, on the own columns right of K (the first one is t = T + 1) and on the right-hand side
-            if constexpr (K >= 1) w2_apply_pivot<NP, W, K - 1, T + 1>(Hh, b, lp);
-            w2_apply_pivot<NP, W, K, T + 1>(Hh, b, l);
-            lu_gj_w2_step<NP, W, K + 1, KEND>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
-        } else {                         // the other wave's column: take its multipliers; they are applied in the next step
-            w2_await(sL, 1 - W, K + 1);
-            const double l = sL[(K & 1) * NP + lane];
-            if constexpr (K + 1 == KEND) {      // last two-wave pivot: nobody owns a "next step", apply it now
-                w2_apply_pivot<NP, W, K, ((K - W + 2) >> 1)>(Hh, b, l);
-            }
-            lu_gj_w2_step<NP, W, K + 1, KEND>(lane, lv, Hh, b, gmax, pmin, l, sL, sR);
-        }
-    }
-}
-
-// dx = -H\g on a two-wave workgroup (Gauss-Jordan, all 64 pivots dealt out to the two waves).  Wave 0 owns the rollout: it
-// carries the right-hand side and returns dx; the helper wave (W = 1) eliminates its columns and publishes its multipliers.
-// diag_own: H(lane,lane) before the elimination (the guard's scale), b0: -g (wave 0 only).
-// Measured and not kept: finishing the trailing 32 x 32 Schur complement with the one-wave DPP-fused solver (both waves
-// redundantly, S copied into both scratch areas) after 32 two-wave pivots - 9.18 ms per 100 steps of the 64-joint tree against 8.92:
-// the two-wave pivots are bound by their update instructions (4.6 k per wave and solve), not by the hand-overs, and the detour
-// (staging, 1.6 k instructions of solve, the U12 x2 product) is no shorter than the 1.5 k instructions it replaces.
+// Wave W's half of H into the shared staging rows sH = [64][H64_STRIDE] (the operands sit in the same LDS: B2 in between).
 template <int NP, int W>
-__device__ __forceinline__ double lu_gj_w2(const int lane, double (&Hh)[NP / 2], const double b0, const double diag_own,
-                                           double* __restrict__ sX, bool& ok) {
-    static_assert(NP == 64, "two-wave elimination: 64-lane trees");
-    double* sL = sX;                 // [2][NP] multipliers, buffer = pivot parity
-    double* sR = sX + 2 * NP;        // [NP] reciprocal pivots
-    double* sF = sX + 3 * NP;        // [2] guard verdict of each wave (the hand-over counters follow)
-    double b = b0;
-    double gmax = 0.0, pmin = 1.0;
-    const double lim = (LU_GROWTH_MAX * LU_GROWTH_MAX) * diag_own;
-    int lv = lane;
-    asm volatile("" : "+v"(lv));     // keeps the lane compares local (see lu_solve_neg_diag)
-    if (lane == 0) w2_counters(sL)[W] = 0;
-    __syncthreads();
-    lu_gj_w2_step<NP, W, 0, NP>(lane, lv, Hh, b, gmax, pmin, 0.0, sL, sR);
-    const bool mine = !__any(!(gmax <= lim)) && (pmin > 0.0);
-    if (lane == 0) sF[W] = mine ? 1.0 : 0.0;
-    __syncthreads();
-    ok = sF[0] != 0.0 && sF[1] != 0.0;
-    const double dx = (W == 0) ? b * sR[lane] : 0.0;
-    __syncthreads();                 // the exchange area is rewritten by the next solve
-    return dx;
+__device__ __forceinline__ void w2_hess_to_lds(const DevModel& M, const int lane, double* __restrict__ sH, const double g_stage) {
+    double hv[4][2][4];
+    w2_hess_tiles<NP, W>(lane, sH, RMX_CONSTS(sH, M.n, NP) + (36 + 6 + 4 + 8 + 1) * cstride(NP), hv);
+    __syncthreads();             // B2: both waves are done with the operands
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sH[(16 * mb + 4 * r + g) * H64_STRIDE + 32 * nb + 2 * j + W] = hv[mb][nb][r];
+    if (W == 0) sH[lane * H64_STRIDE + 64] = -g_stage;
+    __syncthreads();             // B3: H and the right-hand side are complete
 }
 
-// The helper wave (W = 1) of the two-wave kernel: no rollout state at all.  It waits at barrier B1 for wave 0's command; on
-// "solve" it computes its half of H from the operands wave 0 staged, takes part in the elimination, and waits again.
+// The helper wave of a two-wave workgroup: no rollout state.  It waits at B1 for wave 0's command (1: solve, 0: exit); on
+// "solve" it computes its half of H from the operands wave 0 staged, takes its share of the elimination, and waits again.
 template <int NP, bool PROF = false>
-__device__ __forceinline__ void w2_helper_loop(const DevModel& M, const double* __restrict__ sOp0, double* __restrict__ sMine,
-                                               double* __restrict__ sX, const int lane, unsigned long long* prof = nullptr) {
+__device__ __forceinline__ void w2_helper_loop(const DevModel& M, double* __restrict__ sH, const double* __restrict__ sX, const int lane,
+                                               unsigned long long* prof = nullptr) {
     while (true) {
         __syncthreads();             // B1
-        if (sOp0[W2_CMD] == 0.0) break;
+        if (sX[0] == 0.0) break;
         unsigned long long t0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-        double Hh[NP / 2];
-        const double hdiag = sOp0[W2_R_HD * W2_OP_STRIDE + lane];
-        w2_hess_mfma<NP, 1>(M, lane, sOp0, sMine, Hh);
+        w2_hess_to_lds<NP, 1>(M, lane, sH, 0.0);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[1] += t1 - t0; t0 = t1; }
-        bool ok;
-        (void)lu_gj_w2<NP, 1>(lane, Hh, 0.0, hdiag, sX, ok);
+        lu64_helper(sH, lane);
         if (PROF) { prof[2] += __builtin_amdgcn_s_memtime() - t0; prof[3] += 1; }
     }
 }
@@ -2915,13 +2812,13 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
     int iter = 1;
     double gcarry = -1.0;
     while (true) {
-        const double hdiag = eval_hess<NP, false, false, true, 2, 0>(M, lane, fs, Hh, nullptr, sAcc);
+        (void)eval_hess<NP, false, false, true, 2, 0>(M, lane, fs, Hh, nullptr, sAcc, e.g);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[1] += t1 - t0; t0 = t1; }
         const NodeOut e0 = e;
         last = e;
         ++iters;
         bool lu_ok;
-        double dx = lu_gj_w2<NP, 0>(lane, Hh, -e.g, hdiag, sX, lu_ok);
+        double dx = lu_solve_neg_diag64_staged<2>(M.n, lane, sAcc, lu_ok);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
         if (lu_ok) {
             piv.streak = 0;

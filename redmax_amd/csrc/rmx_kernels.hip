@@ -614,23 +614,13 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     const dim3 grid(b->B), block(64);
     if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_step_ct_, RMX_NP)(m, b, integ, o, a);
 #if RMX_NP == 64
-    // Two wavefronts per trajectory (rmx_kernels_w2.hip) when that finishes the batch sooner.  Both kernels run one wavefront per
-    // SIMD and are limited by LDS: workgroups resident per CU = floor(160 KiB / LDS per workgroup), at most 4 one-wave or 2
-    // two-wave ones; the batch takes ceil(B / resident) rounds, and a two-wave round costs 0.84 of a one-wave round (measured on
-    // the 64-joint tree: 9.07 vs 10.79 ms per 100 steps, profiles/r02d_w2_bench.txt).  BASELINE.json configs[2] puts 512
-    // rollouts on a GPU: one round either way.  RMX_W2=0 / 1 in the environment forces the choice (measurements, tests).
+    // Two wavefronts per trajectory (rmx_kernels_w2.hip): opt-in with RMX_W2=1 in the environment (measurements, tests).  It was
+    // the faster kernel while the one-wave solve broadcast its pivot rows with v_readlane (8.86 vs 10.8 ms per 100 steps of the
+    // 64-joint tree, profiles/r02i_w2_bench.txt); with the matrix-core Hessian and the block-column solve in both, one wave takes
+    // 8.08 ms and two take 8.65 (profiles/r02k_w2_bench.txt: barriers, pass A of every phase run by both waves).
     if (integ == INTEG_BDF1) {
         const char* force = getenv("RMX_W2");
-        bool w2;
-        if (force) {
-            w2 = force[0] == '1';
-        } else {
-            const long cus = m->n_simd > 0 ? m->n_simd / 4 : 256, lds = 160 * 1024;
-            const long cap1 = cus * std::min<long>(4, lds / (long)m->smem_bytes), cap2 = cus * std::min<long>(2, lds / (long)rmx_w2_smem_bytes(m));
-            const long r1 = (b->B + cap1 - 1) / cap1, r2 = (b->B + cap2 - 1) / cap2;
-            w2 = cap2 > 0 && 0.84 * (double)r2 < (double)r1;
-        }
-        if (w2) return launch_step_w2_64(m, b, o, a);
+        if (force && force[0] == '1') return launch_step_w2_64(m, b, o, a);
     }
 #endif
     if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);

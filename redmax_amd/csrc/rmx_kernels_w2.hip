@@ -2,11 +2,12 @@
 //
 // A trajectory gets a workgroup of TWO wavefronts.  Wave 0 owns the rollout (state, front, line search, every decision); the
 // second wave is a linear-algebra helper: for every (g,H) solve wave 0 stages the operands of H in LDS and posts a command, each
-// wave assembles the half of H whose columns c = 2 t + W it owns on the matrix cores and they eliminate together.
-// Chosen by the launcher when that finishes the batch sooner (BASELINE.json configs[2] puts 512 rollouts on each GPU's 1024
-// SIMDs), see launch_step_np_64.  LDS of a workgroup: [per-node constants][exchange area][wave 0: front scratch / operand
-// staging / its half of H][helper: its half of H].  Wave 0's evaluation stages order their LDS traffic wave-locally (RMX_SYNC);
-// workgroup barriers only at the hand-overs of a solve (B1 command, B2 operands consumed, elimination start / verdict / end).
+// wave assembles the half of H whose columns c = 2 t + W it owns on the matrix cores, straight into the row-major staging the
+// block-column solve eliminates in (lu_solve_neg_diag64), and they share that elimination (rmx_device.h, "two wavefronts").
+// Opt-in (RMX_W2=1, see launch_step_np_64): since the one-wave kernel runs the same Hessian and solve it is the faster of the two.
+// LDS of a workgroup: [per-node constants][exchange area: the command word][one scratch area: the front's scans / the operand
+// staging / H].  Wave 0's evaluation stages order their LDS traffic wave-locally (RMX_SYNC); workgroup barriers only at the
+// hand-overs of a solve (B1 command, B2 operands consumed, B3 H complete, one per phase 0..2).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -72,7 +73,7 @@ __device__ __forceinline__ void step_bdf1_w2_owner(const DevModel& M, const DevO
             a.histQd[(size_t)s * a.B * M.nr + off] = qd;
         }
     }
-    if (lane == 0) sAcc[W2_CMD] = 0.0;     // command: exit
+    if (lane == 0) sX[0] = 0.0;            // command: exit
     __syncthreads();                       // B1 of the helper's last wait
     if (PROF && lane == 0) {
         for (int c = 0; c < 3; ++c) dprof[(size_t)(2 * traj) * 4 + c] = prof[c];
@@ -95,8 +96,7 @@ __global__ void __launch_bounds__(128) k_step_bdf1_w2(const DevModel M, const De
     constexpr int CS = cstride(NP);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* sX = smem + NCONST * CS;
-    double* sAcc0 = sX + W2_XCH;                       // wave 0: front scratch, operand staging, its half of H
-    double* sAcc1 = sAcc0 + w2_acc_doubles(M.n);       // helper wave: its half of H on the way to row-per-lane
+    double* sAcc0 = sX + W2_XCH;                       // the front's scratch / operand staging / H (shared by the two waves)
     // per-node constants (the layout eval_front_e2 reads; see smem_setup in rmx_kernels.hip)
     if (threadIdx.x < CS) {
         const int j = threadIdx.x;
@@ -127,14 +127,14 @@ __global__ void __launch_bounds__(128) k_step_bdf1_w2(const DevModel M, const De
         step_bdf1_w2_owner<NP, PROF>(M, o, a, sAcc0, sX, dprof);
     } else {
         unsigned long long prof[4] = {0ull, 0ull, 0ull, 0ull};
-        w2_helper_loop<NP, PROF>(M, sAcc0, sAcc1, sX, lane, prof);
+        w2_helper_loop<NP, PROF>(M, sAcc0, sX, lane, prof);
         if (PROF && lane == 0)
             for (int c = 0; c < 4; ++c) dprof[(size_t)(2 * blockIdx.x + 1) * 4 + c] = prof[c];
     }
 }
 
 size_t rmx_w2_smem_bytes(const rmx_model* m) {
-    return sizeof(double) * ((size_t)NCONST * cstride(64) + W2_XCH + 2 * (size_t)w2_acc_doubles(m->n));
+    return sizeof(double) * ((size_t)NCONST * cstride(64) + W2_XCH + (size_t)w2_acc_doubles(m->n));
 }
 
 void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
