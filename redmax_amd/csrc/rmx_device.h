@@ -2797,6 +2797,12 @@ __device__ __attribute__((noinline)) double w2_pivoted_solve(const DevModel& M, 
     return lu_solve_neg<NP>(M.n, lane, Hrow, g);
 }
 
+// Wave 0's part of the shared elimination as a real call: inlined, its 64 + 16 block registers compete with the Newton loop's
+// long-lived values and the front pays for it (22 k instead of 13.5 k cycles per evaluation).
+__device__ __attribute__((noinline)) double w2_solve_call(const int n, const int lane, double* sAcc, bool& ok) {
+    return lu_solve_neg_diag64_staged<2>(n, lane, sAcc, ok);
+}
+
 // newton_impl<NP, false> on wave 0 of a two-wave workgroup: every (g,H) solve is shared with the helper wave, everything else
 // (the front, the line search, all decisions) is the one-wave algorithm on this wave's own scratch.  sX: the exchange area.
 template <int NP, bool PROF = false>
@@ -2818,7 +2824,7 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
         last = e;
         ++iters;
         bool lu_ok;
-        double dx = lu_solve_neg_diag64_staged<2>(M.n, lane, sAcc, lu_ok);
+        double dx = w2_solve_call(M.n, lane, sAcc, lu_ok);
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
         if (lu_ok) {
             piv.streak = 0;
