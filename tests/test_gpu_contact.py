@@ -170,6 +170,71 @@ def test_hand_over_from_free_flight_to_contact(oracle_lib, integ):
         sim2.close()
 
 
+def _free_box_with_arm_over_ground():
+    """A free-flying box (JointFree3D) carrying an arm on a JointSpherical, ForceGroundCuboid on both bodies: multi-DOF joints with
+    Euler-chart switching AND ground contact in one scene (the reference has no such scene; the oracle is the check)."""
+    from redmax_amd.redmax import BodyCuboid, ForceGroundCuboid, JointFree3D, JointSpherical, Scene
+    from redmax_amd.scenes import _T
+    sc = Scene()
+    sc.name = "free box with a spherical-jointed arm over ground"
+    sc.grav = np.array([0.0, 0.0, -980.0])
+    sc.h, sc.tEnd = 5e-4, 0.2
+    b0 = BodyCuboid(1.0, [4, 3, 2])
+    j0 = JointFree3D(None, b0)
+    j0.setJointTransform(_T([0, 0, 5.0]))
+    b0.setBodyTransform(np.eye(4))
+    b1 = BodyCuboid(1.0, [6, 1, 1])
+    j1 = JointSpherical(j0, b1)
+    j1.setJointTransform(_T([2, 0, 0]))
+    b1.setBodyTransform(_T([3, 0, 0]))
+    j0.q[:] = [0.3, -0.2, 0.1, 0, 0, 0]
+    j0.qdot[:] = [6.0, -9.0, 4.0, 5.0, 0, 0]
+    j1.q[:] = [0.2, 0.9, -0.1]
+    j1.qdot[:] = [9.0, -24.0, 6.0]
+    sc.bodies += [b0, b1]
+    sc.joints += [j0, j1]
+    for b in sc.bodies:
+        f = ForceGroundCuboid(b)
+        f.setTransform(np.eye(4))
+        f.setStiffness(1e5, 1e2)
+        f.setDamping(3e1)
+        f.setFriction(0.5)
+        sc.forces.append(f)
+    sc.init()
+    return sc
+
+
+@pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
+def test_spherical_joints_and_ground_contact_together(oracle_lib, integ):
+    """400 steps: ~200 of free flight with tumbling (lean launch, chart switches), then touch-down and sliding (the launch with
+    the contact terms): per-step energies, final state, charts and Newton iteration count against the oracle."""
+    from redmax_amd import BatchSim
+    sc = _free_box_with_arm_over_ground()
+    nsteps = 400
+    q0, qd0 = sc.getQ()
+    sim = BatchSim(sc, batch=2)
+    sim.set_state(np.stack([q0, q0]), np.stack([qd0, 0.5 * qd0]))
+    out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(nsteps, h=sc.h, stats=True, history="full")
+    q, qd = sim.get_state()
+    charts = sim.charts()
+    assert np.all(out["status"] & 7 == 0)
+    for b, scale in enumerate((1.0, 0.5)):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q0, scale * qd0)
+        st, To, Vo = (o.step_bdf1 if integ == "bdf1" else o.step_bdf2)(sc.h, nsteps, history=True)
+        qo, qdo = o.get_state()
+        assert st.diverged == 0 and st.not_converged == 0
+        Ho = To + Vo
+        touch = np.flatnonzero(np.abs(np.diff(Ho)) > 1e-3 * np.abs(Ho).max())
+        assert touch.size and 100 < touch[0] < 350          # free flight first, then the ground
+        assert _rel(q[b], qo) <= 1e-6 and _rel(qd[b], qdo) <= 1e-5
+        Hg = out["T"][:, b] + out["V"][:, b]
+        assert np.abs(Hg - Ho).max() <= 1e-6 * (np.abs(Ho).max() + 1)
+        assert abs(int(out["newton_iters"][b]) - st.newton_iters) <= 3
+        assert list(charts[b]) == list(o.charts())
+    sim.close()
+
+
 def test_contact_is_refused_by_euler_and_adjoint():
     from redmax_amd import BatchSim, RedMaxHipError
     sc = sceneChainGround(4)
