@@ -6,9 +6,12 @@
 // matlab-diff/+redmax/Joint.m:382-613, Body.m:70-135) become
 //   * root->node path products/sums   : serial chains: DPP row scans + row hand-over; trees: pointer jumping (ds_bpermute)
 //   * node->leaves subtree sums       : transpose through LDS, two lanes per component scan the nodes
-//   * the nr x nr Hessian             : n <= 32: two 32x32 products on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), masked
-//                                       by the ancestor/descendant relation; larger trees: lane = row, v_readlane columns
-//   * the dense solve  dx = -H\g      : lane = row, row held in registers, pivot row by batched v_readlane broadcasts
+//   * the nr x nr Hessian             : two products on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), masked by the ancestor /
+//                                       descendant relation (n <= 32: 32x32; 33..64 nodes, plain evaluation: 64x64 in two column
+//                                       halves); padded sizes < 32 and the contact terms of 33..64 nodes: lane = row, v_readlane columns
+//   * the dense solve  dx = -H\g      : diagonal pivots under a growth guard, every update one DPP-fused FMA (n <= 32: column-split
+//                                       first half + row-per-lane tail; 33..64 rows: block columns of 16, H resident in LDS);
+//                                       partial pivoting on demand: lane = row, pivot row by batched v_readlane broadcasts
 // One wave per SIMD means the kernel time is the instruction count on the path: see DESIGN.md "The instruction-count pass".
 // The algebra (world-frame recursive Newton-Euler with analytic derivatives, no J / dJdq tensors)
 // is derived in DESIGN.md and restated executable in tests/proto_worldframe.py.
