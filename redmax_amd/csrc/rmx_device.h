@@ -2827,14 +2827,17 @@ __device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o,
         last = e;
         ++iters;
         bool lu_ok;
-        double dx = w2_solve_call(M.n, lane, sAcc, lu_ok);
+        bool ok2;
+        double dx = w2_solve_call(M.n, lane, sAcc, ok2);
+        lu_ok = ok2;
         if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
         if (lu_ok) {
             piv.streak = 0;
         } else {                     // growth guard tripped: redo this solve with partial pivoting, alone (the helper waits for the next command)
             ++piv.streak;
             status |= 16;
-            dx = w2_pivoted_solve<NP>(M, sAcc, lane, x, qA, qB, eta, e.g);
+            const DevModel Mc = M;       // a copy: see step_bdf1_w2_owner
+            dx = w2_pivoted_solve<NP>(Mc, sAcc, lane, x, qA, qB, eta, e.g);
         }
         const double dxn2 = wave_sum(dx * dx);
         if (!(dxn2 == dxn2)) {

@@ -614,13 +614,14 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     const dim3 grid(b->B), block(64);
     if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_step_ct_, RMX_NP)(m, b, integ, o, a);
 #if RMX_NP == 64
-    // Two wavefronts per trajectory (rmx_kernels_w2.hip): opt-in with RMX_W2=1 in the environment (measurements, tests).  It was
-    // the faster kernel while the one-wave solve broadcast its pivot rows with v_readlane (8.86 vs 10.8 ms per 100 steps of the
-    // 64-joint tree, profiles/r02i_w2_bench.txt); with the matrix-core Hessian and the block-column solve in both, one wave takes
-    // 8.08 ms and two take 8.65 (profiles/r02k_w2_bench.txt: barriers, pass A of every phase run by both waves).
+    // Two wavefronts per trajectory (rmx_kernels_w2.hip) while every CU gets at most one such workgroup (B <= #CUs): there the helper
+    // wave's share of the Hessian and of the elimination shortens a step by 5 % (7.68 vs 8.08 ms per 100 steps of the 64-joint
+    // tree); with two workgroups per CU the four waves contend for the CU's LDS and it is a tie (8.67 vs 8.59 ms at 512 rollouts,
+    // profiles/r02m_w2_bench.txt).  RMX_W2=0 / 1 in the environment forces the choice (measurements, tests).
     if (integ == INTEG_BDF1) {
         const char* force = getenv("RMX_W2");
-        if (force && force[0] == '1') return launch_step_w2_64(m, b, o, a);
+        const long cus = m->n_simd > 0 ? m->n_simd / 4 : 256;
+        if (force ? force[0] == '1' : (long)b->B <= cus) return launch_step_w2_64(m, b, o, a);
     }
 #endif
     if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);

@@ -54,7 +54,20 @@ __device__ __forceinline__ void step_bdf1_w2_owner(const DevModel& M, const DevO
         double x;
         if (o.lu_mode != 0 || piv.hold > 0) {      // wave-uniform: this step on the pivot-only Newton, alone (the helper keeps waiting)
             if (piv.hold > 0) --piv.hold;
-            x = w2_pivot_only_newton<NP>(M, o, sAcc, lane, xg, q0, last, iters, halv, status, piv);
+            // An out-of-line call takes COPIES of everything it gets by reference: an object whose address escapes lives in
+            // scratch for the whole kernel, and for the model constants that turned every M.n / M.rounds / M.grav of the inlined
+            // front into a scratch load (+ s_waitcnt vmcnt(0)): 21.5 k instead of 13.5 k cycles per evaluation.
+            const DevModel Mc = M;
+            const DevOpts oc = o;
+            NodeOut l2;
+            int it2 = 0, hv2 = 0, st2 = 0;
+            PivotPolicy pv2 = piv;
+            x = w2_pivot_only_newton<NP>(Mc, oc, sAcc, lane, xg, q0, l2, it2, hv2, st2, pv2);
+            last = l2;
+            iters += it2;
+            halv += hv2;
+            status |= st2;
+            piv = pv2;
         } else {
             x = newton_w2<NP, PROF>(M, o, sAcc, sX, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, prof);
             pivot_policy_update(piv);
