@@ -4,7 +4,7 @@
 // second wave is a linear-algebra helper: for every (g,H) solve wave 0 stages the operands of H in LDS and posts a command, each
 // wave assembles the half of H whose columns c = 2 t + W it owns on the matrix cores, straight into the row-major staging the
 // block-column solve eliminates in (lu_solve_neg_diag64), and they share that elimination (rmx_device.h, "two wavefronts").
-// Opt-in (RMX_W2=1, see launch_step_np_64): since the one-wave kernel runs the same Hessian and solve it is the faster of the two.
+// Chosen by the launcher while a GPU holds at most one rollout per CU (launch_step_np_64; RMX_W2=0 / 1 forces the choice).
 // LDS of a workgroup: [per-node constants][exchange area: the command word][one scratch area: the front's scans / the operand
 // staging / H].  Wave 0's evaluation stages order their LDS traffic wave-locally (RMX_SYNC); workgroup barriers only at the
 // hand-overs of a solve (B1 command, B2 operands consumed, B3 H complete, one per phase 0..2).
