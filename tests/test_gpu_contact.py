@@ -170,6 +170,47 @@ def test_hand_over_from_free_flight_to_contact(oracle_lib, integ):
         sim2.close()
 
 
+@pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
+def test_contact_on_a_tree_of_more_than_32_nodes(oracle_lib, integ):
+    """40-link chain over the ground: the 64-lane kernels.  Their Hessian stage has two forms - matrix cores with H left in LDS for
+    the block-column solve (plain evaluation: the lean launch, and the contact launch while nothing touches) and the v_readlane
+    columns with the rows handed over in registers (contact terms) - and a rollout that swings into the ground goes through all
+    of them: single evaluations with penetrating corners, then 120 steps from above the ground, against the oracle."""
+    from redmax_amd import BatchSim
+    sc = sceneChainGround(40, ground_z=-1.0)
+    sc.init()
+    rng = np.random.default_rng(11)
+    B = 3
+    q0, qd0, q1 = _penetrating_states("chain", sc.nr, sc.h, B, rng)
+    sim = BatchSim(sc, batch=B)
+    g, H = sim.eval_bdf1(q1, q0, qd0, sc.h)
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        go, Ho = o.eval_bdf1(q1[b], q0[b], qd0[b], sc.h)
+        assert _rel(g[b], go) <= 1e-11 and _rel(H[b], Ho) <= 1e-11
+    q0 = 2e-3 * rng.normal(size=(B, sc.nr))
+    qd0 = 0.05 * rng.normal(size=(B, sc.nr))
+    sim.set_state(q0, qd0)
+    nsteps = 120
+    out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(nsteps, h=sc.h, stats=True, history=True)
+    q, qd = sim.get_state()
+    assert np.all(out["status"] & 5 == 0)
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q0[b], qd0[b])
+        st, To, Vo = (o.step_bdf1 if integ == "bdf1" else o.step_bdf2)(sc.h, nsteps, history=True)
+        qo, qdo = o.get_state()
+        assert st.diverged == 0
+        stalled = st.not_converged > 0
+        assert bool(out["status"][b] & 2) == stalled
+        assert Vo.max() - Vo.min() > 1e2                      # the chain did reach the ground
+        tolq = 1e-5 if stalled else 1e-7
+        assert _rel(q[b], qo) <= tolq and _rel(qd[b], qdo) <= 10 * tolq
+        Hg, Ho = out["T"][:, b] + out["V"][:, b], To + Vo
+        assert np.abs(Hg - Ho).max() <= tolq * (np.abs(Ho).max() + 1)
+    sim.close()
+
+
 def _free_box_with_arm_over_ground():
     """A free-flying box (JointFree3D) carrying an arm on a JointSpherical, ForceGroundCuboid on both bodies: multi-DOF joints with
     Euler-chart switching AND ground contact in one scene (the reference has no such scene; the oracle is the check)."""
