@@ -2276,7 +2276,7 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
 // later column blocks, each DPP row taking its quarter of a block's columns through registers and back to LDS.  The back
 // substitution runs in the same layout, block by block (the value x_k rides on the DPP broadcast).  Every matrix entry sees the
 // same operations on the same values in the same order as in lu_solve_neg_diag<64>: the results are bit-identical.
-template <int P, int K>
+template <int P, int K, bool PINMIN>
 __device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], double (&gm)[4], double (&rown)[4], double& pmin,
                                             double& piv, double& rinv, const int jv) {
     if constexpr (K < 16) {
@@ -2293,6 +2293,9 @@ __device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], 
             asm volatile("" : "+v"(gm[s]));
         }
         pmin = fmin(pmin, piv);
+        // (same reason: 64 v_min and their pivots parked in SGPR spills until the end; in the two-wave kernel the pin costs wave 0
+        // more elsewhere than it saves here: 7.94 instead of 7.72 ms per 100 steps)
+        if constexpr (PINMIN) asm volatile("" : "+v"(pmin));
         if constexpr (K + 1 < 16) {
             fmsub_rowbcast<K>(S[P][K + 1], S[P][K + 1], l[P]);
             piv = readlane_d(S[P][K + 1], K + 1);
@@ -2314,7 +2317,7 @@ __device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], 
 #pragma unroll
         for (int s = P + 1; s < 4; ++s) fmsub_rowbcast<K>(b[s], b[P], l[s]);
         fmsub_rowbcast<K>(b[P], b[P], l[P]);
-        lu64_pass_a<P, K + 1>(S, b, gm, rown, pmin, piv, rinv, jv);
+        lu64_pass_a<P, K + 1, PINMIN>(S, b, gm, rown, pmin, piv, rinv, jv);
     }
 }
 template <int P, int K, int CW>
@@ -2353,7 +2356,7 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
     }
     double piv = readlane_d(S[P][0], 0);
     double rinv = recip(piv);
-    lu64_pass_a<P, 0>(S, b, gm, rown, pmin, piv, rinv, jv);
+    lu64_pass_a<P, 0, NW == 1>(S, b, gm, rown, pmin, piv, rinv, jv);
 #pragma unroll
     for (int B = P + 1; B < 4; ++B) {
         __builtin_amdgcn_sched_barrier(0);      // one block in registers at a time (hoisted loads of all blocks spill)
