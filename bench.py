@@ -46,23 +46,23 @@ METRIC = "sim steps/sec (whole node), 1024-batch 32-DOF chain BDF1; q L2 err vs 
 F_G, F_H, F_LU = 363712, 1418432, 23893
 
 # EXECUTED work of k_step_bdf1<32,false>, per wavefront (= per rollout), split by stage.  Calibrated from the SQ instruction
-# counters of the profiled bench command (separate rocprofv3 --pmc passes, profiles/r02a_pmc_*.csv) by
+# counters of the profiled bench command (separate rocprofv3 --pmc passes, profiles/r02n_pmc_*.csv; r02a, r02g before) by
 # tools/roofline_from_pmc.py: counts(launch) = front_evals * FRONT + newton_iters * NEWTON, fitted on two launches with
 # different iterations-per-step mixes.  flops = 64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 512 x MFMA_MOPS_F64: what the
 # SIMD spent, idle lanes included (a wave-wide instruction costs its issue slots whatever the EXEC mask says).
 EXEC = {
-    "profile": "profiles/r02a_pmc_f64.csv + r02a_pmc_f64_tol3.csv -> profiles/r02a_roofline_calibration.json (tools/roofline_from_pmc.py)",
+    "profile": "profiles/r02n_pmc_f64.csv + r02n_pmc_f64_tol3.csv -> profiles/r02n_roofline_calibration.json (tools/roofline_from_pmc.py)",
     "flops_front": 66945.0,     # one eval_front: 184 ADD + 182 MUL + 340 FMA fp64 wave-instructions (x 64 lanes)
     "flops_newton": 148351.0,   # eval_hess + LU + norms: 42 ADD + 212 MUL + 792 FMA + 60 MFMA MOPS (15 v_mfma_f64_16x16x4_f64)
-    "valu_front": 1345.3,       # VALU wave-instructions of any kind (SQ_INSTS_VALU)
-    "valu_newton": 1935.7,
+    "valu_front": 1221.4,       # VALU wave-instructions of any kind (SQ_INSTS_VALU); 1345.3 / 1935.7 before the guard updates
+    "valu_newton": 1942.6,      # of the solve were pinned (fewer v_accvgpr moves around the front)
 }
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the microarch guide has no fp64 row)
 SHADER_CLOCK_GHZ = 2.4    # max clock (guide); the effective clock under load is lower, so cycle counts below are upper bounds
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
-# HBM bytes per launch from the TCC counters (separate FETCH_SIZE / WRITE_SIZE passes, profiles/r02a_pmc_fetch.csv,
-# r02a_pmc_write.csv, KB as rocprofv3 reports them).  The state is read once and written once per LAUNCH whatever K is.
-HBM_FETCH_KB, HBM_WRITE_KB = 891.1, 608.0      # K=100; K=20: 832.8 + 608.0
+# HBM bytes per launch from the TCC counters (separate FETCH_SIZE / WRITE_SIZE passes, profiles/r02n_pmc_fetch.csv,
+# r02n_pmc_write.csv, KB as rocprofv3 reports them; 891.1 + 608.0 in r02a).  The state is read once and written once per LAUNCH whatever K is.
+HBM_FETCH_KB, HBM_WRITE_KB = 850.1, 608.0      # K=100; K=20: 808.8 + 608.0
 
 
 def _free_port():
