@@ -578,26 +578,36 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
 #define RMX_PART 0
 #endif
 
+// More than 64 KiB of dynamic LDS (trees of 33..64 nodes: 34 KiB of per-node constants + H row-major for the block-column solve)
+// is an opt-in per kernel and device; it costs microseconds, so it is set at every launch rather than cached (a process may
+// drive several devices from several threads).
+#define RMX_LAUNCH(kernel, grid, block, bytes, stream, ...)                                                                         \
+    do {                                                                                                                            \
+        if ((bytes) > 64 * 1024)                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        kernel<<<grid, block, bytes, stream>>>(__VA_ARGS__);                                                                        \
+    } while (0)
+
 #if RMX_PART == 1
 
 void RMX_CAT(launch_eval_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
     const dim3 grid(b->B), block(64);
-    if (wantH) k_eval<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
-    else k_eval<RMX_NP, false, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
+    if (wantH) RMX_LAUNCH((k_eval<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
+    else RMX_LAUNCH((k_eval<RMX_NP, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
 }
 void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
     // every trajectory as far as it stays clear of the ground (all the way in scenes without ForceGroundCuboid) ...
-    if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
-    else k_step_bdf2<RMX_NP, true, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     if (!m->dm.con) return;
     // ... and the rest of its steps with the contact terms
-    if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
-    else k_step_bdf2<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
 void RMX_CAT(launch_energy_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);
-    k_energy<RMX_NP, true><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, b->chart);
+    RMX_LAUNCH((k_energy<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->q, b->qd, dT, dV, b->chart);
 }
 
 #else
@@ -606,8 +616,8 @@ void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool 
     const dim3 grid(b->B), block(64);
     // scenes with ForceGroundCuboid or JointSpherical run the extended instantiations (CT), everything else the plain ones
     if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_eval_ct_, RMX_NP)(m, b, wantH, eta, dg, dH);
-    if (wantH) k_eval<RMX_NP, true, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
-    else k_eval<RMX_NP, false, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
+    if (wantH) RMX_LAUNCH((k_eval<RMX_NP, true, false>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
+    else RMX_LAUNCH((k_eval<RMX_NP, false, false>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, nullptr);
 }
 
 void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
@@ -624,35 +634,35 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
         if (force ? force[0] == '1' : (long)b->B <= cus) return launch_step_w2_64(m, b, o, a);
     }
 #endif
-    if (integ == INTEG_BDF1) k_step_bdf1<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
-    else k_step_bdf2<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
 
 void RMX_CAT(launch_euler_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double h, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
-    k_step_euler<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, h, a);
+    RMX_LAUNCH((k_step_euler<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, h, a);
 }
 
 void RMX_CAT(launch_energy_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);
     if (m->dm.con || m->dm.nsph) return RMX_CAT(launch_energy_ct_, RMX_NP)(m, b, dT, dV);
-    k_energy<RMX_NP, false><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->q, b->qd, dT, dV, nullptr);
+    RMX_LAUNCH((k_energy<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->q, b->qd, dT, dV, nullptr);
 }
 
 void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a) {
     const dim3 grid(b->B), block(64);
-    k_adjoint_fwd<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, o, a);
+    RMX_LAUNCH((k_adjoint_fwd<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     k_adjoint_bwd<RMX_NP><<<grid, block, 0, b->stream>>>(m->dm, o, a);
 }
 
 void RMX_CAT(launch_mfd_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD) {
     const dim3 grid(b->B), block(64);
-    k_eval_mfd<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD);
+    RMX_LAUNCH((k_eval_mfd<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD);
 }
 
 void RMX_CAT(launch_phase_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d) {
     const dim3 grid(b->B), block(64);
-    k_phase_time<RMX_NP><<<grid, block, m->smem_bytes, b->stream>>>(m->dm, reps, b->q, b->qd, h, d);
+    RMX_LAUNCH((k_phase_time<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, reps, b->q, b->qd, h, d);
 }
 
 #endif
