@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
             NodeOut e;
             double Hrow[NP];
             eval_front<NP, true>(M, sAcc, lane, x, (x - q0) / h, x - xB, h, e, fs);
-            eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
+            const double hdiag = eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
             if constexpr (STORE_ONCE) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i) Hs[i] = Hrow[i];
@@ -336,7 +336,23 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
                 }
             }
             ++iters;
-            const double dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);      // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128
+            // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128.  As in the step kernels the solve takes diagonal pivots
+            // under the growth guard first (a third of the instructions of the pivot search) and falls back to partial pivoting
+            // on the saved copy of H when the guard trips; the factors themselves are not kept (the backward pass re-solves).
+            double dx;
+            if constexpr (STORE_ONCE) {
+                bool lu_ok;
+                dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
+                if (!lu_ok) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) Hrow[i] = Hs[i];
+                    dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
+                    status |= 16;
+                }
+            } else {
+                (void)hdiag;
+                dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
+            }
             const double dxn2 = wave_sum(dx * dx);
             if (!(dxn2 == dxn2)) { status |= 4; break; }
             if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }            // :129-132
