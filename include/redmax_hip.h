@@ -228,7 +228,9 @@ typedef struct rmx_task_pointpos {
  * state, forward simLoop (:65-102) with the line-search-free newton (:105-146; opts->iterMaxPerDof should be 5 as at :108)
  * under the torques tau = pscale*p, storing H, M, D of the last evaluated iterate of every step in HBM, then the backward
  * sweep TaskBDF1.calcFinal (TaskBDF1.m:45-81).  p: host [batch][nr]; P: host [batch]; dPdp: host [batch][nr].
- * The batch state is left at the end of the forward rollout. */
+ * The batch state is left at the end of the forward rollout.  The forward solves take diagonal pivots under the growth guard
+ * first, as the step kernels do (RMX_ST_PIVOTED in stats->status when one was redone with partial pivoting; the reference's
+ * lu(H,'vector') always pivots, :127). */
 int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
                      double* P, double* dPdp, rmx_stats* stats);
 
