@@ -140,6 +140,9 @@ class GpuStepper:
         self.sim.stats_reset()
         self.sim.sync()
 
+    def sync_device(self):
+        self.sim.sync()
+
     def launch(self, K):
         if self.integ == "bdf2":      # BDF2 has no async entry point: the synchronous call returns after the kernel
             self._out = self.sim.step_bdf2(K, stats=True)
@@ -245,10 +248,10 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats):
     st.set_opts(h, tol)
     q0, qd0 = gen(shard.first, shard.count)
     st.set_state(q0, qd0)
+    ctx.gather(st, shard)              # warm the collective too (before the warm-up steps: nothing but the barrier + device
+    st.stats_reset()                   # sync the contract asks for lies between the warm-up steps and the timed launch)
     st.warmup(W)
-    ctx.gather(st, shard)              # warm the collective too
-    qw, qdw = st.get_state()           # the state every timed launch starts from
-    st.stats_reset()
+    st.sync_device()
     ctx.barrier()
     t0 = time.perf_counter()
     st.launch(K)
@@ -267,6 +270,10 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats):
         "local_iters": s["newton_iters"].copy(),
     }
     rep_k, rep_w = [], []
+    if repeats > 0:                    # the state every timed launch starts from: the same warm-up once more (deterministic)
+        st.set_state(q0, qd0)
+        st.warmup(W)
+        qw, qdw = st.get_state()
     for _ in range(max(repeats, 0)):
         st.set_state(qw, qdw)
         ctx.barrier()

@@ -631,6 +631,7 @@ extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const d
         if (e != hipSuccess) { (void)hipFree(dg); return fail(RMX_E_NOMEM, "hipMalloc(H)"); }
         (void)hipMemsetAsync(dH, 0, nv * m->nr * sizeof(double), b->stream);
     }
+    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_eval, m, b, H != nullptr, eta, dg, dH);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(g, dg, nv * sizeof(double), hipMemcpyDeviceToHost, b->stream);
@@ -657,6 +658,7 @@ extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, d
     if (e == hipSuccess) e = hipMemcpyAsync(b->tmpA, q, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b->tmpB, qdot, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
+        (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
         DISPATCH_NP(m->NP, launch_mfd, m, b, dM, df, dD);
         e = hipGetLastError();
     }
@@ -699,6 +701,7 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.chart = b->chart;
     a.resume = b->resume;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
+    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
     // BDF2 keeps (q, qdot) of step k-1 in qp/qdp.  BDF1 steps do not maintain them (and, with JointSpherical, may leave q in
     // another Euler chart than qp), so a BDF1 call invalidates the multistep history: the next rmx_step_bdf2 restarts with
@@ -817,6 +820,7 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
     StepArgs a{};
     a.B = b->B; a.nsteps = nsteps; a.q = b->q; a.qd = b->qd; a.histT = dT; a.histV = dV;
     hipError_t e = hipEventRecord(b->ev0, b->stream);
+    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_euler, m, b, h, a);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
@@ -869,6 +873,7 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
         a.Hs = (double*)bufs[0]; a.Ms = (double*)bufs[1]; a.Ds = (double*)bufs[2];
         a.dPdq = (double*)bufs[3]; a.P = (double*)bufs[4]; a.dPdp = (double*)bufs[5];
         e = hipEventRecord(b->ev0, b->stream);
+        (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
         DISPATCH_NP(m->NP, launch_adjoint, m, b, o, a);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
@@ -929,6 +934,7 @@ extern "C" int rmx_profile_phases(rmx_batch* b, int reps, double h, double* cycl
     HIPCHK(hipSetDevice(m->device));
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, sizeof(unsigned long long) * 16 * b->B));
+    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_phase, m, b, reps, h, d);
     std::vector<unsigned long long> hbuf(16 * (size_t)b->B);
     hipError_t e = hipGetLastError();
@@ -952,6 +958,7 @@ extern "C" int rmx_energy(rmx_batch* b, double* T, double* V) {
     HIPCHK(hipMalloc((void**)&dT, sizeof(double) * b->B));
     hipError_t e = hipMalloc((void**)&dV, sizeof(double) * b->B);
     if (e != hipSuccess) { (void)hipFree(dT); return fail(RMX_E_NOMEM, "hipMalloc(energy)"); }
+    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_energy, m, b, dT, dV);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(T, dT, sizeof(double) * b->B, hipMemcpyDeviceToHost, b->stream);
