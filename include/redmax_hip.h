@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 103
+#define RMX_VERSION 104
 
 enum {
     RMX_OK = 0,
@@ -105,6 +105,15 @@ typedef struct rmx_opts {
                                 the top 26 bits of |H(a,k)| (exponent + 14 mantissa bits), lowest row first among equals: exact
                                 ties resolve as LAPACK's first maximum, candidates within 2^-14 relative of each other may be
                                 taken in another order, so results agree with dgetrf to roundoff, not bit for bit  */
+    int compensated;       /* the Newton iterate of newton() (driverRedMaxBDF1.m:94-157):
+                              1 (default) carried as an unevaluated sum x + xlo, |xlo| <= ulp(x)/2; xlo enters the residual where x
+                                enters linearly with large coefficients (dqtmp = q1 - q0 - h qdot0 and qdot1 = (q1 - q0)/h,
+                                :167-169) and nowhere else, and is dropped when the step stores q1.  On long chains in cgs units
+                                |M| ulp(q) reaches the reference's tol = 1e-9: on the lattice of doubles ||g|| < tol is then met only
+                                at lucky points, which MATLAB's Newton finds because its own evaluation noise dithers the update
+                                and a smoother evaluation does not.  With xlo no Newton correction is lost to
+                                the rounding of x and the iteration converges to the evaluation noise, at the reference's constants;
+                              0 plain doubles: the reference's arithmetic, decision for decision  */
 } rmx_opts;
 
 typedef struct rmx_model rmx_model;

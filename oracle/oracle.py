@@ -87,8 +87,9 @@ def lib():
         L.orc_batch_step_bdf1_ex.restype = C.c_long
         L.otf_nr.argtypes = [C.POINTER(_Desc)]
         L.otf_eval.argtypes = [C.POINTER(_Desc), _dp, _dp, _dp, C.c_double, _dp, _dp]
+        L.otf_eval_lo.argtypes = [C.POINTER(_Desc), _dp, _dp, _dp, _dp, C.c_double, _dp, _dp]
         L.otf_batch_step_bdf1.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double,
-                                          C.c_int, C.c_int, _ip, _ip, _ip]
+                                          C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]
         L.otf_batch_step_bdf1.restype = C.c_long
         L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
         L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
@@ -413,14 +414,28 @@ def tensorfree_eval(desc_dict, q, qA, qB, eta, want_H=True):
     return (g, H.reshape(nr, nr).T.copy()) if want_H else g
 
 
-def tensorfree_batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0, tol=1e-9, dxMax=1e3, iterMaxPerDof=10, iterLsMax=20):
-    """simLoop for B rollouts (q, qdot [B][nr], in place), OpenMP over rollouts.  Returns per-rollout counters."""
+def tensorfree_eval_lo(desc_dict, q, qlo, qA, qB, eta, want_H=True):
+    """tensorfree_eval at the compensated iterate q + qlo (qlo enters v = q - qB and qdot = (q - qA)/eta only)."""
+    L = lib()
+    d, keep = make_desc(desc_dict)
+    nr = L.otf_nr(C.byref(d))
+    q, qlo, qA, qB = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, qlo, qA, qB))
+    g = np.zeros(nr)
+    H = np.zeros(nr * nr) if want_H else None
+    L.otf_eval_lo(C.byref(d), _p(q), _p(qlo), _p(qA), _p(qB), float(eta), _p(g), _p(H))
+    return (g, H.reshape(nr, nr).T.copy()) if want_H else g
+
+
+def tensorfree_batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0, tol=1e-9, dxMax=1e3, iterMaxPerDof=10, iterLsMax=20,
+                               compensated=True):
+    """simLoop for B rollouts (q, qdot [B][nr], in place), OpenMP over rollouts.  Returns per-rollout counters.
+    compensated: the Newton iterate as the unevaluated sum x + xlo, as the HIP kernels carry it by default (rmx_opts.compensated)."""
     L = lib()
     d, keep = make_desc(desc_dict)
     assert q.flags.c_contiguous and qdot.flags.c_contiguous and q.dtype == np.float64
     out = {k: np.zeros(q.shape[0], dtype=np.int32) for k in ("newton_iters", "ls_halvings", "status")}
     L.otf_batch_step_bdf1(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads), float(tol), float(dxMax),
-                          int(iterMaxPerDof), int(iterLsMax), *[out[k].ctypes.data_as(_ip) for k in ("newton_iters", "ls_halvings", "status")])
+                          int(iterMaxPerDof), int(iterLsMax), int(bool(compensated)), *[out[k].ctypes.data_as(_ip) for k in ("newton_iters", "ls_halvings", "status")])
     return out
 
 

@@ -144,8 +144,10 @@ long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, d
  * Trees of fixed / revolute / prismatic joints, no contact.  Checked against the literal restatement above. */
 int  otf_nr(const orc_desc* d);
 void otf_eval(const orc_desc* d, const double* q, const double* qA, const double* qB, double eta, double* g, double* H);
+/* the same at the compensated iterate q + qlo (|qlo| <= ulp(q)/2): qlo enters v = q - qB and qdot = (q - qA)/eta only */
+void otf_eval_lo(const orc_desc* d, const double* q, const double* qlo, const double* qA, const double* qB, double eta, double* g, double* H);
 long otf_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, double tol,
-                         double dxMax, int iterMaxPerDof, int iterLsMax, int* iters, int* halvings, int* status);
+                         double dxMax, int iterMaxPerDof, int iterLsMax, int compensated, int* iters, int* halvings, int* status);
 
 #ifdef __cplusplus
 }

@@ -143,14 +143,17 @@ static void tf_destroy(tf_model* m) {
 }
 
 /* g (and H, nr x nr column-major, when non-NULL) at x.  Two O(n) sweeps + one O(n * depth) Hessian fill. */
-static void tf_eval(tf_model* m, const double* x, const double* qA, const double* qB, double eta, double* g, double* H) {
+/* xlo (or NULL): low-order part of a compensated iterate x + xlo (|xlo| <= ulp(x)/2).  It enters where x enters LINEARLY with large
+ * coefficients - v = x - qB (times M) and qdot = (x - qA)/eta (times D) - and nowhere else: the geometry is evaluated at x. */
+static void tf_eval_lo(tf_model* m, const double* x, const double* xlo, const double* qA, const double* qB, double eta, double* g, double* H) {
     const int n = m->n, nr = m->nr;
     const double e2 = eta * eta;
     const double* gv = m->grav;
     /* ---- root -> leaves: transforms, screws, phi, xi, beta, body terms (Joint.update, Body.update, Body.computeMassGrav) */
     for (int j = 0; j < n; j++) {
         const int par = m->parent[j], k = m->idx[j];
-        const double q = k >= 0 ? x[k] : 0.0, qd = k >= 0 ? (x[k] - qA[k]) / eta : 0.0, v = k >= 0 ? x[k] - qB[k] : 0.0;
+        const double lo = (k >= 0 && xlo) ? xlo[k] : 0.0;
+        const double q = k >= 0 ? x[k] : 0.0, qd = k >= 0 ? ((x[k] - qA[k]) + lo) / eta : 0.0, v = k >= 0 ? (x[k] - qB[k]) + lo : 0.0;
         double Q[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, qp[3] = {0, 0, 0};
         const double* a = m->axis + 3 * j;
         if (m->type[j] == ORC_JOINT_REVOLUTE) {      /* Rodrigues: a a' + cos (I - a a') + sin [a]   (se3.aaToMat) */
@@ -244,7 +247,7 @@ static void tf_eval(tf_model* m, const double* x, const double* qA, const double
     for (int j = 0; j < n; j++) {
         const int k = m->idx[j];
         if (k < 0) continue;
-        const double q = x[k], qd = (x[k] - qA[k]) / eta;
+        const double q = x[k], qd = ((x[k] - qA[k]) + (xlo ? xlo[k] : 0.0)) / eta;
         const double* P = m->prm + 8 * j;
         const double hitL = q < P[4] ? 1.0 : 0.0, hitU = q > P[5] ? 1.0 : 0.0;
         const double fr = P[0] + P[1] * (P[3] - q) - P[2] * qd + hitL * (P[6] * (P[4] - q) - P[7] * qd) + hitU * (P[6] * (P[5] - q) - P[7] * qd);
@@ -323,6 +326,10 @@ static void tf_eval(tf_model* m, const double* x, const double* qA, const double
     }
 }
 
+static void tf_eval(tf_model* m, const double* x, const double* qA, const double* qB, double eta, double* g, double* H) {
+    tf_eval_lo(m, x, NULL, qA, qB, eta, g, H);
+}
+
 /* dx = -H\g, LU with partial pivoting (MATLAB mldivide, driverRedMaxBDF1.m:117); H column-major, destroyed */
 static void tf_solve_neg(int n, double* H, const double* g, double* dx) {
     for (int i = 0; i < n; i++) dx[i] = -g[i];
@@ -351,15 +358,18 @@ static void tf_solve_neg(int n, double* H, const double* g, double* dx) {
 #undef A
 }
 
-typedef struct { double *g, *H, *dx, *x0; } tf_work;
+typedef struct { double *g, *H, *dx, *x0, *lo, *lo0; } tf_work;
 
-/* newton (driverRedMaxBDF1.m:94-157), decision for decision */
+/* newton (driverRedMaxBDF1.m:94-157), decision for decision.  comp != 0: the iterate is carried as the unevaluated sum x + lo
+ * (the HIP kernels' default, rmx_opts.compensated): x + lo = x0 + (lo0 + alpha dx) exactly (TwoSum), lo enters the residual through
+ * v and qdot only (tf_eval_lo); on return x is the iterate rounded to nearest and w->lo its low-order part. */
 static void tf_newton(tf_model* m, tf_work* w, double* x, const double* qA, const double* qB, double eta, double tol, double dxMax,
-                      int iterMax, int iterLsMax, int* iters, int* halvings, int* status) {
+                      int iterMax, int iterLsMax, int comp, int* iters, int* halvings, int* status) {
     const int nr = m->nr;
     int iter = 1;
+    for (int i = 0; i < nr; i++) w->lo[i] = 0.0;
     while (1) {
-        tf_eval(m, x, qA, qB, eta, w->g, w->H);
+        tf_eval_lo(m, x, w->lo, qA, qB, eta, w->g, w->H);
         ++*iters;
         tf_solve_neg(nr, w->H, w->g, w->dx);
         double dn = 0.0, f0 = 0.0;
@@ -368,10 +378,25 @@ static void tf_newton(tf_model* m, tf_work* w, double* x, const double* qA, cons
         f0 *= 0.5;
         double alpha = 1.0, gn = 0.0;
         memcpy(w->x0, x, sizeof(double) * nr);
-        int iterLs = 1;
+        memcpy(w->lo0, w->lo, sizeof(double) * nr);
+        int iterLs = 1, stalled = 0;
         while (1) {
-            for (int i = 0; i < nr; i++) x[i] = w->x0[i] + alpha * w->dx[i];
-            tf_eval(m, x, qA, qB, eta, w->g, NULL);
+            int moved = 0;
+            for (int i = 0; i < nr; i++) {
+                const double a = w->x0[i], b = w->lo0[i] + alpha * w->dx[i];
+                const double s = a + b, bb = s - a;
+                x[i] = s;
+                w->lo[i] = comp ? (a - (s - bb)) + (b - bb) : 0.0;
+                moved |= (x[i] != w->x0[i]) || (w->lo[i] != w->lo0[i]);
+            }
+            if (!moved) {      /* the kernels' exact shortcut: every further halving re-evaluates g(x0) bit for bit, the reference runs
+                                  out its trials, keeps x0 and repeats this very iteration until iterMax (rmx_device.h newton_impl) */
+                stalled = 1;
+                iterLs = iterLsMax;
+                gn = 2.0 * f0;
+                break;
+            }
+            tf_eval_lo(m, x, w->lo, qA, qB, eta, w->g, NULL);
             gn = 0.0;
             for (int i = 0; i < nr; i++) gn += w->g[i] * w->g[i];
             if (0.5 * gn < f0) break;
@@ -380,6 +405,10 @@ static void tf_newton(tf_model* m, tf_work* w, double* x, const double* qA, cons
             ++iterLs;
         }
         *halvings += iterLs - 1;
+        if (stalled) {
+            if (!(sqrt(gn) < tol)) *status |= 2 | 8;
+            break;
+        }
         if (sqrt(gn) < tol) break;
         if (iter >= iterMax) { *status |= 2; break; }
         ++iter;
@@ -392,6 +421,11 @@ void otf_eval(const orc_desc* d, const double* q, const double* qA, const double
     tf_eval(m, q, qA, qB, eta, g, H);
     tf_destroy(m);
 }
+void otf_eval_lo(const orc_desc* d, const double* q, const double* qlo, const double* qA, const double* qB, double eta, double* g, double* H) {
+    tf_model* m = tf_create(d);
+    tf_eval_lo(m, q, qlo, qA, qB, eta, g, H);
+    tf_destroy(m);
+}
 int otf_nr(const orc_desc* d) {
     int nr = 0;
     for (int j = 0; j < d->njoints; j++) nr += d->type[j] != ORC_JOINT_FIXED;
@@ -401,7 +435,7 @@ int otf_nr(const orc_desc* d) {
 /* simLoop (driverRedMaxBDF1.m:57-91) for B rollouts, OpenMP over rollouts; q, qdot [B][nr] in/out.  iters / halvings /
  * status: per-rollout outputs [B] or NULL.  Returns the total Newton iteration count. */
 long otf_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, double tol,
-                         double dxMax, int iterMaxPerDof, int iterLsMax, int* iters, int* halvings, int* status) {
+                         double dxMax, int iterMaxPerDof, int iterLsMax, int compensated, int* iters, int* halvings, int* status) {
     long total = 0;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -417,6 +451,8 @@ long otf_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, doub
         w.H = (double*)malloc(sizeof(double) * ((size_t)nr * nr + 1));
         w.dx = (double*)malloc(sizeof(double) * (nr + 1));
         w.x0 = (double*)malloc(sizeof(double) * (nr + 1));
+        w.lo = (double*)calloc((size_t)nr + 1, sizeof(double));
+        w.lo0 = (double*)calloc((size_t)nr + 1, sizeof(double));
         double* x = (double*)malloc(sizeof(double) * (nr + 1));
         double* xB = (double*)malloc(sizeof(double) * (nr + 1));
 #pragma omp for schedule(dynamic, 1)
@@ -426,15 +462,15 @@ long otf_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, doub
             int it = 0, hv = 0, st = 0;
             for (int s = 0; s < nsteps; s++) {
                 for (int i = 0; i < nr; i++) x[i] = xB[i] = qb[i] + h * qdb[i];      /* initial guess = q0 + h qdot0 (:70, :169) */
-                tf_newton(m, &w, x, qb, xB, h, tol, dxMax, iterMaxPerDof * nr, iterLsMax, &it, &hv, &st);
-                for (int i = 0; i < nr; i++) { qdb[i] = (x[i] - qb[i]) / h; qb[i] = x[i]; }
+                tf_newton(m, &w, x, qb, xB, h, tol, dxMax, iterMaxPerDof * nr, iterLsMax, compensated, &it, &hv, &st);
+                for (int i = 0; i < nr; i++) { qdb[i] = ((x[i] - qb[i]) + w.lo[i]) / h; qb[i] = x[i]; }
             }
             if (iters) iters[b] = it;
             if (halvings) halvings[b] = hv;
             if (status) status[b] = st;
             total += it;
         }
-        free(w.g); free(w.H); free(w.dx); free(w.x0); free(x); free(xB);
+        free(w.g); free(w.H); free(w.dx); free(w.x0); free(w.lo); free(w.lo0); free(x); free(xB);
         tf_destroy(m);
     }
     return total;

@@ -46,6 +46,7 @@ extern "C" void rmx_opts_default(rmx_opts* o) {
     o->iterMaxPerDof = 10;  // :97
     o->iterLsMax = 20;      // :98
     o->lu_mode = 0;
+    o->compensated = 1;
 }
 
 namespace {
@@ -682,6 +683,7 @@ static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
     d.iterMax = o->iterMaxPerDof * b->m->nr;    // iterMax = 10*length(xInit) (:97)
     d.iterLsMax = o->iterLsMax;
     d.lu_mode = o->lu_mode;
+    d.comp = o->compensated ? 1.0 : 0.0;
     return RMX_OK;
 }
 

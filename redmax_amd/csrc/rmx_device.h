@@ -18,10 +18,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// Synchronisation and LDS layout hooks.  The single-wave kernels (one 64-lane workgroup per trajectory) use the defaults: a
-// workgroup barrier (which the compiler reduces to the LDS wait for a one-wave workgroup) and the per-node constants right behind
-// the wave's scratch.  The two-wave step kernel (rmx_kernels_w2.hip) redefines both before including this header: its waves run
-// the evaluation stages independently on private scratch (wave-local ordering only) and share one copy of the constants.
+// Synchronisation and LDS layout hooks.  One 64-lane wavefront per trajectory; the defaults are a workgroup barrier (which the
+// compiler reduces to the LDS wait for a one-wave workgroup) and the per-node constants right behind the wave's scratch.  A
+// translation unit whose workgroups hold several independent wavefronts redefines both before including this header: wave-local
+// ordering only, and one copy of the constants shared by the waves of the workgroup.
 #ifndef RMX_SYNC
 #define RMX_SYNC() __syncthreads()
 #endif
@@ -47,11 +47,7 @@ constexpr int HM_ROWS = 57;       // RU 8, RL 12|20, CU 8, CL 12|20, Hdiag 1 (|:
 constexpr int HM_H_STRIDE = 34;   // H staged row-major [32][34] for the hand-over to row-per-lane (16-byte aligned rows)
 // trees of 33..64 nodes (NP = 64): operand rows RU 6, RL 12, CU 6, CL 12, Hdiag 1 of [k][node] with stride 65, then H row-major
 // [64][66] (H64_STRIDE; column 64: the right-hand side); the front's scratch shares the area
-constexpr int W2_OP_STRIDE = 65, W2_OP_ROWS = 37;
-__host__ __device__ constexpr int w2_acc_doubles(const int n) {
-    const int a = (n + 1) * ACC_STRIDE, b = W2_OP_ROWS * W2_OP_STRIDE, c = MAXN * 66;
-    return (a > b ? a : b) > c ? (a > b ? a : b) : c;
-}
+constexpr int H64_OP_STRIDE = 65, H64_OP_ROWS = 37;
 __host__ __device__ constexpr int acc_doubles(const int n, const int NP) {
     const int a = (n + 1) * ACC_STRIDE;
     const int b = NP == 32 ? HM_ROWS * HM_OP_STRIDE : 0;     // 1881 doubles; also covers H: 32*34 = 1088
@@ -100,6 +96,7 @@ struct DevOpts {
     double h, tol, dxMax;
     int iterMax, iterLsMax;
     int lu_mode;      // 0: diagonal pivots under a growth guard, partial pivoting on demand; 1: always partial pivoting
+    double comp;      // 1.0: compensated Newton iterate (x + xlo, see newton_impl); 0.0: plain doubles (the reference's lattice)
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -241,6 +238,13 @@ __device__ __forceinline__ double recip(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     const double e = fma(-x, r, 1.0);
     return fma(r, fma(e, e, e), r);
+}
+
+// s + e = a + b exactly (Knuth's TwoSum, no ordering assumption; six additions that must not be re-associated)
+__device__ __forceinline__ void two_sum(const double a, const double b, double& s, double& e) {
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
 }
 
 // Per-lane (per-node) results of one evaluation that the caller keeps.
@@ -1184,20 +1188,19 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
 }
 
 // Trees of 33..64 nodes: a 64 x 32 half of H (all rows x the columns i = 2 t + W) on the fp64 matrix cores, from operands staged
-// in LDS ([k][node], stride W2_OP_STRIDE):
+// in LDS ([k][node], stride H64_OP_STRIDE):
 //     H(a,i) = [a strict ancestor of i] RU_a.CU_i + [a strict descendant of i] RL_a.CL_i ,  Hdiag on the diagonal,
 // RU = s (6), CU = y - z (6), RL = (r1, -r2w, -r3w) (12), CL = (m1, m2w, sw) (12), as for n <= 32 in eval_hess.  4 x 2 tiles of
 // 16 x 16; in depth-first numbering an ancestor has the smaller index, so 2 of the 8 UP tiles and 2 of the 8 LO tiles are empty:
-// 6 x 2 + 6 x 3 = 30 v_mfma_f64_16x16x4_f64 per half.  The one-wave kernels compute both halves (eval_hess), the two-wave step
-// kernel one per wave (w2_hess_to_lds).
-constexpr int W2_R_RU = 0, W2_R_RL = 6, W2_R_CU = 18, W2_R_CL = 24, W2_R_HD = 36;
-// Wave W's 64 x 32 half of H on the matrix cores (columns i = 2 t + W), masked: hv[mb][nb][r] = H(16 mb + 4 r + g, 32 nb + 2 j + W)
+// 6 x 2 + 6 x 3 = 30 v_mfma_f64_16x16x4_f64 per half; eval_hess computes both halves, one after the other.
+constexpr int H64_R_RU = 0, H64_R_RL = 6, H64_R_CU = 18, H64_R_CL = 24, H64_R_HD = 36;
+// The 64 x 32 half W of H on the matrix cores (columns i = 2 t + W), masked: hv[mb][nb][r] = H(16 mb + 4 r + g, 32 nb + 2 j + W)
 // for g = lane >> 4, j = lane & 15 (the C/D layout of the f64 MFMA).  cRel: the relation-mask rows of the per-node constants.
 template <int NP, int W>
-__device__ __forceinline__ void w2_hess_tiles(const int lane, const double* __restrict__ sOp, const double* __restrict__ cRel,
+__device__ __forceinline__ void hess64_tiles(const int lane, const double* __restrict__ sOp, const double* __restrict__ cRel,
                                               double (&hv)[4][2][4]) {
     static_assert(NP == 64, "64-lane trees");
-    constexpr int ST = W2_OP_STRIDE;
+    constexpr int ST = H64_OP_STRIDE;
     typedef double v4d __attribute__((ext_vector_type(4)));
     const int g = lane >> 4, j = lane & 15;
     constexpr int CSW = cstride(NP);
@@ -1217,9 +1220,9 @@ __device__ __forceinline__ void w2_hess_tiles(const int lane, const double* __re
         const bool kon = 4 * kk + g < 6;
         const int kr = kon ? 4 * kk + g : 0;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) a[mb] = kon ? sOp[(W2_R_RU + kr) * ST + 16 * mb + j] : 0.0;
+        for (int mb = 0; mb < 4; ++mb) a[mb] = kon ? sOp[(H64_R_RU + kr) * ST + 16 * mb + j] : 0.0;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) b[nb] = kon ? sOp[(W2_R_CU + kr) * ST + 32 * nb + 2 * j + W] : 0.0;
+        for (int nb = 0; nb < 2; ++nb) b[nb] = kon ? sOp[(H64_R_CU + kr) * ST + 32 * nb + 2 * j + W] : 0.0;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -1230,9 +1233,9 @@ __device__ __forceinline__ void w2_hess_tiles(const int lane, const double* __re
     for (int kk = 0; kk < 3; ++kk) {       // LO: K = 12
         double a[4], b[2];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) a[mb] = sOp[(W2_R_RL + 4 * kk + g) * ST + 16 * mb + j];
+        for (int mb = 0; mb < 4; ++mb) a[mb] = sOp[(H64_R_RL + 4 * kk + g) * ST + 16 * mb + j];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) b[nb] = sOp[(W2_R_CL + 4 * kk + g) * ST + 32 * nb + 2 * j + W];
+        for (int nb = 0; nb < 2; ++nb) b[nb] = sOp[(H64_R_CL + 4 * kk + g) * ST + 32 * nb + 2 * j + W];
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -1253,7 +1256,7 @@ __device__ __forceinline__ void w2_hess_tiles(const int lane, const double* __re
         amhi[nb] = (unsigned)(am >> 32);
         dmlo[nb] = (unsigned)dm;
         dmhi[nb] = (unsigned)(dm >> 32);
-        hd[nb] = sOp[W2_R_HD * ST + icol[nb]];
+        hd[nb] = sOp[H64_R_HD * ST + icol[nb]];
     }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -1270,18 +1273,11 @@ __device__ __forceinline__ void w2_hess_tiles(const int lane, const double* __re
             }
 }
 
-template <int NP, int W>
-__device__ __forceinline__ void w2_hess_to_lds(const DevModel& M, const int lane, double* __restrict__ sH, const double g_stage);   // two-wave section below
-
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle node slots are the identity.
 // Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
-// NW = 2 (trees of more than 32 nodes, the two-wave step kernel k_step_bdf1_w2, called by wave 0 only): the columns are dealt out
-// to the two wavefronts of the workgroup; wave 0 stages the operands for both and computes columns i = 2 t into Hrow[t]
-// into the shared staging rows (w2_hess_to_lds).  NW = 1 is the whole row.
-template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true, int NW = 1, int W = 0>
-__device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP / NW],
+template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true>
+__device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0) {
-    static_assert(NW == 1 || (NW == 2 && NP > 32 && W == 0), "column split: 64-lane trees, wave 0");
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr int CS = cstride(NP);
     const double eta = fs.eta, e2 = eta * eta;
@@ -1677,35 +1673,35 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
         RMX_SYNC();
-    } else if constexpr (NP == 64 && !CT && NW == 1 && HESS_MFMA64) {
+    } else if constexpr (NP == 64 && !CT && HESS_MFMA64) {
         // 33..64 nodes, one wavefront: the two matrix products of the two-wave kernel, both column halves by this wave.  Operands
         // in [k][node] order in the scratch, 2 x 30 v_mfma_f64_16x16x4_f64, then H row-major [64][H64_STRIDE] in the same scratch
         // (the layout lu_solve_neg_diag64 eliminates in; its right-hand side -g travels in column 64).
-        constexpr int ST = W2_OP_STRIDE;
+        constexpr int ST = H64_OP_STRIDE;
         double* sOp = sAcc;
         {
             double* o = sOp + lane;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                o[(W2_R_RU + c) * ST] = sw[c];
-                o[(W2_R_RU + 3 + c) * ST] = sv[c];
-                o[(W2_R_RL + c) * ST] = r1t[c];
-                o[(W2_R_RL + 3 + c) * ST] = r1f[c];
-                o[(W2_R_RL + 6 + c) * ST] = -r2w[c];
-                o[(W2_R_RL + 9 + c) * ST] = -r3w[c];
+                o[(H64_R_RU + c) * ST] = sw[c];
+                o[(H64_R_RU + 3 + c) * ST] = sv[c];
+                o[(H64_R_RL + c) * ST] = r1t[c];
+                o[(H64_R_RL + 3 + c) * ST] = r1f[c];
+                o[(H64_R_RL + 6 + c) * ST] = -r2w[c];
+                o[(H64_R_RL + 9 + c) * ST] = -r3w[c];
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) o[(W2_R_CU + c) * ST] = cv[c];
+            for (int c = 0; c < 6; ++c) o[(H64_R_CU + c) * ST] = cv[c];
 #pragma unroll
-            for (int c = 6; c < 18; ++c) o[(W2_R_CL + c - 6) * ST] = cv[c];
-            o[W2_R_HD * ST] = Hdiag;
+            for (int c = 6; c < 18; ++c) o[(H64_R_CL + c - 6) * ST] = cv[c];
+            o[H64_R_HD * ST] = Hdiag;
         }
         RMX_SYNC();
         const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;
         double h0[4][2][4], h1[4][2][4];
-        w2_hess_tiles<NP, 0>(lane, sOp, cRel, h0);
+        hess64_tiles<NP, 0>(lane, sOp, cRel, h0);
         __builtin_amdgcn_sched_barrier(0);      // one half's accumulators at a time
-        w2_hess_tiles<NP, 1>(lane, sOp, cRel, h1);
+        hess64_tiles<NP, 1>(lane, sOp, cRel, h1);
         RMX_SYNC();             // every lane is done with the operands: the same LDS now takes H
         {
             typedef double v2d __attribute__((ext_vector_type(2)));
@@ -1734,37 +1730,10 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
         RMX_SYNC();
-    } else if constexpr (NW == 2) {
-        // Two-wave kernel, 64 rows (wave 0 only runs eval_hess): stage the operands of the two matrix products in [k][node] order
-        // in the shared scratch, post the "solve" command for the helper wave, and compute this wave's half of H into the
-        // staging rows (w2_hess_to_lds).  Hrow is not written: the solve (lu_solve_neg_diag64_staged<2>) takes H from LDS.
-        static_assert(NP == 64 && !CT && W == 0, "two-wave Hessian: 64-lane plain models, called by wave 0");
-        constexpr int ST = W2_OP_STRIDE;
-        double* sOp = sAcc;
-        {
-            double* o = sOp + lane;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                o[(W2_R_RU + c) * ST] = sw[c];
-                o[(W2_R_RU + 3 + c) * ST] = sv[c];
-                o[(W2_R_RL + c) * ST] = r1t[c];
-                o[(W2_R_RL + 3 + c) * ST] = r1f[c];
-                o[(W2_R_RL + 6 + c) * ST] = -r2w[c];
-                o[(W2_R_RL + 9 + c) * ST] = -r3w[c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) o[(W2_R_CU + c) * ST] = cv[c];
-#pragma unroll
-            for (int c = 6; c < 18; ++c) o[(W2_R_CL + c - 6) * ST] = cv[c];
-            o[W2_R_HD * ST] = Hdiag;
-            if (lane == 0) const_cast<double*>(RMX_CONSTS(sAcc, M.n, NP))[NCONST * CS] = 1.0;   // exchange area, behind the constants: 1 = solve
-        }
-        __syncthreads();             // B1: operands and command are in LDS; the helper wave has been waiting here
-        w2_hess_to_lds<NP, 0>(M, lane, sAcc, g_stage);
     } else {
 #pragma unroll
-        for (int t = 0; t < NP / NW; ++t) {
-            const int i = NW * t + W;
+        for (int t = 0; t < NP; ++t) {
+            const int i = t;
             double Ci[NCV];
 #pragma unroll
             for (int c = 0; c < NCV; ++c) Ci[c] = readlane_d(cv[c], i);
@@ -2296,8 +2265,7 @@ __device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], 
             asm volatile("" : "+v"(gm[s]));
         }
         pmin = fmin(pmin, piv);
-        // (same reason: 64 v_min and their pivots parked in SGPR spills until the end; in the two-wave kernel the pin costs wave 0
-        // more elsewhere than it saves here: 7.94 instead of 7.72 ms per 100 steps)
+        // (same reason: 64 v_min and their pivots parked in SGPR spills until the end)
         if constexpr (PINMIN) asm volatile("" : "+v"(pmin));
         if constexpr (K + 1 < 16) {
             fmsub_rowbcast<K>(S[P][K + 1], S[P][K + 1], l[P]);
@@ -2336,15 +2304,12 @@ __device__ __forceinline__ void lu64_pass_b(const double (&S)[4][16], double (&X
         lu64_pass_b<P, K + 1, CW>(S, X, jv);
     }
 }
-// One phase.  NW = 2 (the two-wave step kernel): both wavefronts run pass A (it is replicated per DPP row anyway, and so every
-// DPP row of either wave holds the multipliers) and share pass B - eight DPP rows, two columns of every later block each - with a
-// workgroup barrier where the next phase collects its pivot columns; the helper wave (W = 1) sits out phase 3, which has no pass
-// B, so that phase ends wave-locally.
-template <int P, int NW = 1, int W = 0>
+// One phase of 16 pivots.
+template <int P>
 __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&b)[4], double (&gm)[4], double (&rown)[4],
                                            double& pmin, const int jv) {
     typedef double v2d __attribute__((ext_vector_type(2)));
-    constexpr int CW = 4 / NW;                 // columns of a later block per DPP row
+    constexpr int CW = 4;                      // columns of a later block per DPP row
     const int r4 = lane >> 4, j = lane & 15;
     double S[4][16];
 #pragma unroll
@@ -2359,12 +2324,12 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
     }
     double piv = readlane_d(S[P][0], 0);
     double rinv = recip(piv);
-    lu64_pass_a<P, 0, NW == 1>(S, b, gm, rown, pmin, piv, rinv, jv);
+    lu64_pass_a<P, 0, true>(S, b, gm, rown, pmin, piv, rinv, jv);
 #pragma unroll
     for (int B = P + 1; B < 4; ++B) {
         __builtin_amdgcn_sched_barrier(0);      // one block in registers at a time (hoisted loads of all blocks spill)
         double X[4][CW];
-        const int col = 16 * B + CW * (4 * W + r4);
+        const int col = 16 * B + CW * r4;
 #pragma unroll
         for (int s = P; s < 4; ++s) {
             const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * s + j) * H64_STRIDE + col);
@@ -2383,11 +2348,9 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
             for (int c = 0; c < CW / 2; ++c) w[c] = v2d{X[s][2 * c], X[s][2 * c + 1]};
         }
     }
-    if (NW == 2 && P < 3) __syncthreads();     // the next phase reads what all the DPP rows (of both waves) have written
-    else RMX_SYNC();
-    // the finished rows of this phase: their part of U, for the back substitution.  Written behind the hand-over: until then the
-    // other wave may still be collecting these very entries (as they were before the phase) for its own pass A.
-    if (W == 0 && lane < 16) {
+    RMX_SYNC();                                // the next phase reads what all the DPP rows have written
+    // the finished rows of this phase: their part of U, for the back substitution
+    if (lane < 16) {
         v2d* w = reinterpret_cast<v2d*>(sH + (16 * P + j) * H64_STRIDE + 16 * P);
 #pragma unroll
         for (int c = 0; c < 8; ++c) w[c] = v2d{S[P][2 * c], S[P][2 * c + 1]};
@@ -2415,7 +2378,6 @@ __device__ __forceinline__ void lu64_back_off(double& bs, const double xP, const
 }
 
 // H and the right-hand side are in place: sAcc = [64][H64_STRIDE], row-major, column 64 = -g
-template <int NW = 1>
 __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const int lane, double* sAcc, bool& ok) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     double* sH = sAcc;                                   // the front's scratch is free during the solve
@@ -2429,10 +2391,10 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
         b[s] = row[64];
         lim[s] = (LU_GROWTH_MAX * LU_GROWTH_MAX) * row[16 * s + j];
     }
-    lu64_phase<0, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<1, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<2, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<3, NW, 0>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<0>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<1>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<2>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<3>(sH, lane, b, gm, rown, pmin, jv);
     RMX_SYNC();                 // (the finished rows of phase 3)
     // back substitution, block column by block column from the right
     double x[4];
@@ -2475,17 +2437,6 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     return dx;
 }
 
-// The helper wave's part of a two-wave solve: phases 0..2 next to wave 0 (pass A for the multipliers, its share of pass B); the
-// right-hand side, the guard and the back substitution are wave 0's.
-__device__ __forceinline__ void lu64_helper(double* sH, const int lane) {
-    int jv = lane & 15;
-    asm volatile("" : "+v"(jv));
-    double b[4] = {0.0, 0.0, 0.0, 0.0}, gm[4] = {0.0, 0.0, 0.0, 0.0}, rown[4] = {0.0, 0.0, 0.0, 0.0}, pmin = 1.0;
-    lu64_phase<0, 2, 1>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<1, 2, 1>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<2, 2, 1>(sH, lane, b, gm, rown, pmin, jv);
-}
-
 // the row-per-lane form of the interface (callers whose Hessian stage leaves H in registers)
 __device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lane, double* sAcc, const double (&Hrow)[64], const double g,
                                                       bool& ok) {
@@ -2497,7 +2448,7 @@ __device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lan
         sAcc[lane * H64_STRIDE + 64] = -g;
     }
     RMX_SYNC();
-    return lu_solve_neg_diag64_staged<1>(n, lane, sAcc, ok);
+    return lu_solve_neg_diag64_staged(n, lane, sAcc, ok);
 }
 
 // BATCHED: pivot-row broadcasts in batches ahead of their FMAs (see lu_solve_neg_diag).  The Euler and adjoint kernels use
@@ -2598,11 +2549,21 @@ constexpr int ST_LEFT_LEAN = 64;
 template <int NP, bool PIVOT_ONLY, bool CT = false, bool LEAN = false>
 __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
-                                              int& iters, int& halvings, int& status, PivotPolicy& piv) {
+                                              int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
     (void)sCol;
     double Hrow[NP];
     FrontState fs;
     NodeOut e;
+    // The iterate is carried as an unevaluated sum x + lo, |lo| <= ulp(x)/2 (o.comp = 1; 0 keeps lo = 0: plain doubles, the
+    // reference's arithmetic).  g depends on x at the resolution of one ulp only where x enters LINEARLY with large coefficients:
+    // v = x - qB (times the mass matrix) and qdot = (x - qA)/eta (times D); the geometry cannot resolve a fraction of an ulp of x
+    // (sin, cos are rounded to their own ulp).  For the 32-link chain |M| ulp(x) ~ 1e-9 = the reference's tol: on the lattice of
+    // doubles |g| < tol is reachable only at lucky points, and Newton finds them only if something dithers its update - in
+    // MATLAB / the literal oracle their own evaluation noise does (0.1 % of steps fail), the world-frame evaluation has a smoother
+    // error and sticks on 13 % of the steps (tools/reference_tol_stats.py).  With lo in v and qdot the
+    // Newton correction is never lost to the rounding of x and the iteration converges quadratically to the evaluation noise
+    // (~1e-10).  x is what a step stores (already rounded to nearest: two_sum), lo is dropped there.
+    double lo = 0.0;
     eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
     if (LEAN && fs.touched) {
         status |= ST_LEFT_LEAN;
@@ -2624,7 +2585,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
             else if constexpr (NP == 64 && LU_SPLIT64) {
                 // the matrix-core Hessian stage (plain models, and contact-capable ones while nothing touches the ground) has left
                 // H and -g in the scratch; the v_readlane stage (contact terms) hands the rows over in registers
-                if (HESS_MFMA64 && (!CT || !fs.touched)) dx = lu_solve_neg_diag64_staged<1>(M.n, lane, sAcc, lu_ok);
+                if (HESS_MFMA64 && (!CT || !fs.touched)) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
                 else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
             }
             else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
@@ -2636,7 +2597,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 // H was destroyed in place.  The front is re-evaluated too (same x, same arithmetic) so that its state does
                 // not have to stay live in registers across the fast-path LU for the sake of this rare branch.
                 NodeOut e2;
-                eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
+                eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e2, fs);
                 eval_hess<NP, false, CT>(M, lane, fs, Hrow, nullptr, sAcc);
                 dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
             }
@@ -2655,14 +2616,15 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         // deterministic reduction), so it is carried over instead of being reduced again
         const double g0n2 = gcarry >= 0.0 ? gcarry : wave_sum(e.g * e.g);
         const double f0 = 0.5 * g0n2;
-        const double x0 = x;
+        const double x0 = x, lo0 = lo;
         int iterLs = 1;
         double gn2 = g0n2;
         bool stalled = false;
         while (true) {
-            x = x0 + alpha * dx;
-            if (__all(x == x0)) {
-                // alpha*dx is below one ulp of x in every DOF: this and every further halving re-evaluates g at x0
+            two_sum(x0, fma(alpha, dx, lo0), x, lo);       // x + lo = x0 + (lo0 + alpha dx)
+            lo *= o.comp;
+            if (__all(x == x0 && lo == lo0)) {
+                // alpha*dx no longer changes the iterate in any DOF: this and every further halving re-evaluates g at x0
                 // bit-for-bit, so f == f0 is never a strict decrease, the reference runs out its iterLsMax trials and
                 // keeps x0 (:132-138).  Same outcome, without the evaluations.
                 stalled = true;
@@ -2670,7 +2632,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 e = e0;              // the evaluation at x0
                 break;
             }
-            eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
+            eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, fs);
             if (LEAN && fs.touched) {
                 status |= ST_LEFT_LEAN;
                 return x;
@@ -2697,18 +2659,19 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         }
         ++iter;
     }
+    xlo = lo;
     return x;
 }
 
 template <int NP, bool CT, bool LEAN>
 __device__ __forceinline__ double newton_policy(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                                 double x, const double qA, const double qB, const double eta, NodeOut& last,
-                                                int& iters, int& halvings, int& status, PivotPolicy& piv) {
+                                                int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
     if (o.lu_mode != 0 || piv.hold > 0) {     // wave-uniform
         if (piv.hold > 0) --piv.hold;
-        return newton_impl<NP, true, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+        return newton_impl<NP, true, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
     }
-    const double r = newton_impl<NP, false, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+    const double r = newton_impl<NP, false, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
     pivot_policy_update(piv);
     return r;
 }
@@ -2720,14 +2683,15 @@ __device__ __forceinline__ double newton_policy(const DevModel& M, const DevOpts
 template <int NP, bool CT = false, bool LEAN = false>
 __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
-                                              int& iters, int& halvings, int& status, PivotPolicy& piv) {
+                                              int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
+    xlo = 0.0;
     if constexpr (!LEAN) {
-        return newton_policy<NP, CT, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv);
+        return newton_policy<NP, CT, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
     } else {
         int it2 = 0, hv2 = 0, st2 = 0;
         PivotPolicy pv2 = piv;
         NodeOut l2;
-        const double r = newton_policy<NP, false, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, l2, it2, hv2, st2, pv2);
+        const double r = newton_policy<NP, false, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, l2, it2, hv2, st2, pv2, xlo);
         if (st2 & ST_LEFT_LEAN) {
             status |= ST_LEFT_LEAN;
             return x;
@@ -2739,161 +2703,6 @@ __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& 
         last = l2;
         return r;
     }
-}
-
-// ----------------------------------------------------------------------------- two wavefronts per trajectory (trees of 33..64 nodes)
-//
-// One wavefront per trajectory leaves SIMDs idle whenever a GPU holds fewer rollouts than it has SIMDs (BASELINE.json
-// configs[2]: 4096 rollouts over 8 GPUs = 512 per GPU on 1024 SIMDs), and for 64-row systems the instruction stream of one
-// Newton iteration is dominated by the Hessian assembly and the elimination, both of which split by COLUMNS.  The two-wave step
-// kernel (k_step_bdf1_w2, rmx_kernels_w2.hip) gives a trajectory a workgroup of two wavefronts that share one scratch area:
-//   * wave 0 owns the rollout: state, front, line search, every decision (newton_w2 = the one-wave Newton with shared solves);
-//   * wave 1 is a helper without rollout state (w2_helper_loop): it waits for wave 0's command, computes the half of H whose
-//     columns c = 2 t + 1 it owns from the operands wave 0 staged (w2_hess_tiles, fp64 matrix cores; wave 0 takes c = 2 t), and
-//     takes its share of the elimination;
-//   * elimination: lu_solve_neg_diag64's block-column layout with eight DPP rows instead of four (lu64_phase<P, 2, W>).  Pass A
-//     of a phase (inside the 16 pivot columns) is replicated per DPP row anyway, so both waves run it and neither waits for
-//     multipliers; pass B (the later column blocks) is shared, two columns of a block per DPP row; a workgroup barrier per
-//     phase where the next pivot columns are collected.  Right-hand side, guard and back substitution stay with wave 0.
-// Workgroup barriers of one solve: command (B1), operands consumed (B2), H complete (B3), phases 0, 1, 2.  When the guard trips,
-// wave 0 alone redoes the solve with full partial pivoting (the single-wave code); steps that the pivot policy assigns to the
-// pivot-only Newton run on wave 0 alone.  The helper waits at B1 meanwhile.
-constexpr int W2_XCH = 8;      // LDS doubles of the exchange area: [0] the command word for the helper wave (1 solve, 0 exit)
-
-// Wave W's half of H into the shared staging rows sH = [64][H64_STRIDE] (the operands sit in the same LDS: B2 in between).
-template <int NP, int W>
-__device__ __forceinline__ void w2_hess_to_lds(const DevModel& M, const int lane, double* __restrict__ sH, const double g_stage) {
-    double hv[4][2][4];
-    w2_hess_tiles<NP, W>(lane, sH, RMX_CONSTS(sH, M.n, NP) + (36 + 6 + 4 + 8 + 1) * cstride(NP), hv);
-    __syncthreads();             // B2: both waves are done with the operands
-    const int g = lane >> 4, j = lane & 15;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sH[(16 * mb + 4 * r + g) * H64_STRIDE + 32 * nb + 2 * j + W] = hv[mb][nb][r];
-    if (W == 0) sH[lane * H64_STRIDE + 64] = -g_stage;
-    __syncthreads();             // B3: H and the right-hand side are complete
-}
-
-// The helper wave of a two-wave workgroup: no rollout state.  It waits at B1 for wave 0's command (1: solve, 0: exit); on
-// "solve" it computes its half of H from the operands wave 0 staged, takes its share of the elimination, and waits again.
-template <int NP, bool PROF = false>
-__device__ __forceinline__ void w2_helper_loop(const DevModel& M, double* __restrict__ sH, const double* __restrict__ sX, const int lane,
-                                               unsigned long long* prof = nullptr) {
-    while (true) {
-        __syncthreads();             // B1
-        if (sX[0] == 0.0) break;
-        unsigned long long t0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-        w2_hess_to_lds<NP, 1>(M, lane, sH, 0.0);
-        if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[1] += t1 - t0; t0 = t1; }
-        lu64_helper(sH, lane);
-        if (PROF) { prof[2] += __builtin_amdgcn_s_memtime() - t0; prof[3] += 1; }
-    }
-}
-
-// The rare single-wave detour of the two-wave kernel is a real function call (not inlined): inlined, its uniform values (model
-// constants, masks) stay resident in scalar registers across the whole Newton loop of wave 0.
-template <int NP>
-__device__ __attribute__((noinline)) double w2_pivoted_solve(const DevModel& M, double* sAcc, const int lane, const double x, const double qA,
-                                                             const double qB, const double eta, const double g) {
-    double Hrow[NP];
-    FrontState fs;
-    NodeOut e2;
-    eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e2, fs);
-    eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
-    return lu_solve_neg<NP>(M.n, lane, Hrow, g);
-}
-
-// Wave 0's part of the shared elimination as a real call: inlined, its 64 + 16 block registers compete with the Newton loop's
-// long-lived values and the front pays for it (22 k instead of 13.5 k cycles per evaluation).
-__device__ __attribute__((noinline)) double w2_solve_call(const int n, const int lane, double* sAcc, bool& ok) {
-    return lu_solve_neg_diag64_staged<2>(n, lane, sAcc, ok);
-}
-
-// newton_impl<NP, false> on wave 0 of a two-wave workgroup: every (g,H) solve is shared with the helper wave, everything else
-// (the front, the line search, all decisions) is the one-wave algorithm on this wave's own scratch.  sX: the exchange area.
-template <int NP, bool PROF = false>
-__device__ __forceinline__ double newton_w2(const DevModel& M, const DevOpts& o, double* sAcc, double* sX, const int lane, double x,
-                                            const double qA, const double qB, const double eta, NodeOut& last, int& iters, int& halvings,
-                                            int& status, PivotPolicy& piv, unsigned long long* prof = nullptr) {
-    double Hh[NP / 2];
-    FrontState fs;
-    NodeOut e;
-    unsigned long long t0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-    eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
-    if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
-    int iter = 1;
-    double gcarry = -1.0;
-    while (true) {
-        (void)eval_hess<NP, false, false, true, 2, 0>(M, lane, fs, Hh, nullptr, sAcc, e.g);
-        if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[1] += t1 - t0; t0 = t1; }
-        const NodeOut e0 = e;
-        last = e;
-        ++iters;
-        bool lu_ok;
-        bool ok2;
-        double dx = w2_solve_call(M.n, lane, sAcc, ok2);
-        lu_ok = ok2;
-        if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[2] += t1 - t0; t0 = t1; }
-        if (lu_ok) {
-            piv.streak = 0;
-        } else {                     // growth guard tripped: redo this solve with partial pivoting, alone (the helper waits for the next command)
-            ++piv.streak;
-            status |= 16;
-            const DevModel Mc = M;       // a copy: see step_bdf1_w2_owner
-            dx = w2_pivoted_solve<NP>(Mc, sAcc, lane, x, qA, qB, eta, e.g);
-        }
-        const double dxn2 = wave_sum(dx * dx);
-        if (!(dxn2 == dxn2)) {
-            status |= 4;
-            break;
-        }
-        if (sqrt(dxn2) > o.dxMax) {
-            status |= 1;
-            break;
-        }
-        double alpha = 1.0;
-        const double g0n2 = gcarry >= 0.0 ? gcarry : wave_sum(e.g * e.g);
-        const double f0 = 0.5 * g0n2;
-        const double x0 = x;
-        int iterLs = 1;
-        double gn2 = g0n2;
-        bool stalled = false;
-        while (true) {
-            x = x0 + alpha * dx;
-            if (__all(x == x0)) {
-                stalled = true;
-                iterLs = o.iterLsMax;
-                e = e0;
-                break;
-            }
-            if (PROF) t0 = __builtin_amdgcn_s_memtime();
-            eval_front<NP, true>(M, sAcc, lane, x, (x - qA) / eta, x - qB, eta, e, fs);
-            if (PROF) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); prof[0] += t1 - t0; t0 = t1; }
-            gn2 = wave_sum(e.g * e.g);
-            if (0.5 * gn2 < f0) break;
-            if (iterLs >= o.iterLsMax) break;
-            alpha *= 0.5;
-            ++iterLs;
-        }
-        last = e;
-        halvings += iterLs - 1;
-        if (stalled) {
-            if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
-            break;
-        }
-        gcarry = gn2;
-        if (sqrt(gn2) < o.tol) break;
-        if (iter >= o.iterMax) {
-            status |= 2;
-            break;
-        }
-        ++iter;
-        if (PROF) t0 = __builtin_amdgcn_s_memtime();
-    }
-    return x;
 }
 
 }  // namespace rmx

@@ -56,7 +56,7 @@ struct rmx_model {
     void* dsph = nullptr;           // axis variants of the spherical group nodes
     DevModel dm{};
     size_t smem_bytes = 0;
-    int n_simd = 0;                 // SIMDs of the device (4 per CU): the two-wave kernel is used while 2 x batch fits
+    int n_simd = 0;                 // SIMDs of the device (4 per CU)
 };
 
 struct rmx_batch {
@@ -87,9 +87,6 @@ struct rmx_batch {
     void RMX_CAT(launch_eval_ct_, NPV)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH); \
     void RMX_CAT(launch_step_ct_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a); \
     void RMX_CAT(launch_energy_ct_, NPV)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV);
-// rmx_kernels_w2.hip: the two-wave BDF1 step kernel for trees of 33..64 nodes (plain models)
-void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a);
-size_t rmx_w2_smem_bytes(const rmx_model* m);
 RMX_DECLARE_LAUNCHERS(4)
 RMX_DECLARE_LAUNCHERS(8)
 RMX_DECLARE_LAUNCHERS(16)

@@ -76,13 +76,14 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
         NodeOut last;
-        const double x = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv);
+        double xlo;
+        const double x = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo);
         if (LEAN && (status & ST_LEFT_LEAN)) {
             status &= ~ST_LEFT_LEAN;
             stop = s;
             break;
         }
-        qd = (x - q0) / o.h;                       // (:72)
+        qd = ((x - q0) + xlo) / o.h;               // (:72), with the low-order part of the iterate the residual was evaluated at
         q = x;
         if constexpr (CT) {                        // jroot.reparam() (:78)
             double np0 = 0.0, np1 = 0.0;
@@ -141,12 +142,13 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
     int stop = a.nsteps;
     for (int s = s0; s < a.nsteps; ++s) {
         NodeOut last;
+        double xlo;       // low-order part of the converged iterate: below the rounding of the multistep velocity formulas, not used
         if (s == 0 && !started) {
             const double al = (2.0 - sqrt(2.0)) / 2.0;    // (:74)
             const double q0 = q, qd0 = qd;
             // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
             const double xa0 = q0 + al * h * qd0;
-            const double qa = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv);
+            const double qa = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv, xlo);
             if (LEAN && (status & ST_LEFT_LEAN)) {
                 status &= ~ST_LEFT_LEAN;
                 stop = s;
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             const double x10 = qa + (1.0 - al) * h * qda;
             const double qA = q0 + (1.0 - al) * h * qda;
             const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-            const double q1 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv);
+            const double q1 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv, xlo);
             if (LEAN && (status & ST_LEFT_LEAN)) {
                 status &= ~ST_LEFT_LEAN;
                 stop = s;
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpt
             const double x0 = q1 + h * qd1;
             const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
             const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-            const double q2 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv);
+            const double q2 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv, xlo);
             if (LEAN && (status & ST_LEFT_LEAN)) {
                 status &= ~ST_LEFT_LEAN;
                 stop = s;
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
     for (int s = 1; s <= a.nsteps; ++s) {
         const double q0 = q, qd0 = qd;
         const double xB = q0 + h * qd0;
-        double x = xB;
+        double x = xB, xlo = 0.0;      // compensated iterate x + xlo (newton_impl in rmx_device.h)
         double* Hk = a.Hs + ((size_t)traj * a.nsteps + (s - 1)) * nn;
         double* Mk = a.Ms + ((size_t)traj * a.nsteps + (s - 1)) * nn;
         double* Dk = a.Ds + ((size_t)traj * a.nsteps + (s - 1)) * nn;
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
         while (true) {
             NodeOut e;
             double Hrow[NP];
-            eval_front<NP, true>(M, sAcc, lane, x, (x - q0) / h, x - xB, h, e, fs);
+            eval_front<NP, true>(M, sAcc, lane, x, ((x - q0) + xlo) / h, (x - xB) + xlo, h, e, fs);
             const double hdiag = eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
             if constexpr (STORE_ONCE) {
 #pragma unroll
@@ -356,7 +358,11 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
             const double dxn2 = wave_sum(dx * dx);
             if (!(dxn2 == dxn2)) { status |= 4; break; }
             if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }            // :129-132
-            x = x + dx;                                                   // :134, before the convergence test
+            {                                                             // x = x + dx, :134, before the convergence test
+                const double xa = x;
+                two_sum(xa, xlo + dx, x, xlo);
+                xlo *= o.comp;
+            }
             if (sqrt(wave_sum(e.g * e.g)) < o.tol) break;                 // :135-138
             if (iter >= o.iterMax) { status |= 2; break; }                // :139-142
             ++iter;
@@ -374,7 +380,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
                     }
             }
         }
-        qd = (x - q0) / h;
+        qd = ((x - q0) + xlo) / h;
         q = x;
         if (s == a.task_step) {    // TaskBDF1PointPos.calcStep :67-107 at the final state of this step
             NodeOut e;
@@ -639,17 +645,6 @@ void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool 
 void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
     if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_step_ct_, RMX_NP)(m, b, integ, o, a);
-#if RMX_NP == 64
-    // Two wavefronts per trajectory (rmx_kernels_w2.hip) while every CU gets at most one such workgroup (B <= #CUs): there the helper
-    // wave's share of the Hessian and of the elimination shortens a step by 5 % (7.68 vs 8.08 ms per 100 steps of the 64-joint
-    // tree); with two workgroups per CU the four waves contend for the CU's LDS and it is a tie (8.67 vs 8.59 ms at 512 rollouts,
-    // profiles/r02m_w2_bench.txt).  RMX_W2=0 / 1 in the environment forces the choice (measurements, tests).
-    if (integ == INTEG_BDF1) {
-        const char* force = getenv("RMX_W2");
-        const long cus = m->n_simd > 0 ? m->n_simd / 4 : 256;
-        if (force ? force[0] == '1' : (long)b->B <= cus) return launch_step_w2_64(m, b, o, a);
-    }
-#endif
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }

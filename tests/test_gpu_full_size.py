@@ -128,12 +128,10 @@ def test_config5_chain_ground_full_size(oracle_lib):
         assert _rel(qa[b], qo) <= 1e-7, (b, _rel(qa[b], qo))
 
 
-def test_two_wave_kernel_matches_single_wave_and_oracle(oracle_lib, monkeypatch):
-    """Trees of 33..64 nodes run the two-wave step kernel (k_step_bdf1_w2: two wavefronts per trajectory, columns of the Hessian and
-    of the elimination dealt out to them, Gauss-Jordan elimination with the multipliers handed over through LDS) while 2 x batch
-    still fits the SIMDs, the one-wave kernel otherwise; RMX_W2=0/1 forces the choice.  Both must give the reference's result:
-    against each other (different elimination order: agreement to roundoff, not bitwise) and against the oracle, with identical
-    Newton iteration counts."""
+def test_trees_of_33_to_64_nodes_match_oracle(oracle_lib):
+    """Trees of 33..64 nodes (one row of H per lane: matrix-core Hessian in two column halves, block-column DPP solve with H resident
+    in LDS) against the oracle with identical Newton iteration counts, and lu_mode = 1 (always partial pivoting, the row-per-lane
+    solve) against the default to roundoff."""
     from redmax_amd import BatchSim
     from redmax_amd.scenes import sceneChain, sceneTree
     for sc, K in ((sceneTree(64), 10), (sceneChain(48), 6), (sceneTree(40), 8)):
@@ -141,25 +139,16 @@ def test_two_wave_kernel_matches_single_wave_and_oracle(oracle_lib, monkeypatch)
         B = 6
         q, qd = _tree_states(sc, B)
         res = {}
-        # long chains in cgs units: |g| < 1e-9 sits at the fp64 noise floor of g and the iteration counts become roundoff-dependent
-        # (DESIGN.md §5), so the chain runs at the bench tolerance; the trees run the reference's constants
-        tol = 1e-8 if "chain" in sc.name else 1e-9
-        oracle_lib.set_newton(tol=tol)
-        for mode in ("0", "1"):
-            monkeypatch.setenv("RMX_W2", mode)
+        for mode in (0, 1):
             sim = BatchSim(sc, batch=B)
-            sim.opts.tol = tol
+            sim.opts.lu_mode = mode
             sim.set_state(q, qd)
             out = sim.step_bdf1(K, h=1e-2, stats=True, history="full")
             res[mode] = (sim.get_state(), out)
             sim.close()
-        (q0, qd0), o0 = res["0"]
-        (q1, qd1), o1 = res["1"]
-        assert (o1["status"] & 15 == 0).all()
-        if "chain" in sc.name:      # a 480 cm chain: one iteration more or fewer where |g| lands within roundoff of tol
-            assert np.abs(o0["newton_iters"] - o1["newton_iters"]).max() <= 1
-        else:
-            assert np.array_equal(o0["newton_iters"], o1["newton_iters"])
+        (q0, qd0), o0 = res[0]
+        (q1, qd1), o1 = res[1]
+        assert (o0["status"] & 15 == 0).all() and (o1["status"] & 15 == 0).all()
         assert np.allclose(o0["T"], o1["T"], rtol=1e-9, atol=1e-9) and np.allclose(o0["q"], o1["q"], rtol=1e-9, atol=1e-11)
         for b in range(B):
             assert _rel(q1[b], q0[b]) <= 1e-10, (sc.name, b, _rel(q1[b], q0[b]))
@@ -168,38 +157,8 @@ def test_two_wave_kernel_matches_single_wave_and_oracle(oracle_lib, monkeypatch)
             o.set_state(q[b], qd[b])
             st = o.step_bdf1(1e-2, K)
             qo, _ = o.get_state()
-            assert _rel(q1[b], qo) <= 1e-8, (sc.name, b, _rel(q1[b], qo))
-            assert abs(int(o1["newton_iters"][b]) - st.newton_iters) <= (1 if "chain" in sc.name else 0)
-    oracle_lib.set_newton()
-    monkeypatch.delenv("RMX_W2")
-
-
-def test_two_wave_kernel_pivot_paths(oracle_lib, monkeypatch):
-    """lu_mode = 1 (always partial pivoting) runs every step on wave 0 alone inside the two-wave kernel; it must equal the
-    one-wave kernel to roundoff (same code on the same data), and so must the default mode."""
-    from redmax_amd import BatchSim
-    from redmax_amd.scenes import sceneTree
-    sc = sceneTree(64)
-    sc.init()
-    B, K = 4, 5
-    q, qd = _tree_states(sc, B)
-    got = {}
-    for w2 in ("0", "1"):
-        monkeypatch.setenv("RMX_W2", w2)
-        sim = BatchSim(sc, batch=B)
-        sim.opts.lu_mode = 1
-        sim.set_state(q, qd)
-        sim.step_bdf1(K, h=1e-2)
-        got[w2] = sim.get_state()
-        sim.close()
-    # same source on the same data, but compiled in two translation units (FMA contraction may differ): agreement to roundoff
-    assert _rel(got["1"][0], got["0"][0]) <= 1e-12 and _rel(got["1"][1], got["0"][1]) <= 1e-10
-    monkeypatch.setenv("RMX_W2", "1")
-    sim = BatchSim(sc, batch=B)
-    sim.set_state(q, qd)
-    sim.step_bdf1(K, h=1e-2)
-    qa, _ = sim.get_state()
-    sim.close()
-    for b in range(B):
-        assert _rel(qa[b], got["1"][0][b]) <= 1e-10
-    monkeypatch.delenv("RMX_W2")
+            assert _rel(q0[b], qo) <= 1e-8, (sc.name, b, _rel(q0[b], qo))
+            # long chains in cgs units: |M| ulp(q) reaches tol, the oracle's last iterations of a step wander over the lattice of
+            # doubles until |g| < tol is met; the compensated iterate converges without them
+            ng, no = int(o0["newton_iters"][b]), st.newton_iters
+            assert (no - 3 * K <= ng <= no) if "chain" in sc.name else ng == no, (sc.name, b, ng, no)

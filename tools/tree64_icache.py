@@ -4,7 +4,6 @@ second workgroup of a CU contends for."""
 import os
 import sys
 
-os.environ["RMX_W2"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from redmax_amd import BatchSim, sceneTree, syntheticStates  # noqa: E402
 
