@@ -149,6 +149,14 @@ __device__ __forceinline__ void fmsub_rowbcast(double& acc, const double src, co
         asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
 }
 
+// the value of lane N of the caller's own 16-lane row, in every lane (v_mov_b64_dpp row_newbcast; the compiler takes care of the
+// wait states after a VALU write of the source)
+template <int N>
+__device__ __forceinline__ double row_bcast(const double v) {
+    static_assert(N >= 0 && N < 16, "row_newbcast lane");
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xF, 0xF, true);
+}
+
 // v_permlane32_swap (gfx950): swaps lanes 32..63 of its first operand with lanes 0..31 of the second.
 // dup_lo: every lane l >= 32 receives the value of lane l-32 (lanes < 32 keep theirs); take_hi: every lane l < 32 receives
 // the value of lane l+32.
@@ -2003,6 +2011,49 @@ __device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restric
 // its cost is paid only when needed.
 constexpr double LU_GROWTH_MAX = 8.0;
 constexpr int LU_BATCH = 8;
+// The positive-pivot half of the guard: every pivot must be positive, finite and non-zero.  It is tested on the reciprocals, which
+// the solves compute anyway, with ONE integer instruction per pivot: as unsigned integers the high words of doubles order as
+// positive finite < +inf, NaN (0x7ff00000 ...) < negative (0x80000000 ...), so the running unsigned maximum of the high words
+// stays below 0x7ff00000 exactly when every reciprocal is positive and finite (a zero or denormal pivot gives inf / NaN).
+// (fmin on the pivots cost two instructions each: the compiler canonicalises the scalar operand of v_min_f64 first.)
+#ifndef RMX_PIVGUARD_INT
+#define RMX_PIVGUARD_INT 1
+#endif
+// The growth half of the guard, l'^2 = l^2 u_kk / d_i <= LU_GROWTH_MAX^2 with l^2 u_kk = a_ik l: the running maximum of the products
+// a_ik l is kept on their HIGH WORDS as signed integers (for non-negative doubles integer order is numeric order; a negative product
+// or -0 - a row that is not being eliminated has l = 0 - compares low and is ignored: negative products need a negative pivot, which
+// PivGuard reports; a NaN with a clear sign bit compares high and trips the guard, where v_max_f64 would drop it).  One integer
+// instruction per update: fmax cost two once the accumulators are pinned (an empty asm makes the compiler canonicalise its output
+// before the next v_max_f64), and a threshold that is a heuristic anyway loses nothing to the 2^-20 granularity of the high word.
+struct GrowGuard {
+    int hi = 0;
+    __device__ __forceinline__ void see(const double prod) {
+        const int h = __double2hiint(prod);
+        hi = h > hi ? h : hi;
+    }
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(hi)); }
+    __device__ __forceinline__ bool bad(const double lim) const { return hi > __double2hiint(lim); }      // lim = 64 d_i > 0
+};
+struct PivGuard {
+#if RMX_PIVGUARD_INT
+    unsigned hi = 0u;
+    __device__ __forceinline__ void see(const double piv, const double rinv) {
+        (void)piv;
+        const unsigned h = (unsigned)__double2hiint(rinv);
+        hi = h > hi ? h : hi;
+    }
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(hi)); }
+    __device__ __forceinline__ bool ok() const { return hi < 0x7ff00000u; }
+#else
+    double pmin = 1.0;
+    __device__ __forceinline__ void see(const double piv, const double rinv) {
+        (void)rinv;
+        pmin = fmin(pmin, piv);
+    }
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(pmin)); }
+    __device__ __forceinline__ bool ok() const { return pmin > 0.0; }
+#endif
+};
 __device__ __forceinline__ void lu_pin(double (&pv)[LU_BATCH]) {
     asm volatile("" : "+s"(pv[0]), "+s"(pv[1]), "+s"(pv[2]), "+s"(pv[3]), "+s"(pv[4]), "+s"(pv[5]), "+s"(pv[6]), "+s"(pv[7]));
 }
@@ -2010,15 +2061,15 @@ __device__ __forceinline__ void lu_pin(double (&pv)[LU_BATCH]) {
 // eliminated sits in the pivot row's own 16-lane DPP row, so the pivot-row broadcast rides on the FMA (fmsub_rowbcast).  Rows
 // in the other DPP rows are finished (l == 0: they add 0 x a finite entry of one of their own finished rows) or idle mirrors.
 template <int NP, int K, int NR>
-__device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, double& gmax, double& pmin, double& piv, double& rinv,
+__device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, GrowGuard& gmax, PivGuard& pg, double& piv, double& rinv,
                                              double (&rinvs)[NR], double& rinv_own, const int lv) {
     if constexpr (K < NP) {
         constexpr int N = K - (NP - 16);
         if constexpr (NR == NP) rinvs[K] = rinv;
         else rinv_own = (lv == K) ? rinv : rinv_own;
         const double l = (lv > K) ? Hrow[K] * rinv : 0.0;
-        gmax = fmax(gmax, Hrow[K] * l);
-        pmin = fmin(pmin, piv);
+        gmax.see(Hrow[K] * l);
+        pg.see(piv, rinv);
         constexpr bool LAST = K + 2 >= NP;      // too few instructions left in a step to separate dependent broadcasts
         if constexpr (K + 1 < NP) {
             fmsub_rowbcast<N, LAST>(Hrow[K + 1], Hrow[K + 1], l);
@@ -2028,7 +2079,7 @@ __device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, doub
 #pragma unroll
         for (int c = K + 2; c < NP; ++c) fmsub_rowbcast<N>(Hrow[c], Hrow[c], l);
         fmsub_rowbcast<N, LAST>(b, b, l);
-        lu_diag_tail<NP, K + 1, NR>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
+        lu_diag_tail<NP, K + 1, NR>(Hrow, b, gmax, pg, piv, rinv, rinvs, rinv_own, lv);
     }
 }
 
@@ -2039,7 +2090,8 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     // guard state: the largest scaled multiplier seen by this lane and the smallest pivot (wave-uniform), compared once at the
     // end (v_max / v_min per step instead of two compares and two mask updates; a NaN passes through v_max but shows up in dx,
     // which the caller checks)
-    double gmax = 0.0, pmin = 1.0;
+    GrowGuard gmax;
+    PivGuard pg;
     // The lane comparisons below (lane > k, lane == k, lane < k for 32..64 values of k) are invariant across Newton iterations;
     // hoisted out of the loops they would be ~100 64-bit masks held in SGPRs, spilled to VGPR lanes and fetched back with
     // v_readlane inside the elimination, and the starved allocator would serialise the pivot-row broadcasts.  An opaque copy
@@ -2062,8 +2114,8 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         if constexpr (KEEP_ALL) rinvs[k] = rinv;
         else rinv_own = (lv == k) ? rinv : rinv_own;
         const double l = (lv > k) ? Hrow[k] * rinv : 0.0;
-        gmax = fmax(gmax, Hrow[k] * l);          // l^2 u_kk = a_ik l
-        pmin = fmin(pmin, piv);
+        gmax.see(Hrow[k] * l);                   // l^2 u_kk = a_ik l
+        pg.see(piv, rinv);
         if (k + 1 < NP) {
             Hrow[k + 1] -= l * readlane_d(Hrow[k + 1], k);
             piv = readlane_d(Hrow[k + 1], k + 1);
@@ -2096,7 +2148,7 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         }
         b -= l * readlane_d(b, k);
     }
-    if constexpr (KTAIL < NP) lu_diag_tail<NP, KTAIL>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
+    if constexpr (KTAIL < NP) lu_diag_tail<NP, KTAIL>(Hrow, b, gmax, pg, piv, rinv, rinvs, rinv_own, lv);
     double dx = 0.0;
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
@@ -2107,7 +2159,7 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
         if (lv < k) b -= Hrow[k] * xk;
     }
     // lanes beyond the padded size may carry mirrored rows (eval_hess ZERO_IDLE = false): their guard is ignored
-    ok = !__any(lane < NP && !(gmax <= lim)) && (pmin > 0.0);
+    ok = !__any(lane < NP && gmax.bad(lim)) && pg.ok();
     return dx;
 }
 
@@ -2122,21 +2174,25 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
 // per matrix entry: the results are bit-identical to lu_solve_neg_diag.
 template <int K>
 __device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], double (&B)[16], double (&BX)[4], double& bA,
-                                            double& bB, double& gmaxA, double& gmaxB, double& pmin, double& piv, double& rinv,
+                                            double& bB, GrowGuard& gmaxA, GrowGuard& gmaxB, PivGuard& pg, double& piv, double& rinv,
                                             double (&rinvs)[32], const int jv) {
     if constexpr (K < 16) {
         rinvs[K] = rinv;
         const double lA = (jv > K) ? A[K] * rinv : 0.0;
         const double lB = B[K] * rinv;
-        gmaxA = fmax(gmaxA, A[K] * lA);
-        gmaxB = fmax(gmaxB, B[K] * lB);
-        pmin = fmin(pmin, piv);
+        gmaxA.see(A[K] * lA);
+        gmaxB.see(B[K] * lB);
+        pg.see(piv, rinv);
         // pinned where they are computed: left alone, a third of these guard updates sink out of the elimination with their
         // operands parked in AGPRs (400 v_accvgpr moves in the kernel): 4.67 -> 4.47 ms per 100 steps of the 32-chain
-        asm volatile("" : "+v"(gmaxA), "+v"(gmaxB), "+v"(pmin));
+        gmaxA.pin();
+        gmaxB.pin();
+        pg.pin();
         if constexpr (K + 1 < 16) {
+            // the pivot columns are replicated in the four DPP rows: the next pivot is lane K + 1 of the lane's own row, one
+            // v_mov_b64_dpp instead of two v_readlane plus the wait states of the scalar round trip (the reciprocal's operand)
             fmsub_rowbcast<K>(A[K + 1], A[K + 1], lA);
-            piv = readlane_d(A[K + 1], K + 1);
+            piv = row_bcast<K + 1>(A[K + 1]);
             rinv = recip(piv);
         } else {                       // pivot 16 is row 16 (set B of lane 0), column 16 (first extra column of DPP row 0)
             fmsub_rowbcast<K>(BX[0], AX[0], lB);
@@ -2154,7 +2210,7 @@ __device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], do
         }
         fmsub_rowbcast<K>(bB, bA, lB);
         fmsub_rowbcast<K>(bA, bA, lA);
-        lu32_phase1<K + 1>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pmin, piv, rinv, rinvs, jv);
+        lu32_phase1<K + 1>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pg, piv, rinv, rinvs, jv);
     }
 }
 
@@ -2191,11 +2247,12 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
     const double limA = (LU_GROWTH_MAX * LU_GROWTH_MAX) * rowA[j], limB = (LU_GROWTH_MAX * LU_GROWTH_MAX) * rowB[16 + j];
     int jv = j, lv = lane;                               // opaque copies: see lu_solve_neg_diag
     asm volatile("" : "+v"(jv), "+v"(lv));
-    double gmaxA = 0.0, gmaxB = 0.0, pmin = 1.0;
+    GrowGuard gmaxA, gmaxB;
+    PivGuard pg;
     double rinvs[NP];
-    double piv = readlane_d(A[0], 0);
+    double piv = row_bcast<0>(A[0]);
     double rinv = recip(piv);
-    lu32_phase1<0>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pmin, piv, rinv, rinvs, jv);
+    lu32_phase1<0>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pg, piv, rinv, rinvs, jv);
     // the column quarters 16 + 4 r .. of both row sets go back to their rows; lane = row reads columns 16..31
     RMX_SYNC();
     {
@@ -2221,10 +2278,11 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
     }
     const bool rowsA = (lane & 16) == 0;                 // lanes 0..15 (and their idle mirrors 32..47) carry set A
     double b = rowsA ? bA : bB;
-    double gmax = rowsA ? gmaxA : gmaxB;
+    GrowGuard gmax;
+    gmax.hi = rowsA ? gmaxA.hi : gmaxB.hi;
     const double lim = rowsA ? limA : limB;
     double rinv_own = 0.0;
-    lu_diag_tail<NP, 16>(Hrow, b, gmax, pmin, piv, rinv, rinvs, rinv_own, lv);
+    lu_diag_tail<NP, 16>(Hrow, b, gmax, pg, piv, rinv, rinvs, rinv_own, lv);
     double dx = 0.0;
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
@@ -2232,7 +2290,7 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
         if (lv == k) dx = xk;
         if (lv < k) b -= Hrow[k] * xk;
     }
-    ok = !__any(lane < NP && !(gmax <= lim)) && (pmin > 0.0);
+    ok = !__any(lane < NP && gmax.bad(lim)) && pg.ok();
     RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
     if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
     RMX_SYNC();
@@ -2249,7 +2307,7 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
 // substitution runs in the same layout, block by block (the value x_k rides on the DPP broadcast).  Every matrix entry sees the
 // same operations on the same values in the same order as in lu_solve_neg_diag<64>: the results are bit-identical.
 template <int P, int K, bool PINMIN>
-__device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], double (&gm)[4], double (&rown)[4], double& pmin,
+__device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], GrowGuard (&gm)[4], double (&rown)[4], PivGuard& pg,
                                             double& piv, double& rinv, const int jv) {
     if constexpr (K < 16) {
         rown[P] = (jv == K) ? rinv : rown[P];
@@ -2259,17 +2317,17 @@ __device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], 
         for (int s = P + 1; s < 4; ++s) l[s] = S[s][K] * rinv;
 #pragma unroll
         for (int s = P; s < 4; ++s) {
-            gm[s] = fmax(gm[s], S[s][K] * l[s]);
+            gm[s].see(S[s][K] * l[s]);
             // pinned here: left alone, the compiler sinks all 230 guard updates of a solve to its end and keeps their operands
             // alive (in scratch) until then
-            asm volatile("" : "+v"(gm[s]));
+            gm[s].pin();
         }
-        pmin = fmin(pmin, piv);
-        // (same reason: 64 v_min and their pivots parked in SGPR spills until the end)
-        if constexpr (PINMIN) asm volatile("" : "+v"(pmin));
+        pg.see(piv, rinv);
+        // (same reason: 64 guard updates and their pivots parked in SGPR spills until the end)
+        if constexpr (PINMIN) pg.pin();
         if constexpr (K + 1 < 16) {
             fmsub_rowbcast<K>(S[P][K + 1], S[P][K + 1], l[P]);
-            piv = readlane_d(S[P][K + 1], K + 1);
+            piv = row_bcast<K + 1>(S[P][K + 1]);       // replicated pivot columns: see lu32_phase1
             rinv = recip(piv);
         }
         // the multipliers stay where the column was (rows at or above the pivot keep their U entries)
@@ -2288,7 +2346,7 @@ __device__ __forceinline__ void lu64_pass_a(double (&S)[4][16], double (&b)[4], 
 #pragma unroll
         for (int s = P + 1; s < 4; ++s) fmsub_rowbcast<K>(b[s], b[P], l[s]);
         fmsub_rowbcast<K>(b[P], b[P], l[P]);
-        lu64_pass_a<P, K + 1, PINMIN>(S, b, gm, rown, pmin, piv, rinv, jv);
+        lu64_pass_a<P, K + 1, PINMIN>(S, b, gm, rown, pg, piv, rinv, jv);
     }
 }
 template <int P, int K, int CW>
@@ -2306,8 +2364,8 @@ __device__ __forceinline__ void lu64_pass_b(const double (&S)[4][16], double (&X
 }
 // One phase of 16 pivots.
 template <int P>
-__device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&b)[4], double (&gm)[4], double (&rown)[4],
-                                           double& pmin, const int jv) {
+__device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&b)[4], GrowGuard (&gm)[4], double (&rown)[4],
+                                           PivGuard& pg, const int jv) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     constexpr int CW = 4;                      // columns of a later block per DPP row
     const int r4 = lane >> 4, j = lane & 15;
@@ -2322,9 +2380,9 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
             S[s][2 * c + 1] = t[1];
         }
     }
-    double piv = readlane_d(S[P][0], 0);
+    double piv = row_bcast<0>(S[P][0]);
     double rinv = recip(piv);
-    lu64_pass_a<P, 0, true>(S, b, gm, rown, pmin, piv, rinv, jv);
+    lu64_pass_a<P, 0, true>(S, b, gm, rown, pg, piv, rinv, jv);
 #pragma unroll
     for (int B = P + 1; B < 4; ++B) {
         __builtin_amdgcn_sched_barrier(0);      // one block in registers at a time (hoisted loads of all blocks spill)
@@ -2384,17 +2442,19 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     const int r4 = lane >> 4, j = lane & 15;
     int jv = j;                                          // opaque copy: see lu_solve_neg_diag
     asm volatile("" : "+v"(jv));
-    double b[4], lim[4], gm[4] = {0.0, 0.0, 0.0, 0.0}, rown[4] = {0.0, 0.0, 0.0, 0.0}, pmin = 1.0;
+    double b[4], lim[4], rown[4] = {0.0, 0.0, 0.0, 0.0};
+    GrowGuard gm[4];
+    PivGuard pg;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const double* row = sH + (16 * s + j) * H64_STRIDE;
         b[s] = row[64];
         lim[s] = (LU_GROWTH_MAX * LU_GROWTH_MAX) * row[16 * s + j];
     }
-    lu64_phase<0>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<1>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<2>(sH, lane, b, gm, rown, pmin, jv);
-    lu64_phase<3>(sH, lane, b, gm, rown, pmin, jv);
+    lu64_phase<0>(sH, lane, b, gm, rown, pg, jv);
+    lu64_phase<1>(sH, lane, b, gm, rown, pg, jv);
+    lu64_phase<2>(sH, lane, b, gm, rown, pg, jv);
+    lu64_phase<3>(sH, lane, b, gm, rown, pg, jv);
     RMX_SYNC();                 // (the finished rows of phase 3)
     // back substitution, block column by block column from the right
     double x[4];
@@ -2428,8 +2488,8 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     }
     bool bad = false;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bad = bad || !(gm[s] <= lim[s]);
-    ok = !__any(bad) && (pmin > 0.0);
+    for (int s = 0; s < 4; ++s) bad = bad || gm[s].bad(lim[s]);
+    ok = !__any(bad) && pg.ok();
     const double dx = r4 == 0 ? x[0] : (r4 == 1 ? x[1] : (r4 == 2 ? x[2] : x[3]));
     RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
     if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;

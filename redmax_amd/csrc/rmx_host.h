@@ -86,7 +86,8 @@ struct rmx_batch {
     void RMX_CAT(launch_mfd_, NPV)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD); \
     void RMX_CAT(launch_eval_ct_, NPV)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH); \
     void RMX_CAT(launch_step_ct_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a); \
-    void RMX_CAT(launch_energy_ct_, NPV)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV);
+    void RMX_CAT(launch_energy_ct_, NPV)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV); \
+    void RMX_CAT(launch_step_fullchain_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 RMX_DECLARE_LAUNCHERS(4)
 RMX_DECLARE_LAUNCHERS(8)
 RMX_DECLARE_LAUNCHERS(16)

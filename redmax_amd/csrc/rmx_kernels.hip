@@ -53,9 +53,23 @@ __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, dou
 // kernel the contact terms' registers (72 accumulators for the K/D blocks on top of the Hessian stage's state) put the whole
 // Newton loop into scratch - 34 us per iteration in free flight against 12 us for the plain kernel (tools/ct_overhead.py) -
 // and an out-of-line call of the contact solve tripled ITS cost (the model constants arrive as a pointer into scratch).
-template <int NP, bool CT, bool LEAN = false>
-__global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpts o, const StepArgs a) {
+// FULLCHAIN: an instantiation for serial chains that fill every node slot (is_chain && n == NP, decided by the launcher): the two
+// model facts are compile-time constants there, so the tree paths (pointer jumping, relation masks, subtree ranges) and the
+// per-row bounds of partly filled sizes are not even compiled in - fewer live masks, a smaller loop body.
+template <int NP, bool FULLCHAIN>
+__device__ __forceinline__ DevModel model_view(const DevModel& Min) {
+    DevModel M = Min;
+    if constexpr (FULLCHAIN) {
+        M.n = NP;
+        M.is_chain = 1;
+    }
+    return M;
+}
+
+template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false>
+__global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
+    const DevModel M = model_view<NP, FULLCHAIN>(Min);
     const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
     if (s0 >= a.nsteps) return;                    // the lean launch took this trajectory all the way
     double *sAcc, *sCol;
@@ -117,9 +131,10 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel M, const DevOpt
 }
 
 // simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.  CT / LEAN: see k_step_bdf1.
-template <int NP, bool CT, bool LEAN = false>
-__global__ void __launch_bounds__(64) k_step_bdf2(const DevModel M, const DevOpts o, const StepArgs a) {
+template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false>
+__global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
+    const DevModel M = model_view<NP, FULLCHAIN>(Min);
     const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
     if (s0 >= a.nsteps) return;
     double *sAcc, *sCol;
@@ -595,7 +610,8 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
 // ============================================================================ launchers (declared in rmx_host.h)
 //
 // RMX_PART 0: the plain kernels (every scene without ForceGroundCuboid / JointSpherical) plus Euler, adjoint, phase timing.
-// RMX_PART 1: the extended (CT) instantiations of eval / step / energy.  Two objects per size, so the builds run in parallel.
+// RMX_PART 1: the extended (CT) instantiations of eval / step / energy.
+// RMX_PART 2: the FULLCHAIN instantiations of the plain step kernels.  One object per part and size, so the builds run in parallel.
 #ifndef RMX_PART
 #define RMX_PART 0
 #endif
@@ -610,7 +626,15 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
         kernel<<<grid, block, bytes, stream>>>(__VA_ARGS__);                                                                        \
     } while (0)
 
-#if RMX_PART == 1
+#if RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
+
+void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+}
+
+#elif RMX_PART == 1
 
 void RMX_CAT(launch_eval_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
     const dim3 grid(b->B), block(64);
@@ -645,6 +669,9 @@ void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool 
 void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
     if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_step_ct_, RMX_NP)(m, b, integ, o, a);
+#if RMX_NP >= 16 && !defined(RMX_NO_FULLCHAIN)      // (the macro: development aid, tools/build_variant.py)
+    if (m->dm.is_chain && m->dm.n == RMX_NP) return RMX_CAT(launch_step_fullchain_, RMX_NP)(m, b, integ, o, a);
+#endif
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }

@@ -1,7 +1,7 @@
 """Behaviour of the BDF1 rollout of BASELINE.json configs[1] at the reference's own Newton constant (tol = 1e-9,
 driverRedMaxBDF1.m:95), per step, on every implementation available:
 
-    python tools/reference_tol_stats.py [--rollouts 64] [--steps 100] [--no-gpu] [--no-literal] [--json out.json]
+    python tests/reference_tol.py [--rollouts 64] [--steps 100] [--no-gpu] [--no-literal] [--json out.json]
 
 gpu / gpu_plain                  the HIP library through the C ABI, one step per call: rmx_opts.compensated = 1 (default) / 0
 tensor_free / tensor_free_plain  oracle/redmax_tensorfree.c (the algorithm the GPU executes, scalar C), the same two modes
@@ -9,7 +9,8 @@ literal                          oracle/redmax_oracle.c (the literal restatement
 
 Per implementation: Newton iterations and line-search halvings per trajectory-step, fraction of trajectory-steps whose Newton ended
 "did not converge" / "diverged", and the same split over the first / second half of the rollout (the roundoff floor of |g| is
-reached later in the rollout).  tests/test_gpu_reference_tol.py asserts the bands; this script prints the numbers behind them."""
+reached later in the rollout).  tests/test_gpu_reference_tol.py and tests/test_oracle_tensorfree.py assert the bands; run as a script
+this prints the numbers behind them."""
 import argparse
 import json
 import os

@@ -1,7 +1,7 @@
 """bench.py's own rank code (shard plans, input generation from global indices, the timed region with its barriers, the final
 gather, max-over-ranks timing, JSON assembly) driven at world_size 2 on CPU: torch.distributed backend gloo, and an
 oracle-backed stepper standing in for the HIP one (same methods as bench.GpuStepper; there is no GPU here).  Covers the weak
-line, the strong-scaling line with UNEVEN shards (3 rollouts over 2 ranks: the padded gather), and the reference-tol line."""
+line, the strong-scaling line with UNEVEN shards (3 rollouts over 2 ranks: the padded gather), and the side measurements."""
 import json
 import os
 import socket
@@ -26,8 +26,8 @@ class OracleStepper:
         self._acc = None
         self.stats_reset()
 
-    def set_opts(self, h, tol):
-        self.h, self.tol = h, tol
+    def set_opts(self, h, tol, compensated=1):
+        self.h, self.tol = h, tol           # (the literal oracle has plain doubles only)
 
     def set_state(self, q, qd):
         self.q, self.qd = np.ascontiguousarray(q, dtype=np.float64).copy(), np.ascontiguousarray(qd, dtype=np.float64).copy()
@@ -84,7 +84,7 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import bench
-    args = bench.parse_args(["--gpus", str(world), "--links", "4", "--batch", "3", "--steps", "3", "--warmup", "1", "--repeats", "1",
+    args = bench.parse_args(["--gpus", str(world), "--links", "4", "--batch", "3", "--steps", "3", "--warmup", "1", "--repeats", "1", "--ref-steps", "4",
                              "--json-out", out])
     assert bench.rank_main(args, make_stepper=OracleStepper, backend="gloo") == 0
 
@@ -101,9 +101,11 @@ def test_bench_rank_code_world_size_2(tmp_path):
     assert d["repeat"]["launches"] == 2
     s = d["strong_scaling"]
     assert s["global_batch"] == 3 and s["value"] > 0                                   # 2 + 1 rollouts: uneven shards
-    r = d["value_at_reference_tol"]
-    assert r["newton_tol"] == 1e-9 and r["value"] > 0 and r["all_finite"]
-    assert d["value_at_survey_init"]["value"] > 0
+    assert d["config"]["newton_tol"] == 1e-9 == d["config"]["reference_newton_tol"]      # the headline runs the reference's constant
+    r = d["value_plain_iterate"]
+    assert r["newton_tol"] == 1e-9 and r["steps"] == 4 and r["value"] > 0 and r["all_finite"]
+    assert d["value_at_survey_init"]["value"] > 0 and d["value_at_survey_init"]["steps"] == 4
+    assert d["value_at_tol_1e-8"]["steps"] == 3
     assert d["roofline"] is None and "cpu_baseline" not in d                            # GPU-only objects
 
 

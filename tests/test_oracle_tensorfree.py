@@ -56,3 +56,45 @@ def test_rollout_matches_the_literal_oracle(name, nsteps):
     if name != "chain32":          # on the 320 cm chain |g| < 1e-9 is decided by roundoff: counts may differ
         assert np.array_equal(ca["newton_iters"], cb["newton_iters"])
         assert (cb["status"] == 0).all() and (ca["bad"] == 0).all()
+
+
+def test_compensated_iterate_converges_where_plain_doubles_stick():
+    """The 32-link chain at the reference's tol = 1e-9 over the reference's 100 steps (CPU side of tests/test_gpu_reference_tol.py):
+    on plain doubles the world-frame evaluation sticks on the lattice of doubles on a sizeable fraction of the trajectory-steps (the
+    literal oracle escapes through its own evaluation noise); with the compensated iterate x + xlo - the mode
+    the HIP kernels run by default - every step converges in no more iterations than the literal oracle needs, to the same state."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from reference_tol import run_stats
+    r = run_stats(8, 100, tol=1e-9, gpu=False, first=1)
+    tf, tfp, lit = r["tensor_free"], r["tensor_free_plain"], r["literal"]
+    assert tf["bad_frac"] == 0.0 and tf["halvings_per_step"] <= 0.01
+    assert tfp["bad_frac"] >= 0.03 and tfp["bad_frac_second_half"] >= 5 * tfp["bad_frac_first_half"]
+    assert lit["bad_frac"] <= 0.02
+    assert tf["iters_per_step"] <= lit["iters_per_step"] + 0.05
+    for a in (tf, tfp):
+        e = np.linalg.norm(a["q"] - lit["q"], axis=1) / np.linalg.norm(lit["q"], axis=1)
+        assert e.max() <= 1e-10, e.max()
+
+
+def test_compensated_low_part_enters_v_and_qdot_only():
+    """otf_eval_lo: the low-order part of the iterate shifts v = x - qB and qdot = (x - qA)/eta and nothing else, i.e.
+    g(x, lo) = g(x) + (M - eta D) lo to first order, with M - eta D read off two evaluations of H."""
+    sc = _scene("chain32")
+    sc.init()
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-0.3, 0.3, sc.nr)
+    qA = q - 1e-2 * rng.uniform(-0.1, 0.1, sc.nr)
+    qB = qA + 1e-4 * rng.uniform(-0.1, 0.1, sc.nr)
+    eta = 1e-2
+    lo = 0.5 * np.spacing(q) * rng.uniform(-1, 1, sc.nr)
+    g0 = orc.tensorfree_eval(sc.desc(), q, qA, qB, eta, want_H=False)
+    g1 = orc.tensorfree_eval_lo(sc.desc(), q, lo, qA, qB, eta, want_H=False)
+    # the same shift applied to qA, qB in exact arithmetic: v and qdot see q + lo, the geometry sees q.  Scale the test up so that
+    # the shift is representable: lo -> 2^30 lo, compare with shifted qA, qB
+    big = lo * 2.0 ** 30
+    gA = orc.tensorfree_eval_lo(sc.desc(), q, big, qA, qB, eta, want_H=False)
+    gB = orc.tensorfree_eval(sc.desc(), q, qA - big, qB - big, eta, want_H=False)
+    assert np.linalg.norm(gA - gB) <= 1e-9 * np.linalg.norm(gA - g0)
+    assert 0 < np.linalg.norm(g1 - g0) < 1e-7           # a sub-ulp shift of x moves g by ~|M| ulp(x): the lattice spacing of g

@@ -18,10 +18,10 @@ if has bench; then
   head -c 600 $OUT/bench.json; echo
 fi
 if has bench2; then
-  timeout 900 python bench.py --gpus 2 --no-reference-tol > $OUT/bench_gpus2.json 2> $OUT/bench_gpus2.err; echo "bench --gpus 2 rc=$?"
+  timeout 900 python bench.py --gpus 2 --no-side-legs > $OUT/bench_gpus2.json 2> $OUT/bench_gpus2.err; echo "bench --gpus 2 rc=$?"
   tail -3 $OUT/bench_gpus2.err
 fi
-BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-reference-tol --repeats 0"
+BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-side-legs --repeats 0"
 if has prof; then
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- $BENCH > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
@@ -39,7 +39,7 @@ if has pmc; then
   EXTRA="--tol 1e-3"       # another iterations-per-step mix for the two-parameter calibration
   P f64_tol3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES
   EXTRA=""
-  BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-tol --repeats 0"
+  BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-legs --repeats 0"
   P fetch_k20 FETCH_SIZE
   P write_k20 WRITE_SIZE
   cd $ROOT

@@ -12,7 +12,7 @@ sc = sceneChain(32)
 sc.init()
 q, qd = syntheticStates(32, 1024)
 sim = BatchSim(sc, batch=1024)
-sim.opts.tol = 1e-8
+sim.opts.tol = float(os.environ.get("RMX_TOL", "1e-9"))
 ms = []
 for r in range(R):
     sim.set_state(q, qd)
