@@ -243,6 +243,16 @@ typedef struct rmx_task_pointpos {
 int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
                      double* P, double* dPdp, rmx_stats* stats);
 
+/* The same for driverRedMaxAdjointBDF2.m:38-62 with TaskBDF2 / TaskBDF2PointPos (matlab-diff/+redmax/TaskBDF2.m, TaskBDF2PointPos.m;
+ * scene 101, scenesRedMax.m:437-471): the forward simLoop (:65-136) takes the SDIRK2a / SDIRK2b start step and BDF2 steps with the
+ * line-search-free newton (:139-181), the backward sweep is TaskBDF2.calcFinal (TaskBDF2.m:45-107: four off-diagonal blocks per
+ * step, the k == 1 variants with the SDIRK2 coefficients).  As in the reference dg/dp = -(4/9) h^2 pscale I is used for every step
+ * and dg/dqa of the start step is dropped (TaskBDF2PointPos.m:97-106, TaskBDF2.m:52-55), so dPdp carries the reference's own
+ * O(1/nsteps) start-step error.  Arguments as rmx_adjoint_bdf1.  The batch is left at the end of the forward rollout with the
+ * BDF2 history in place (rmx_step_bdf2 may continue it). */
+int rmx_adjoint_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
+                     double* P, double* dPdp, rmx_stats* stats);
+
 /* euler() of matlab-simple/testRedMax.m:67-109 (BASELINE.json configs[0]): nsteps linearly-implicit Euler steps,
  *   Mr = J'MmJ ; (Mr + h Dr - h^2 Kr) qdot1 = Mr qdot0 + h (J'(fm - Mm Jdot qdot0) + fr) ; q1 = q0 + h qdot1.
  * hist_T/hist_V as in rmx_step_bdf1. */

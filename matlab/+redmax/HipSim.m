@@ -78,8 +78,12 @@ classdef HipSim < handle
 			redmax_hip_mex('setcharts', this.h, int32(c));
 		end
 
-		function [P, dPdp, stats] = adjoint(this, hstep, nsteps, task, p)
-			[P, dPdp, stats] = redmax_hip_mex('adjoint', this.h, hstep, nsteps, task, p);
+		function [P, dPdp, stats] = adjoint(this, hstep, nsteps, task, p, itype)
+			% taskObjective of driverRedMaxAdjointBDF1.m (itype 1, default) / driverRedMaxAdjointBDF2.m (itype 2)
+			if nargin < 6
+				itype = 1;
+			end
+			[P, dPdp, stats] = redmax_hip_mex('adjoint', this.h, hstep, nsteps, task, p, itype);
 		end
 	end
 end

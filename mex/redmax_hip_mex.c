@@ -34,7 +34,8 @@
  *   [T, V]       = redmax_hip_mex('energy', h)                           Joint/Body.computeEnergies
  *   c            = redmax_hip_mex('getcharts', h)                        nsph x B int32, JointSpherical.chart
  *                  redmax_hip_mex('setcharts', h, c)
- *   [P,dPdp,st]  = redmax_hip_mex('adjoint', h, hstep, nsteps, task, p)  taskObjective, driverRedMaxAdjointBDF1.m:39-62;
+ *   [P,dPdp,st]  = redmax_hip_mex('adjoint', h, hstep, nsteps, task, p [, integrator])  taskObjective of
+ *                  driverRedMaxAdjointBDF1.m:39-62 (integrator 1, default) or driverRedMaxAdjointBDF2.m:38-62 (integrator 2);
  *                  task: struct body (1-based listing index), xlocal, xtarget, step, pscale, wreg, wpos; p: nr x B;
  *                  st: B x 2 int32 [newton iterations, status]
  */
@@ -149,14 +150,12 @@ static void cmd_create(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[
             d.qRestR = f64(s, "qRestR", nr, 1);
         }
     }
-    const int slot = live_slot(NULL);
-    if (slot < 0) die("too many live handles (destroy some first)");
-    handle_t* h = (handle_t*)mxCalloc(1, sizeof *h);
-    mexMakeMemoryPersistent(h);
-    if (rmx_model_create(&d, device, &h->m)) { mxFree(h); die_rmx("rmx_model_create"); }
-    if (field(s, "contact", 0)) {   /* scene.forces holds ForceGroundCuboid objects (scenesRedMax.m:303-309) */
-        rmx_ground_contact gc;
-        memset(&gc, 0, sizeof gc);
+    /* every field of desc is read and validated BEFORE anything is created: a validation failure leaves through
+     * mexErrMsgIdAndTxt (a longjmp out of the MEX function), which must not strand a device model or a persistent handle */
+    const int has_contact = field(s, "contact", 0) != NULL;
+    rmx_ground_contact gc;
+    memset(&gc, 0, sizeof gc);
+    if (has_contact) {   /* scene.forces holds ForceGroundCuboid objects (scenesRedMax.m:303-309) */
         gc.flags = i32(s, "contact", n, 1);
         gc.sides = f64(s, "sides", 3 * n, 1);
         memcpy(gc.E, f64(s, "groundE", 16, 1), 16 * sizeof(double));
@@ -164,8 +163,13 @@ static void cmd_create(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[
         gc.kt = scalar_field(s, "kt", 0.0);
         gc.mu = scalar_field(s, "mu", 0.0);
         gc.kd = scalar_field(s, "kd", 0.0);
-        if (rmx_model_set_ground_contact(h->m, &gc)) { rmx_model_destroy(h->m); mxFree(h); die_rmx("rmx_model_set_ground_contact"); }
     }
+    const int slot = live_slot(NULL);
+    if (slot < 0) die("too many live handles (destroy some first)");
+    handle_t* h = (handle_t*)mxCalloc(1, sizeof *h);
+    mexMakeMemoryPersistent(h);
+    if (rmx_model_create(&d, device, &h->m)) { mxFree(h); die_rmx("rmx_model_create"); }
+    if (has_contact && rmx_model_set_ground_contact(h->m, &gc)) { rmx_model_destroy(h->m); mxFree(h); die_rmx("rmx_model_set_ground_contact"); }
     h->nr = rmx_model_nr(h->m);
     h->nm = rmx_model_nm(h->m);
     h->nsph = rmx_model_nsph(h->m);
@@ -289,7 +293,7 @@ static void cmd_eval(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
 
 static void cmd_adjoint(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     handle_t* h = get_handle(nrhs, prhs);
-    if (nrhs < 6) die("usage: [P,dPdp,stats] = redmax_hip_mex('adjoint', h, hstep, nsteps, task, p)");
+    if (nrhs < 6) die("usage: [P,dPdp,stats] = redmax_hip_mex('adjoint', h, hstep, nsteps, task, p [, integrator])");
     const mxArray* t = prhs[4];
     if (!mxIsStruct(t)) die("task must be a struct");
     rmx_task_pointpos task;
@@ -318,7 +322,11 @@ static void cmd_adjoint(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs
     stats.newton_iters = sp;
     stats.ls_halvings = NULL;
     stats.status = sp + h->B;
-    if (rmx_adjoint_bdf1(h->b, &o, nsteps, &task, p, mxGetPr(P), mxGetPr(dPdp), &stats)) die_rmx("rmx_adjoint_bdf1");
+    /* optional 7th argument: the integrator, 1 = BDF1 (driverRedMaxAdjointBDF1.m, default), 2 = BDF2 (driverRedMaxAdjointBDF2.m) */
+    const int integ = nrhs > 6 ? (int)mxGetScalar(prhs[6]) : 1;
+    if (integ != 1 && integ != 2) die("adjoint: the integrator must be 1 (BDF1) or 2 (BDF2)");
+    if ((integ == 1 ? rmx_adjoint_bdf1 : rmx_adjoint_bdf2)(h->b, &o, nsteps, &task, p, mxGetPr(P), mxGetPr(dPdp), &stats))
+        die_rmx(integ == 1 ? "rmx_adjoint_bdf1" : "rmx_adjoint_bdf2");
     plhs[0] = P;
     if (nlhs > 1) plhs[1] = dPdp;
     if (nlhs > 2) plhs[2] = st;

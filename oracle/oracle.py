@@ -95,6 +95,8 @@ def lib():
         L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
         L.orc_adjoint_bdf1.restype = C.c_double
+        L.orc_adjoint_bdf2.argtypes = L.orc_adjoint_bdf1.argtypes
+        L.orc_adjoint_bdf2.restype = C.c_double
         _lib = L
     return _lib
 
@@ -358,7 +360,11 @@ class Oracle:
         self._L.orc_step_bdf2(self._h, float(h), int(step0), int(nsteps), C.byref(st), None, None)
         return st
 
-    def adjoint_bdf1(self, h, nsteps, task, p):
+    def adjoint_bdf2(self, h, nsteps, task, p):
+        """taskObjective of driverRedMaxAdjointBDF2.m:38-62 (TaskBDF2PointPos, scene 101).  Returns (P, dPdp, stats)."""
+        return self.adjoint_bdf1(h, nsteps, task, p, _fn="orc_adjoint_bdf2")
+
+    def adjoint_bdf1(self, h, nsteps, task, p, _fn="orc_adjoint_bdf1"):
         """taskObjective (driverRedMaxAdjointBDF1.m:39-62). task: dict(body, xlocal, xtarget, t, pscale, wreg, wpos).
         Returns (P, dPdp, stats)."""
         tk = TaskPointPos()
@@ -370,7 +376,7 @@ class Oracle:
         p = np.ascontiguousarray(p, dtype=np.float64)
         dPdp = np.zeros(self.nr)
         st = Stats()
-        P = self._L.orc_adjoint_bdf1(self._h, float(h), int(nsteps), C.byref(tk), _p(p), _p(dPdp), C.byref(st))
+        P = getattr(self._L, _fn)(self._h, float(h), int(nsteps), C.byref(tk), _p(p), _p(dPdp), C.byref(st))
         return float(P), dPdp, st
 
     def step_euler_simple(self, h, nsteps):

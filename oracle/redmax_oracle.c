@@ -1415,6 +1415,153 @@ double orc_adjoint_bdf1(orc_scene* s, double h, int nsteps, const orc_task_point
     return P;
 }
 
+/* taskObjective (driverRedMaxAdjointBDF2.m:38-62) for TaskBDF2PointPos (scene 101, scenesRedMax.m:437-471): scene.reset(), the
+ * forward simLoop (:65-136: SDIRK2a + SDIRK2b on the first step, BDF2 afterwards) with the line-search-free newton (:139-181, x = x+dx
+ * BEFORE the |g| < tol test, iterMax = 5 nr), saveHistory of the factors of H and of M, D, J of the LAST evaluated iterate of the
+ * step's final solve (step 1: SDIRK2b), TaskBDF2PointPos.applyStep / calcStep (TaskBDF2PointPos.m:58-108) and the backward sweep
+ * TaskBDF2.calcFinal (TaskBDF2.m:45-107) with its four off-diagonal blocks.  Every solve is the common residual
+ *     qdot = (x - qA)/eta,  dqtmp = x - qB,  g = M dqtmp - eta^2 f,  H = M - eta D - eta^2 K + dMdq dqtmp
+ * (evalSDIRK2a :184-216, evalSDIRK2b :219-252, evalBDF2 :255-287).  As in the reference, dg/dp = -(4/9) h^2 pscale I is used for
+ * EVERY step (TaskBDF2PointPos.m:97-106), the SDIRK start step included, and dg/dqa is dropped (TaskBDF2.m:52-55).  p: nr
+ * parameters (reduced order).  Returns P, fills dPdp (nr). */
+double orc_adjoint_bdf2(orc_scene* s, double h, int nsteps, const orc_task_pointpos* task, const double* p, double* dPdp, orc_stats* st) {
+    const int nr = s->nr, nm = s->nm;
+    const size_t n2 = (size_t)nr * nr;
+    double* LUh = (double*)calloc(n2 * (size_t)nsteps + 1, sizeof(double));
+    double* Mh = (double*)calloc(n2 * (size_t)nsteps + 1, sizeof(double));
+    double* Dh = (double*)calloc(n2 * (size_t)nsteps + 1, sizeof(double));
+    int* Ph = (int*)calloc((size_t)nr * nsteps + 1, sizeof(int));
+    double* dPdq = (double*)calloc((size_t)nr * nsteps + 1, sizeof(double));
+    const size_t sz = (size_t)nr + 1;
+    double *q0 = calloc(sz, 8), *qd0 = calloc(sz, 8), *q1 = calloc(sz, 8), *qd1 = calloc(sz, 8), *qa = calloc(sz, 8), *qda = calloc(sz, 8);
+    double *x = calloc(sz, 8), *qA = calloc(sz, 8), *qB = calloc(sz, 8), *xd = calloc(sz, 8), *g = calloc(sz, 8), *dx = calloc(sz, 8);
+    double *H = calloc(n2 + 1, 8), *M = calloc(n2 + 1, 8), *f = calloc(sz, 8), *K = calloc(n2 + 1, 8), *D = calloc(n2 + 1, 8);
+    double *dMdq = calloc(n2 * nr + 1, 8), *Jk = calloc((size_t)nm * nr + 1, 8), *LUs = calloc(n2 + 1, 8);
+    int* Ps = (int*)calloc(sz, sizeof(int));
+    const double tol = 1e-9, dxMax = 1e3;           /* :140-141 */
+    const int iterMax = 5 * nr;                      /* :142 */
+    const double al = (2.0 - sqrt(2.0)) / 2.0;
+    if (st) memset(st, 0, sizeof(*st));
+    orc_reset(s);
+    double P = 0.0, t = 0.0;
+    for (int k = 1; k <= nsteps; k++) {
+        for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) s->nd[i].tau = task->pscale * p[s->nd[i].idxR];      /* applyStep */
+        double* LUk = LUh + n2 * (size_t)(k - 1); int* Pk = Ph + (size_t)nr * (k - 1);
+        const int nsolve = k == 1 ? 2 : 1;
+        for (int sv = 0; sv < nsolve; sv++) {
+            double eta;
+            if (k == 1 && sv == 0) {            /* SDIRK2a :78-84 */
+                orc_get_state(s, q0, qd0);
+                eta = al * h;
+                for (int i = 0; i < nr; i++) { x[i] = q0[i] + al * h * qd0[i]; qA[i] = q0[i]; qB[i] = q0[i] + (al * h) * qd0[i]; }
+            } else if (k == 1) {                /* SDIRK2b :89-92 */
+                eta = al * h;
+                for (int i = 0; i < nr; i++) {
+                    x[i] = qa[i] + (1 - al) * h * qda[i];
+                    qA[i] = q0[i] + (1 - al) * h * qda[i];
+                    qB[i] = q0[i] + (2 * al - 1) * h * qd0[i] + 2 * (1 - al) * h * qda[i];
+                }
+            } else {                            /* BDF2 :103-113 */
+                for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) { q0[s->nd[i].idxR] = s->nd[i].q1; qd0[s->nd[i].idxR] = s->nd[i].qdot1; }
+                orc_get_state(s, q1, qd1);
+                for (int i = 0; i < s->n; i++) { s->nd[i].q1 = s->nd[i].q; s->nd[i].qdot1 = s->nd[i].qdot; }
+                eta = (2.0 / 3.0) * h;
+                for (int i = 0; i < nr; i++) {
+                    x[i] = q1[i] + h * qd1[i];
+                    qA[i] = (4.0 / 3.0) * q1[i] - (1.0 / 3.0) * q0[i];
+                    qB[i] = (4.0 / 3.0) * q1[i] - (1.0 / 3.0) * q0[i] + (8.0 / 9.0) * h * qd1[i] - (2.0 / 9.0) * h * qd0[i];
+                }
+            }
+            const int keep = !(k == 1 && sv == 0);      /* the SDIRK2a solve leaves nothing in the history */
+            double* LUx = keep ? LUk : LUs; int* Px = keep ? Pk : Ps;
+            int iter = 1;
+            while (1) {
+                for (int i = 0; i < nr; i++) xd[i] = (x[i] - qA[i]) / eta;
+                set_q(s, x, xd); scene_update(s);
+                orc_compute_values(s, M, f, dMdq, K, D);
+                memcpy(Jk, s->J, sizeof(double) * (size_t)nm * nr);
+                for (int a = 0; a < nr; a++) { double tt = 0; for (int b = 0; b < nr; b++) tt += M[(size_t)b * nr + a] * (x[b] - qB[b]); g[a] = tt - eta * eta * f[a]; }
+                for (size_t i = 0; i < n2; i++) H[i] = M[i] - eta * D[i] - eta * eta * K[i];
+                for (int i = 0; i < nr; i++) {
+                    const double* Di = dMdq + (size_t)i * n2;
+                    for (int a = 0; a < nr; a++) { double tt = 0; for (int b = 0; b < nr; b++) tt += Di[(size_t)b * nr + a] * (x[b] - qB[b]); H[(size_t)i * nr + a] += tt; }
+                }
+                if (st) { st->newton_iters++; st->hessian_evals++; }
+                memcpy(LUx, H, sizeof(double) * n2);
+                lu_factor(nr, LUx, Px);
+                lu_apply_neg(nr, LUx, Px, g, dx);
+                if (vnorm(nr, dx) > dxMax) { if (st) st->diverged++; break; }
+                for (int i = 0; i < nr; i++) x[i] += dx[i];
+                if (vnorm(nr, g) < tol) break;
+                if (iter >= iterMax) { if (st) st->not_converged++; break; }
+                iter++;
+            }
+            if (k == 1 && sv == 0) {
+                for (int i = 0; i < nr; i++) { qa[i] = x[i]; qda[i] = (x[i] - q0[i]) / (al * h); }
+            } else if (k == 1) {
+                for (int i = 0; i < nr; i++) xd[i] = (x[i] - q0[i] - (1 - al) * h * qda[i]) / (al * h);
+                set_q(s, x, xd);
+                for (int i = 0; i < s->n; i++) if (s->nd[i].ndof) { s->nd[i].q1 = q0[s->nd[i].idxR]; s->nd[i].qdot1 = qd0[s->nd[i].idxR]; }
+            } else {
+                for (int i = 0; i < nr; i++) xd[i] = (3.0 / (2.0 * h)) * (x[i] - (4.0 / 3.0) * q1[i] + (1.0 / 3.0) * q0[i]);
+                set_q(s, x, xd);
+            }
+        }
+        scene_update(s);
+        t += h;
+        memcpy(Mh + n2 * (size_t)(k - 1), M, sizeof(double) * n2);
+        memcpy(Dh + n2 * (size_t)(k - 1), D, sizeof(double) * n2);
+        if (fabs(task->t - t) < 1e-6) {         /* TaskBDF2PointPos.calcStep :67-95 */
+            const onode* b = &s->nd[task->body];
+            double xw[3], dxw[3];
+            for (int a = 0; a < 3; a++) {
+                xw[a] = b->E_wi[a][0] * task->xlocal[0] + b->E_wi[a][1] * task->xlocal[1] + b->E_wi[a][2] * task->xlocal[2] + b->E_wi[a][3];
+                dxw[a] = xw[a] - task->xtarget[a];
+            }
+            P += task->wpos * 0.5 * (dxw[0] * dxw[0] + dxw[1] * dxw[1] + dxw[2] * dxw[2]);
+            double G[3][6], xb[3][3], RG[3][6];
+            se3_brac3(xb, task->xlocal);
+            for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) { G[a][c] = xb[c][a]; G[a][3 + c] = (a == c); }
+            for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) { double tt = 0; for (int e = 0; e < 3; e++) tt += b->E_wi[a][e] * G[e][c]; RG[a][c] = tt; }
+            double wm[6];
+            for (int c = 0; c < 6; c++) wm[c] = (RG[0][c] * dxw[0] + RG[1][c] * dxw[1] + RG[2][c] * dxw[2]) * task->wpos;
+            for (int a = 0; a < nr; a++) {
+                double tt = 0;
+                for (int c = 0; c < 6; c++) tt += Jk[(size_t)a * nm + b->idxM + c] * wm[c];
+                dPdq[(size_t)nr * (k - 1) + a] = tt;
+            }
+        }
+    }
+    /* TaskBDF2.calcFinal  TaskBDF2.m:45-107 */
+    double wreg2 = 0; for (int i = 0; i < nr; i++) wreg2 += p[i] * p[i];
+    P += task->wreg * 0.5 * wreg2;
+    double* z = (double*)calloc((size_t)nr * (nsteps + 5) + 1, sizeof(double));
+    double* yk = (double*)calloc(sz, sizeof(double));
+    for (int k = nsteps; k >= 1; k--) {
+        for (int a = 0; a < nr; a++) yk[a] = dPdq[(size_t)nr * (k - 1) + a];
+        for (int j = 1; j <= 4; j++) {
+            if (!(k < nsteps - (j - 1))) continue;
+            double cm, cd;                       /* block = cm M + cd h D of step k + j   (:66-96) */
+            if (j == 1) { cm = (k == 1) ? -((8.0 / (9.0 * al)) + (4.0 / 3.0)) : -(8.0 / 3.0); cd = 8.0 / 9.0; }
+            else if (j == 2) { cm = (k == 1) ? ((2.0 / (9.0 * al)) + (19.0 / 9.0)) : (22.0 / 9.0); cd = -2.0 / 9.0; }
+            else if (j == 3) { cm = -8.0 / 9.0; cd = 0.0; }
+            else { cm = 1.0 / 9.0; cd = 0.0; }
+            const double* Mj = Mh + n2 * (size_t)(k + j - 1); const double* Dj = Dh + n2 * (size_t)(k + j - 1); const double* zj = z + (size_t)nr * (k + j - 1);
+            for (int a = 0; a < nr; a++) { double tt = 0; for (int c = 0; c < nr; c++) tt += (cm * Mj[(size_t)a * nr + c] + cd * h * Dj[(size_t)a * nr + c]) * zj[c]; yk[a] -= tt; }
+        }
+        lu_apply_transposed(nr, LUh + n2 * (size_t)(k - 1), Ph + (size_t)nr * (k - 1), yk, z + (size_t)nr * (k - 1));
+    }
+    for (int a = 0; a < nr; a++) {               /* dPdp = wreg*p' - z'*dgdp, dgdp(kk,:) = -(4/9) h^2 pscale I */
+        double zs = 0; for (int k = 0; k < nsteps; k++) zs += z[(size_t)nr * k + a];
+        dPdp[a] = task->wreg * p[a] + (4.0 / 9.0) * h * h * task->pscale * zs;
+    }
+    for (int i = 0; i < s->n; i++) s->nd[i].tau = 0.0;
+    free(LUh); free(Mh); free(Dh); free(Ph); free(dPdq); free(q0); free(qd0); free(q1); free(qd1); free(qa); free(qda);
+    free(x); free(qA); free(qB); free(xd); free(g); free(dx); free(H); free(M); free(f); free(K); free(D); free(dMdq); free(Jk); free(LUs); free(Ps);
+    free(z); free(yk);
+    return P;
+}
+
 /* -------------------------------------------------- batch CPU baseline */
 
 long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad);

@@ -130,6 +130,8 @@ typedef struct orc_task_pointpos {
  * TaskBDF1.calcFinal.  Returns P, fills dPdp[nr].  Pinned only by the finite-difference identity (testGrad :46-61): the
  * reference holds no golden numbers for this path ("parity unpinned" beyond FD). */
 double orc_adjoint_bdf1(orc_scene* s, double h, int nsteps, const orc_task_pointpos* task, const double* p, double* dPdp, orc_stats* st);
+/* the same for driverRedMaxAdjointBDF2.m / TaskBDF2.m / TaskBDF2PointPos.m (scene 101) */
+double orc_adjoint_bdf2(orc_scene* s, double h, int nsteps, const orc_task_pointpos* task, const double* p, double* dPdp, orc_stats* st);
 
 /* Batch helper for the timed CPU baseline: B independent trajectories of the same scene,
  * OpenMP over trajectories (nthreads), q/qdot [B][nr] in/out. Returns total Newton iterations. */

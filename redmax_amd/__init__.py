@@ -8,6 +8,6 @@ from .redmax import (Body, BodyCuboid, ForceGroundCuboid, Joint, JointFixed, Joi
 from .scenes import (IN_SCOPE_SCENES, sceneAdjointChain, sceneChain, sceneChainGround, scenesRedMax, sceneTree,  # noqa: F401
                      syntheticStates)
 from .batch import BatchSim  # noqa: F401
-from .driver import (driverRedMaxAdjointBDF1, driverRedMaxBDF1, driverRedMaxBDF2, simLoop, taskObjective,  # noqa: F401
+from .driver import (driverRedMaxAdjointBDF1, driverRedMaxAdjointBDF2, driverRedMaxBDF1, driverRedMaxBDF2, simLoop, taskObjective,  # noqa: F401
                      testRedMax)
 from ._abi import RedMaxHipError  # noqa: F401

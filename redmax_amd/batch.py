@@ -169,7 +169,12 @@ class BatchSim:
         out["ms"] = self._L.rmx_last_step_ms(self._batch)
         return out
 
-    def adjoint_bdf1(self, nsteps, h, task, p, stats=False):
+    def adjoint_bdf2(self, nsteps, h, task, p, stats=False):
+        """taskObjective of driverRedMaxAdjointBDF2.m:38-62 (TaskBDF2PointPos): SDIRK2 start step + BDF2 forward, TaskBDF2.calcFinal
+        backward.  Arguments and results as adjoint_bdf1."""
+        return self.adjoint_bdf1(nsteps, h, task, p, stats, _fn="rmx_adjoint_bdf2")
+
+    def adjoint_bdf1(self, nsteps, h, task, p, stats=False, _fn="rmx_adjoint_bdf1"):
         """taskObjective (driverRedMaxAdjointBDF1.m:39-62) for every trajectory: forward rollout from the current state
         under torques pscale*p, then the backward sweep.  task: dict(body, xlocal, xtarget, t | step, pscale, wreg, wpos);
         p: [B][nr].  Returns (P[B], dPdp[B][nr], info)."""
@@ -193,8 +198,8 @@ class BatchSim:
             info["newton_iters"] = np.zeros(self.B, dtype=np.int32)
             info["status"] = np.zeros(self.B, dtype=np.int32)
             st = _abi.Stats(_abi.iptr(info["newton_iters"]), None, _abi.iptr(info["status"]))
-        _abi.check(self._L.rmx_adjoint_bdf1(self._batch, C.byref(opts), int(nsteps), C.byref(tk), _abi.dptr(p), _abi.dptr(P),
-                                            _abi.dptr(dPdp), C.byref(st) if st is not None else None), "rmx_adjoint_bdf1")
+        _abi.check(getattr(self._L, _fn)(self._batch, C.byref(opts), int(nsteps), C.byref(tk), _abi.dptr(p), _abi.dptr(P),
+                                         _abi.dptr(dPdp), C.byref(st) if st is not None else None), _fn)
         info["ms"] = self._L.rmx_last_step_ms(self._batch)
         return P, dPdp, info
 

@@ -32,6 +32,19 @@ static int fail(int code, const std::string& msg) {
 
 
 extern "C" const char* rmx_last_error(void) { return g_err.c_str(); }
+
+// An error already pending in this thread's HIP state when an entry point is about to launch.  If this batch still has an
+// asynchronous launch of its own that nobody waited for (rmx_step_bdf1_async without rmx_sync), the error is reported as that
+// launch's and nothing is launched on top of it.  Otherwise it was left behind by another user of HIP in this process: it is taken
+// out of this launch's verdict (hipGetLastError clears it), but not silently - rmx_last_error() keeps the note.
+static int pending_error_check(rmx_batch* b, const char* who) {
+    const hipError_t prev = hipGetLastError();
+    if (prev == hipSuccess) return RMX_OK;
+    if (b && b->async_pending)
+        return fail(RMX_E_HIP, std::string(who) + ": an earlier asynchronous launch of this batch failed: " + hipGetErrorString(prev));
+    g_err = std::string(who) + ": note: a HIP error was already pending before this call (left by another user of the process): " + hipGetErrorString(prev);
+    return RMX_OK;
+}
 extern "C" int rmx_version(void) { return RMX_VERSION; }
 extern "C" int rmx_device_count(void) {
     int n = 0;
@@ -489,7 +502,13 @@ extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_conta
         const hipError_t e = hipMemcpy(fresh, con.data(), con.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(fresh); return fail(RMX_E_HIP, std::string("hipMemcpy(contact): ") + hipGetErrorString(e)); }
     }
-    HIPCHK(hipDeviceSynchronize());
+    {
+        const hipError_t es = hipDeviceSynchronize();
+        if (es != hipSuccess) {
+            if (fresh) (void)hipFree(fresh);
+            return fail(RMX_E_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(es));
+        }
+    }
     if (m->dcon) (void)hipFree(m->dcon);
     m->dcon = fresh;
     m->dm.con = (const double*)fresh;
@@ -620,6 +639,7 @@ extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const d
     if (!(eta > 0)) return fail(RMX_E_INVALID, "eta must be positive");
     rmx_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = pending_error_check(b, "rmx_eval")) return rc;
     const size_t nv = (size_t)b->B * m->nr;
     if (nv == 0) return RMX_OK;
     double *dg = nullptr, *dH = nullptr;
@@ -632,7 +652,6 @@ extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const d
         if (e != hipSuccess) { (void)hipFree(dg); return fail(RMX_E_NOMEM, "hipMalloc(H)"); }
         (void)hipMemsetAsync(dH, 0, nv * m->nr * sizeof(double), b->stream);
     }
-    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_eval, m, b, H != nullptr, eta, dg, dH);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(g, dg, nv * sizeof(double), hipMemcpyDeviceToHost, b->stream);
@@ -650,6 +669,7 @@ extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, d
     if (m->dm.con) return fail(RMX_E_INVALID, "rmx_eval_mfd: models with ground contact are outside this hook (the contact K/D blocks only exist inside H)");
     if (m->dm.nsph) return fail(RMX_E_INVALID, "rmx_eval_mfd: models with spherical joints are outside this hook");
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = pending_error_check(b, "rmx_eval_mfd")) return rc;
     const size_t nv = (size_t)b->B * m->nr, nn = nv * m->nr;
     if (nv == 0) return RMX_OK;
     double* buf = nullptr;
@@ -659,8 +679,7 @@ extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, d
     if (e == hipSuccess) e = hipMemcpyAsync(b->tmpA, q, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b->tmpB, qdot, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
-        (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
-        DISPATCH_NP(m->NP, launch_mfd, m, b, dM, df, dD);
+            DISPATCH_NP(m->NP, launch_mfd, m, b, dM, df, dD);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(M, dM, nn * sizeof(double), hipMemcpyDeviceToHost, b->stream);
@@ -702,8 +721,9 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.histQ = dQ; a.histQd = dQd; a.histC = dC;
     a.chart = b->chart;
     a.resume = b->resume;
+    rc = pending_error_check(b, "rmx_step");
+    if (rc) return rc;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
-    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
     // BDF2 keeps (q, qdot) of step k-1 in qp/qdp.  BDF1 steps do not maintain them (and, with JointSpherical, may leave q in
     // another Euler chart than qp), so a BDF1 call invalidates the multistep history: the next rmx_step_bdf2 restarts with
@@ -812,6 +832,7 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
     rmx_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
     if (nsteps == 0 || m->nr == 0) return RMX_OK;
+    if (int rc = pending_error_check(b, "rmx_step_euler")) return rc;
     double *dT = nullptr, *dV = nullptr;
     const size_t nh = (size_t)nsteps * b->B;
     if (hT) {
@@ -822,7 +843,6 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
     StepArgs a{};
     a.B = b->B; a.nsteps = nsteps; a.q = b->q; a.qd = b->qd; a.histT = dT; a.histV = dV;
     hipError_t e = hipEventRecord(b->ev0, b->stream);
-    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_euler, m, b, h, a);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
@@ -843,18 +863,20 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
 }
 
 
-extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
-                                double* P, double* dPdp, rmx_stats* stats) {
+static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p, double* P,
+                        double* dPdp, rmx_stats* stats, const int integ) {
     if (!b || !task || !p || !P || !dPdp) return fail(RMX_E_INVALID, "null argument");
     rmx_model* m = b->m;
     if (nsteps < 1) return fail(RMX_E_INVALID, "nsteps < 1");
-    if (m->dm.con) return fail(RMX_E_INVALID, "rmx_adjoint_bdf1: ground contact is outside the adjoint path (SURVEY.md 8(f))");
-    if (m->dm.nsph) return fail(RMX_E_INVALID, "rmx_adjoint_bdf1: spherical joints are outside the adjoint path (SURVEY.md 8(f))");
+    if (m->dm.con) return fail(RMX_E_INVALID, "rmx_adjoint: ground contact is outside the adjoint path (SURVEY.md 8(f))");
+    if (m->dm.nsph) return fail(RMX_E_INVALID, "rmx_adjoint: spherical joints are outside the adjoint path (SURVEY.md 8(f))");
     if (task->body < 0 || task->body >= m->nlist) return fail(RMX_E_INVALID, "task body out of range");
     if (task->step < 1 || task->step > nsteps) return fail(RMX_E_INVALID, "task step must be in [1, nsteps]");
     HIPCHK(hipSetDevice(m->device));
     DevOpts o;
     int rc = make_opts(b, opts, o);
+    if (rc) return rc;
+    rc = pending_error_check(b, "rmx_adjoint");
     if (rc) return rc;
     const size_t nn = (size_t)m->n * m->n, nv = (size_t)b->B * m->nr;
     const size_t hist = (size_t)b->B * nsteps * nn * sizeof(double);
@@ -863,7 +885,7 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
     a.B = b->B; a.nsteps = nsteps; a.task_step = task->step; a.task_node = m->node_of_listing[task->body];
     for (int c = 0; c < 3; ++c) { a.xl[c] = task->xlocal[c]; a.xt[c] = task->xtarget[c]; }
     a.pscale = task->pscale; a.wreg = task->wreg; a.wpos = task->wpos;
-    a.q = b->q; a.qd = b->qd; a.p = b->tmpA;
+    a.q = b->q; a.qd = b->qd; a.qp = b->qp; a.qdp = b->qdp; a.p = b->tmpA;
     a.it = stats ? b->it : nullptr; a.status = b->status;
     void* bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t sizes[6] = {hist, hist, hist, (size_t)b->B * m->n * sizeof(double), (size_t)b->B * sizeof(double), nv * sizeof(double)};
@@ -875,11 +897,11 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
         a.Hs = (double*)bufs[0]; a.Ms = (double*)bufs[1]; a.Ds = (double*)bufs[2];
         a.dPdq = (double*)bufs[3]; a.P = (double*)bufs[4]; a.dPdp = (double*)bufs[5];
         e = hipEventRecord(b->ev0, b->stream);
-        (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
-        DISPATCH_NP(m->NP, launch_adjoint, m, b, o, a);
+            DISPATCH_NP(m->NP, launch_adjoint, m, b, integ, o, a);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(b->started, 0, sizeof(int), b->stream);
+        // after a BDF2 rollout (q, qdot) of step k-1 are in place: rmx_step_bdf2 may continue it; a BDF1 rollout invalidates them
+        if (e == hipSuccess) e = hipMemsetAsync(b->started, integ == INTEG_BDF2 ? 1 : 0, sizeof(int), b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(P, a.P, sizes[4], hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dPdp, a.dPdp, sizes[5], hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess && stats) {
@@ -894,15 +916,26 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
     }
     for (void* ptr : bufs)
         if (ptr) (void)hipFree(ptr);
-    if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_adjoint_bdf1: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_adjoint: ") + hipGetErrorString(e));
     return RMX_OK;
+}
+
+extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
+                                double* P, double* dPdp, rmx_stats* stats) {
+    return adjoint_impl(b, opts, nsteps, task, p, P, dPdp, stats, INTEG_BDF1);
+}
+extern "C" int rmx_adjoint_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
+                                double* P, double* dPdp, rmx_stats* stats) {
+    return adjoint_impl(b, opts, nsteps, task, p, P, dPdp, stats, INTEG_BDF2);
 }
 
 extern "C" int rmx_step_bdf1_async(rmx_batch* b, const rmx_opts* opts, int nsteps) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     if (nsteps <= 0 || b->m->nr == 0) return RMX_OK;
     HIPCHK(hipSetDevice(b->m->device));
-    return launch_step(b, opts, nsteps, INTEG_BDF1, true, nullptr, nullptr);   // counters accumulate on the device
+    const int rc = launch_step(b, opts, nsteps, INTEG_BDF1, true, nullptr, nullptr);   // counters accumulate on the device
+    if (rc == RMX_OK) b->async_pending = true;      // until rmx_sync (or any synchronous call on this batch) has waited for it
+    return rc;
 }
 extern "C" int rmx_stats_reset(rmx_batch* b) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
@@ -924,7 +957,9 @@ extern "C" int rmx_stats_read(rmx_batch* b, rmx_stats* st) {
 extern "C" int rmx_sync(rmx_batch* b) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     HIPCHK(hipSetDevice(b->m->device));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    const hipError_t es = hipStreamSynchronize(b->stream);
+    b->async_pending = false;
+    if (es != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_sync: the asynchronous launch failed: ") + hipGetErrorString(es));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
     return RMX_OK;
@@ -934,9 +969,9 @@ extern "C" int rmx_profile_phases(rmx_batch* b, int reps, double h, double* cycl
     if (!b || !cycles4 || reps < 1) return fail(RMX_E_INVALID, "bad argument");
     rmx_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = pending_error_check(b, "rmx_profile_phases")) return rc;
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, sizeof(unsigned long long) * 16 * b->B));
-    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_phase, m, b, reps, h, d);
     std::vector<unsigned long long> hbuf(16 * (size_t)b->B);
     hipError_t e = hipGetLastError();
@@ -956,11 +991,11 @@ extern "C" int rmx_energy(rmx_batch* b, double* T, double* V) {
     if (!b || !T || !V) return fail(RMX_E_INVALID, "null argument");
     rmx_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
+    if (int rc = pending_error_check(b, "rmx_energy")) return rc;
     double *dT = nullptr, *dV = nullptr;
     HIPCHK(hipMalloc((void**)&dT, sizeof(double) * b->B));
     hipError_t e = hipMalloc((void**)&dV, sizeof(double) * b->B);
     if (e != hipSuccess) { (void)hipFree(dT); return fail(RMX_E_NOMEM, "hipMalloc(energy)"); }
-    (void)hipGetLastError();      // a sticky error left behind by another HIP user of this process is not this launch's
     DISPATCH_NP(m->NP, launch_energy, m, b, dT, dV);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(T, dT, sizeof(double) * b->B, hipMemcpyDeviceToHost, b->stream);

@@ -2643,9 +2643,10 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
             bool lu_ok;
             if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
             else if constexpr (NP == 64 && LU_SPLIT64) {
-                // the matrix-core Hessian stage (plain models, and contact-capable ones while nothing touches the ground) has left
-                // H and -g in the scratch; the v_readlane stage (contact terms) hands the rows over in registers
-                if (HESS_MFMA64 && (!CT || !fs.touched)) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
+                // the matrix-core Hessian stage (evaluations without contact terms: eval_hess compiles it for !CT only) has left H and
+                // -g in the scratch; the v_readlane stage of the kernels with the contact terms hands the rows over in registers,
+                // whether or not a corner touches the ground at this iterate
+                if constexpr (HESS_MFMA64 && !CT) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
                 else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
             }
             else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);

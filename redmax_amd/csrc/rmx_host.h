@@ -37,6 +37,7 @@ struct AdjArgs {
     int B, nsteps, task_step, task_node;
     double xl[3], xt[3], pscale, wreg, wpos;
     double *q, *qd;
+    double *qp, *qdp;         // BDF2: state of step k-1 after the rollout (out)
     const double* p;
     double *Hs, *Ms, *Ds;     // [B][nsteps][n*n]
     double* dPdq;             // [B][n]   dP/dq of the task step
@@ -71,6 +72,7 @@ struct rmx_batch {
     int *it = nullptr, *ls = nullptr, *status = nullptr;
     int* resume = nullptr;          // [B] see StepArgs.resume
     double last_ms = 0.0;
+    bool async_pending = false;     // an rmx_step_bdf1_async launch nobody has waited for yet (see pending_error_check)
 };
 
 // launchers defined by rmx_kernels.hip for one RMX_NP each
@@ -81,7 +83,7 @@ struct rmx_batch {
     void RMX_CAT(launch_step_np_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a); \
     void RMX_CAT(launch_euler_, NPV)(const rmx_model* m, const rmx_batch* b, double h, const StepArgs& a); \
     void RMX_CAT(launch_energy_, NPV)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV); \
-    void RMX_CAT(launch_adjoint_, NPV)(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a); \
+    void RMX_CAT(launch_adjoint_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const AdjArgs& a); \
     void RMX_CAT(launch_phase_, NPV)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d); \
     void RMX_CAT(launch_mfd_, NPV)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD); \
     void RMX_CAT(launch_eval_ct_, NPV)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH); \

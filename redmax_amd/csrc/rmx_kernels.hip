@@ -275,15 +275,17 @@ __global__ void __launch_bounds__(64) k_step_euler(const DevModel M, const doubl
     }
 }
 
-// ---------------------------------------------------------------- adjoint BDF1 (BASELINE.json configs[3])
+// ---------------------------------------------------------------- adjoint BDF1 / BDF2 (BASELINE.json configs[3])
 //
-// taskObjective of driverRedMaxAdjointBDF1.m:39-62 for TaskBDF1PointPos, batched: parameters p[B][nr] are constant joint
-// torques tau = pscale*p (TaskBDF1PointPos.applyStep :58-64).  Forward = simLoop :65-102 with the line-search-free newton
-// :105-146; per step the H, M, D of the LAST EVALUATED iterate are kept in HBM ([B][nsteps][n*n], column-major over nodes),
-// which is what Scene.saveHistory stores (the reference keeps lu(H), the backward kernel re-factors H').  Backward =
-// TaskBDF1.calcFinal :45-81.
+// taskObjective of driverRedMaxAdjointBDF1.m:39-62 (TaskBDF1PointPos) and driverRedMaxAdjointBDF2.m:38-62 (TaskBDF2PointPos), batched:
+// parameters p[B][nr] are constant joint torques tau = pscale*p (applyStep, TaskBDF1PointPos.m:58-64).  Forward = simLoop (BDF1
+// :65-102; BDF2 :65-136 with the SDIRK2a / SDIRK2b start step) with the line-search-free newton (:105-146 / :139-181); per step the
+// H, M, D of the LAST EVALUATED iterate of the step's final solve are kept in HBM ([B][nsteps][n*n], column-major over nodes), which
+// is what Scene.saveHistory stores (the reference keeps lu(H), the backward kernel re-factors H').  Backward = TaskBDF1.calcFinal
+// (TaskBDF1.m:45-81) / TaskBDF2.calcFinal (TaskBDF2.m:45-107).  Every forward solve is the common residual
+//     qdot = (x - qA)/eta,  v = x - qB,  g = M v - eta^2 f,  H = dg/dx      (evalBDF1, evalSDIRK2a/b, evalBDF2).
 
-template <int NP>
+template <int NP, int INTEG>
 __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevOpts o, const AdjArgs a) {
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
@@ -292,6 +294,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     double q = id >= 0 ? a.q[off] : 0.0;
     double qd = id >= 0 ? a.qd[off] : 0.0;
+    double qp = 0.0, qdp = 0.0;             // BDF2: the state of step k-1 (Joint.q1 / qdot1)
     const double pj = id >= 0 ? a.p[off] : 0.0;
     const double h = o.h;
     FrontState fs;
@@ -301,103 +304,144 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
     int iters = 0, status = 0;
     double Ptask = 0.0;
     const size_t nn = (size_t)n * n;
+    const double al = (2.0 - sqrt(2.0)) / 2.0;       // SDIRK2 (driverRedMaxAdjointBDF2.m:80)
     for (int s = 1; s <= a.nsteps; ++s) {
-        const double q0 = q, qd0 = qd;
-        const double xB = q0 + h * qd0;
-        double x = xB, xlo = 0.0;      // compensated iterate x + xlo (newton_impl in rmx_device.h)
         double* Hk = a.Hs + ((size_t)traj * a.nsteps + (s - 1)) * nn;
         double* Mk = a.Ms + ((size_t)traj * a.nsteps + (s - 1)) * nn;
         double* Dk = a.Ds + ((size_t)traj * a.nsteps + (s - 1)) * nn;
         double Jw[3] = {0.0, 0.0, 0.0}, Jv[3] = {0.0, 0.0, 0.0};   // J(idxM_body, this joint) of the last evaluated iterate
-        int iter = 1;
-        // Scene.saveHistory keeps H, M, D of the LAST evaluated iterate of the step (driverRedMaxAdjointBDF1.m:100, 127).  Up to 32
-        // nodes H rides in registers through the Newton loop (the solve destroys its working copy) and M, D are formed ONCE, after
-        // the loop, from the state the last evaluation left behind (fs) - they do not enter the Newton iteration itself; all three
-        // go to HBM once per step.  Larger trees (3 x 64 doubles per lane) form and store them at every iterate, the last store wins.
-        constexpr bool STORE_ONCE = NP <= 32;
-        double Hs[STORE_ONCE ? NP : 1];
-        while (true) {
-            NodeOut e;
-            double Hrow[NP];
-            eval_front<NP, true>(M, sAcc, lane, x, ((x - q0) + xlo) / h, (x - xB) + xlo, h, e, fs);
-            const double hdiag = eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
-            if constexpr (STORE_ONCE) {
-#pragma unroll
-                for (int i = 0; i < NP; ++i) Hs[i] = Hrow[i];
-            } else {
-                double Mrow[NP], Drow[NP];
-                eval_MD<NP>(M, lane, fs, Mrow, Drow);
-                if (lane < n) {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i)
-                        if (i < n) {
-                            Hk[(size_t)i * n + lane] = Hrow[i];
-                            Mk[(size_t)i * n + lane] = Mrow[i];
-                            Dk[(size_t)i * n + lane] = Drow[i];
-                        }
-                }
+        const double q0 = (INTEG == 2 && s > 1) ? qp : q, qd0 = (INTEG == 2 && s > 1) ? qdp : qd;      // BDF2: step k-1
+        const double q1 = q, qd1 = qd;                                                                  // BDF2: step k
+        double qa = 0.0, qda = 0.0;                  // SDIRK2a's result
+        double x = 0.0, xlo = 0.0;                   // compensated iterate x + xlo (newton_impl in rmx_device.h)
+        const int nsolve = (INTEG == 2 && s == 1) ? 2 : 1;
+        for (int sv = 0; sv < nsolve; ++sv) {
+            double qA, qB, eta;
+            if (INTEG == 1) {                        // evalBDF1 :160-176
+                eta = h; qA = q0; qB = q0 + h * qd0; x = qB;
+            } else if (s == 1 && sv == 0) {          // SDIRK2a :78-84, evalSDIRK2a :184-216
+                eta = al * h; qA = q0; qB = q0 + (al * h) * qd0; x = q0 + al * h * qd0;
+            } else if (s == 1) {                     // SDIRK2b :89-92, evalSDIRK2b :219-252
+                eta = al * h;
+                x = qa + (1.0 - al) * h * qda;
+                qA = q0 + (1.0 - al) * h * qda;
+                qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
+            } else {                                 // BDF2 :103-113, evalBDF2 :255-287
+                eta = (2.0 / 3.0) * h;
+                x = q1 + h * qd1;
+                qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
+                qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
             }
-            if (s == a.task_step) {   // J(body rows, joint) = Ad(E_body^-1) s_joint : body-frame twist of the task body per unit qdot
-                double Rb[9], pb[3], t3[3], d3[3];
+            xlo = 0.0;
+            const bool last_solve = sv + 1 == nsolve;    // the SDIRK2a solve leaves nothing in the history
+            int iter = 1;
+            // Scene.saveHistory keeps H, M, D of the LAST evaluated iterate of the step (driverRedMaxAdjointBDF1.m:100, 127).  Up to 32
+            // nodes H rides in registers through the Newton loop (the solve destroys its working copy) and M, D are formed ONCE, after
+            // the loop, from the state the last evaluation left behind (fs) - they do not enter the Newton iteration itself; all three
+            // go to HBM once per step.  Larger trees (3 x 64 doubles per lane) form and store them at every iterate, the last store wins.
+            constexpr bool STORE_ONCE = NP <= 32;
+            double Hs[STORE_ONCE ? NP : 1];
+            while (true) {
+                NodeOut e;
+                double Hrow[NP];
+                eval_front<NP, true>(M, sAcc, lane, x, ((x - qA) + xlo) / eta, (x - qB) + xlo, eta, e, fs);
+                const double hdiag = eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
+                if constexpr (STORE_ONCE) {
 #pragma unroll
-                for (int c = 0; c < 9; ++c) Rb[c] = readlane_d(fs.Rw[c], a.task_node);
+                    for (int i = 0; i < NP; ++i) Hs[i] = Hrow[i];
+                } else if (last_solve) {
+                    double Mrow[NP], Drow[NP];
+                    eval_MD<NP>(M, lane, fs, Mrow, Drow);
+                    if (lane < n) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) pb[c] = readlane_d(fs.pw[c], a.task_node);
-                cross3(pb, fs.sw, t3);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) d3[c] = fs.sv[c] - t3[c];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {   // R' (.)
-                    Jw[c] = on_path ? (Rb[c] * fs.sw[0] + Rb[3 + c] * fs.sw[1] + Rb[6 + c] * fs.sw[2]) : 0.0;
-                    Jv[c] = on_path ? (Rb[c] * d3[0] + Rb[3 + c] * d3[1] + Rb[6 + c] * d3[2]) : 0.0;
-                }
-            }
-            ++iters;
-            // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128.  As in the step kernels the solve takes diagonal pivots
-            // under the growth guard first (a third of the instructions of the pivot search) and falls back to partial pivoting
-            // on the saved copy of H when the guard trips; the factors themselves are not kept (the backward pass re-solves).
-            double dx;
-            if constexpr (STORE_ONCE) {
-                bool lu_ok;
-                dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
-                if (!lu_ok) {
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) Hrow[i] = Hs[i];
-                    dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
-                    status |= 16;
-                }
-            } else {
-                (void)hdiag;
-                dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
-            }
-            const double dxn2 = wave_sum(dx * dx);
-            if (!(dxn2 == dxn2)) { status |= 4; break; }
-            if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }            // :129-132
-            {                                                             // x = x + dx, :134, before the convergence test
-                const double xa = x;
-                two_sum(xa, xlo + dx, x, xlo);
-                xlo *= o.comp;
-            }
-            if (sqrt(wave_sum(e.g * e.g)) < o.tol) break;                 // :135-138
-            if (iter >= o.iterMax) { status |= 2; break; }                // :139-142
-            ++iter;
-        }
-        if constexpr (STORE_ONCE) {
-            double Mrow[NP], Drow[NP];
-            eval_MD<NP>(M, lane, fs, Mrow, Drow);       // fs: the state of the last evaluated iterate
-            if (lane < n) {
-#pragma unroll
-                for (int i = 0; i < NP; ++i)
-                    if (i < n) {
-                        Hk[(size_t)i * n + lane] = Hs[i];
-                        Mk[(size_t)i * n + lane] = Mrow[i];
-                        Dk[(size_t)i * n + lane] = Drow[i];
+                        for (int i = 0; i < NP; ++i)
+                            if (i < n) {
+                                Hk[(size_t)i * n + lane] = Hrow[i];
+                                Mk[(size_t)i * n + lane] = Mrow[i];
+                                Dk[(size_t)i * n + lane] = Drow[i];
+                            }
                     }
+                }
+                if (s == a.task_step && last_solve) {   // J(body rows, joint) = Ad(E_body^-1) s_joint : body-frame twist of the task body per unit qdot
+                    double Rb[9], pb[3], t3[3], d3[3];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) Rb[c] = readlane_d(fs.Rw[c], a.task_node);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) pb[c] = readlane_d(fs.pw[c], a.task_node);
+                    cross3(pb, fs.sw, t3);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) d3[c] = fs.sv[c] - t3[c];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {   // R' (.)
+                        Jw[c] = on_path ? (Rb[c] * fs.sw[0] + Rb[3 + c] * fs.sw[1] + Rb[6 + c] * fs.sw[2]) : 0.0;
+                        Jv[c] = on_path ? (Rb[c] * d3[0] + Rb[3 + c] * d3[1] + Rb[6 + c] * d3[2]) : 0.0;
+                    }
+                }
+                ++iters;
+                // [Hl,Hu,Hp] = lu(H,'vector'); dx = -(Hu\(Hl\g(Hp)))  :127-128.  As in the step kernels the solve takes diagonal pivots
+                // under the growth guard first (a third of the instructions of the pivot search) and falls back to partial pivoting
+                // on the saved copy of H when the guard trips; the factors themselves are not kept (the backward pass re-solves).
+                double dx;
+                if constexpr (STORE_ONCE) {
+                    bool lu_ok;
+                    dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
+                    if (!lu_ok) {
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) Hrow[i] = Hs[i];
+                        dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
+                        status |= 16;
+                    }
+                } else {
+                    (void)hdiag;
+                    dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
+                }
+                const double dxn2 = wave_sum(dx * dx);
+                if (!(dxn2 == dxn2)) { status |= 4; break; }
+                if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }            // :129-132
+                {                                                             // x = x + dx, :134, before the convergence test
+                    const double xa = x;
+                    two_sum(xa, xlo + dx, x, xlo);
+                    xlo *= o.comp;
+                }
+                if (sqrt(wave_sum(e.g * e.g)) < o.tol) break;                 // :135-138
+                if (iter >= o.iterMax) { status |= 2; break; }                // :139-142
+                ++iter;
+            }
+            if constexpr (STORE_ONCE) {
+                if (last_solve) {
+                    double Mrow[NP], Drow[NP];
+                    eval_MD<NP>(M, lane, fs, Mrow, Drow);       // fs: the state of the last evaluated iterate
+                    if (lane < n) {
+#pragma unroll
+                        for (int i = 0; i < NP; ++i)
+                            if (i < n) {
+                                Hk[(size_t)i * n + lane] = Hs[i];
+                                Mk[(size_t)i * n + lane] = Mrow[i];
+                                Dk[(size_t)i * n + lane] = Drow[i];
+                            }
+                    }
+                }
+            }
+            if (INTEG == 2 && s == 1 && sv == 0) {   // :85-87
+                qa = x;
+                qda = ((x - q0) + xlo) / (al * h);
             }
         }
-        qd = ((x - q0) + xlo) / h;
-        q = x;
-        if (s == a.task_step) {    // TaskBDF1PointPos.calcStep :67-107 at the final state of this step
+        if (INTEG == 1) {
+            qd = ((x - q0) + xlo) / h;
+            q = x;
+        } else if (s == 1) {                         // :93-98: setQ(q1, qdot1), setQ1(q0, qdot0)
+            qd = (x - q0 - (1.0 - al) * h * qda) / (al * h);
+            q = x;
+            qp = q0;
+            qdp = qd0;
+        } else {                                     // :114-117
+            qd = (3.0 / (2.0 * h)) * (x - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
+            q = x;
+            qp = q1;
+            qdp = qd1;
+        }
+        if (s == a.task_step) {    // TaskBDF1PointPos.calcStep :67-107 (TaskBDF2PointPos.calcStep is the same) at the final state of this step
             NodeOut e;
             eval_front<NP, false>(M, sAcc, lane, q, qd, 0.0, 1.0, e, fs);
             double Rb[9], pb[3], dxw[3], vl[3], t3[3];
@@ -421,10 +465,14 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
     if (id >= 0) {
         a.q[off] = q;
         a.qd[off] = qd;
+        if (INTEG == 2) {
+            a.qp[off] = qp;
+            a.qdp[off] = qdp;
+        }
     }
     const double preg = wave_sum(pj * pj);
     if (lane == 0) {
-        a.P[traj] = Ptask + a.wreg * 0.5 * preg;      // TaskBDF1.calcFinal :49
+        a.P[traj] = Ptask + a.wreg * 0.5 * preg;      // TaskBDF1.calcFinal :49 / TaskBDF2.calcFinal :49
         if (a.it) {
             a.it[traj] = iters;
             a.status[traj] = status;
@@ -432,32 +480,47 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
     }
 }
 
+// yk -= (cm M_j + cd h D_j)' z_j : one off-diagonal block of the backward sweep; this lane's entry = column `col` of the block . z
 template <int NP>
+__device__ __forceinline__ void adj_block(double& y, const double* __restrict__ Mj, const double* __restrict__ Dj, const int n, const int lane,
+                                          const int col, const double cm, const double cdh, const double z) {
+    const double* Mc = Mj + (size_t)col * n;
+    const double* Dc = Dj + (size_t)col * n;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        double blk = 0.0;
+        if (j < n && lane < n) blk = cdh != 0.0 ? (cm * Mc[j] + cdh * Dc[j]) : cm * Mc[j];
+        y -= blk * readlane_d(z, j);
+    }
+}
+
+template <int NP, int INTEG>
 __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevOpts o, const AdjArgs a) {
     const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
     const int id = (lane < n) ? M.idx[lane] : -1;
     const size_t nn = (size_t)n * n;
     const double h = o.h;
     const int col = lane < n ? lane : 0;
-    double z1 = 0.0, z2 = 0.0, zs = 0.0;
+    const double al = (2.0 - sqrt(2.0)) / 2.0;
+    double z1 = 0.0, z2 = 0.0, z3 = 0.0, z4 = 0.0, zs = 0.0;      // z of steps k+1 .. k+4
+    const double* Mb = a.Ms + (size_t)traj * a.nsteps * nn;
+    const double* Db = a.Ds + (size_t)traj * a.nsteps * nn;
     for (int k = a.nsteps; k >= 1; --k) {
         double y = (k == a.task_step && lane < n) ? a.dPdq[(size_t)traj * n + lane] : 0.0;
-        if (k < a.nsteps) {       // yk -= (-2 M_{k+1} + h D_{k+1})' z_{k+1}     TaskBDF1.m:58-64
-            const double* Mc = a.Ms + ((size_t)traj * a.nsteps + k) * nn + (size_t)col * n;
-            const double* Dc = a.Ds + ((size_t)traj * a.nsteps + k) * nn + (size_t)col * n;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const double blk = (j < n && lane < n) ? (-2.0 * Mc[j] + h * Dc[j]) : 0.0;
-                y -= blk * readlane_d(z1, j);
-            }
-        }
-        if (k < a.nsteps - 1) {   // yk -= M_{k+2}' z_{k+2}                      :65-70
-            const double* Mc = a.Ms + ((size_t)traj * a.nsteps + k + 1) * nn + (size_t)col * n;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const double blk = (j < n && lane < n) ? Mc[j] : 0.0;
-                y -= blk * readlane_d(z2, j);
-            }
+        if (INTEG == 1) {
+            // yk -= (-2 M_{k+1} + h D_{k+1})' z_{k+1}   TaskBDF1.m:58-64 ;   yk -= M_{k+2}' z_{k+2}   :65-70
+            if (k < a.nsteps) adj_block<NP>(y, Mb + (size_t)k * nn, Db + (size_t)k * nn, n, lane, col, -2.0, h, z1);
+            if (k < a.nsteps - 1) adj_block<NP>(y, Mb + (size_t)(k + 1) * nn, Db + (size_t)(k + 1) * nn, n, lane, col, 1.0, 0.0, z2);
+        } else {
+            // TaskBDF2.m:66-96: blocks of steps k+1 .. k+4; the k == 1 variants carry the SDIRK2 start step's coefficients
+            if (k < a.nsteps)
+                adj_block<NP>(y, Mb + (size_t)k * nn, Db + (size_t)k * nn, n, lane, col, k == 1 ? -((8.0 / (9.0 * al)) + (4.0 / 3.0)) : -(8.0 / 3.0),
+                              (8.0 / 9.0) * h, z1);
+            if (k < a.nsteps - 1)
+                adj_block<NP>(y, Mb + (size_t)(k + 1) * nn, Db + (size_t)(k + 1) * nn, n, lane, col, k == 1 ? ((2.0 / (9.0 * al)) + (19.0 / 9.0)) : (22.0 / 9.0),
+                              -(2.0 / 9.0) * h, z2);
+            if (k < a.nsteps - 2) adj_block<NP>(y, Mb + (size_t)(k + 2) * nn, Db + (size_t)(k + 2) * nn, n, lane, col, -(8.0 / 9.0), 0.0, z3);
+            if (k < a.nsteps - 3) adj_block<NP>(y, Mb + (size_t)(k + 3) * nn, Db + (size_t)(k + 3) * nn, n, lane, col, 1.0 / 9.0, 0.0, z4);
         }
         // z_k = H_k'^-1 y_k  (zkk0(Hp) = Hl'\(Hu'\yk) :76): this lane's "row" of H' is column `lane` of H
         double Hrow[NP];
@@ -466,12 +529,15 @@ __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevO
         for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? Hc[i] : ((i == lane) ? 1.0 : 0.0);
         const double z = lu_solve_neg<NP, true>(n, lane, Hrow, -y);
         zs += z;
+        z4 = z3;
+        z3 = z2;
         z2 = z1;
         z1 = z;
     }
-    if (id >= 0) {   // dPdp = wreg*p' - z'*dgdp, dgdp(kk,:) = -h^2*pscale*I      :79, TaskBDF1PointPos.m:104-105
-        const size_t off = (size_t)traj * M.nr + id;
-        a.dPdp[off] = a.wreg * a.p[off] + h * h * a.pscale * zs;
+    if (id >= 0) {   // dPdp = wreg*p' - z'*dgdp, dgdp(kk,:) = -eta^2*pscale*I with eta^2 = h^2 (TaskBDF1PointPos.m:104-105) or (4/9) h^2 for
+        const size_t off = (size_t)traj * M.nr + id;                 // EVERY step (TaskBDF2PointPos.m:97-106)
+        const double e2 = INTEG == 1 ? h * h : (4.0 / 9.0) * h * h;
+        a.dPdp[off] = a.wreg * a.p[off] + e2 * a.pscale * zs;
     }
 }
 
@@ -687,10 +753,15 @@ void RMX_CAT(launch_energy_, RMX_NP)(const rmx_model* m, const rmx_batch* b, dou
     RMX_LAUNCH((k_energy<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->q, b->qd, dT, dV, nullptr);
 }
 
-void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const AdjArgs& a) {
+void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const AdjArgs& a) {
     const dim3 grid(b->B), block(64);
-    RMX_LAUNCH((k_adjoint_fwd<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
-    k_adjoint_bwd<RMX_NP><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+    if (integ == INTEG_BDF1) {
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 1>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 1><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+    } else {
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 2><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+    }
 }
 
 void RMX_CAT(launch_mfd_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD) {

@@ -89,9 +89,9 @@ def testRedMax(sceneID=0, device=0, verbose=True):
     return scene, H, passed
 
 
-def taskObjective(p, scene, sim=None, device=0):
-    """taskObjective of driverRedMaxAdjointBDF1.m:39-62: scene.reset(), forward simLoop under the task parameters,
-    task.calcFinal() -> (P, dPdp).  `p` may be [nr] (one rollout) or [B][nr] (a batch of parameter vectors, each its own
+def taskObjective(p, scene, sim=None, device=0, bdf2=False):
+    """taskObjective of driverRedMaxAdjointBDF1.m:39-62 (bdf2: of driverRedMaxAdjointBDF2.m:38-62): scene.reset(), forward simLoop
+    under the task parameters, task.calcFinal() -> (P, dPdp).  `p` may be [nr] (one rollout) or [B][nr] (a batch of parameter vectors, each its own
     rollout).  Forward and backward sweeps are two kernel launches inside rmx_adjoint_bdf1."""
     import numpy as np
     p = np.atleast_2d(np.asarray(p, dtype=np.float64))
@@ -100,30 +100,35 @@ def taskObjective(p, scene, sim=None, device=0):
         sim = BatchSim(scene, batch=p.shape[0], device=device)
     q0, qd0 = scene.qInit, scene.qdotInit                       # Scene.reset (Scene.m:122-131)
     sim.set_state(np.broadcast_to(q0, (sim.B, scene.nr)), np.broadcast_to(qd0, (sim.B, scene.nr)))
-    P, dPdp, info = sim.adjoint_bdf1(scene.nsteps, scene.h, scene.task, p, stats=True)
+    P, dPdp, info = (sim.adjoint_bdf2 if bdf2 else sim.adjoint_bdf1)(scene.nsteps, scene.h, scene.task, p, stats=True)
     if own:
         sim.close()
     return P, dPdp, info
 
 
-def driverRedMaxAdjointBDF1(nlinks=2, device=0, verbose=True, maxiter=50):
+def driverRedMaxAdjointBDF1(nlinks=2, device=0, verbose=True, maxiter=50, bdf2=False):
     """driverRedMaxAdjointBDF1.m:1-36 with scene 100 (or its n-link generalisation): minimise the task objective over the
     joint torques.  MATLAB's fminunc (quasi-Newton, gradient supplied) is replaced by scipy's BFGS with the same
     objective/gradient callback."""
     import numpy as np
     from scipy.optimize import minimize
     from .scenes import sceneAdjointChain
-    scene = sceneAdjointChain(nlinks)
+    scene = sceneAdjointChain(nlinks, bdf2=bdf2)
     scene.init()
     sim = BatchSim(scene, batch=1, device=device)
 
     def fun(p):
-        P, dPdp, _ = taskObjective(p, scene, sim=sim)
+        P, dPdp, _ = taskObjective(p, scene, sim=sim, bdf2=bdf2)
         return float(P[0]), dPdp[0]
 
     res = minimize(fun, np.zeros(scene.nr), jac=True, method="BFGS", options={"maxiter": maxiter, "disp": verbose})
     sim.close()
     return scene, res
+
+
+def driverRedMaxAdjointBDF2(nlinks=2, device=0, verbose=True, maxiter=50):
+    """driverRedMaxAdjointBDF2.m:1-36 with scene 101 (TaskBDF2PointPos): the same optimisation over the SDIRK2 + BDF2 rollout."""
+    return driverRedMaxAdjointBDF1(nlinks, device, verbose, maxiter, bdf2=True)
 
 
 def _main(argv=None):

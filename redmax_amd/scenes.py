@@ -234,6 +234,8 @@ def scenesRedMax(sceneID):
         scene.forces = [f]
     elif sceneID == 100:
         return sceneAdjointChain(2)                            # scenesRedMax.m:402-436 ('Adjoint BDF1')
+    elif sceneID == 101:
+        return sceneAdjointChain(2, bdf2=True)                 # scenesRedMax.m:437-471 ('Adjoint BDF2')
     else:
         raise ValueError("scene %r is out of scope (needs joint/force types outside SURVEY.md §8)" % (sceneID,))
     return scene
@@ -244,13 +246,15 @@ COMPOSITE_SCENES = (4, 5, 6, 8)             # JointPlanar / Translational / Free
 SPHERICAL_SCENES = (7, 9)                   # JointSpherical / JointFree3D (Euler charts with switching)
 
 
-def sceneAdjointChain(n=2):
+def sceneAdjointChain(n=2, bdf2=False):
     """Scene 100 'Adjoint BDF1' (scenesRedMax.m:402-436) generalised to n links (BASELINE.json configs[3] uses n=16):
     revolute y-axis chain of [10 1 1] cuboids, q = pi/2 at the root and pi/4 elsewhere, qdot = 1, joint stiffness and
     damping 1e4, and a TaskBDF1PointPos on the last body (point [5 0 0], target [10 0 -10], pscale 1e5, weights 1e-2/1e2,
-    measured at tEnd)."""
+    measured at tEnd).  bdf2: scene 101 'Adjoint BDF2' (:437-471), the same chain with a TaskBDF2PointPos whose target is
+    [-10 0 -10]."""
     scene = Scene()
-    scene.name = "Adjoint BDF1" if n == 2 else "Adjoint BDF1, %d links" % n
+    tag = "Adjoint BDF2" if bdf2 else "Adjoint BDF1"
+    scene.name = tag if n == 2 else "%s, %d links" % (tag, n)
     for i in range(n):
         scene.bodies.append(BodyCuboid(1.0, [10, 1, 1]))
         parent = scene.joints[i - 1] if i else None
@@ -262,7 +266,7 @@ def sceneAdjointChain(n=2):
         j.setDamping(1e4)
         scene.joints.append(j)
         scene.bodies[-1].setBodyTransform(_T([5, 0, 0]))
-    scene.task = {"body": n - 1, "xlocal": [5.0, 0.0, 0.0], "xtarget": [10.0, 0.0, -10.0], "t": scene.tEnd,
+    scene.task = {"body": n - 1, "xlocal": [5.0, 0.0, 0.0], "xtarget": [-10.0 if bdf2 else 10.0, 0.0, -10.0], "t": scene.tEnd,
                   "pscale": 1e5, "wreg": 1e-2, "wpos": 1e2}
     return scene
 

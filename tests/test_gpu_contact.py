@@ -173,9 +173,11 @@ def test_hand_over_from_free_flight_to_contact(oracle_lib, integ):
 @pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
 def test_contact_on_a_tree_of_more_than_32_nodes(oracle_lib, integ):
     """40-link chain over the ground: the 64-lane kernels.  Their Hessian stage has two forms - matrix cores with H left in LDS for
-    the block-column solve (plain evaluation: the lean launch, and the contact launch while nothing touches) and the v_readlane
-    columns with the rows handed over in registers (contact terms) - and a rollout that swings into the ground goes through all
-    of them: single evaluations with penetrating corners, then 120 steps from above the ground, against the oracle."""
+    the block-column solve (the evaluation without contact terms: the lean launch) and the v_readlane columns with the rows handed
+    over in registers (the launch with the contact terms, whether or not a corner touches at an iterate) - and a rollout that
+    swings into the ground, bounces and lifts off again goes through all of them: single evaluations with penetrating corners, then
+    120 steps from above the ground, against the oracle.  No solve may fall back to partial pivoting (status bit 16: a solve that
+    eliminated anything but H would trip the growth guard) and the Newton iteration counts must be the oracle's."""
     from redmax_amd import BatchSim
     sc = sceneChainGround(40, ground_z=-1.0)
     sc.init()
@@ -195,6 +197,7 @@ def test_contact_on_a_tree_of_more_than_32_nodes(oracle_lib, integ):
     out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(nsteps, h=sc.h, stats=True, history=True)
     q, qd = sim.get_state()
     assert np.all(out["status"] & 5 == 0)
+    assert np.all(out["status"] & 16 == 0), out["status"]
     for b in range(B):
         o = oracle_lib.Oracle(sc.desc())
         o.set_state(q0[b], qd0[b])
@@ -203,6 +206,8 @@ def test_contact_on_a_tree_of_more_than_32_nodes(oracle_lib, integ):
         assert st.diverged == 0
         stalled = st.not_converged > 0
         assert bool(out["status"][b] & 2) == stalled
+        if not stalled:
+            assert abs(int(out["newton_iters"][b]) - st.newton_iters) <= max(2, 0.02 * st.newton_iters), (b, out["newton_iters"][b], st.newton_iters)
         assert Vo.max() - Vo.min() > 1e2                      # the chain did reach the ground
         tolq = 1e-5 if stalled else 1e-7
         assert _rel(q[b], qo) <= tolq and _rel(qd[b], qdo) <= 10 * tolq

@@ -319,6 +319,85 @@ def test_adjoint_bdf1_matches_oracle(oracle_lib, n):
         assert info["newton_iters"][b] == st.newton_iters
 
 
+def test_adjoint_scene100_at_its_own_horizon(oracle_lib):
+    """The reference's own adjoint scene (scene 100, scenesRedMax.m:402-436: 2 links, tEnd = 1, h = 1e-2) for its full 100 steps:
+    forward + backward sweep against the oracle (P, dP/dp, final state, Newton counts), and the reference's testGrad identity
+    (driverRedMaxAdjointBDF1.m:46-61: central differences of P against dPdp . direction) on the device."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import scenesRedMax
+    sc = scenesRedMax(100)
+    sc.init()
+    nsteps = int(round(sc.tEnd / sc.h))
+    assert nsteps == 100 and sc.nr == 2
+    B = 6
+    rng = np.random.default_rng(100)
+    p = 0.1 * rng.standard_normal((B, sc.nr))
+    p[0] = 0.0                                   # p0 = zeros(scene.task.np, 1) (:24)
+    sim = BatchSim(sc, batch=B)
+    q0, qd0 = sc.getQ()
+    sim.set_state(q0[None, :], qd0[None, :])
+    P, dPdp, info = sim.adjoint_bdf1(nsteps, sc.h, sc.task, p, stats=True)
+    assert (info["status"] == 0).all()
+    qg, _ = sim.get_state()
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        Po, dPo, st = o.adjoint_bdf1(sc.h, nsteps, sc.task, p[b])
+        qo, _ = o.get_state()
+        assert st.not_converged == 0 and st.diverged == 0
+        assert _rel(qg[b], qo) <= 1e-9 and abs(P[b] - Po) <= 1e-9 * abs(Po) and _rel(dPdp[b], dPo) <= 1e-7, (b, P[b], Po)
+        assert info["newton_iters"][b] == st.newton_iters
+    nd, eps = 3, 1e-5
+    d = rng.standard_normal((nd, sc.nr))
+    pp = np.repeat(p[1:2], 2 * nd, axis=0)
+    pp[0::2] += eps * d
+    pp[1::2] -= eps * d
+    fd = BatchSim(sc, batch=2 * nd)
+    fd.set_state(q0[None, :], qd0[None, :])
+    Pf, _, _ = fd.adjoint_bdf1(nsteps, sc.h, sc.task, pp)
+    num, ana = (Pf[0::2] - Pf[1::2]) / (2 * eps), d @ dPdp[1]
+    assert np.allclose(num, ana, rtol=2e-5, atol=1e-6 * np.abs(ana).max()), (num, ana)
+
+
+@pytest.mark.parametrize("n,nsteps", [(2, 100), (5, 20), (16, 10)])
+def test_adjoint_bdf2_matches_oracle(oracle_lib, n, nsteps):
+    """driverRedMaxAdjointBDF2 / TaskBDF2 / TaskBDF2PointPos (scene 101, scenesRedMax.m:437-471, at its own 100-step horizon, and its
+    n-link forms): SDIRK2 start step + BDF2 forward, four-block backward sweep - P, dP/dp, the final state and the Newton counts
+    against the oracle's literal restatement (tests/test_oracle_adjoint.py pins that one by the reference's FD identity)."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneAdjointChain, scenesRedMax
+    sc = scenesRedMax(101) if n == 2 else sceneAdjointChain(n, bdf2=True)
+    sc.init()
+    B = 4
+    rng = np.random.default_rng(19)
+    p = 0.1 * rng.standard_normal((B, sc.nr))
+    p[0] = 0.0
+    task = dict(sc.task, t=nsteps * sc.h)
+    sim = BatchSim(sc, batch=B)
+    q0, qd0 = sc.getQ()
+    sim.set_state(q0[None, :], qd0[None, :])
+    P, dPdp, info = sim.adjoint_bdf2(nsteps, sc.h, task, p, stats=True)
+    assert (info["status"] == 0).all()
+    qg, qdg = sim.get_state()
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        Po, dPo, st = o.adjoint_bdf2(sc.h, nsteps, task, p[b])
+        qo, qdo = o.get_state()
+        assert st.not_converged == 0 and st.diverged == 0
+        assert _rel(qg[b], qo) <= 1e-9 and _rel(qdg[b], qdo) <= 1e-7, (n, b, _rel(qg[b], qo))
+        assert abs(P[b] - Po) <= 1e-9 * abs(Po), (n, b, P[b], Po)
+        assert _rel(dPdp[b], dPo) <= 1e-7, (n, b, _rel(dPdp[b], dPo))
+        assert info["newton_iters"][b] == st.newton_iters
+    # the rollout leaves the BDF2 history in place: two more BDF2 steps continue it exactly as the oracle's integrator does
+    sim.step_bdf2(2, h=sc.h)
+    q2, _ = sim.get_state()
+    o = oracle_lib.Oracle(sc.desc())
+    o.adjoint_bdf2(sc.h, nsteps, task, p[1])
+    # (the oracle's adjoint leaves tau = 0 behind, so does the library: rmx_adjoint_* applies the torques inside the call only)
+    o.step_bdf2(sc.h, 2, step0=nsteps)
+    qo2, _ = o.get_state()
+    assert _rel(q2[1], qo2) <= 1e-8, _rel(q2[1], qo2)
+
+
 @pytest.mark.parametrize("name,integ", [("2", "bdf1"), ("chain32", "bdf1"), ("3", "bdf2")])
 def test_per_step_trajectory_matches_oracle(oracle_lib, name, integ):
     """rmx_step_history (Scene.saveHistory, Scene.m:134-161): q and qdot after EVERY step vs the oracle stepped one step at a
