@@ -47,24 +47,38 @@ METRIC = "sim steps/sec (whole node), 1024-batch 32-DOF chain BDF1; q L2 err vs 
 # recursion), so this figure is reported as `algorithmic_equiv_tflops`, NOT as the roofline fraction.
 F_G, F_H, F_LU = 363712, 1418432, 23893
 
-# EXECUTED work of k_step_bdf1<32,false>, per wavefront (= per rollout), split by stage.  Calibrated from the SQ instruction
-# counters of the profiled bench command (separate rocprofv3 --pmc passes, profiles/r02n_pmc_*.csv; r02a, r02g before) by
-# tools/roofline_from_pmc.py: counts(launch) = front_evals * FRONT + newton_iters * NEWTON, fitted on two launches with
-# different iterations-per-step mixes.  flops = 64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 512 x MFMA_MOPS_F64: what the
-# SIMD spent, idle lanes included (a wave-wide instruction costs its issue slots whatever the EXEC mask says).
-EXEC = {
-    "profile": "profiles/r02n_pmc_f64.csv + r02n_pmc_f64_tol3.csv -> profiles/r02n_roofline_calibration.json (tools/roofline_from_pmc.py)",
-    "flops_front": 66945.0,     # one eval_front: 184 ADD + 182 MUL + 340 FMA fp64 wave-instructions (x 64 lanes)
-    "flops_newton": 148351.0,   # eval_hess + LU + norms: 42 ADD + 212 MUL + 792 FMA + 60 MFMA MOPS (15 v_mfma_f64_16x16x4_f64)
-    "valu_front": 1221.4,       # VALU wave-instructions of any kind (SQ_INSTS_VALU); 1345.3 / 1935.7 before the guard updates
-    "valu_newton": 1942.6,      # of the solve were pinned (fewer v_accvgpr moves around the front)
-}
+# EXECUTED work of the headline kernel k_step_bdf1<32,false,false,true> (the FULLCHAIN instantiation), per wavefront (= per rollout),
+# split by stage: profiles/roofline_calibration.json, produced by tools/roofline_from_pmc.py from the SQ instruction counters of the
+# profiled bench command (separate rocprofv3 --pmc passes): counts(launch) = front_evals * FRONT + newton_iters * NEWTON, fitted on
+# two launches with different iterations-per-step mixes.  flops = 64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 512 x MFMA_MOPS_F64:
+# what the SIMD spent, idle lanes included.  The file also holds the static FINGERPRINT of the kernel it was measured on (instruction
+# counts per class + a hash of the opcode sequence, tools/isa_blocks.py); __graft_entry__.build() writes the fingerprint of the code
+# it has just compiled next to the library.  If the two differ the calibration is stale: the roofline object then says so and carries
+# no achieved / frac (tests/test_host_logic.py and tests/test_gpu_bench_contract.py fail on it).
+CALIBRATION_FILE = os.path.join(ROOT, "profiles", "roofline_calibration.json")
+FINGERPRINT_FILE = os.path.join(ROOT, "redmax_amd", "kernel_fingerprint.json")
+
+
+def load_calibration():
+    """(calibration dict, stale reason or None)"""
+    try:
+        cal = json.load(open(CALIBRATION_FILE))
+    except (OSError, ValueError) as e:
+        return None, "no calibration file (%s)" % e
+    try:
+        fp = json.load(open(FINGERPRINT_FILE))
+    except (OSError, ValueError) as e:
+        return cal, "the library carries no kernel fingerprint (%s): run __graft_entry__.build()" % e
+    want = cal.get("fingerprint", {})
+    if fp.get("opcode_sha16") != want.get("opcode_sha16") or fp.get("classes") != want.get("classes"):
+        return cal, ("calibrated on opcode_sha16 %s, the built kernel is %s: re-run tools/gpu_session.sh <tag> pmc and "
+                     "tools/roofline_from_pmc.py" % (want.get("opcode_sha16"), fp.get("opcode_sha16")))
+    return cal, None
+
+
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the microarch guide has no fp64 row)
 SHADER_CLOCK_GHZ = 2.4    # max clock (guide); the effective clock under load is lower, so cycle counts below are upper bounds
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
-# HBM bytes per launch from the TCC counters (separate FETCH_SIZE / WRITE_SIZE passes, profiles/r02n_pmc_fetch.csv,
-# r02n_pmc_write.csv, KB as rocprofv3 reports them; 891.1 + 608.0 in r02a).  The state is read once and written once per LAUNCH whatever K is.
-HBM_FETCH_KB, HBM_WRITE_KB = 850.1, 608.0      # K=100; K=20: 808.8 + 608.0
 
 
 def _free_port():
@@ -302,45 +316,54 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
 
 
 def roofline(m, K, B_local, world, n, wl):
-    """Executed-work roofline of k_step_bdf1<32,false> for one rank's launch (rank 0's counters stand for all: identical work
+    """Executed-work roofline of the headline kernel for one rank's launch (rank 0's counters stand for all: identical work
     distribution by construction)."""
     if wl != "chain" or n != 32 or m["kernel_ms"] <= 0:
         return None
+    cal, stale = load_calibration()
     iters_rank, halv_rank = m["iters"] / world, m["halvings"] / world
     steps_rank = B_local * K
     fronts = steps_rank + iters_rank + halv_rank          # one per step (initial guess) + one per line-search trial
     sec = m["kernel_ms"] * 1e-3
-    flops = fronts * EXEC["flops_front"] + iters_rank * EXEC["flops_newton"]
-    ach = flops / sec / 1e12
     alg = (iters_rank * (F_H + F_LU) + (iters_rank + halv_rank) * F_G) / sec / 1e12
-    # issue-bound ceiling: a lone wavefront per SIMD issues at most one VALU instruction per 4 cycles (fp64: 16 lanes/clk/SIMD)
-    valu_wave = (fronts * EXEC["valu_front"] + iters_rank * EXEC["valu_newton"]) / B_local      # per wave (mean)
+    out = {"bound": "valu-issue", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+           "kernel": "k_step_bdf1<32,false,false,true>", "kernel_ms": round(m["kernel_ms"], 4),
+           "newton_iters_per_step": round(iters_rank / steps_rank, 3), "ls_halvings_per_step": round(halv_rank / steps_rank, 4),
+           "front_evals": fronts, "newton_iters": iters_rank, "algorithmic_equiv_tflops": round(alg, 2)}
+    if cal is None or stale:
+        out["calibration_stale"] = stale
+        return out
+    ex = cal["per_wave"]
+    flops = fronts * ex["flops"]["front"] + iters_rank * ex["flops"]["newton"]
+    ach = flops / sec / 1e12
+    # issue-bound ceiling: the fp64 pipe takes one wave-wide instruction per 4 cycles (16 lanes / clk / SIMD)
+    valu_wave = (fronts * ex["SQ_INSTS_VALU"]["front"] + iters_rank * ex["SQ_INSTS_VALU"]["newton"]) / B_local      # per wave (mean)
     slowest = float(m["local_iters"].max()) / max(float(m["local_iters"].mean()), 1.0)          # the launch ends with its slowest wave
     cycles = sec * SHADER_CLOCK_GHZ * 1e9
-    return {
-        "bound": "valu-issue", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 4),
-        "traffic": int((HBM_FETCH_KB + HBM_WRITE_KB) * 1024),
-        "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): %.1f KB + %.1f KB for "
-                        "1024 rollouts; the state is read once and written once per LAUNCH, so the figure holds for any --steps "
-                        "(profiled at K=100 and K=20); algorithmic = 1 MiB (q, qdot in + out).  Reported at face value: the guide's "
-                        "x2 FETCH correction is calibrated for 16 B/lane streams, this kernel reads 8 B/lane once" % (HBM_FETCH_KB, HBM_WRITE_KB),
-        "kernel": "k_step_bdf1<32,false>", "kernel_ms": round(m["kernel_ms"], 4),
-        "executed_flops_per_front_eval": EXEC["flops_front"], "executed_flops_per_newton_iter": EXEC["flops_newton"],
-        "calibration": EXEC["profile"],
+    hb = cal.get("hbm_kb_per_launch", {})
+    out.update({
+        "achieved": round(ach, 3), "frac": round(ach / FP64_PEAK_TFLOPS, 4),
+        "traffic": int((hb["fetch"] + hb["write"]) * 1024) if hb else None,
+        "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): %.1f KB + %.1f KB for 1024 rollouts; "
+                        "the state is read once and written once per LAUNCH, so the figure holds for any --steps; algorithmic = 1 MiB (q, qdot in + "
+                        "out).  Reported at face value: the guide's x2 FETCH correction is calibrated for 16 B/lane streams, this kernel reads 8 B/lane "
+                        "once" % (hb.get("fetch", 0.0), hb.get("write", 0.0)) if hb else None,
+        "executed_flops_per_front_eval": round(ex["flops"]["front"], 1), "executed_flops_per_newton_iter": round(ex["flops"]["newton"], 1),
+        "valu_insts_per_front_eval": round(ex["SQ_INSTS_VALU"]["front"], 1), "valu_insts_per_newton_iter_beyond_its_front": round(ex["SQ_INSTS_VALU"]["newton"], 1),
+        "calibration": cal.get("source", CALIBRATION_FILE), "kernel_opcode_sha16": cal["fingerprint"]["opcode_sha16"],
         "issue_bound": {"valu_insts_per_wave": round(valu_wave, 1), "cycles_at_4_per_inst": round(4.0 * valu_wave * slowest, 1),
                         "kernel_cycles_at_%.1fGHz" % SHADER_CLOCK_GHZ: round(cycles, 1),
                         "frac": round(4.0 * valu_wave * slowest / cycles, 4),
-                        "note": "one wavefront per SIMD (490 VGPRs, 1024 rollouts on 1024 SIMDs): the kernel is bound by the issue "
-                                "rate of a single wave (<= 1 VALU instruction / 4 cycles for fp64), not by fp64 throughput; "
-                                "frac = (VALU instructions of the slowest wave x 4 cycles) / kernel cycles"},
-        "algorithmic_equiv_tflops": round(alg, 2),
-        "newton_iters_per_step": round(iters_rank / steps_rank, 3), "ls_halvings_per_step": round(halv_rank / steps_rank, 4),
+                        "note": "one wavefront per SIMD (1024 rollouts on 1024 SIMDs): a lone wavefront issues one VALU instruction per ~8 "
+                                "cycles (tools/ubench2.hip: 6.0 ticks per independent v_fma_f64 alone, 4.0 with two waves per SIMD), the fp64 pipe "
+                                "could take one per 4; frac = (VALU instructions of the slowest wave x 4 cycles) / kernel cycles"},
         "note": "achieved = EXECUTED fp64 flops (per-stage counts calibrated on the SQ_INSTS_VALU_*_F64 / MFMA_MOPS_F64 counters x the "
                 "measured front-evaluation and Newton-iteration counts of THIS launch) / kernel time measured with HIP events on "
-                "the kernel's stream; peak = 78.6 TF (fp64 vector = fp64 matrix on MI355X).  algorithmic_equiv_tflops is the "
-                "SURVEY.md §8(d) contract figure (flops a J/dJdq-based evaluation would need x measured counts / time): it exceeds "
-                "the peak because the kernel executes ~10x fewer flops than that formulation, and is not a utilisation",
-    }
+                "the kernel's stream; peak = 78.6 TF (fp64 vector = fp64 matrix on MI355X); bound = issue rate of a lone wavefront, not a "
+                "pipe.  algorithmic_equiv_tflops is the SURVEY.md 8(d) contract figure (flops a J/dJdq-based evaluation would need x measured "
+                "counts / time): it exceeds the peak because the kernel executes ~10x fewer flops than that formulation, and is not a utilisation",
+    })
+    return out
 
 
 def rank_main(args, make_stepper=None, backend=None):
@@ -489,9 +512,10 @@ def cpu_baselines(scene, args, h):
     q, qd = syntheticStates(scene.nr, nb)
     desc = scene.desc()
 
-    def gpu_counts(K):
+    def gpu_counts(K, tol=None):
         sim = BatchSim(scene, batch=nb)
-        sim.opts.tol = args.tol
+        sim.opts.tol = args.tol if tol is None else tol
+        sim.opts.compensated = 0 if args.plain_iterate else 1
         sim.set_state(q, qd)
         per = np.zeros((K, nb), dtype=np.int64)
         for s in range(K):
@@ -516,6 +540,18 @@ def cpu_baselines(scene, args, h):
         dt += time.perf_counter() - t0
         per_o[s] = c["newton_iters"]
     orc.set_newton()
+    # ---- Newton counts against the literal port above the lattice of doubles (tol 1e-8): at the reference's 1e-9 the literal port's last
+    # iterations of a step wander over lattice points, so its counts are path dependent there
+    per_o8 = per_g8 = None
+    if args.tol < 1e-8:
+        k8 = min(ks, 10)
+        orc.set_newton(tol=1e-8)
+        q8, qd8 = np.ascontiguousarray(q.copy()), np.ascontiguousarray(qd.copy())
+        per_o8 = np.zeros((k8, nb), dtype=np.int64)
+        for s in range(k8):
+            per_o8[s] = orc.batch_step_bdf1(desc, q8, qd8, h, 1, nthreads=cores, counters=True)["newton_iters"]
+        orc.set_newton()
+        per_g8, _ = gpu_counts(k8, tol=1e-8)
     # ---- tensor-free: the full 100 steps; whole-rollout calls repeated for ~5 s give the timing, one per-step pass the counts
     kt = 100
     reps, dtt = 0, 0.0

@@ -82,3 +82,24 @@ def test_benchmark_scenes_shapes():
     assert len(t.joints) == 64 and t.nr == 64
     types = {j.jtype for j in t.joints}
     assert types == {1, 2}
+
+
+def test_roofline_calibration_matches_the_built_kernel():
+    """bench.py's roofline multiplies per-stage executed-instruction counts (profiles/roofline_calibration.json, measured with the SQ
+    counters) by the iteration counts of the timed launch.  Those counts belong to ONE build of the headline kernel: the calibration
+    file stores that build's static fingerprint, __graft_entry__.build() writes the fingerprint of the code it compiled next to the
+    library, and a kernel change without a fresh calibration fails here (and leaves bench.py's roofline without achieved / frac)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import __graft_entry__ as ge
+    ge.build()
+    cal, stale = bench.load_calibration()
+    assert cal is not None and stale is None, stale
+    assert cal["fingerprint"] == json.load(open(bench.FINGERPRINT_FILE))
+    for k in ("flops", "SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
+        assert cal["per_wave"][k]["front"] >= 0 and cal["per_wave"][k]["newton"] > 0
+    assert abs(cal["per_wave"]["SQ_INSTS_VALU_MFMA_MOPS_F64"]["newton"] - 60.0) < 0.5      # 15 v_mfma_f64_16x16x4_f64 per Newton iteration

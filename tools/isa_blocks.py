@@ -26,6 +26,31 @@ def cls(s):
     return 'other'
 
 
+def kernel_instructions(path, prefix):
+    """the instruction lines (labels, comments and directives dropped) of the first function whose mangled name starts with prefix"""
+    lines = open(path).read().split('\n')
+    start = [i for i, l in enumerate(lines) if l.startswith(prefix) and (l.rstrip().endswith(':') or ': ;' in l)][0]
+    end = [i for i in range(start, len(lines)) if lines[i].strip().startswith('.Lfunc_end')][0]
+    out = []
+    for l in lines[start + 1:end]:
+        s = l.strip()
+        if not s or s.startswith((';', '.')) or re.match(r'^\.?LBB\d+_\d+:', s):
+            continue
+        out.append(s)
+    return out
+
+
+def fingerprint(path, prefix):
+    """Static identity of a kernel's machine code: instruction counts per class and a hash of the opcode sequence.  bench.py compares
+    the fingerprint of the library it runs (written by __graft_entry__.build()) with the one stored beside the roofline
+    calibration: per-stage executed-instruction counts are only valid for the code they were measured on."""
+    import hashlib
+    ins = kernel_instructions(path, prefix)
+    c = collections.Counter(cls(s) for s in ins)
+    h = hashlib.sha256("\n".join(s.split()[0] for s in ins).encode()).hexdigest()[:16]
+    return {"kernel": prefix, "instructions": len(ins), "classes": dict(sorted(c.items())), "opcode_sha16": h}
+
+
 def main():
     path, prefix = sys.argv[1], sys.argv[2]
     minsize = int(sys.argv[3]) if len(sys.argv) > 3 else 100
@@ -56,4 +81,5 @@ def main():
     print("TOTAL %d  %s" % (sum(tot.values()), ' '.join('%s=%d' % kv for kv in sorted(tot.items(), key=lambda kv: -kv[1]))))
 
 
-main()
+if __name__ == "__main__":
+    main()
