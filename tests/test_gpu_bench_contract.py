@@ -54,7 +54,9 @@ def test_default_workload_line():
     # (one differing step would already be 1.6 %), so the 99 % bar is applied to the 1600-step sample and to the full-size
     # checks in tests/test_gpu_soak.py; here the small sample must not differ in more than one step
     assert n["vs_tensor_free"]["frac"] >= 0.99
-    assert n["vs_oracle"]["trajectory_steps"] - n["vs_oracle"]["trajectory_steps_with_equal_count"] <= 1
+    o8 = n["vs_oracle_at_tol_1e-8"]
+    assert o8["trajectory_steps"] - o8["trajectory_steps_with_equal_count"] <= 1
+    assert n["vs_oracle"]["gpu_iters"] <= n["vs_oracle"]["cpu_iters"]      # at the reference's tol the literal port wanders over the lattice
     assert d["repeat"]["launches"] >= 6 and d["repeat"]["kernel_ms_min"] <= d["repeat"]["kernel_ms_median"]
     assert "strong_scaling" not in d          # one rank: weak and strong coincide
 
