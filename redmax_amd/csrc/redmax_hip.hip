@@ -360,6 +360,25 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
         if (e != hipSuccess) { (void)hipFree(m->dbuf); if (m->dsph) (void)hipFree(m->dsph); delete m; return fail(RMX_E_HIP, "spherical variant table"); }
         m->dm.sphV = (const double*)m->dsph;
     }
+    if (m->NP == 64 && nsph == 0) {
+        // Trees of 33..64 nodes: a second copy of the per-node constants, staged as the kernels read them, in global memory.  Batches
+        // of more than two rollouts per CU run the kernels that read it from there (33.8 KB of LDS per wavefront instead of 68.6 KB:
+        // four wavefronts per CU instead of two); RMX_GCONST_MIN in the environment moves the threshold (tests, measurements).
+        e = hipMalloc(&m->dgconst, sizeof(double) * (size_t)NCONST * cstride(64));
+        if (e == hipSuccess) {
+            launch_stage_consts_64(m, (double*)m->dgconst, nullptr);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (e != hipSuccess) {
+            std::string msg = std::string("staging the constants table: ") + hipGetErrorString(e);
+            rmx_model_destroy(m);
+            return fail(RMX_E_HIP, msg);
+        }
+        m->dm.gconst = (const double*)m->dgconst;
+        const char* thr = getenv("RMX_GCONST_MIN");
+        m->gconst_min_batch = thr ? atoi(thr) : (m->n_simd > 0 ? m->n_simd / 2 + 1 : 513);
+    }
     *out = m;
     return RMX_OK;
 }
@@ -477,6 +496,7 @@ extern "C" void rmx_model_destroy(rmx_model* m) {
     if (m->dbuf) (void)hipFree(m->dbuf);
     if (m->dcon) (void)hipFree(m->dcon);
     if (m->dsph) (void)hipFree(m->dsph);
+    if (m->dgconst) (void)hipFree(m->dgconst);
     delete m;
 }
 

@@ -25,8 +25,16 @@
 #ifndef RMX_SYNC
 #define RMX_SYNC() __syncthreads()
 #endif
+// RMX_GLOBAL_CONSTS (a translation unit compiled with it, rmx_kernels.hip RMX_PART 3): the per-node constants are NOT staged in LDS
+// but read from a table in global memory (DevModel::gconst, same [row][node] layout, L2-resident and shared by the whole batch).
+// A 64-lane tree needs 33.8 KB of scratch (H for the block-column solve) plus 34.8 KB of constants per wavefront: two wavefronts
+// per CU; without the constants four fit, and a batch of more than two rollouts per CU runs in half the time.
 #ifndef RMX_CONSTS
+#ifdef RMX_GLOBAL_CONSTS
+#define RMX_CONSTS(sAcc, n, NP) (M.gconst)
+#else
 #define RMX_CONSTS(sAcc, n, NP) ((sAcc) + acc_doubles((n), (NP)))
+#endif
 #endif
 
 namespace rmx {
@@ -87,6 +95,7 @@ struct DevModel {
     double gn[3], gx[3]; // plane normal (Z axis of the ground frame) and origin   ForceGroundCuboid.m:56-57
     double kn, kt, mu, kdc;   // setStiffness(kn, kt), setFriction(mu), setDamping(kd)
     // JointSpherical / JointFree3D: group g = nodes sph_first[g] .. +2 (revolute about the axes of the group's Euler chart)
+    const double* gconst;   // [NCONST][cstride(NP)] the per-node constants as smem_setup stages them, in global memory (RMX_GLOBAL_CONSTS)
     int nsph;
     const double* sphV;  // [nsph][3 nodes][3 axes][SPH_ROWS]  K and sb of each group node for axis x, y, z
     signed char sph_first[MAXSPH + 3];

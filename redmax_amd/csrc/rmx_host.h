@@ -58,6 +58,8 @@ struct rmx_model {
     DevModel dm{};
     size_t smem_bytes = 0;
     int n_simd = 0;                 // SIMDs of the device (4 per CU)
+    void* dgconst = nullptr;        // 64-lane plain models: the staged per-node constants in global memory (DevModel::gconst)
+    int gconst_min_batch = 0;       // batches of at least this many rollouts run the global-constants kernels (0: never)
 };
 
 struct rmx_batch {
@@ -90,6 +92,9 @@ struct rmx_batch {
     void RMX_CAT(launch_step_ct_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a); \
     void RMX_CAT(launch_energy_ct_, NPV)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV); \
     void RMX_CAT(launch_step_fullchain_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
+// 64-lane plain step kernels reading the per-node constants from global memory (rmx_kernels.hip RMX_PART 3) and the staging kernel
+void launch_step_gconst_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
+void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream);
 RMX_DECLARE_LAUNCHERS(4)
 RMX_DECLARE_LAUNCHERS(8)
 RMX_DECLARE_LAUNCHERS(16)

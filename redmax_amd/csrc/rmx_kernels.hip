@@ -13,17 +13,15 @@
 
 
 
+// the per-node constants in the layout the evaluation reads them in, [NCONST][cstride(NP)] (see eval_front_e2): into the wavefront's
+// LDS (smem_setup) or, once per model, into a global table (k_stage_consts for the RMX_GLOBAL_CONSTS kernels)
 template <int NP>
-__device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, double*& sCol) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    sAcc = smem;
-    sCol = smem + acc_doubles(M.n, NP);       // per-node constants, [NCONST][NP] (see eval_front_e2)
-    if (threadIdx.x < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + threadIdx.x] = 0.0;   // zero row n (end-of-tree suffix)
+__device__ __forceinline__ void stage_consts(const DevModel& M, double* __restrict__ dst) {
     constexpr int CS = cstride(NP);
     if (threadIdx.x < CS) {       // column NP (trees padded to < 64 lanes) and the unused node slots n..NP-1: idle defaults
         const int j = threadIdx.x;
         const bool in = j < M.n;
-        double* c = sCol;
+        double* c = dst;
         for (int r = 0; r < 36; ++r) c[r * CS + j] = in ? M.K[r * MAXN + j] : ((r == 0 || r == 4 || r == 8) ? 1.0 : 0.0);   // identity
         c += 36 * CS;
         for (int r = 0; r < 6; ++r) c[r * CS + j] = in ? M.sb[r * MAXN + j] : 0.0;
@@ -43,7 +41,25 @@ __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, dou
         c += CS;
         for (int r = 0; r < 4; ++r) c[r * CS + j] = (in && M.con) ? M.con[r * MAXN + j] : 0.0;
     }
+}
+
+template <int NP>
+__device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, double*& sCol) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    sAcc = smem;
+    if (threadIdx.x < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + threadIdx.x] = 0.0;   // zero row n (end-of-tree suffix)
+#ifdef RMX_GLOBAL_CONSTS
+    sCol = const_cast<double*>(M.gconst);     // read-only here: the kernels of this translation unit never switch Euler charts
+#else
+    sCol = smem + acc_doubles(M.n, NP);       // per-node constants, [NCONST][NP] (see eval_front_e2)
+    stage_consts<NP>(M, sCol);
+#endif
     __syncthreads();
+}
+
+template <int NP>
+__global__ void __launch_bounds__(64) k_stage_consts(const DevModel M, double* __restrict__ dst) {
+    stage_consts<NP>(M, dst);
 }
 
 // simLoop (driverRedMaxBDF1.m:57-91): all steps of one trajectory inside one wavefront.
@@ -66,7 +82,8 @@ __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
     return M;
 }
 
-template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false>
+// TAG: unused, it keeps the kernel names of a translation unit compiled with other macros (RMX_GLOBAL_CONSTS) distinct
+template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
 __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     const DevModel M = model_view<NP, FULLCHAIN>(Min);
@@ -131,7 +148,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevO
 }
 
 // simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.  CT / LEAN: see k_step_bdf1.
-template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false>
+template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
 __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     const DevModel M = model_view<NP, FULLCHAIN>(Min);
@@ -692,7 +709,19 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
         kernel<<<grid, block, bytes, stream>>>(__VA_ARGS__);                                                                        \
     } while (0)
 
-#if RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
+#if RMX_PART == 3      // 64-lane plain step kernels with the per-node constants in global memory (RMX_GLOBAL_CONSTS): four wavefronts per CU
+#ifndef RMX_GLOBAL_CONSTS
+#error "RMX_PART 3 is compiled with -DRMX_GLOBAL_CONSTS"
+#endif
+
+void RMX_CAT(launch_step_gconst_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    const size_t bytes = sizeof(double) * (size_t)acc_doubles(m->n, RMX_NP);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, 3>), grid, block, bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, 3>), grid, block, bytes, b->stream, m->dm, o, a);
+}
+
+#elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
 
 void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
@@ -738,6 +767,11 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
 #if RMX_NP >= 16 && !defined(RMX_NO_FULLCHAIN)      // (the macro: development aid, tools/build_variant.py)
     if (m->dm.is_chain && m->dm.n == RMX_NP) return RMX_CAT(launch_step_fullchain_, RMX_NP)(m, b, integ, o, a);
 #endif
+#if RMX_NP == 64
+    // More than two rollouts per CU: the kernels that read the per-node constants from global memory (33.8 KB of LDS per wavefront
+    // instead of 68.6 KB: four wavefronts per CU instead of two).  Up to two per CU the LDS-resident constants are faster (-7 %).
+    if (m->dm.gconst && m->gconst_min_batch > 0 && b->B >= m->gconst_min_batch) return launch_step_gconst_64(m, b, integ, o, a);
+#endif
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
@@ -768,6 +802,12 @@ void RMX_CAT(launch_mfd_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double
     const dim3 grid(b->B), block(64);
     RMX_LAUNCH((k_eval_mfd<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD);
 }
+
+#if RMX_NP == 64
+void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream) {
+    k_stage_consts<64><<<dim3(1), dim3(64), 0, stream>>>(m->dm, dst);
+}
+#endif
 
 void RMX_CAT(launch_phase_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d) {
     const dim3 grid(b->B), block(64);

@@ -162,3 +162,37 @@ def test_trees_of_33_to_64_nodes_match_oracle(oracle_lib):
             # doubles until |g| < tol is met; the compensated iterate converges without them
             ng, no = int(o0["newton_iters"][b]), st.newton_iters
             assert (no - 3 * K <= ng <= no) if "chain" in sc.name else ng == no, (sc.name, b, ng, no)
+
+
+def test_tree64_global_constants_kernels(oracle_lib, monkeypatch):
+    """Batches of more than two rollouts per CU run the 64-lane step kernels that read the per-node constants from global memory
+    instead of LDS (four wavefronts per CU instead of two; rmx_kernels.hip RMX_PART 3).  Same arithmetic on the same values: the
+    results must equal the LDS-constants kernels' (RMX_GCONST_MIN moves the threshold, read at model creation), BDF1 and BDF2, and
+    the oracle's."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneTree
+    sc = sceneTree(64)
+    sc.init()
+    B, K = 6, 8
+    q, qd = _tree_states(sc, B)
+    res = {}
+    for integ in ("bdf1", "bdf2"):
+        for thr in ("100000", "1"):          # never / always
+            monkeypatch.setenv("RMX_GCONST_MIN", thr)
+            sim = BatchSim(sc, batch=B)
+            sim.set_state(q, qd)
+            out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(K, h=1e-2, stats=True)
+            res[(integ, thr)] = (sim.get_state(), out)
+            sim.close()
+        (qa, qda), oa = res[(integ, "100000")]
+        (qb, qdb), ob = res[(integ, "1")]
+        assert (ob["status"] & 15 == 0).all() and np.array_equal(oa["newton_iters"], ob["newton_iters"])
+        assert _rel(qb, qa) <= 1e-13 and _rel(qdb, qda) <= 1e-11, (integ, _rel(qb, qa))
+    monkeypatch.delenv("RMX_GCONST_MIN")
+    (qb, _), ob = res[("bdf1", "1")]
+    for b in (0, B - 1):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        st = o.step_bdf1(1e-2, K)
+        qo, _ = o.get_state()
+        assert _rel(qb[b], qo) <= 1e-8 and int(ob["newton_iters"][b]) == st.newton_iters

@@ -30,7 +30,7 @@ def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC]
     ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if (a.part == 1 or a.np == 64) else []
-    if a.np == 32 and not a.no_vform:
+    if a.np >= 32 and not a.no_vform:
         ilp += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
     vdir = os.path.join(ROOT, "build", "variants")
     os.makedirs(vdir, exist_ok=True)
@@ -49,6 +49,7 @@ def main():
             if part == 2 and n < 16:
                 continue
             objs.append(obj if (n == a.np and part == a.part) else os.path.join(ge.OBJ_DIR, "rmx_kernels_np%d_p%d.o" % (n, part)))
+    objs.append(os.path.join(ge.OBJ_DIR, "rmx_kernels_np64_p3.o"))
     out = os.path.join(ROOT, "redmax_amd", "variants", "libredmax_hip_%s.so" % a.name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs)
     print(out)
