@@ -277,6 +277,10 @@ int rmx_sync(rmx_batch* b);
  * LU solve, the two norm reductions} of one Newton iteration at the current state (reps repetitions per trajectory)
  * in cycles16[0..3]; cycles16[4..15] split the residual+Hessian evaluation into its 12 stages (rmx_device.h RMX_STAMP). */
 int rmx_profile_phases(rmx_batch* b, int reps, double h, double* cycles16);
+/* Per-rollout share of the last rmx_step_bdf1 / bdf2 / history / bdf1_async launch: ticks[batch] = shader-clock ticks (s_memtime) each
+ * rollout's wavefront spent inside the kernel(s) of that call.  All rollouts of a batch run concurrently (one wavefront each) and the
+ * launch ends with the slowest: the distribution (median, 99th percentile, maximum) says how much of the launch time is its tail. */
+int rmx_step_ticks(rmx_batch* b, unsigned long long* ticks);
 int rmx_stats_reset(rmx_batch* b);
 int rmx_stats_read(rmx_batch* b, rmx_stats* stats);
 

@@ -395,6 +395,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nrhs < 3 || !mxIsInt32(prhs[2]) || mxGetNumberOfElements(prhs[2]) != (size_t)h->nsph * (size_t)h->B)
             die("charts must be an int32 nsph x batch array");
         if (h->nsph && rmx_set_charts(h->b, (const int*)mxGetData(prhs[2]))) die_rmx("rmx_set_charts");
+    } else if (!strcmp(cmd, "ticks")) {      /* t = redmax_hip_mex('ticks', h): per-rollout share of the last step launch (rmx_step_ticks) */
+        handle_t* h = get_handle(nrhs, prhs);
+        unsigned long long* t = (unsigned long long*)mxCalloc((size_t)h->B, sizeof *t);
+        if (rmx_step_ticks(h->b, t)) { mxFree(t); die_rmx("rmx_step_ticks"); }
+        mxArray* out = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);
+        for (int i = 0; i < h->B; ++i) mxGetPr(out)[i] = (double)t[i];
+        mxFree(t);
+        plhs[0] = out;
     } else if (!strcmp(cmd, "adjoint")) {
         cmd_adjoint(nlhs, plhs, nrhs, prhs);
     } else {

@@ -25,7 +25,7 @@ SYMBOLS = (
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
     "rmx_eval", "rmx_eval_mfd", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_history", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_adjoint_bdf2", "rmx_energy",
     "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_sync",
-    "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases",
+    "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases", "rmx_step_ticks",
 )
 
 
@@ -110,6 +110,7 @@ def lib():
     L.rmx_step_euler.argtypes = [vp, C.c_double, C.c_int, _dp, _dp]
     L.rmx_adjoint_bdf1.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(TaskPointPos), _dp, _dp, _dp, C.POINTER(Stats)]
     L.rmx_adjoint_bdf2.argtypes = L.rmx_adjoint_bdf1.argtypes
+    L.rmx_step_ticks.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.rmx_energy.argtypes = [vp, _dp, _dp]
     L.rmx_last_step_ms.argtypes = [vp]
     L.rmx_last_step_ms.restype = C.c_double

@@ -203,6 +203,12 @@ class BatchSim:
         info["ms"] = self._L.rmx_last_step_ms(self._batch)
         return P, dPdp, info
 
+    def step_ticks(self):
+        """Shader-clock ticks each rollout's wavefront spent in the kernel(s) of the last step call (rmx_step_ticks): [B] uint64."""
+        t = np.zeros(self.B, dtype=np.uint64)
+        _abi.check(self._L.rmx_step_ticks(self._batch, t.ctypes.data_as(C.POINTER(C.c_ulonglong))), "rmx_step_ticks")
+        return t
+
     def step_bdf1_async(self, nsteps, h=None):
         if h is not None:
             self.opts.h = float(h)

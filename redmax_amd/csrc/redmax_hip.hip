@@ -564,6 +564,7 @@ extern "C" int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out) {
     alloc((void**)&b->started, sizeof(int));
     alloc((void**)&b->it, sizeof(int) * batch); alloc((void**)&b->ls, sizeof(int) * batch); alloc((void**)&b->status, sizeof(int) * batch);
     alloc((void**)&b->resume, sizeof(int) * batch);
+    alloc((void**)&b->ticks, sizeof(unsigned long long) * batch);
     if (m->dm.nsph) {   // every JointSpherical starts in CHART_XYZ (JointSpherical.m:33)
         const std::vector<int> c7((size_t)batch * m->dm.nsph, 7);
         if (e == hipSuccess) e = hipMalloc((void**)&b->chart, c7.size() * sizeof(int));
@@ -586,7 +587,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     (void)hipSetDevice(b->m->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart, (void*)b->ticks})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -741,8 +742,10 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.histQ = dQ; a.histQd = dQd; a.histC = dC;
     a.chart = b->chart;
     a.resume = b->resume;
+    a.ticks = b->ticks;
     rc = pending_error_check(b, "rmx_step");
     if (rc) return rc;
+    HIPCHK(hipMemsetAsync(b->ticks, 0, sizeof(unsigned long long) * b->B, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
     // BDF2 keeps (q, qdot) of step k-1 in qp/qdp.  BDF1 steps do not maintain them (and, with JointSpherical, may leave q in
@@ -974,6 +977,16 @@ extern "C" int rmx_stats_read(rmx_batch* b, rmx_stats* st) {
     HIPCHK(hipStreamSynchronize(b->stream));
     return RMX_OK;
 }
+// How the time of the last rmx_step_* launch was spread over the rollouts: shader-clock ticks (s_memtime) every rollout's wavefront
+// spent inside the kernel(s).  A launch ends with its slowest rollout; this is the per-rollout distribution behind that.
+extern "C" int rmx_step_ticks(rmx_batch* b, unsigned long long* ticks) {
+    if (!b || !ticks) return fail(RMX_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(b->m->device));
+    HIPCHK(hipMemcpyAsync(ticks, b->ticks, sizeof(unsigned long long) * b->B, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RMX_OK;
+}
+
 extern "C" int rmx_sync(rmx_batch* b) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     HIPCHK(hipSetDevice(b->m->device));

@@ -31,6 +31,7 @@ struct StepArgs {
     double* histQd;
     int* histC;       // [nsteps][B][nsph] or null: Euler charts after every step
     int* resume;      // [B] contact-capable kernels: first step the lean launch left to the launch with the contact terms
+    unsigned long long* ticks;   // [B] or null: s_memtime ticks each rollout's wavefront spent in the launch(es) of this call (accumulated)
 };
 
 struct AdjArgs {
@@ -73,6 +74,7 @@ struct rmx_batch {
     int* chart = nullptr;           // [B][nsph] current Euler chart of every spherical joint (JointSpherical.chart), 1..12
     int *it = nullptr, *ls = nullptr, *status = nullptr;
     int* resume = nullptr;          // [B] see StepArgs.resume
+    unsigned long long* ticks = nullptr;   // [B] see StepArgs.ticks (rmx_step_ticks)
     double last_ms = 0.0;
     bool async_pending = false;     // an rmx_step_bdf1_async launch nobody has waited for yet (see pending_error_check)
 };

@@ -87,6 +87,7 @@ template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 
 __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     const DevModel M = model_view<NP, FULLCHAIN>(Min);
+    const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
     const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
     if (s0 >= a.nsteps) return;                    // the lean launch took this trajectory all the way
     double *sAcc, *sCol;
@@ -145,6 +146,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevO
         a.ls[traj] += halv;
         a.status[traj] |= status;
     }
+    if (lane == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
 }
 
 // simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.  CT / LEAN: see k_step_bdf1.
@@ -152,6 +154,7 @@ template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 
 __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     const DevModel M = model_view<NP, FULLCHAIN>(Min);
+    const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
     const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
     if (s0 >= a.nsteps) return;
     double *sAcc, *sCol;
@@ -249,6 +252,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevO
         a.ls[traj] += halv;
         a.status[traj] |= status;
     }
+    if (lane == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
 }
 
 // euler (matlab-simple/testRedMax.m:67-109), BASELINE.json configs[0]: linearly-implicit Euler,
