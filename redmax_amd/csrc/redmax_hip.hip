@@ -125,9 +125,16 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     if (ndev <= 0) return fail(RMX_E_NODEVICE, "no HIP device visible: redmax_hip has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(RMX_E_INVALID, "device index out of range");
     const int n = d->njoints;
-    if (n < 1 || n > MAXN) return fail(RMX_E_INVALID, "njoints must be in [1," + std::to_string(MAXN) + "] (one wavefront per tree)");
+    if (n < 1 || n > BIG_MAXN)
+        return fail(RMX_E_INVALID, "the scene needs " + std::to_string(n) + " 1-DOF nodes; the limit is " + std::to_string(BIG_MAXN) +
+                                       " (up to " + std::to_string(MAXN) + ": one wavefront per tree; beyond: one workgroup per tree)");
     if (!d->parent || !d->type || !d->axis || !d->E0_pj || !d->E0_ji || !d->I_i)
         return fail(RMX_E_INVALID, "parent/type/axis/E0_pj/E0_ji/I_i are required");
+    // node stride of the SoA constant arrays and rows of the ancestor table: the one-wavefront kernels (n <= 64) and the
+    // one-workgroup kernels for larger trees (rmx_big.hip)
+    const bool big = n > MAXN;
+    const int NS = big ? BIG_MAXN : MAXN;
+    const int NROUNDS = big ? BIG_MAXROUNDS : MAXROUNDS;
     // ---- validate the listing: exactly one root first, parents before children (Scene.m:66-67)
     for (int i = 0; i < n; ++i) {
         if (d->type[i] < 0 || d->type[i] > 2) return fail(RMX_E_INVALID, "unsupported joint type");
@@ -172,6 +179,7 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     }
     int rounds = 0;
     while ((1 << rounds) < maxdepth + 1) ++rounds;
+    if (rounds > NROUNDS) return fail(RMX_E_INVALID, "tree too deep");
 
     // constants of listed joint L for joint type jtype about axis_in: Kc[36] = rows R(9),p(3) of K0,K1,K2 ; sbc[6] = A0_ij S
     auto joint_consts = [&](const int L, const int jtype, const double* axis_in, double* Kc, double* sbc) -> bool {
@@ -253,9 +261,9 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
         return true;
     };
     // ---- constants per node
-    std::vector<double> K(36 * MAXN, 0.0), sb(6 * MAXN, 0.0), I4(4 * MAXN, 0.0), prm(8 * MAXN, 0.0);
-    std::vector<int> type(MAXN, 0), idx(MAXN, -1), endd(MAXN, 0), anc(MAXROUNDS * MAXN, -1);
-    std::vector<unsigned long long> rel(2 * MAXN, 0ull);
+    std::vector<double> K(36 * NS, 0.0), sb(6 * NS, 0.0), I4(4 * NS, 0.0), prm(8 * NS, 0.0);
+    std::vector<int> type(NS, 0), idx(NS, -1), endd(NS, 0), anc(NROUNDS * NS, -1);
+    std::vector<unsigned long long> rel(2 * MAXN, 0ull);      // relation bit masks: trees of up to 64 nodes only
     for (int k = 0; k < n; ++k) {
         const int L = order[k];
         type[k] = d->type[L];
@@ -267,36 +275,38 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
             std::vector<int> chain;   // chain[t] = ancestor t+1 levels up
             for (int t = par[k]; t >= 0; t = par[t]) {
                 chain.push_back(t);
-                rel[k] |= 1ull << t;            // t is a strict ancestor of k
-                rel[MAXN + t] |= 1ull << k;     // k is a strict descendant of t
+                if (!big) {
+                    rel[k] |= 1ull << t;            // t is a strict ancestor of k
+                    rel[MAXN + t] |= 1ull << k;     // k is a strict descendant of t
+                }
             }
-            for (int r = 0; r < MAXROUNDS; ++r) {
+            for (int r = 0; r < NROUNDS; ++r) {
                 int lv = 1 << r;
-                anc[r * MAXN + k] = (lv <= (int)chain.size()) ? chain[lv - 1] : -1;
+                anc[r * NS + k] = (lv <= (int)chain.size()) ? chain[lv - 1] : -1;
             }
         }
         (void)a;
         {
             double Kc[36], sbc[6];
             if (!joint_consts(L, type[k], d->axis + 3 * L, Kc, sbc)) return fail(RMX_E_INVALID, "zero joint axis");
-            for (int c = 0; c < 36; ++c) K[c * MAXN + k] = Kc[c];
-            for (int c = 0; c < 6; ++c) sb[c * MAXN + k] = sbc[c];
+            for (int c = 0; c < 36; ++c) K[c * NS + k] = Kc[c];
+            for (int c = 0; c < 6; ++c) sb[c * NS + k] = sbc[c];
         }
         // inertia: the reference allows a general diagonal, but mass entries must agree (Body.m:107 uses M_i(4,4))
         const double* Ii = d->I_i + 6 * L;
-        I4[0 * MAXN + k] = Ii[0];
-        I4[1 * MAXN + k] = Ii[1];
-        I4[2 * MAXN + k] = Ii[2];
-        I4[3 * MAXN + k] = Ii[3];
+        I4[0 * NS + k] = Ii[0];
+        I4[1 * NS + k] = Ii[1];
+        I4[2 * NS + k] = Ii[2];
+        I4[3 * NS + k] = Ii[3];
         if (Ii[3] != Ii[4] || Ii[3] != Ii[5]) return fail(RMX_E_INVALID, "I_i(4:6) must all equal the body mass");
-        prm[0 * MAXN + k] = d->tau ? d->tau[L] : 0.0;
-        prm[1 * MAXN + k] = d->stiffness ? d->stiffness[L] : 0.0;
-        prm[2 * MAXN + k] = d->damping ? d->damping[L] : 0.0;
-        prm[3 * MAXN + k] = d->qRest ? d->qRest[L] : 0.0;
-        prm[4 * MAXN + k] = d->qLimL ? d->qLimL[L] : -1e8;   // Joint.m:77-80 defaults
-        prm[5 * MAXN + k] = d->qLimU ? d->qLimU[L] : 1e8;
-        prm[6 * MAXN + k] = d->qLimK ? d->qLimK[L] : 1e8;
-        prm[7 * MAXN + k] = d->qLimD ? d->qLimD[L] : 0.0;
+        prm[0 * NS + k] = d->tau ? d->tau[L] : 0.0;
+        prm[1 * NS + k] = d->stiffness ? d->stiffness[L] : 0.0;
+        prm[2 * NS + k] = d->damping ? d->damping[L] : 0.0;
+        prm[3 * NS + k] = d->qRest ? d->qRest[L] : 0.0;
+        prm[4 * NS + k] = d->qLimL ? d->qLimL[L] : -1e8;   // Joint.m:77-80 defaults
+        prm[5 * NS + k] = d->qLimU ? d->qLimU[L] : 1e8;
+        prm[6 * NS + k] = d->qLimK ? d->qLimK[L] : 1e8;
+        prm[7 * NS + k] = d->qLimD ? d->qLimD[L] : 0.0;
     }
 
     // axis variants of the spherical group nodes: chart switches (JointSpherical.reparam_) swap them into LDS on the device
@@ -320,8 +330,9 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     m->nm = 6 * n;
     m->idx_listing = idxL;
     m->node_of_listing = pos;
-    m->NP = n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : 64;
-    m->smem_bytes = sizeof(double) * ((size_t)acc_doubles(n, m->NP) + (size_t)NCONST * cstride(m->NP));
+    m->NP = n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : n <= 64 ? 64 : BIG_MAXN;
+    m->big = big;
+    m->smem_bytes = big ? 0 : sizeof(double) * ((size_t)acc_doubles(n, m->NP) + (size_t)NCONST * cstride(m->NP));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_simd = 4 * prop.multiProcessorCount;
@@ -338,6 +349,7 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     auto put = [&](const void* src, size_t nb) { std::memcpy(hp, src, nb); const void* dptr = dp; hp += nb; dp += nb; return dptr; };
     m->dm.n = n;
     m->dm.nr = nr;
+    m->dm.stride = NS;
     m->dm.rounds = rounds;
     m->dm.is_chain = is_chain;
     m->dm.K = (const double*)put(K.data(), K.size() * sizeof(double));
@@ -354,7 +366,7 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     if (e != hipSuccess) { (void)hipFree(m->dbuf); delete m; return fail(RMX_E_HIP, std::string("hipMemcpy(model): ") + hipGetErrorString(e)); }
     m->dm.nsph = nsph;
     if (nsph) {
-        for (int g = 0; g < nsph; ++g) m->dm.sph_first[g] = (signed char)pos[(*sph_first)[g]];
+        for (int g = 0; g < nsph; ++g) m->dm.sph_first[g] = (short)pos[(*sph_first)[g]];
         e = hipMalloc(&m->dsph, sphV.size() * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy(m->dsph, sphV.data(), sphV.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(m->dbuf); if (m->dsph) (void)hipFree(m->dsph); delete m; return fail(RMX_E_HIP, "spherical variant table"); }
@@ -394,7 +406,7 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
 extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model** out) {
     if (!d || !out) return fail(RMX_E_INVALID, "null argument");
     const int n = d->njoints;
-    if (n < 1 || n > MAXN) return fail(RMX_E_INVALID, "njoints must be in [1," + std::to_string(MAXN) + "] (one wavefront per tree)");
+    if (n < 1 || n > BIG_MAXN) return fail(RMX_E_INVALID, "njoints must be in [1," + std::to_string(BIG_MAXN) + "]");
     if (!d->parent || !d->type || !d->axis || !d->E0_pj || !d->E0_ji || !d->I_i)
         return fail(RMX_E_INVALID, "parent/type/axis/E0_pj/E0_ji/I_i are required");
     bool composite = false;
@@ -464,8 +476,8 @@ extern "C" int rmx_model_create(const rmx_model_desc* d, int device, rmx_model**
         }
         last[L] = (int)type.size() - 1;
     }
-    if ((int)type.size() > MAXN)
-        return fail(RMX_E_INVALID, "the scene needs " + std::to_string(type.size()) + " 1-DOF nodes after lowering its multi-DOF joints; the limit is " + std::to_string(MAXN));
+    if ((int)type.size() > BIG_MAXN)
+        return fail(RMX_E_INVALID, "the scene needs " + std::to_string(type.size()) + " 1-DOF nodes after lowering its multi-DOF joints; the limit is " + std::to_string(BIG_MAXN));
     rmx_model_desc x{};
     x.njoints = (int)type.size();
     x.parent = parent.data(); x.type = type.data(); x.axis = axis.data();
@@ -505,6 +517,7 @@ extern "C" void rmx_model_destroy(rmx_model* m) {
 extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc) {
     if (!m || !gc || !gc->flags || !gc->sides) return fail(RMX_E_INVALID, "null argument");
     if (!(gc->kn >= 0) || !(gc->kt >= 0) || !(gc->mu >= 0) || !(gc->kd >= 0)) return fail(RMX_E_INVALID, "contact constants must be >= 0");
+    if (m->big) return fail(RMX_E_INVALID, "rmx_model_set_ground_contact: trees of more than 64 nodes have no contact kernels");
     HIPCHK(hipSetDevice(m->device));
     std::vector<double> con(4 * MAXN, 0.0);
     bool any = false;
@@ -565,6 +578,10 @@ extern "C" int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out) {
     alloc((void**)&b->it, sizeof(int) * batch); alloc((void**)&b->ls, sizeof(int) * batch); alloc((void**)&b->status, sizeof(int) * batch);
     alloc((void**)&b->resume, sizeof(int) * batch);
     alloc((void**)&b->ticks, sizeof(unsigned long long) * batch);
+    if (m->big) {      // trees of more than 64 nodes: the per-rollout workspace of the one-workgroup-per-tree kernels
+        b->bigws_stride = big_ws_doubles(m);
+        alloc((void**)&b->bigws, sizeof(double) * b->bigws_stride * (size_t)batch);
+    }
     if (m->dm.nsph) {   // every JointSpherical starts in CHART_XYZ (JointSpherical.m:33)
         const std::vector<int> c7((size_t)batch * m->dm.nsph, 7);
         if (e == hipSuccess) e = hipMalloc((void**)&b->chart, c7.size() * sizeof(int));
@@ -587,7 +604,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     (void)hipSetDevice(b->m->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart, (void*)b->ticks})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart, (void*)b->ticks, (void*)b->bigws})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -673,7 +690,8 @@ extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const d
         if (e != hipSuccess) { (void)hipFree(dg); return fail(RMX_E_NOMEM, "hipMalloc(H)"); }
         (void)hipMemsetAsync(dH, 0, nv * m->nr * sizeof(double), b->stream);
     }
-    DISPATCH_NP(m->NP, launch_eval, m, b, H != nullptr, eta, dg, dH);
+    if (m->big) launch_big_eval(m, b, H != nullptr, eta, dg, dH);
+    else DISPATCH_NP(m->NP, launch_eval, m, b, H != nullptr, eta, dg, dH);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(g, dg, nv * sizeof(double), hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess && H) e = hipMemcpyAsync(H, dH, nv * m->nr * sizeof(double), hipMemcpyDeviceToHost, b->stream);
@@ -689,6 +707,7 @@ extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, d
     rmx_model* m = b->m;
     if (m->dm.con) return fail(RMX_E_INVALID, "rmx_eval_mfd: models with ground contact are outside this hook (the contact K/D blocks only exist inside H)");
     if (m->dm.nsph) return fail(RMX_E_INVALID, "rmx_eval_mfd: models with spherical joints are outside this hook");
+    if (m->big) return fail(RMX_E_INVALID, "rmx_eval_mfd: trees of more than 64 nodes are outside this hook");
     HIPCHK(hipSetDevice(m->device));
     if (int rc = pending_error_check(b, "rmx_eval_mfd")) return rc;
     const size_t nv = (size_t)b->B * m->nr, nn = nv * m->nr;
@@ -747,7 +766,8 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(b->ticks, 0, sizeof(unsigned long long) * b->B, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
-    DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
+    if (m->big) launch_big_step(m, b, integ, o, a);
+    else DISPATCH_NP(m->NP, launch_step_np, m, b, integ, o, a);
     // BDF2 keeps (q, qdot) of step k-1 in qp/qdp.  BDF1 steps do not maintain them (and, with JointSpherical, may leave q in
     // another Euler chart than qp), so a BDF1 call invalidates the multistep history: the next rmx_step_bdf2 restarts with
     // SDIRK2, as a fresh driverRedMaxBDF2 run from that state would (driverRedMaxBDF2.m:64-88).
@@ -850,6 +870,7 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
     if (!b) return fail(RMX_E_INVALID, "null batch");
     if (b->m->dm.con) return fail(RMX_E_INVALID, "rmx_step_euler: matlab-simple has no ForceGroundCuboid; use rmx_step_bdf1/bdf2");
     if (b->m->dm.nsph) return fail(RMX_E_INVALID, "rmx_step_euler: matlab-simple has no JointSpherical; use rmx_step_bdf1/bdf2");
+    if (b->m->big) return fail(RMX_E_INVALID, "rmx_step_euler: trees of more than 64 nodes run rmx_step_bdf1/bdf2 only");
     if (nsteps < 0 || !(h > 0)) return fail(RMX_E_INVALID, "bad nsteps / h");
     if ((hT == nullptr) != (hV == nullptr)) return fail(RMX_E_INVALID, "hist_T and hist_V must be given together");
     rmx_model* m = b->m;
@@ -893,6 +914,7 @@ static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rm
     if (nsteps < 1) return fail(RMX_E_INVALID, "nsteps < 1");
     if (m->dm.con) return fail(RMX_E_INVALID, "rmx_adjoint: ground contact is outside the adjoint path (SURVEY.md 8(f))");
     if (m->dm.nsph) return fail(RMX_E_INVALID, "rmx_adjoint: spherical joints are outside the adjoint path (SURVEY.md 8(f))");
+    if (m->big) return fail(RMX_E_INVALID, "rmx_adjoint: trees of more than 64 nodes are outside the adjoint path");
     if (task->body < 0 || task->body >= m->nlist) return fail(RMX_E_INVALID, "task body out of range");
     if (task->step < 1 || task->step > nsteps) return fail(RMX_E_INVALID, "task step must be in [1, nsteps]");
     HIPCHK(hipSetDevice(m->device));
@@ -1001,6 +1023,7 @@ extern "C" int rmx_sync(rmx_batch* b) {
 extern "C" int rmx_profile_phases(rmx_batch* b, int reps, double h, double* cycles4) {
     if (!b || !cycles4 || reps < 1) return fail(RMX_E_INVALID, "bad argument");
     rmx_model* m = b->m;
+    if (m->big) return fail(RMX_E_INVALID, "rmx_profile_phases: one-wavefront kernels only (trees of up to 64 nodes)");
     HIPCHK(hipSetDevice(m->device));
     if (int rc = pending_error_check(b, "rmx_profile_phases")) return rc;
     unsigned long long* d = nullptr;
@@ -1029,7 +1052,8 @@ extern "C" int rmx_energy(rmx_batch* b, double* T, double* V) {
     HIPCHK(hipMalloc((void**)&dT, sizeof(double) * b->B));
     hipError_t e = hipMalloc((void**)&dV, sizeof(double) * b->B);
     if (e != hipSuccess) { (void)hipFree(dT); return fail(RMX_E_NOMEM, "hipMalloc(energy)"); }
-    DISPATCH_NP(m->NP, launch_energy, m, b, dT, dV);
+    if (m->big) launch_big_energy(m, b, dT, dV);
+    else DISPATCH_NP(m->NP, launch_energy, m, b, dT, dV);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(T, dT, sizeof(double) * b->B, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(V, dV, sizeof(double) * b->B, hipMemcpyDeviceToHost, b->stream);

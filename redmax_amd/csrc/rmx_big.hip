@@ -1,0 +1,756 @@
+// rmx_big.hip -- the general kernels for trees of 65..BIG_MAXN (256) nodes: ONE WORKGROUP per trajectory, thread = node.
+//
+// The one-wavefront kernels (rmx_device.h, rmx_kernels.hip) hold a tree in the 64 lanes of a wavefront and stop at 64 nodes, where
+// every multi-DOF joint counts one node per DOF (a JointFree3D body is 6 nodes).  The reference has no size limit.  These kernels
+// remove the limit with the SAME algebra - the world-frame recursive Newton-Euler with analytic derivatives of DESIGN.md section 3,
+// restated node by node in oracle/redmax_tensorfree.c - laid out for a workgroup instead of a wavefront:
+//   * root->node path products / sums : pointer jumping over the ancestor table (log2(depth) rounds), the per-node values in a
+//                                       global workspace (L2-resident), one workgroup barrier per round
+//   * node->leaves subtree sums       : a suffix scan over the depth-first order (Hillis-Steele, log2(n) rounds), subtree(j) =
+//                                       suffix(j) - suffix(end_j)
+//   * the nr x nr Hessian             : thread = row, a loop over the columns (ancestor test j < i < end_j), column-major in the workspace
+//   * dx = -H\g                       : LU with partial pivoting (MATLAB mldivide, driverRedMaxBDF1.m:117; first maximum wins),
+//                                       thread = row, implicit row permutation, the pivot row read through the cache
+// Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
+// of newton_impl (rmx_device.h).  Nothing here is tuned: a 128-link chain costs ~100x a 32-link chain per step.  Covered: BDF1, BDF2
+// (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching; not covered: ground
+// contact, the adjoint, matlab-simple Euler, rmx_eval_mfd (refused by the C ABI for such models).
+#include <hip/hip_runtime.h>
+
+#include "rmx_host.h"
+
+namespace {
+
+constexpr int BT = BIG_MAXN;          // threads per workgroup = node slots
+
+// Per-rollout workspace in global memory (doubles).  Rows of per-node data are [component][BT].
+struct BigWs {
+    double* E[2];     // [12][BT] x 2  world transforms (R row-major 9, p 3), double-buffered for the pointer jumping
+    double* V[2];     // [6][BT] x 2   path sums (phi, beta)
+    double* S[2];     // [28][BT] x 2  body terms / suffix sums
+    double* cu;       // [6][BT]   y - z          (column i as seen from its strict ancestors)
+    double* cl;       // [12][BT]  m1, m2w, sw    (column i as seen from its strict descendants)
+    double* red;      // [BT]      block reductions / broadcasts
+    double* vec;      // [4][BT]   reduced-order vectors: b, x, scratch
+    double* H;        // [nr][nr]  column-major
+};
+__host__ __device__ constexpr size_t big_ws_doubles_n(const int nr) {
+    return (size_t)BT * (2 * 12 + 2 * 6 + 2 * 28 + 6 + 12 + 1 + 4) + (size_t)nr * nr;
+}
+__device__ __forceinline__ BigWs big_ws(double* base, const int nr) {
+    BigWs w;
+    double* p = base;
+    w.E[0] = p; p += 12 * BT; w.E[1] = p; p += 12 * BT;
+    w.V[0] = p; p += 6 * BT;  w.V[1] = p; p += 6 * BT;
+    w.S[0] = p; p += 28 * BT; w.S[1] = p; p += 28 * BT;
+    w.cu = p; p += 6 * BT;
+    w.cl = p; p += 12 * BT;
+    w.red = p; p += BT;
+    w.vec = p; p += 4 * BT;
+    w.H = p;
+    (void)nr;
+    return w;
+}
+
+// sum over the workgroup, identical in every thread (fixed tree order).  (The LDS arrays are function-local statics, not pointer
+// arguments: a generic pointer into LDS handed to an out-of-line device function trips a compiler bug on gfx950 - an illegal
+// V_CMP_NE_U32 against src_shared_base.)
+__device__ __forceinline__ double block_sum(double v, const int t) {
+    __shared__ double sred[BT];
+    sred[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = BT / 2; s > 0; s >>= 1) {
+        if (t < s) sred[t] += sred[t + s];
+        __syncthreads();
+    }
+    const double r = sred[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int block_all(const bool v, const int t) {
+    __shared__ int sflag;
+    if (t == 0) sflag = 1;
+    __syncthreads();
+    if (!v) sflag = 0;        // benign race: every writer stores 0
+    __syncthreads();
+    const int r = sflag;
+    __syncthreads();
+    return r;
+}
+
+// This node's constants: the model's arrays, or - for a node of a JointSpherical group - the variant of the group's current chart
+struct NodeConsts {
+    const double* K;   int ks;     // K[r * ks], r = 0..35
+    const double* sb;  int ss;     // sb[r * ss], r = 0..5
+};
+__device__ __forceinline__ NodeConsts node_consts(const DevModel& M, const int t, const int* chart) {
+    NodeConsts c;
+    c.K = M.K + t; c.ks = M.stride;
+    c.sb = M.sb + t; c.ss = M.stride;
+    for (int g = 0; g < M.nsph; ++g) {
+        const int k = t - M.sph_first[g];
+        if (k >= 0 && k < 3) {
+            int a1, a2, a3;
+            chart_axes(chart[g], a1, a2, a3);
+            const int a = k == 0 ? a1 : (k == 1 ? a2 : a3);
+            c.K = M.sphV + ((size_t)(g * 3 + k) * 3 + a) * SPH_ROWS; c.ks = 1;
+            c.sb = c.K + 36; c.ss = 1;
+        }
+    }
+    return c;
+}
+
+struct BigOut {
+    double g, eT, eV;
+};
+
+// evalBDF1 / computeValues for the generic implicit residual (see eval_front_e2 / eval_hess in rmx_device.h for the wavefront form and
+// oracle/redmax_tensorfree.c tf_eval for the node-by-node restatement this follows).  Thread t = node t; q, qd, v are this node's.
+template <bool WANT_H>
+__device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc, const int t, const double q, const double qd,
+                         const double v, const double eta, BigOut& out) {
+    const int n = M.n, NS = M.stride;
+    const bool act = t < n;
+    const int tj = act ? t : 0;
+    const double e2 = eta * eta;
+    const int type = act ? M.type[tj] : 0;
+    const bool dof = type != 0;
+    // ---- joint transform T_j(q) = K0 + u K1 + w K2
+    double u = 0.0, ww = 0.0;
+    if (type == 1) sincos(q, &u, &ww);
+    else if (type == 2) u = q;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) R[c] = nc.K[c * nc.ks] + u * nc.K[(12 + c) * nc.ks] + ww * nc.K[(24 + c) * nc.ks];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = nc.K[(9 + c) * nc.ks] + u * nc.K[(21 + c) * nc.ks] + ww * nc.K[(33 + c) * nc.ks];
+    }
+    // ---- world transforms: pointer jumping, E_w,j = E_w,anc T_j...
+    int cur = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) w.E[0][c * BT + t] = R[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w.E[0][(9 + c) * BT + t] = p[c];
+    __syncthreads();
+    for (int r = 0; r < M.rounds; ++r) {
+        const int a = act ? M.anc[r * NS + tj] : -1;
+        if (a >= 0) {
+            double Ra[9], pa[3];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) Ra[c] = w.E[cur][c * BT + a];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pa[c] = w.E[cur][(9 + c) * BT + a];
+            double Rn[9], pn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
+                pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[c] = pn[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) w.E[cur ^ 1][c * BT + t] = R[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w.E[cur ^ 1][(9 + c) * BT + t] = p[c];
+        cur ^= 1;
+        __syncthreads();
+    }
+    // ---- world-frame joint screw
+    double sw[3] = {0, 0, 0}, sv[3] = {0, 0, 0}, t3[3];
+    if (act) {
+        const double sbw[3] = {nc.sb[0], nc.sb[nc.ss], nc.sb[2 * nc.ss]}, sbv[3] = {nc.sb[3 * nc.ss], nc.sb[4 * nc.ss], nc.sb[5 * nc.ss]};
+        mat3v(R, sbw, sw);
+        mat3v(R, sbv, sv);
+        cross3(p, sw, t3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sv[c] += t3[c];
+    }
+    // path sum of a 6-vector (own value in x6, result in x6)
+    auto path_sum6 = [&](double (&x6)[6]) {
+        int cv = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) w.V[0][c * BT + t] = x6[c];
+        __syncthreads();
+        for (int r = 0; r < M.rounds; ++r) {
+            const int a = act ? M.anc[r * NS + tj] : -1;
+            if (a >= 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) x6[c] += w.V[cv][c * BT + a];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) w.V[cv ^ 1][c * BT + t] = x6[c];
+            cv ^= 1;
+            __syncthreads();
+        }
+    };
+    double ph[6], be[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ph[c] = sw[c] * qd;
+        ph[3 + c] = sv[c] * qd;
+    }
+    path_sum6(ph);
+    const double* phw = ph;
+    const double* phv = ph + 3;
+    double xiw[3], xiv[3];
+    cross3(phw, sw, xiw);
+    cross3(phv, sw, xiv);
+    cross3(phw, sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xiv[c] += t3[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        be[c] = sw[c] * v + e2 * qd * xiw[c];
+        be[3 + c] = sv[c] * v + e2 * qd * xiv[c];
+    }
+    path_sum6(be);
+    const double* bw = be;
+    const double* bv = be + 3;
+    // ---- body terms (Body.computeMassGrav): world-frame inertia about the origin, momentum, wrench, B block
+    const double I1 = act ? M.I4[0 * NS + tj] : 0.0, I2 = act ? M.I4[1 * NS + tj] : 0.0, I3 = act ? M.I4[2 * NS + tj] : 0.0, ms = act ? M.I4[3 * NS + tj] : 0.0;
+    double mc[3], Ib[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mc[c] = ms * p[c];
+    {
+        const double cc = dot3(p, p);
+        Ib[0] = I1 * R[0] * R[0] + I2 * R[1] * R[1] + I3 * R[2] * R[2] + ms * (cc - p[0] * p[0]);
+        Ib[1] = I1 * R[0] * R[3] + I2 * R[1] * R[4] + I3 * R[2] * R[5] - ms * p[0] * p[1];
+        Ib[2] = I1 * R[0] * R[6] + I2 * R[1] * R[7] + I3 * R[2] * R[8] - ms * p[0] * p[2];
+        Ib[3] = I1 * R[3] * R[3] + I2 * R[4] * R[4] + I3 * R[5] * R[5] + ms * (cc - p[1] * p[1]);
+        Ib[4] = I1 * R[3] * R[6] + I2 * R[4] * R[7] + I3 * R[5] * R[8] - ms * p[1] * p[2];
+        Ib[5] = I1 * R[6] * R[6] + I2 * R[7] * R[7] + I3 * R[8] * R[8] + ms * (cc - p[2] * p[2]);
+    }
+    double ht[3], hf[3], bt[3], bf[3], a3[3], b3[3], c3[3], fgt[3];
+    sym3v(Ib, phw, ht);
+    cross3(mc, phv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ht[c] += t3[c];
+    cross3(mc, phw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) hf[c] = ms * phv[c] - t3[c];
+    sym3v(Ib, bw, bt);
+    cross3(mc, bv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bt[c] += t3[c];
+    cross3(mc, bw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bf[c] = ms * bv[c] - t3[c];
+    const double gv[3] = {M.grav[0], M.grav[1], M.grav[2]};
+    cross3(phw, ht, a3);
+    cross3(phv, hf, b3);
+    cross3(phw, hf, c3);
+    cross3(mc, gv, fgt);
+    double S[28];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        S[c] = bt[c] - e2 * (-a3[c] - b3[c] + fgt[c]);
+        S[3 + c] = bf[c] - e2 * (-c3[c] + ms * gv[c]);
+    }
+    S[6] = ms;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S[7 + c] = mc[c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[10 + c] = Ib[c];
+    {
+        const double Ibf[9] = {Ib[0], Ib[1], Ib[2], Ib[1], Ib[3], Ib[4], Ib[2], Ib[4], Ib[5]};
+        const double Om[9] = {0.0, -phw[2], phw[1], phw[2], 0.0, -phw[0], -phw[1], phw[0], 0.0};
+        const double Vx[9] = {0.0, -phv[2], phv[1], phv[2], 0.0, -phv[0], -phv[1], phv[0], 0.0};
+        const double Mc[9] = {0.0, -mc[2], mc[1], mc[2], 0.0, -mc[0], -mc[1], mc[0], 0.0};
+        const double Ht[9] = {0.0, -ht[2], ht[1], ht[2], 0.0, -ht[0], -ht[1], ht[0], 0.0};
+        double X[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double tt = 0.0;
+#pragma unroll
+                for (int l = 0; l < 3; ++l) tt += Ibf[3 * i + l] * Om[3 * l + k] + Mc[3 * i + l] * Vx[3 * l + k];
+                X[3 * i + k] = tt;
+            }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) S[16 + 3 * i + k] = X[3 * i + k] + X[3 * k + i] + Ht[3 * i + k];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S[25 + c] = hf[c];
+    // energies (Body.computeEnergies, Joint.computeEnergies)
+    const double stiff = act ? M.prm[1 * NS + tj] : 0.0, damp = act ? M.prm[2 * NS + tj] : 0.0;
+    const double tau = act ? M.prm[0 * NS + tj] : 0.0, qRest = act ? M.prm[3 * NS + tj] : 0.0;
+    const double qLimL = act ? M.prm[4 * NS + tj] : 0.0, qLimU = act ? M.prm[5 * NS + tj] : 0.0;
+    const double qLimK = act ? M.prm[6 * NS + tj] : 0.0, qLimD = act ? M.prm[7 * NS + tj] : 0.0;
+    const double hitL = (dof && q < qLimL) ? 1.0 : 0.0, hitU = (dof && q > qLimU) ? 1.0 : 0.0;
+    {
+        out.eT = act ? 0.5 * (dot3(phw, ht) + dot3(phv, hf)) : 0.0;
+        double eV = act ? -dot3(gv, mc) : 0.0;
+        if (dof) {
+            const double dq = q - qRest;
+            const double dqL = hitL * (qLimL - q), dqU = hitU * (qLimU - q);
+            eV += 0.5 * stiff * (dq * dq) + 0.5 * qLimK * (dqL * dqL + dqU * dqU);
+        }
+        out.eV = eV;
+    }
+    // ---- subtree sums: suffix scan over the depth-first order, subtree(j) = suffix(j) - suffix(end_j)
+    {
+        int cs = 0;
+#pragma unroll
+        for (int c = 0; c < 28; ++c) w.S[0][c * BT + t] = act ? S[c] : 0.0;
+        __syncthreads();
+        for (int d = 1; d < BT; d <<= 1) {
+            double add[28];
+            const bool on = t + d < BT;
+#pragma unroll
+            for (int c = 0; c < 28; ++c) add[c] = on ? w.S[cs][c * BT + t + d] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 28; ++c) S[c] = (act ? S[c] : 0.0) + add[c];
+#pragma unroll
+            for (int c = 0; c < 28; ++c) w.S[cs ^ 1][c * BT + t] = S[c];
+            cs ^= 1;
+            __syncthreads();
+        }
+        const int en = act ? M.end[tj] : BT;
+        if (en < BT) {
+#pragma unroll
+            for (int c = 0; c < 28; ++c) S[c] -= w.S[cs][c * BT + en];
+        }
+        __syncthreads();
+    }
+    // ---- residual  g_j = s_j . W_j - eta^2 fr_j
+    const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) + hitU * (qLimK * (qLimU - q) - qLimD * qd);
+    out.g = dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
+    if (!WANT_H) return;
+    // ---- Hessian vectors of this node (eval_hess in rmx_device.h)
+    const double kd = stiff + (hitL + hitU) * qLimK, dd = damp + (hitL + hitU) * qLimD;
+    const double* Wt = &S[0];
+    const double* Wf = &S[3];
+    const double mS = S[6];
+    const double* mcS = &S[7];
+    const double* IbS = &S[10];
+    const double* TL = &S[16];
+    const double* hfS = &S[25];
+    double zw[3], zv[3], m1w[3], m1v[3], m2w[3];
+    cross3(bw, sw, zw);
+    cross3(bv, sw, zv);
+    cross3(bw, sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) zv[c] += t3[c];
+    cross3(phw, xiw, a3);
+    cross3(phv, xiw, b3);
+    cross3(phw, xiv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        zw[c] += e2 * a3[c];
+        zv[c] += e2 * (b3[c] + t3[c]);
+        m1w[c] = sw[c] + 2.0 * eta * xiw[c] + zw[c];
+        m1v[c] = sv[c] + 2.0 * eta * xiv[c] + zv[c];
+        m2w[c] = eta * sw[c] + e2 * xiw[c];
+    }
+    double yt[3], yf[3], gxs[3], kt[3];
+    sym3v(IbS, m1w, yt);
+    cross3(mcS, m1v, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yt[c] += t3[c];
+    cross3(mcS, m1w, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yf[c] = mS * m1v[c] - t3[c];
+    mat3v(TL, m2w, a3);
+    cross3(hfS, m2w, b3);
+    cross3(gv, sw, gxs);
+    cross3(mcS, gxs, kt);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        yt[c] -= a3[c] + e2 * kt[c];
+        yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c];
+    }
+    double zt[3], zf[3];
+    cross3(sw, Wt, a3);
+    cross3(sv, Wf, b3);
+    cross3(sw, Wf, zf);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        zt[c] = -a3[c] - b3[c];
+        zf[c] = -zf[c];
+    }
+    const double Hdiag = dof ? (dot3(sw, yt) + dot3(sv, yf) + eta * dd + e2 * kd) : 1.0;
+    double rl[12];          // r1, -r2w, -r3w
+    sym3v(IbS, sw, rl);
+    cross3(mcS, sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rl[c] += t3[c];
+    cross3(mcS, sw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rl[3 + c] = mS * sv[c] - t3[c];
+    cross3(hfS, sv, b3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rl[6 + c] = -(TL[c] * sw[0] + TL[3 + c] * sw[1] + TL[6 + c] * sw[2] - 2.0 * b3[c]);
+    cross3(gv, t3, a3);
+    cross3(gv, sv, b3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rl[9 + c] = -e2 * (a3[c] - mS * b3[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        w.cu[c * BT + t] = yt[c] - zt[c];
+        w.cu[(3 + c) * BT + t] = yf[c] - zf[c];
+        w.cl[c * BT + t] = m1w[c];
+        w.cl[(3 + c) * BT + t] = m1v[c];
+        w.cl[(6 + c) * BT + t] = m2w[c];
+        w.cl[(9 + c) * BT + t] = sw[c];
+    }
+    __syncthreads();
+    // ---- row of this node: H(a, i) = s_a . cu_i for a a strict ancestor of i, rl_a . cl_i for a strict descendant, Hdiag on the
+    // diagonal, 0 otherwise.  Depth-first order: a is a strict ancestor of i iff a < i < end_a.
+    const int nr = M.nr;
+    const int ka = act ? M.idx[tj] : -1;
+    if (ka >= 0) {
+        const int ea = M.end[tj];
+        for (int i = 0; i < n; ++i) {
+            const int ki = M.idx[i];
+            if (ki < 0) continue;
+            double h = 0.0;
+            if (i == t) {
+                h = Hdiag;
+            } else if (t < i && i < ea) {          // this row's node is a strict ancestor of column node i
+#pragma unroll
+                for (int c = 0; c < 3; ++c) h += sw[c] * w.cu[c * BT + i] + sv[c] * w.cu[(3 + c) * BT + i];
+            } else if (i < t && t < M.end[i]) {    // strict descendant
+#pragma unroll
+                for (int c = 0; c < 12; ++c) h += rl[c] * w.cl[c * BT + i];
+            }
+            w.H[(size_t)ki * nr + ka] = h;
+        }
+    }
+    __syncthreads();
+}
+
+// dx = -H\g: LU with partial pivoting on the workspace copy of H (column-major nr x nr), thread = reduced row.  The permutation is
+// implicit (rows are never moved): piv[r] = the step at which row r served as the pivot row, or -1.  First maximum wins (dgetf2).
+// bneg: this node's -g (nodes without a DOF: ignored).  Returns this node's dx.
+__device__ double big_solve(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
+    __shared__ double sred[BT];
+    __shared__ int sarg[BT];         // argmax candidates of the pivot search
+    __shared__ int spiv[BT];         // pivot row of step k
+    const int nr = M.nr;
+    double* b = w.vec;               // [nr]
+    double* xs = w.vec + BT;         // [nr] solution in reduced order
+    if (ka >= 0) b[ka] = -g;
+    __syncthreads();
+    const int r = t;                 // this thread's reduced row
+    const bool row = r < nr;
+    int mystep = -1;
+    for (int k = 0; k < nr; ++k) {
+        // pivot search over the unused rows: max |H(r,k)|, lowest row among equals
+        const double cand = (row && mystep < 0) ? fabs(w.H[(size_t)k * nr + r]) : -1.0;
+        sred[t] = cand;
+        sarg[t] = t;
+        __syncthreads();
+        for (int s = BT / 2; s > 0; s >>= 1) {
+            if (t < s) {
+                const double o = sred[t + s];
+                const int oi = sarg[t + s];
+                if (o > sred[t] || (o == sred[t] && oi < sarg[t])) {
+                    sred[t] = o;
+                    sarg[t] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        const int pr = sarg[0];
+        __syncthreads();
+        if (t == 0) spiv[k] = pr;
+        if (r == pr) mystep = k;
+        const double pvv = w.H[(size_t)k * nr + pr];
+        if (row && mystep < 0) {
+            const double l = w.H[(size_t)k * nr + r] / pvv;
+            for (int c = k + 1; c < nr; ++c) w.H[(size_t)c * nr + r] -= l * w.H[(size_t)c * nr + pr];
+            b[r] -= l * b[pr];
+        }
+        __syncthreads();
+    }
+    // back substitution on the implicitly permuted upper triangle
+    for (int k = nr - 1; k >= 0; --k) {
+        const int pr = spiv[k];
+        if (r == pr) xs[k] = b[r] / w.H[(size_t)k * nr + r];
+        __syncthreads();
+        if (row && mystep < k) b[r] -= w.H[(size_t)k * nr + r] * xs[k];
+        __syncthreads();
+    }
+    const double dx = ka >= 0 ? xs[ka] : 0.0;
+    __syncthreads();
+    return dx;
+}
+
+// newton (driverRedMaxBDF1.m:94-157) for one implicit solve; see newton_impl (rmx_device.h) for the stall shortcut and the
+// compensated iterate x + lo.  Every decision is workgroup-uniform (norms come out of block_sum identical in all threads).
+__device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w, const NodeConsts& nc, const int t,
+                             const int ka, double x, const double qA, const double qB, const double eta, BigOut& last, int& iters,
+                             int& halvings, int& status, double& xlo) {
+    double lo = 0.0;
+    BigOut e;
+    int iter = 1;
+    while (true) {
+        big_eval<true>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+        const BigOut e0 = e;
+        last = e;
+        ++iters;
+        const double dx = big_solve(M, w, t, ka, e.g);
+        const double dxn2 = block_sum(dx * dx, t);
+        if (!(dxn2 == dxn2)) { status |= 4; break; }
+        if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }
+        double alpha = 1.0;
+        const double g0n2 = block_sum(e.g * e.g, t);
+        const double f0 = 0.5 * g0n2;
+        const double x0 = x, lo0 = lo;
+        int iterLs = 1;
+        double gn2 = g0n2;
+        bool stalled = false;
+        while (true) {
+            two_sum(x0, fma(alpha, dx, lo0), x, lo);
+            lo *= o.comp;
+            if (block_all(x == x0 && lo == lo0, t)) {
+                stalled = true;
+                iterLs = o.iterLsMax;
+                e = e0;
+                break;
+            }
+            big_eval<false>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+            gn2 = block_sum(e.g * e.g, t);
+            if (0.5 * gn2 < f0) break;
+            if (iterLs >= o.iterLsMax) break;
+            alpha *= 0.5;
+            ++iterLs;
+        }
+        last = e;
+        halvings += iterLs - 1;
+        if (stalled) {
+            if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+            break;
+        }
+        if (sqrt(gn2) < o.tol) break;
+        if (iter >= o.iterMax) { status |= 2; break; }
+        ++iter;
+    }
+    xlo = lo;
+    return x;
+}
+
+// Joint.reparam -> JointSpherical.reparam_ for every spherical group (sph_reparam in rmx_device.h, with the group's values read from
+// the workspace instead of v_readlane).  Returns true if a chart changed (the caller refreshes its NodeConsts).
+template <bool WITH_PREV>
+__device__ bool big_reparam(const DevModel& M, const BigWs& w, const int t, int* chart, double& q, double& qd, double& qp, double& qdp) {
+    double* sq = w.vec;          // [4][BT]: q, qd, qp, qdp per node
+    sq[t] = q;
+    sq[BT + t] = qd;
+    sq[2 * BT + t] = qp;
+    sq[3 * BT + t] = qdp;
+    __syncthreads();
+    bool switched = false;
+    for (int g = 0; g < M.nsph; ++g) {
+        const int first = M.sph_first[g];
+        const int c0 = chart[g];
+        const double qv[3] = {sq[first], sq[first + 1], sq[first + 2]};
+        double Told[9];
+        const double detTold = euler_T(c0, qv, Told);
+        if (fabs(detTold) > 0.5) continue;
+        const double qdv[3] = {sq[BT + first], sq[BT + first + 1], sq[BT + first + 2]};
+        const double q1v[3] = {sq[2 * BT + first], sq[2 * BT + first + 1], sq[2 * BT + first + 2]};
+        const double qd1v[3] = {sq[3 * BT + first], sq[3 * BT + first + 1], sq[3 * BT + first + 2]};
+        double R[9], R1[9], Tt[9];
+        euler_R(c0, qv, R);
+        if (WITH_PREV) euler_R(c0, q1v, R1);
+        int best = 1;
+        double bestv = -1.0;
+        for (int k = 1; k <= 12; ++k) {
+            double qk[3];
+            euler_inv(k, R, qk);
+            double vv = fabs(euler_T(k, qk, Tt));
+            vv = (vv == vv) ? vv : 0.0;
+            if (WITH_PREV) {
+                euler_inv(k, R1, qk);
+                double v1 = fabs(euler_T(k, qk, Tt));
+                v1 = (v1 == v1) ? v1 : 0.0;
+                vv = v1 < vv ? v1 : vv;
+            }
+            if (vv > bestv) {
+                bestv = vv;
+                best = k;
+            }
+        }
+        double wv[3], Tn[9], qn[3], qdn[3], q1n[3] = {0, 0, 0}, qd1n[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wv[i] = Told[3 * i] * qdv[0] + Told[3 * i + 1] * qdv[1] + Told[3 * i + 2] * qdv[2];
+        euler_inv(best, R, qn);
+        euler_T(best, qn, Tn);
+        solve3(Tn, wv, qdn);
+        if (WITH_PREV) {
+            euler_T(c0, q1v, Told);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wv[i] = Told[3 * i] * qd1v[0] + Told[3 * i + 1] * qd1v[1] + Told[3 * i + 2] * qd1v[2];
+            euler_inv(best, R1, q1n);
+            euler_T(best, q1n, Tn);
+            solve3(Tn, wv, qd1n);
+        }
+        for (int k = 0; k < 3; ++k)
+            if (t == first + k) {
+                q = qn[k];
+                qd = qdn[k];
+                if (WITH_PREV) {
+                    qp = q1n[k];
+                    qdp = qd1n[k];
+                }
+            }
+        if (best != c0) switched = true;
+        __syncthreads();                 // every thread has read chart[g]
+        if (best != c0 && t == 0) chart[g] = best;
+    }
+    __syncthreads();
+    return switched;
+}
+
+// simLoop of driverRedMaxBDF1.m:57-91 (INTEG 1) / driverRedMaxBDF2.m:57-125 (INTEG 2), all steps inside one launch
+template <int INTEG>
+__global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts o, const StepArgs a, double* wsbase, const size_t wsstride) {
+    const int t = threadIdx.x, traj = blockIdx.x;
+    const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
+    const BigWs w = big_ws(wsbase + (size_t)traj * wsstride, M.nr);
+    const int id = (t < M.n) ? M.idx[t] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    double qp = (INTEG == 2 && id >= 0) ? a.qp[off] : 0.0;
+    double qdp = (INTEG == 2 && id >= 0) ? a.qdp[off] : 0.0;
+    const bool started = INTEG == 2 && (*a.started) != 0;
+    int* const chart = M.nsph ? a.chart + (size_t)traj * M.nsph : nullptr;
+    NodeConsts nc = node_consts(M, t < M.n ? t : 0, chart);
+    const double h = o.h;
+    int iters = 0, halv = 0, status = 0;
+    for (int s = 0; s < a.nsteps; ++s) {
+        BigOut last;
+        double xlo;
+        if (INTEG == 1) {
+            const double q0 = q, qd0 = qd;
+            const double xg = q0 + h * qd0;
+            const double x = big_newton(M, o, w, nc, t, id, xg, q0, xg, h, last, iters, halv, status, xlo);
+            qd = ((x - q0) + xlo) / h;
+            q = x;
+        } else if (s == 0 && !started) {
+            const double al = (2.0 - sqrt(2.0)) / 2.0;
+            const double q0 = q, qd0 = qd;
+            const double qa = big_newton(M, o, w, nc, t, id, q0 + al * h * qd0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, xlo);
+            const double qda = (qa - q0) / (al * h);
+            const double x10 = qa + (1.0 - al) * h * qda;
+            const double qA = q0 + (1.0 - al) * h * qda;
+            const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
+            const double q1 = big_newton(M, o, w, nc, t, id, x10, qA, qB, al * h, last, iters, halv, status, xlo);
+            qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
+            q = q1;
+            qp = q0;
+            qdp = qd0;
+        } else {
+            const double q0 = qp, qd0 = qdp, q1 = q, qd1 = qd;
+            const double x0 = q1 + h * qd1;
+            const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
+            const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
+            const double q2 = big_newton(M, o, w, nc, t, id, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, xlo);
+            qp = q1;
+            qdp = qd1;
+            qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
+            q = q2;
+        }
+        if (M.nsph) {      // jroot.reparam() (driverRedMaxBDF1.m:78, driverRedMaxBDF2.m:112)
+            double np0 = 0.0, np1 = 0.0;
+            const bool sw = INTEG == 1 ? big_reparam<false>(M, w, t, chart, q, qd, np0, np1) : big_reparam<true>(M, w, t, chart, q, qd, qp, qdp);
+            if (sw) {
+                status |= 32;
+                nc = node_consts(M, t < M.n ? t : 0, chart);
+            }
+        }
+        if (a.histT) {
+            const double T = block_sum(last.eT, t), V = block_sum(last.eV, t);
+            if (t == 0) {
+                a.histT[(size_t)s * a.B + traj] = T;
+                a.histV[(size_t)s * a.B + traj] = V;
+            }
+        }
+        if (a.histQ && id >= 0) {
+            a.histQ[(size_t)s * a.B * M.nr + off] = q;
+            a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+        }
+        if (a.histC && t < M.nsph) a.histC[((size_t)s * a.B + traj) * M.nsph + t] = chart[t];
+    }
+    if (id >= 0) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+        if (INTEG == 2) {
+            a.qp[off] = qp;
+            a.qdp[off] = qdp;
+        }
+    }
+    if (t == 0 && a.it) {
+        a.it[traj] += iters;
+        a.ls[traj] += halv;
+        a.status[traj] |= status;
+    }
+    if (t == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;
+}
+
+// Parity hook (rmx_eval): one residual (+ Hessian) evaluation per trajectory
+template <bool WANT_H>
+__global__ void __launch_bounds__(BT) k_big_eval(const DevModel M, const double* __restrict__ q, const double* __restrict__ qA, const double* __restrict__ qB,
+                                                 const double eta, double* __restrict__ g, double* __restrict__ H, const int* __restrict__ charts,
+                                                 double* wsbase, const size_t wsstride) {
+    const int t = threadIdx.x, traj = blockIdx.x;
+    const BigWs w = big_ws(wsbase + (size_t)traj * wsstride, M.nr);
+    const int id = (t < M.n) ? M.idx[t] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    const double x = id >= 0 ? q[off] : 0.0, xa = id >= 0 ? qA[off] : 0.0, xb = id >= 0 ? qB[off] : 0.0;
+    const NodeConsts nc = node_consts(M, t < M.n ? t : 0, M.nsph ? charts + (size_t)traj * M.nsph : nullptr);
+    BigOut e;
+    big_eval<WANT_H>(M, w, nc, t, x, (x - xa) / eta, x - xb, eta, e);
+    if (id >= 0) g[off] = e.g;
+    if (WANT_H) {
+        const size_t nn = (size_t)M.nr * M.nr;
+        for (size_t i = t; i < nn; i += BT) H[(size_t)traj * nn + i] = w.H[i];
+    }
+}
+
+// Joint.computeEnergies / Body.computeEnergies at the stored state
+__global__ void __launch_bounds__(BT) k_big_energy(const DevModel M, const double* __restrict__ q, const double* __restrict__ qd, double* __restrict__ T,
+                                                   double* __restrict__ V, const int* __restrict__ charts, double* wsbase, const size_t wsstride) {
+    const int t = threadIdx.x, traj = blockIdx.x;
+    const BigWs w = big_ws(wsbase + (size_t)traj * wsstride, M.nr);
+    const int id = (t < M.n) ? M.idx[t] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    const NodeConsts nc = node_consts(M, t < M.n ? t : 0, M.nsph ? charts + (size_t)traj * M.nsph : nullptr);
+    BigOut e;
+    big_eval<false>(M, w, nc, t, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, e);
+    const double tt = block_sum(e.eT, t), vv = block_sum(e.eV, t);
+    if (t == 0) {
+        T[traj] = tt;
+        V[traj] = vv;
+    }
+}
+
+}  // namespace
+
+size_t big_ws_doubles(const rmx_model* m) { return big_ws_doubles_n(m->nr); }
+
+void launch_big_step(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(BT);
+    if (integ == INTEG_BDF1) k_big_step<1><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
+    else k_big_step<2><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
+}
+void launch_big_eval(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
+    const dim3 grid(b->B), block(BT);
+    if (wantH) k_big_eval<true><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+    else k_big_eval<false><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+}
+void launch_big_energy(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
+    const dim3 grid(b->B), block(BT);
+    k_big_energy<<<grid, block, 0, b->stream>>>(m->dm, b->q, b->qd, dT, dV, b->chart, b->bigws, b->bigws_stride);
+}

@@ -40,6 +40,8 @@
 namespace rmx {
 
 constexpr int MAXN = 64;          // nodes per tree handled by one wavefront
+constexpr int BIG_MAXN = 256;     // nodes per tree handled by one workgroup (rmx_big.hip: the general kernels for trees of more than 64 nodes)
+constexpr int BIG_MAXROUNDS = 8;  // log2(BIG_MAXN)
 constexpr int NACC = 28;          // subtree-accumulated numbers per body (w6, m1, mc3, Ibar6, TL9, hf3)
 constexpr int ACC_STRIDE = 29;    // odd stride: conflict-free lane=node LDS writes
 constexpr int NCOL = 18;          // column-side Hessian vectors per node (yz6, m1 6, m2w3, sw3)
@@ -77,6 +79,7 @@ constexpr int NCOLX = 24;         // with ground contact the column side also ne
 // Constant per-model data, SoA over nodes (stride MAXN) so lane=node loads coalesce.
 struct DevModel {
     int n;            // nodes (joints == bodies)
+    int stride;       // node stride of the SoA arrays below: MAXN, or BIG_MAXN for trees of more than 64 nodes
     int nr;           // reduced DOFs
     int rounds;       // pointer-jumping rounds = ceil(log2(max depth + 1))
     int is_chain;     // every subtree ends at n (serial chain): skip the range subtraction
@@ -98,7 +101,7 @@ struct DevModel {
     const double* gconst;   // [NCONST][cstride(NP)] the per-node constants as smem_setup stages them, in global memory (RMX_GLOBAL_CONSTS)
     int nsph;
     const double* sphV;  // [nsph][3 nodes][3 axes][SPH_ROWS]  K and sb of each group node for axis x, y, z
-    signed char sph_first[MAXSPH + 3];
+    short sph_first[MAXSPH + 3];
 };
 
 struct DevOpts {

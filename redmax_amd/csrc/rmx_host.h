@@ -61,6 +61,7 @@ struct rmx_model {
     int n_simd = 0;                 // SIMDs of the device (4 per CU)
     void* dgconst = nullptr;        // 64-lane plain models: the staged per-node constants in global memory (DevModel::gconst)
     int gconst_min_batch = 0;       // batches of at least this many rollouts run the global-constants kernels (0: never)
+    bool big = false;               // more than 64 nodes: the one-workgroup-per-tree kernels of rmx_big.hip
 };
 
 struct rmx_batch {
@@ -75,6 +76,8 @@ struct rmx_batch {
     int *it = nullptr, *ls = nullptr, *status = nullptr;
     int* resume = nullptr;          // [B] see StepArgs.resume
     unsigned long long* ticks = nullptr;   // [B] see StepArgs.ticks (rmx_step_ticks)
+    double* bigws = nullptr;        // trees of more than 64 nodes: per-rollout workspace of the rmx_big.hip kernels
+    size_t bigws_stride = 0;        // doubles per rollout
     double last_ms = 0.0;
     bool async_pending = false;     // an rmx_step_bdf1_async launch nobody has waited for yet (see pending_error_check)
 };
@@ -97,6 +100,11 @@ struct rmx_batch {
 // 64-lane plain step kernels reading the per-node constants from global memory (rmx_kernels.hip RMX_PART 3) and the staging kernel
 void launch_step_gconst_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream);
+// rmx_big.hip: trees of 65..BIG_MAXN nodes, one workgroup per rollout
+size_t big_ws_doubles(const rmx_model* m);
+void launch_big_step(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
+void launch_big_eval(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH);
+void launch_big_energy(const rmx_model* m, const rmx_batch* b, double* dT, double* dV);
 RMX_DECLARE_LAUNCHERS(4)
 RMX_DECLARE_LAUNCHERS(8)
 RMX_DECLARE_LAUNCHERS(16)

@@ -1,0 +1,23 @@
+"""Cost of the one-workgroup-per-trajectory kernels (rmx_big.hip, trees of 65..256 nodes): kernel time per BDF1 step of an n-link
+chain and of 20 free bodies at a few batch sizes, next to the 32-link chain on the one-wavefront kernels."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np  # noqa: E402
+from redmax_amd import BatchSim, sceneChain, syntheticStates  # noqa: E402
+
+for n, tol in ((32, 1e-9), (64, 1e-9), (72, 1e-8), (128, 1e-7), (256, 1e-6)):
+    sc = sceneChain(n)
+    sc.init()
+    for B in (256, 1024):
+        q, qd = syntheticStates(sc.nr, B)
+        sim = BatchSim(sc, batch=B)
+        sim.opts.tol = tol
+        sim.set_state(q, qd)
+        sim.step_bdf1(2, h=1e-2)
+        o = sim.step_bdf1(20, h=1e-2, stats=True)
+        print("chain %3d  B=%4d tol %g: %.3f ms per step, %.2f Newton iterations per step, %.1f k rollout-steps/s, bad %d" % (
+            n, B, tol, o["ms"] / 20, o["newton_iters"].sum() / (20 * B), B * 20 / o["ms"], int(((o["status"] & 15) != 0).sum())), flush=True)
+        sim.close()

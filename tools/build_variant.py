@@ -43,7 +43,7 @@ def main():
                                       stderr=subprocess.DEVNULL))
     if any(p.wait() != 0 for p in procs):
         raise SystemExit("hipcc failed")
-    objs = [os.path.join(ge.OBJ_DIR, "redmax_hip.o")]
+    objs = [os.path.join(ge.OBJ_DIR, "redmax_hip.o"), os.path.join(ge.OBJ_DIR, "rmx_big.o")]
     for n in ge.HIP_NPS:
         for part in (0, 1, 2):
             if part == 2 and n < 16:
