@@ -104,6 +104,8 @@ def parse_args(argv=None):
     ap.add_argument("--tol", type=float, default=1e-9, help="Newton |g| tolerance: the reference's hard-coded 1e-9 (driverRedMaxBDF1.m:95)")
     ap.add_argument("--plain-iterate", action="store_true", help="rmx_opts.compensated = 0 for the headline line (plain doubles)")
     ap.add_argument("--repeats", type=int, default=5, help="extra timed launches of the same K steps from the same state")
+    ap.add_argument("--burn-in", type=float, default=60.0, help="milliseconds of untimed launches of the same K steps, each from the initial state, BEFORE "
+                                                                "the W warm-up steps (brings the GPU out of its idle clock state); 0: none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-tol", "--no-side-legs", dest="no_reference_tol", action="store_true",
                     help="skip the side measurements (plain iterate, SURVEY init ranges, tol 1e-8)")
@@ -260,7 +262,7 @@ class RankContext:
         return int(t.item())
 
 
-def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, compensated=1):
+def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, compensated=1, burn_in=0):
     """The contract's timed region for one shard plan: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier +
     device sync on both sides, MAX over ranks; then `repeats` more launches of the same K steps from the same (post-warm-up)
     state for the spread.  Returns a dict (identical on every rank where it matters)."""
@@ -273,7 +275,18 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
     q0, qd0 = gen(shard.first, shard.count)
     st.set_state(q0, qd0)
     ctx.gather(st, shard)              # warm the collective too (before the warm-up steps: nothing but the barrier + device
-    st.stats_reset()                   # sync the contract asks for lies between the warm-up steps and the timed launch)
+    burned, burn_ms = 0, 0.0           # sync the contract asks for lies between the warm-up steps and the timed launch)
+    while burn_ms < burn_in and burned < 200:
+        # burn-in: untimed launches of the very kernel that will be timed, each from the initial state, until the GPU has been busy
+        # for `burn_in` milliseconds: an idle MI355X runs its first ~20 ms of work about 5 % below its sustained clock (s_memtime
+        # ticks per rollout stay the same, the launch takes longer: tools/first_launch_probe.py).  The state is put back afterwards.
+        st.set_state(q0, qd0)
+        st.launch(K)
+        burn_ms += st.wait()
+        burned += 1
+    if burned:
+        st.set_state(q0, qd0)
+    st.stats_reset()
     st.warmup(W)
     st.sync_device()
     ctx.barrier()
@@ -292,6 +305,7 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
         "finite": bool(np.isfinite(qf).all() and np.isfinite(qdf).all()), "rollouts": shard.global_batch,
         "gathered_rows": int(gathered[0].shape[0]) if gathered is not None else shard.count,
         "local_iters": s["newton_iters"].copy(),
+        "burned": burned,
     }
     if hasattr(st, "rollout_ticks"):      # how the launch time is spread over this rank's rollouts (all run concurrently, one wavefront each)
         tk = st.rollout_ticks().astype(np.float64)
@@ -409,21 +423,22 @@ def rank_main(args, make_stepper=None, backend=None):
     n = scene.nr
     weak = sharding.plan(rank, world, B, "weak")
     comp = 0 if args.plain_iterate else 1
-    m = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, K, W, args.repeats, comp)
+    burn = args.burn_in if on_gpu else 0.0         # a clock ramp is a GPU matter: the CPU stand-ins of the tests skip it
+    m = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, K, W, args.repeats, comp, burn)
     plain = strong = wide = soft = None
     KR = args.ref_steps
     if wl == "chain" and not args.no_reference_tol:
         # side measurements, always over the reference's own rollout length: the lattice of doubles binds (and the wide initial
         # states fail) late in a rollout, a short --steps window would hide it
         if comp:
-            plain = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, KR, W, 0, 0)
+            plain = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, KR, W, 0, 0, burn)
         from redmax_amd import syntheticStates
         wide = measure(ctx, make_stepper, scene, lambda first, count: syntheticStates(scene.nr, count, first=first, sq=np.pi / 4, sv=1.0),
-                       weak, h, args.tol, integ, KR, W, 0, comp)
+                       weak, h, args.tol, integ, KR, W, 0, comp, burn)
         if args.tol != 1e-8:
-            soft = measure(ctx, make_stepper, scene, gen, weak, h, 1e-8, integ, K, W, 0, comp)
+            soft = measure(ctx, make_stepper, scene, gen, weak, h, 1e-8, integ, K, W, 0, comp, burn)
     if world > 1 and not args.no_strong:
-        strong = measure(ctx, make_stepper, scene, gen, sharding.plan(rank, world, B, "strong"), h, args.tol, integ, K, W, args.repeats, comp)
+        strong = measure(ctx, make_stepper, scene, gen, sharding.plan(rank, world, B, "strong"), h, args.tol, integ, K, W, args.repeats, comp, burn)
 
     if rank == 0:
         value = m["rollouts"] * K / m["elapsed"]
@@ -445,7 +460,7 @@ def rank_main(args, make_stepper=None, backend=None):
                        "parallelism": "batch-sharded x%d (redmax_amd.sharding), one %s all-gather of the final (q,qdot)%s" % (
                            world, "RCCL" if backend == "nccl" else backend,
                            "; ranks share a device, so the gather runs on gloo with host tensors" if (on_gpu and shared) else ""),
-                       "steps_per_launch": K, "not_converged_trajectories": m["bad"], "trajectories_with_pivoted_fallback": m["pivoted"],
+                       "steps_per_launch": K, "untimed_burn_in": {"ms": burn, "launches": m.get("burned", 0)}, "not_converged_trajectories": m["bad"], "trajectories_with_pivoted_fallback": m["pivoted"],
                        "all_finite": m["finite"], "gathered_rows": m["gathered_rows"]},
             "roofline": roofline(m, K, B, world, n, wl) if on_gpu else None,
         }
@@ -642,8 +657,10 @@ def adjoint_main(args, ctx):
     def run():
         sim.set_state(q0[None, :], qd0[None, :])
         return sim.adjoint_bdf1(K, sc.h, task, p, stats=True)
-    for _ in range(max(1, min(args.warmup, 2))):
-        run()
+    burn_ms, burned = 0.0, 0            # untimed launches of the same job: warm-up and clock ramp (see measure())
+    while burned < max(1, min(args.warmup, 2)) or (burn_ms < args.burn_in and burned < 200):
+        burn_ms += run()[2]["ms"]
+        burned += 1
     ctx.barrier()
     t0 = time.perf_counter()
     P, dPdp, info = run()
@@ -667,6 +684,7 @@ def adjoint_main(args, ctx):
                "config": {"workload": "adjoint BDF1 forward+backward (rmx_adjoint_bdf1), %d-DOF chain of scene 100's pattern, batch=%d per GPU, "
                                       "horizon %d steps (BASELINE.json configs[3])" % (n, B, K),
                           "batch_per_gpu": B, "links": n, "h": sc.h, "params": "p~N(0,1e-2), rng(20240+rank)",
+                          "untimed_burn_in": {"ms": args.burn_in, "launches": burned},
                           "newton_iters_per_step": round(iters / (B * K), 3), "not_converged_trajectories": bad,
                           "all_finite": bool(np.isfinite(P).all() and np.isfinite(dPdp).all()),
                           "timed_region": "set_state + forward kernel + backward kernel + copy-out of P, dPdp (host buffers at the ABI)"},
