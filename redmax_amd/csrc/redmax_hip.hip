@@ -604,7 +604,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     (void)hipSetDevice(b->m->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart, (void*)b->ticks, (void*)b->bigws})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -935,7 +935,23 @@ static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rm
     void* bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t sizes[6] = {hist, hist, hist, (size_t)b->B * m->n * sizeof(double), (size_t)b->B * sizeof(double), nv * sizeof(double)};
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipMalloc(&bufs[i], sizes[i] ? sizes[i] : 8);
+    {   // one workspace per batch, kept between calls (grow-only): parts at 256-byte boundaries
+        size_t total = 0, offs[6];
+        for (int i = 0; i < 6; ++i) {
+            offs[i] = total;
+            total += (sizes[i] + 255) & ~(size_t)255;
+        }
+        if (total > b->adjws_bytes) {
+            if (b->adjws) (void)hipFree(b->adjws);
+            b->adjws = nullptr;
+            b->adjws_bytes = 0;
+            e = hipMalloc(&b->adjws, total);
+            if (e == hipSuccess) b->adjws_bytes = total;
+            else b->adjws = nullptr;
+        }
+        if (e == hipSuccess)
+            for (int i = 0; i < 6; ++i) bufs[i] = (char*)b->adjws + offs[i];
+    }
     if (e == hipSuccess) e = hipMemsetAsync(bufs[3], 0, sizes[3], b->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b->tmpA, p, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
@@ -959,8 +975,7 @@ static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rm
             if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
         }
     }
-    for (void* ptr : bufs)
-        if (ptr) (void)hipFree(ptr);
+    if (e == hipErrorOutOfMemory) return fail(RMX_E_NOMEM, "rmx_adjoint: no device memory for the history (H, M, D per step and rollout)");
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_adjoint: ") + hipGetErrorString(e));
     return RMX_OK;
 }

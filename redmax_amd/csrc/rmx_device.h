@@ -161,6 +161,23 @@ __device__ __forceinline__ void fmsub_rowbcast(double& acc, const double src, co
         asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
 }
 
+// acc += m * (value of src in lane N of the caller's own 16-lane row).  Same instruction and hazard note as fmsub_rowbcast; the
+// column loops that use it (eval_hess / eval_MD up to 16 nodes) read registers written long before the loop.
+template <int N>
+__device__ __forceinline__ void fmadd_rowbcast(double& acc, const double src, const double m) {
+    static_assert(N >= 0 && N < 16, "row_newbcast lane");
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(N));
+}
+
+// The DPP hazard above, for operands the compiler is free to compute late: every v[c] is materialised (an empty volatile asm takes it
+// as an operand; volatile asm statements keep their order) and two wait states pass before the first broadcast that follows.
+template <int N>
+__device__ __forceinline__ void dpp_settle(double (&v)[N]) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) asm volatile("" : "+v"(v[c]));
+    asm volatile("s_nop 1");
+}
+
 // the value of lane N of the caller's own 16-lane row, in every lane (v_mov_b64_dpp row_newbcast; the compiler takes care of the
 // wait states after a VALU write of the source)
 template <int N>
@@ -1138,6 +1155,35 @@ __device__ __forceinline__ void eval_mass(const DevModel& M, const int lane, con
 // (TaskBDF1.m:58-70):  D(a,i) = s_a.(Bc_i s_i - 2 Ic_i xi_i)  a ancestor-or-self of i ;
 //                              = (Bc_a' s_a).s_i - 2 (Ic_a s_a).xi_i  a strict descendant ;  + Dr on the diagonal.
 // Idle rows/columns: identity in M, zero in D.
+// Column I (and on) of M and D for trees of up to 16 nodes (eval_MD's loop with the column broadcast fused into the FMAs).
+template <int NP, int I>
+__device__ __forceinline__ void md_columns_dpp(const double (&cv)[24], const double (&sw)[3], const double (&sv)[3], const double (&r1)[6],
+                                               const double (&r2w)[3], const unsigned long long desc_m, const unsigned long long anc_m,
+                                               const int lane, const double mdiag, const double ddiag, double (&Mrow)[NP], double (&Drow)[NP]) {
+    if constexpr (I < NP) {
+        double m_lo = 0.0, m_up = 0.0, d_a = 0.0, d_b = 0.0, d_up = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            fmadd_rowbcast<I>(m_lo, cv[c], r1[c]);
+            fmadd_rowbcast<I>(d_b, cv[6 + c], r1[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {         // accumulators in turn, see hess_columns_dpp
+            fmadd_rowbcast<I>(m_up, cv[12 + c], sw[c]);
+            fmadd_rowbcast<I>(d_a, cv[c], r2w[c]);
+            fmadd_rowbcast<I>(d_up, cv[18 + c], sw[c]);
+            fmadd_rowbcast<I>(m_up, cv[15 + c], sv[c]);
+            fmadd_rowbcast<I>(d_up, cv[21 + c], sv[c]);
+        }
+        const double d_lo = d_a - 2.0 * d_b;
+        const double mu = (double)(unsigned)((desc_m >> I) & 1ull);
+        const double ml = (double)(unsigned)((anc_m >> I) & 1ull);
+        Mrow[I] = (I == lane) ? mdiag : (mu * m_up + ml * m_lo);
+        Drow[I] = (I == lane) ? ddiag : (mu * d_up + ml * d_lo);
+        md_columns_dpp<NP, I + 1>(cv, sw, sv, r1, r2w, desc_m, anc_m, lane, mdiag, ddiag, Mrow, Drow);
+    }
+}
+
 template <int NP>
 __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const FrontState& fs, double (&Mrow)[NP], double (&Drow)[NP]) {
     const bool act = fs.act;
@@ -1190,6 +1236,11 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
     const double syD = fs.sw[0] * yD[0] + fs.sw[1] * yD[1] + fs.sw[2] * yD[2] + fs.sv[0] * yD[3] + fs.sv[1] * yD[4] + fs.sv[2] * yD[5];
     const double mdiag = fs.dof ? sr1 : 1.0;
     const double ddiag = fs.dof ? (syD - fs.dd) : 0.0;
+    if constexpr (NP <= 16) {     // one DPP row holds the tree: broadcasts fused into the FMAs (see eval_hess)
+        dpp_settle(cv);
+        md_columns_dpp<NP, 0>(cv, fs.sw, fs.sv, r1, r2w, desc_m, anc_m, lane, mdiag, ddiag, Mrow, Drow);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         double Ci[24];
@@ -1295,6 +1346,38 @@ __device__ __forceinline__ void hess64_tiles(const int lane, const double* __res
 
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle node slots are the identity.
 // Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
+// Column I (and on) of H for trees of up to 16 nodes, see eval_hess: H(a, i) = [i strict descendant of a] s_a . cu_i +
+// [i strict ancestor of a] (r1_a . m1_i - r2w_a . m2w_i - r3w_a . sw_i  - contact terms), Hdiag on the diagonal.
+template <int NP, bool CT, int I, int NCV>
+__device__ __forceinline__ void hess_columns_dpp(const double (&cv)[NCV], const double (&sw)[3], const double (&sv)[3], const double (&r1t)[3],
+                                                 const double (&r1f)[3], const double (&r2w)[3], const double (&r3w)[3],
+                                                 const double (&cxr2)[6], const double (&cxr3)[6], const unsigned long long desc_m,
+                                                 const unsigned long long anc_m, const int lane, const double Hdiag, double (&Hrow)[NP]) {
+    if constexpr (I < NP) {
+        // three accumulators taken in turn: two consecutive FMAs into the same register cost a wait state each
+        double up = 0.0, lo = 0.0, lo2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            fmadd_rowbcast<I>(up, cv[c], sw[c]);
+            fmadd_rowbcast<I>(lo, cv[6 + c], r1t[c]);
+            fmsub_rowbcast<I>(lo2, cv[12 + c], r2w[c]);
+            fmadd_rowbcast<I>(up, cv[3 + c], sv[c]);
+            fmadd_rowbcast<I>(lo, cv[9 + c], r1f[c]);
+            fmsub_rowbcast<I>(lo2, cv[15 + c], r3w[c]);
+            if constexpr (CT) {
+                fmsub_rowbcast<I>(lo, cv[18 + c], cxr2[3 + c]);
+                fmsub_rowbcast<I>(lo2, cv[21 + c], cxr3[3 + c]);
+            }
+        }
+        lo += lo2;
+        const double mu = (double)(unsigned)((desc_m >> I) & 1ull);   // column node I is a strict descendant of this row's node
+        const double ml = (double)(unsigned)((anc_m >> I) & 1ull);    // column node I is a strict ancestor
+        const double hv = mu * up + ml * lo;
+        Hrow[I] = (I == lane) ? Hdiag : hv;
+        hess_columns_dpp<NP, CT, I + 1>(cv, sw, sv, r1t, r1f, r2w, r3w, cxr2, cxr3, desc_m, anc_m, lane, Hdiag, Hrow);
+    }
+}
+
 template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
                                           unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0) {
@@ -1750,6 +1833,13 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
         if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
         RMX_SYNC();
+    } else if constexpr (NP <= 16) {
+        // up to 16 nodes the whole tree sits in one 16-lane DPP row: the broadcast of column node i rides on the FMA
+        // (v_fmac_f64_dpp row_newbcast, fmadd_rowbcast) - 18 instructions per column instead of 36 v_readlane + 18 FMA, and no
+        // scalar registers: hoisted ahead of their FMAs, the broadcasts of 16 columns were 576 SGPRs, spilled to VGPR lanes and
+        // back (1100 v_writelane / v_readlane pairs per call, two thirds of the adjoint forward kernel at 16 nodes).
+        dpp_settle(cv);
+        hess_columns_dpp<NP, CT, 0>(cv, sw, sv, r1t, r1f, r2w, r3w, cxr2, cxr3, desc_m, anc_m, lane, Hdiag, Hrow);
     } else {
 #pragma unroll
         for (int t = 0; t < NP; ++t) {

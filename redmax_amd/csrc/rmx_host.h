@@ -78,6 +78,8 @@ struct rmx_batch {
     unsigned long long* ticks = nullptr;   // [B] see StepArgs.ticks (rmx_step_ticks)
     double* bigws = nullptr;        // trees of more than 64 nodes: per-rollout workspace of the rmx_big.hip kernels
     size_t bigws_stride = 0;        // doubles per rollout
+    void* adjws = nullptr;          // rmx_adjoint_*: H, M, D of every step and rollout, dP/dq, P, dP/dp - one allocation that is kept
+    size_t adjws_bytes = 0;         // between calls and only ever grows (hipMalloc + hipFree of 3 x 20 MB cost more than the kernels)
     double last_ms = 0.0;
     bool async_pending = false;     // an rmx_step_bdf1_async launch nobody has waited for yet (see pending_error_check)
 };
