@@ -143,10 +143,11 @@ class GpuStepper:
         self.B, self.nr = batch, scene.nr
         self._out = None
 
-    def set_opts(self, h, tol, compensated=1):
+    def set_opts(self, h, tol, compensated=1, ls_fail_limit=0):
         self.sim.opts.h = h
         self.sim.opts.tol = tol
         self.sim.opts.compensated = int(compensated)
+        self.sim.opts.ls_fail_limit = int(ls_fail_limit)
 
     def set_state(self, q, qd):
         self.sim.set_state(q, qd)
@@ -262,7 +263,7 @@ class RankContext:
         return int(t.item())
 
 
-def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, compensated=1, burn_in=0):
+def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, compensated=1, burn_in=0, ls_fail_limit=0):
     """The contract's timed region for one shard plan: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier +
     device sync on both sides, MAX over ranks; then `repeats` more launches of the same K steps from the same (post-warm-up)
     state for the spread.  Returns a dict (identical on every rank where it matters)."""
@@ -271,7 +272,10 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
     if integ == "bdf2":
         repeats = 0                    # a restored state restarts BDF2 with its SDIRK2 step: not the same work as the timed launch
     st = make_stepper(scene, shard.count, ctx.device, integ)
-    st.set_opts(h, tol, compensated)
+    if ls_fail_limit:
+        st.set_opts(h, tol, compensated, ls_fail_limit)
+    else:
+        st.set_opts(h, tol, compensated)
     q0, qd0 = gen(shard.first, shard.count)
     st.set_state(q0, qd0)
     ctx.gather(st, shard)              # warm the collective too (before the warm-up steps: nothing but the barrier + device
@@ -425,8 +429,12 @@ def rank_main(args, make_stepper=None, backend=None):
     comp = 0 if args.plain_iterate else 1
     burn = args.burn_in if on_gpu else 0.0         # a clock ramp is a GPU matter: the CPU stand-ins of the tests skip it
     m = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, K, W, args.repeats, comp, burn)
-    plain = strong = wide = soft = None
+    plain = strong = wide = soft = cutleg = None
     KR = args.ref_steps
+    if wl == "ground" and on_gpu and not args.no_reference_tol:
+        # the opt-in straggler policy (rmx_opts.ls_fail_limit, NOT reference behaviour): same launch, Newton loop of a step cut at its
+        # second failed line search.  A side figure; `value` is the reference's loop.
+        cutleg = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, K, W, 0, comp, burn, 2)
     if wl == "chain" and not args.no_reference_tol:
         # side measurements, always over the reference's own rollout length: the lattice of doubles binds (and the wide initial
         # states fail) late in a rollout, a short --steps window would hide it
@@ -503,6 +511,14 @@ def rank_main(args, make_stepper=None, backend=None):
                 "kernel_ms": round(soft["kernel_ms"], 4), "newton_iters_per_step": round(soft["iters"] / (soft["rollouts"] * K), 3),
                 "not_converged_trajectories": soft["bad"],
                 "note": "rounds 1 and 2 ran the headline at tol = 1e-8 (above the lattice spacing of g); kept for comparison with BENCH_r01/r02"}
+        if cutleg is not None:
+            out["value_with_ls_fail_limit_2"] = {
+                "value": round(cutleg["rollouts"] * K / cutleg["elapsed"], 1), "unit": "rollout-steps/s", "kernel_ms": round(cutleg["kernel_ms"], 4),
+                "newton_iters_per_step": round(cutleg["iters"] / (cutleg["rollouts"] * K), 3), "not_converged_trajectories": cutleg["bad"],
+                "rollout_ms": cutleg.get("rollout_ms"),
+                "note": "rmx_opts.ls_fail_limit = 2, the opt-in straggler policy (off by default, NOT the reference's loop): a step stops "
+                        "iterating at its second failed line search instead of creeping on to iterMax = 320 iterations; rollouts it "
+                        "does not touch are bit-identical (tests/test_gpu_straggler_policy.py)"}
         if strong is not None:
             out["note"] = ("METRIC-CONFORMANT FIGURE AT N > 1: strong_scaling.value (BASELINE.json's metric is a 1024-rollout batch: 1024 rollouts "
                            "in TOTAL over the %d ranks).  `value` is the weak-scaling figure the bench contract asks for: %d rollouts per GPU, a "

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 104
+#define RMX_VERSION 105
 
 enum {
     RMX_OK = 0,
@@ -62,7 +62,8 @@ enum {
 /* RMX_ST_PIVOTED is informational: at least one linear solve tripped the diagonal-pivot growth guard and was redone
  * with full partial pivoting (see rmx_device.h lu_solve_neg_diag). */
 enum { RMX_ST_DIVERGED = 1, RMX_ST_MAXITER = 2, RMX_ST_NAN = 4, RMX_ST_STALLED = 8, RMX_ST_PIVOTED = 16,
-       RMX_ST_CHART = 32 /* informational: a JointSpherical changed its Euler chart (the reference prints 'XYZ->YXZ') */ };
+       RMX_ST_CHART = 32 /* informational: a JointSpherical changed its Euler chart (the reference prints 'XYZ->YXZ') */,
+       RMX_ST_LS_CUT = 128 /* with RMX_ST_MAXITER: rmx_opts.ls_fail_limit ended the Newton loop of a step (off by default) */ };
 
 /* Scene listing, one entry per joint/body pair in the order the scene file lists them
  * (parent before child; scenesRedMax.m).  Replaces the handle-object graph that Scene.init()
@@ -114,6 +115,16 @@ typedef struct rmx_opts {
                                 and a smoother evaluation does not.  With xlo no Newton correction is lost to
                                 the rounding of x and the iteration converges to the evaluation noise, at the reference's constants;
                               0 plain doubles: the reference's arithmetic, decision for decision  */
+    int ls_fail_limit;     /* straggler policy for batches, 0 (default) = off = the reference: newton() keeps iterating after a line
+                              search that ran out its iterLsMax trials without a decrease of ||g|| (:126-138), up to iterMax = 10 nr
+                              times - at a non-smooth point of the residual (stick/slip or touch-down of a ground contact) every one of
+                              them fails or creeps the same way, ~4600 evaluations for one step of one rollout, and the launch of a whole
+                              batch ends with its slowest wavefront.  N > 0: the Newton loop of a step ends ("did not converge", status
+                              RMX_ST_MAXITER | RMX_ST_LS_CUT) at the N-th failed line search of that step (failed and barely
+                              successful ones alternate at such a point, so they are not required to be consecutive); the iterate
+                              is the one that line search left (x0 + 2^-19 dx, as in the reference).  The state after such a step
+                              differs from the reference's by the drift of the iterations not run; a step in which no line search
+                              fails N times runs exactly as without the option  */
 } rmx_opts;
 
 typedef struct rmx_model rmx_model;

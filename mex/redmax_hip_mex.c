@@ -28,7 +28,7 @@
  *                  (Scene.saveHistory energies); st: B x 3 int32 [newton iterations, line-search halvings, RMX_ST_* bits];
  *                  Q, Qd (only when requested): nr x B x nsteps, the full Scene.saveHistory record (Scene.m:134-161);
  *                  C (only when requested): nsph x B x nsteps int32, the Euler chart of every spherical joint after each step.
- *                  opts: struct with any of tol, dxMax, iterMaxPerDof, iterLsMax, lu_mode, compensated (driverRedMaxBDF1.m:95-98).
+ *                  opts: struct with any of tol, dxMax, iterMaxPerDof, iterLsMax, lu_mode, compensated, ls_fail_limit (driverRedMaxBDF1.m:95-98).
  *   [T, V]       = redmax_hip_mex('euler', h, hstep, nsteps)             matlab-simple/testRedMax.m:67-109
  *   [g, H]       = redmax_hip_mex('eval', h, q, qA, qB, eta)             evalBDF1 & co (driverRedMaxBDF1.m:160-187); H: nr x nr x B
  *   [T, V]       = redmax_hip_mex('energy', h)                           Joint/Body.computeEnergies
@@ -211,6 +211,7 @@ static void read_opts(const mxArray* s, rmx_opts* o) {
     o->dxMax = scalar_field(s, "dxMax", o->dxMax);
     o->iterMaxPerDof = (int)scalar_field(s, "iterMaxPerDof", o->iterMaxPerDof);
     o->iterLsMax = (int)scalar_field(s, "iterLsMax", o->iterLsMax);
+    o->ls_fail_limit = (int)scalar_field(s, "ls_fail_limit", o->ls_fail_limit);
     o->lu_mode = (int)scalar_field(s, "lu_mode", o->lu_mode);
     o->compensated = (int)scalar_field(s, "compensated", o->compensated);
 }

@@ -92,6 +92,7 @@ def lib():
                                           C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]
         L.otf_batch_step_bdf1.restype = C.c_long
         L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_set_ls_fail_limit.argtypes = [C.c_int]
         L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
         L.orc_adjoint_bdf1.restype = C.c_double
@@ -389,6 +390,11 @@ class Oracle:
 def set_newton(tol=1e-9, dxMax=1e3, iterMaxPerDof=10, iterLsMax=20):
     """Newton constants for every subsequent step call (defaults = driverRedMaxBDF1.m:95-98)."""
     lib().orc_set_newton(float(tol), float(dxMax), int(iterMaxPerDof), int(iterLsMax))
+
+
+def set_ls_fail_limit(n=0):
+    """rmx_opts.ls_fail_limit restated (0 = off = the reference's newton)."""
+    lib().orc_set_ls_fail_limit(int(n))
 
 
 def batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0, counters=False):

@@ -911,6 +911,11 @@ static int g_iterMaxPerDof = 10, g_iterLsMax = 20;
 void orc_set_newton(double tol, double dxMax, int iterMaxPerDof, int iterLsMax) {
     g_tol = tol; g_dxMax = dxMax; g_iterMaxPerDof = iterMaxPerDof; g_iterLsMax = iterLsMax;
 }
+/* NOT in the reference: the library's opt-in straggler policy rmx_opts.ls_fail_limit restated, so that the option has a checker
+ * too.  0 (default) = the reference's newton().  N > 0: the loop ends, "not converged", at the N-th line search of the call that
+ * ran out its iterLsMax trials without a decrease of f. */
+static int g_lsFailLimit = 0;
+void orc_set_ls_fail_limit(int n) { g_lsFailLimit = n > 0 ? n : 0; }
 
 /* newton (driverRedMaxBDF1.m:94-157): x updated in place */
 static void newton(orc_scene* s, double* x, const double* qA, const double* qB, double eta, orc_stats* st) {
@@ -921,7 +926,7 @@ static void newton(orc_scene* s, double* x, const double* qA, const double* qB, 
     double* H = (double*)calloc((size_t)nr * nr + 1, sizeof(double));
     double* dx = (double*)calloc((size_t)nr + 1, sizeof(double));
     double* x0 = (double*)calloc((size_t)nr + 1, sizeof(double));
-    int iter = 1;
+    int iter = 1, lsfail = 0;
     while (1) {
         orc_eval_residual(s, x, qA, qB, eta, g, H);
         if (st) { st->hessian_evals++; st->newton_iters++; }
@@ -930,13 +935,13 @@ static void newton(orc_scene* s, double* x, const double* qA, const double* qB, 
         double alpha = 1.0;
         double f0 = 0; for (int i = 0; i < nr; i++) f0 += g[i] * g[i]; f0 *= 0.5;
         memcpy(x0, x, sizeof(double) * (size_t)nr);
-        int iterLs = 1;
+        int iterLs = 1, decreased = 0;
         while (1) {
             for (int i = 0; i < nr; i++) x[i] = x0[i] + alpha * dx[i];
             orc_eval_residual(s, x, qA, qB, eta, g, NULL);
             if (st) st->residual_evals++;
             double f = 0; for (int i = 0; i < nr; i++) f += g[i] * g[i]; f *= 0.5;
-            if (f < f0) break;
+            if (f < f0) { decreased = 1; break; }
             if (iterLs >= iterLsMax) break;
             alpha = 0.5 * alpha;
             iterLs++;
@@ -944,6 +949,8 @@ static void newton(orc_scene* s, double* x, const double* qA, const double* qB, 
         if (st) st->ls_halvings += iterLs - 1;
         if (vnorm(nr, g) < tol) break;
         if (iter >= iterMax) { if (st) st->not_converged++; break; }
+        lsfail += decreased ? 0 : 1;
+        if (g_lsFailLimit > 0 && lsfail >= g_lsFailLimit) { if (st) st->not_converged++; break; }     /* orc_set_ls_fail_limit */
         iter++;
     }
     free(g); free(H); free(dx); free(x0);

@@ -103,6 +103,8 @@ typedef struct orc_stats {
 /* Newton constants used by every orc_step_* call (process-global).  Defaults = the reference's hard-coded
  * values tol=1e-9, dxMax=1e3, iterMax=10*nr, iterLsMax=20 (driverRedMaxBDF1.m:95-98). */
 void orc_set_newton(double tol, double dxMax, int iterMaxPerDof, int iterLsMax);
+/* rmx_opts.ls_fail_limit restated (NOT reference behaviour; 0 = off = the reference) */
+void orc_set_ls_fail_limit(int n);
 
 /* driverRedMaxBDF1.m simLoop:57-91 + newton:94-157.  Advances nsteps steps.
  * If Hist_T/Hist_V non-NULL they receive T,V after each step (Scene.saveHistory). */

@@ -47,7 +47,7 @@ class ModelDesc(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("h", C.c_double), ("tol", C.c_double), ("dxMax", C.c_double),
-                ("iterMaxPerDof", C.c_int), ("iterLsMax", C.c_int), ("lu_mode", C.c_int), ("compensated", C.c_int)]
+                ("iterMaxPerDof", C.c_int), ("iterLsMax", C.c_int), ("lu_mode", C.c_int), ("compensated", C.c_int), ("ls_fail_limit", C.c_int)]
 
 
 class TaskPointPos(C.Structure):

@@ -60,6 +60,7 @@ extern "C" void rmx_opts_default(rmx_opts* o) {
     o->iterLsMax = 20;      // :98
     o->lu_mode = 0;
     o->compensated = 1;
+    o->ls_fail_limit = 0;   // the reference: never cut the Newton loop short
 }
 
 namespace {
@@ -743,6 +744,8 @@ static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
     d.iterLsMax = o->iterLsMax;
     d.lu_mode = o->lu_mode;
     d.comp = o->compensated ? 1.0 : 0.0;
+    if (o->ls_fail_limit < 0) return fail(RMX_E_INVALID, "opts.ls_fail_limit must be >= 0");
+    d.lsFailLimit = o->ls_fail_limit;
     return RMX_OK;
 }
 

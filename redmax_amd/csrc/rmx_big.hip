@@ -492,7 +492,7 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
                              int& halvings, int& status, double& xlo) {
     double lo = 0.0;
     BigOut e;
-    int iter = 1;
+    int iter = 1, lsfail = 0;
     while (true) {
         big_eval<true>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
         const BigOut e0 = e;
@@ -533,6 +533,8 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
         }
         if (sqrt(gn2) < o.tol) break;
         if (iter >= o.iterMax) { status |= 2; break; }
+        lsfail += (0.5 * gn2 < f0) ? 0 : 1;              // rmx_opts.ls_fail_limit, see newton_impl
+        if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) { status |= 2 | ST_LS_CUT; break; }
         ++iter;
     }
     xlo = lo;

@@ -109,6 +109,7 @@ struct DevOpts {
     int iterMax, iterLsMax;
     int lu_mode;      // 0: diagonal pivots under a growth guard, partial pivoting on demand; 1: always partial pivoting
     double comp;      // 1.0: compensated Newton iterate (x + xlo, see newton_impl); 0.0: plain doubles (the reference's lattice)
+    int lsFailLimit;  // rmx_opts.ls_fail_limit: > 0 ends a step's Newton loop at its N-th failed line search
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -2708,6 +2709,7 @@ __device__ __forceinline__ void pivot_policy_update(PivotPolicy& piv) {   // aft
 // LEAN (contact-capable kernels, see newton_node): the evaluations carry no contact terms but test whether any cuboid of the tree
 // comes near the ground; the first one that does ends the solve with status bit 64 and the caller redoes it with CT = true.
 constexpr int ST_LEFT_LEAN = 64;
+constexpr int ST_LS_CUT = 128;     // RMX_ST_LS_CUT
 template <int NP, bool PIVOT_ONLY, bool CT = false, bool LEAN = false>
 __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
@@ -2731,7 +2733,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         status |= ST_LEFT_LEAN;
         return x;
     }
-    int iter = 1;
+    int iter = 1, lsfail = 0;
     double gcarry = -1.0;
     while (true) {
         const double hdiag = eval_hess<NP, false, CT, PIVOT_ONLY>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
@@ -2818,6 +2820,13 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         if (sqrt(gn2) < o.tol) break;
         if (iter >= o.iterMax) {
             status |= 2;         // "Newton did not converge" (:150-153)
+            break;
+        }
+        // rmx_opts.ls_fail_limit (off by default): a line search that ran out its trials without a decrease leaves x0 + 2^-19 dx;
+        // the reference goes on to iterMax, failing the same way every time (a non-smooth point of g: stick/slip, touch-down)
+        lsfail += (0.5 * gn2 < f0) ? 0 : 1;          // counted over the step, not consecutive: failed and barely successful ones alternate
+        if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) {
+            status |= 2 | ST_LS_CUT;
             break;
         }
         ++iter;
