@@ -56,17 +56,44 @@ __device__ __forceinline__ BigWs big_ws(double* base, const int nr) {
 // arguments: a generic pointer into LDS handed to an out-of-line device function trips a compiler bug on gfx950 - an illegal
 // V_CMP_NE_U32 against src_shared_base.)
 __device__ __forceinline__ double block_sum(double v, const int t) {
-    __shared__ double sred[BT];
-    sred[t] = v;
+    __shared__ double sred[BT / 64];
+    const double ws = wave_sum(v);          // identical in every lane of the wavefront (rmx_device.h)
+    if ((t & 63) == 0) sred[t >> 6] = ws;
     __syncthreads();
+    double r = sred[0];
 #pragma unroll
-    for (int s = BT / 2; s > 0; s >>= 1) {
-        if (t < s) sred[t] += sred[t + s];
-        __syncthreads();
-    }
-    const double r = sred[0];
+    for (int k = 1; k < BT / 64; ++k) r += sred[k];
     __syncthreads();
     return r;
+}
+// index of the largest v over the workgroup, the lowest index among equals (dgetf2's first maximum); v >= -1, NaN never wins
+__device__ __forceinline__ int block_argmax(double v, int idx, const int t) {
+    __shared__ double sv[BT / 64];
+    __shared__ int si[BT / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+    if ((t & 63) == 0) {
+        sv[t >> 6] = v;
+        si[t >> 6] = idx;
+    }
+    __syncthreads();
+    double bv = sv[0];
+    int bi = si[0];
+#pragma unroll
+    for (int k = 1; k < BT / 64; ++k)
+        if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) {
+            bv = sv[k];
+            bi = si[k];
+        }
+    __syncthreads();
+    return bi;
 }
 __device__ __forceinline__ int block_all(const bool v, const int t) {
     __shared__ int sflag;
@@ -409,6 +436,10 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     const int ka = act ? M.idx[tj] : -1;
     if (ka >= 0) {
         const int ea = M.end[tj];
+        const double* __restrict__ cu = w.cu;     // read-only here and distinct from H: lets the loads of later columns start
+        const double* __restrict__ cl = w.cl;     // before the stores of earlier ones
+        double* __restrict__ Hw = w.H;
+#pragma unroll 4
         for (int i = 0; i < n; ++i) {
             const int ki = M.idx[i];
             if (ki < 0) continue;
@@ -417,12 +448,12 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
                 h = Hdiag;
             } else if (t < i && i < ea) {          // this row's node is a strict ancestor of column node i
 #pragma unroll
-                for (int c = 0; c < 3; ++c) h += sw[c] * w.cu[c * BT + i] + sv[c] * w.cu[(3 + c) * BT + i];
+                for (int c = 0; c < 3; ++c) h += sw[c] * cu[c * BT + i] + sv[c] * cu[(3 + c) * BT + i];
             } else if (i < t && t < M.end[i]) {    // strict descendant
 #pragma unroll
-                for (int c = 0; c < 12; ++c) h += rl[c] * w.cl[c * BT + i];
+                for (int c = 0; c < 12; ++c) h += rl[c] * cl[c * BT + i];
             }
-            w.H[(size_t)ki * nr + ka] = h;
+            Hw[(size_t)ki * nr + ka] = h;
         }
     }
     __syncthreads();
@@ -432,52 +463,51 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
 // implicit (rows are never moved): piv[r] = the step at which row r served as the pivot row, or -1.  First maximum wins (dgetf2).
 // bneg: this node's -g (nodes without a DOF: ignored).  Returns this node's dx.
 __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
-    __shared__ double sred[BT];
-    __shared__ int sarg[BT];         // argmax candidates of the pivot search
     __shared__ int spiv[BT];         // pivot row of step k
     const int nr = M.nr;
+    double* __restrict__ H = w.H;
     double* b = w.vec;               // [nr]
     double* xs = w.vec + BT;         // [nr] solution in reduced order
     if (ka >= 0) b[ka] = -g;
     __syncthreads();
-    const int r = t;                 // this thread's reduced row
-    const bool row = r < nr;
+    // thread = (reduced row r, column group cg): the BT / nr threads of a row share its trailing columns (c = k+1+cg, step ncg); with
+    // one thread per row the update of a row was nr - k dependent global round trips per pivot, which is where the time went
+    const int ncg = BT / nr > 0 ? BT / nr : 1;
+    const int r = t % nr, cg = t / nr;
+    const bool row = cg < ncg;
     int mystep = -1;
     for (int k = 0; k < nr; ++k) {
         // pivot search over the unused rows: max |H(r,k)|, lowest row among equals
-        const double cand = (row && mystep < 0) ? fabs(w.H[(size_t)k * nr + r]) : -1.0;
-        sred[t] = cand;
-        sarg[t] = t;
-        __syncthreads();
-        for (int s = BT / 2; s > 0; s >>= 1) {
-            if (t < s) {
-                const double o = sred[t + s];
-                const int oi = sarg[t + s];
-                if (o > sred[t] || (o == sred[t] && oi < sarg[t])) {
-                    sred[t] = o;
-                    sarg[t] = oi;
-                }
-            }
-            __syncthreads();
-        }
-        const int pr = sarg[0];
-        __syncthreads();
+        const double cand = (row && cg == 0 && mystep < 0) ? fabs(H[(size_t)k * nr + r]) : -1.0;
+        const int pr = block_argmax(cand, r, t);
         if (t == 0) spiv[k] = pr;
         if (r == pr) mystep = k;
-        const double pvv = w.H[(size_t)k * nr + pr];
         if (row && mystep < 0) {
-            const double l = w.H[(size_t)k * nr + r] / pvv;
-            for (int c = k + 1; c < nr; ++c) w.H[(size_t)c * nr + r] -= l * w.H[(size_t)c * nr + pr];
-            b[r] -= l * b[pr];
+            const double l = H[(size_t)k * nr + r] / H[(size_t)k * nr + pr];
+            int c = k + 1 + cg;
+            for (; c + 3 * ncg < nr; c += 4 * ncg) {       // four columns in flight: loads first, then the stores
+                double* h0 = H + (size_t)c * nr;
+                double* h1 = h0 + (size_t)ncg * nr;
+                double* h2 = h1 + (size_t)ncg * nr;
+                double* h3 = h2 + (size_t)ncg * nr;
+                const double p0 = h0[pr], p1 = h1[pr], p2 = h2[pr], p3 = h3[pr];
+                const double a0 = h0[r], a1 = h1[r], a2 = h2[r], a3 = h3[r];
+                h0[r] = a0 - l * p0;
+                h1[r] = a1 - l * p1;
+                h2[r] = a2 - l * p2;
+                h3[r] = a3 - l * p3;
+            }
+            for (; c < nr; c += ncg) H[(size_t)c * nr + r] -= l * H[(size_t)c * nr + pr];
+            if (cg == 0) b[r] -= l * b[pr];
         }
         __syncthreads();
     }
     // back substitution on the implicitly permuted upper triangle
     for (int k = nr - 1; k >= 0; --k) {
         const int pr = spiv[k];
-        if (r == pr) xs[k] = b[r] / w.H[(size_t)k * nr + r];
+        if (cg == 0 && r == pr) xs[k] = b[r] / H[(size_t)k * nr + r];
         __syncthreads();
-        if (row && mystep < k) b[r] -= w.H[(size_t)k * nr + r] * xs[k];
+        if (row && cg == 0 && mystep < k) b[r] -= H[(size_t)k * nr + r] * xs[k];
         __syncthreads();
     }
     const double dx = ka >= 0 ? xs[ka] : 0.0;

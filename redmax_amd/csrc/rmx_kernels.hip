@@ -599,9 +599,13 @@ __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, cons
 // e2 = 1 (g = M v - e2 f = -f); M and D rows come from the subtree sums the same front pass leaves behind (eval_MD).
 template <int NP>
 __global__ void __launch_bounds__(64) k_eval_mfd(const DevModel M, const int B, const double* __restrict__ q, const double* __restrict__ qd,
-                                                 double* __restrict__ Mo, double* __restrict__ fo, double* __restrict__ Do) {
+                                                 double* __restrict__ Mo, double* __restrict__ fo, double* __restrict__ Do,
+                                                 const int* __restrict__ chart) {
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
+    // JointSpherical / JointFree3D: the group's three revolute nodes about the axes of the trajectory's Euler chart ARE the joint in
+    // the chart's coordinates (S = T of JointSpherical.m:298-303), so M, f, D come out in those coordinates with no further term
+    if (M.nsph) sph_setup<NP>(M, sCol, threadIdx.x, chart + (size_t)blockIdx.x * M.nsph);
     const int lane = threadIdx.x, traj = blockIdx.x;
     const int id = (lane < M.n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
@@ -804,7 +808,7 @@ void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
 
 void RMX_CAT(launch_mfd_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD) {
     const dim3 grid(b->B), block(64);
-    RMX_LAUNCH((k_eval_mfd<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD);
+    RMX_LAUNCH((k_eval_mfd<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD, b->chart);
 }
 
 #if RMX_NP == 64

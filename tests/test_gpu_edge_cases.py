@@ -76,7 +76,7 @@ def test_maximum_size_chain64(oracle_lib):
 
 def test_too_many_joints_is_an_error_not_a_fallback():
     from redmax_amd import BatchSim, RedMaxHipError
-    sc = sceneChain(65)
+    sc = sceneChain(257)          # 65..256 nodes run on the one-workgroup-per-trajectory kernels (tests/test_gpu_big_trees.py)
     sc.init()
     with pytest.raises(RedMaxHipError, match="njoints"):
         BatchSim(sc, batch=1)
@@ -237,13 +237,13 @@ def test_planar_joint_with_a_skew_plane_matches_oracle(oracle_lib):
     sim.close()
 
 
-def test_lowered_tree_larger_than_a_wavefront_is_an_error():
+def test_lowered_tree_larger_than_the_node_limit_is_an_error():
     from redmax_amd import BatchSim, RedMaxHipError
     from redmax_amd.redmax import JointFree3D
     sc = Scene()
     prev = None
-    for i in range(11):                                       # 11 x 6 DOF = 66 nodes after lowering
-        b = BodyCuboid(1.0, [1, 1, 1])
+    for i in range(43):                                       # 43 x 6 DOF = 258 nodes after lowering; the limit is 256
+        b = BodyCuboid(1.0, [1, 1, 1])                        # (66 nodes - 11 bodies - run: tests/test_gpu_big_trees.py, free20)
         j = JointFree3D(prev, b)
         j.setJointTransform(se3.transform(p=[1, 0, 0]))
         sc.bodies.append(b)

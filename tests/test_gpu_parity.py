@@ -456,7 +456,7 @@ def test_bdf1_steps_restart_the_bdf2_history(oracle_lib):
     sim.close()
 
 
-@pytest.mark.parametrize("name", ["0", "2", "3", "14", "chain8skew", "tree15", "chain32"])
+@pytest.mark.parametrize("name", ["0", "2", "3", "14", "chain8skew", "tree15", "chain32", "7", "9"])
 def test_compute_values_hook_matches_oracle(oracle_lib, name):
     """rmx_eval_mfd = computeValues (driverRedMaxBDF1.m:190-243): M = J'MmJ, f = fr + J'(fm - Mm Jdot qdot), D = df/dqdot vs the
     oracle's literal dense restatement (J, Jdot, the dJ/dq tensors), 1e-11 relative."""

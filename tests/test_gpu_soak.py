@@ -66,7 +66,7 @@ def test_random_tree_matches_oracle_extended(oracle_lib, seed, monkeypatch):
         monkeypatch.setattr(tf, "_random_scene", lambda s, contact=False, big=False: orig(s, contact=contact, big=True))
     try:
         tf.test_random_tree_matches_oracle(oracle_lib, seed)
-    except RedMaxHipError as e:      # the generator's node estimate can overshoot the 64-node limit of one wavefront
-        if "the limit is 64" not in str(e):
+    except RedMaxHipError as e:      # the generator's node estimate can overshoot the 64 nodes of one wavefront: such a scene runs on the
+        if "more than 64 nodes have no contact kernels" not in str(e):   # large-tree kernels, which refuse ground contact
             raise
-        pytest.skip("random scene needs more than 64 nodes")
+        pytest.skip("random contact scene needs more than 64 nodes")
