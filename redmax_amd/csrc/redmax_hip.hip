@@ -336,7 +336,11 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     m->smem_bytes = big ? 0 : sizeof(double) * ((size_t)acc_doubles(n, m->NP) + (size_t)NCONST * cstride(m->NP));
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_simd = 4 * prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            m->n_simd = 4 * prop.multiProcessorCount;
+            m->lds_limit = (int)prop.sharedMemPerBlock;
+        }
+        if (const char* lim = getenv("RMX_BIG_LDS_LIMIT")) m->lds_limit = atoi(lim);     // development aid (0: H of large trees stays in HBM)
     }
     if (hipSetDevice(device) != hipSuccess) { delete m; return fail(RMX_E_HIP, "hipSetDevice failed"); }
     const size_t nd = K.size() + sb.size() + I4.size() + prm.size();

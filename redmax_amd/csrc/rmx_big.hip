@@ -52,6 +52,21 @@ __device__ __forceinline__ BigWs big_ws(double* base, const int nr) {
     return w;
 }
 
+// H in LDS (HL): up to ~136 reduced DOFs the nr x nr matrix fits the CU's 160 KB next to the small static arrays, and one pivot
+// step of the LU is a few LDS round trips instead of global ones (the solve is latency-bound: thread = row, a barrier per pivot).
+// The accesses name the LDS array itself: no generic pointer into LDS is ever formed (see block_sum).
+extern __shared__ double dynH[];
+template <bool HL>
+__device__ __forceinline__ double hget(const double* __restrict__ Hg, const size_t i) {
+    if constexpr (HL) return dynH[i];
+    else return Hg[i];
+}
+template <bool HL>
+__device__ __forceinline__ void hput(double* __restrict__ Hg, const size_t i, const double v) {
+    if constexpr (HL) dynH[i] = v;
+    else Hg[i] = v;
+}
+
 // sum over the workgroup, identical in every thread (fixed tree order).  (The LDS arrays are function-local statics, not pointer
 // arguments: a generic pointer into LDS handed to an out-of-line device function trips a compiler bug on gfx950 - an illegal
 // V_CMP_NE_U32 against src_shared_base.)
@@ -134,7 +149,7 @@ struct BigOut {
 
 // evalBDF1 / computeValues for the generic implicit residual (see eval_front_e2 / eval_hess in rmx_device.h for the wavefront form and
 // oracle/redmax_tensorfree.c tf_eval for the node-by-node restatement this follows).  Thread t = node t; q, qd, v are this node's.
-template <bool WANT_H>
+template <bool WANT_H, bool HL = false>
 __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc, const int t, const double q, const double qd,
                          const double v, const double eta, BigOut& out) {
     const int n = M.n, NS = M.stride;
@@ -453,7 +468,7 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
 #pragma unroll
                 for (int c = 0; c < 12; ++c) h += rl[c] * cl[c * BT + i];
             }
-            Hw[(size_t)ki * nr + ka] = h;
+            hput<HL>(Hw, (size_t)ki * nr + ka, h);
         }
     }
     __syncthreads();
@@ -462,12 +477,13 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
 // dx = -H\g: LU with partial pivoting on the workspace copy of H (column-major nr x nr), thread = reduced row.  The permutation is
 // implicit (rows are never moved): piv[r] = the step at which row r served as the pivot row, or -1.  First maximum wins (dgetf2).
 // bneg: this node's -g (nodes without a DOF: ignored).  Returns this node's dx.
+template <bool HL>
 __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
     __shared__ int spiv[BT];         // pivot row of step k
+    __shared__ double b[BT];         // right-hand side, reduced order
+    __shared__ double xs[BT];        // solution, reduced order
     const int nr = M.nr;
     double* __restrict__ H = w.H;
-    double* b = w.vec;               // [nr]
-    double* xs = w.vec + BT;         // [nr] solution in reduced order
     if (ka >= 0) b[ka] = -g;
     __syncthreads();
     // thread = (reduced row r, column group cg): the BT / nr threads of a row share its trailing columns (c = k+1+cg, step ncg); with
@@ -478,26 +494,28 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
     int mystep = -1;
     for (int k = 0; k < nr; ++k) {
         // pivot search over the unused rows: max |H(r,k)|, lowest row among equals
-        const double cand = (row && cg == 0 && mystep < 0) ? fabs(H[(size_t)k * nr + r]) : -1.0;
+        const size_t ck = (size_t)k * nr;
+        const double cand = (row && cg == 0 && mystep < 0) ? fabs(hget<HL>(H, ck + r)) : -1.0;
         const int pr = block_argmax(cand, r, t);
         if (t == 0) spiv[k] = pr;
         if (r == pr) mystep = k;
         if (row && mystep < 0) {
-            const double l = H[(size_t)k * nr + r] / H[(size_t)k * nr + pr];
+            const double l = hget<HL>(H, ck + r) / hget<HL>(H, ck + pr);
+            const size_t st = (size_t)ncg * nr;
             int c = k + 1 + cg;
             for (; c + 3 * ncg < nr; c += 4 * ncg) {       // four columns in flight: loads first, then the stores
-                double* h0 = H + (size_t)c * nr;
-                double* h1 = h0 + (size_t)ncg * nr;
-                double* h2 = h1 + (size_t)ncg * nr;
-                double* h3 = h2 + (size_t)ncg * nr;
-                const double p0 = h0[pr], p1 = h1[pr], p2 = h2[pr], p3 = h3[pr];
-                const double a0 = h0[r], a1 = h1[r], a2 = h2[r], a3 = h3[r];
-                h0[r] = a0 - l * p0;
-                h1[r] = a1 - l * p1;
-                h2[r] = a2 - l * p2;
-                h3[r] = a3 - l * p3;
+                const size_t c0 = (size_t)c * nr, c1 = c0 + st, c2 = c1 + st, c3 = c2 + st;
+                const double p0 = hget<HL>(H, c0 + pr), p1 = hget<HL>(H, c1 + pr), p2 = hget<HL>(H, c2 + pr), p3 = hget<HL>(H, c3 + pr);
+                const double a0 = hget<HL>(H, c0 + r), a1 = hget<HL>(H, c1 + r), a2 = hget<HL>(H, c2 + r), a3 = hget<HL>(H, c3 + r);
+                hput<HL>(H, c0 + r, a0 - l * p0);
+                hput<HL>(H, c1 + r, a1 - l * p1);
+                hput<HL>(H, c2 + r, a2 - l * p2);
+                hput<HL>(H, c3 + r, a3 - l * p3);
             }
-            for (; c < nr; c += ncg) H[(size_t)c * nr + r] -= l * H[(size_t)c * nr + pr];
+            for (; c < nr; c += ncg) {
+                const size_t cc = (size_t)c * nr;
+                hput<HL>(H, cc + r, hget<HL>(H, cc + r) - l * hget<HL>(H, cc + pr));
+            }
             if (cg == 0) b[r] -= l * b[pr];
         }
         __syncthreads();
@@ -505,9 +523,9 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
     // back substitution on the implicitly permuted upper triangle
     for (int k = nr - 1; k >= 0; --k) {
         const int pr = spiv[k];
-        if (cg == 0 && r == pr) xs[k] = b[r] / H[(size_t)k * nr + r];
+        if (cg == 0 && r == pr) xs[k] = b[r] / hget<HL>(H, (size_t)k * nr + r);
         __syncthreads();
-        if (row && cg == 0 && mystep < k) b[r] -= H[(size_t)k * nr + r] * xs[k];
+        if (row && cg == 0 && mystep < k) b[r] -= hget<HL>(H, (size_t)k * nr + r) * xs[k];
         __syncthreads();
     }
     const double dx = ka >= 0 ? xs[ka] : 0.0;
@@ -517,6 +535,7 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
 
 // newton (driverRedMaxBDF1.m:94-157) for one implicit solve; see newton_impl (rmx_device.h) for the stall shortcut and the
 // compensated iterate x + lo.  Every decision is workgroup-uniform (norms come out of block_sum identical in all threads).
+template <bool HL>
 __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w, const NodeConsts& nc, const int t,
                              const int ka, double x, const double qA, const double qB, const double eta, BigOut& last, int& iters,
                              int& halvings, int& status, double& xlo) {
@@ -524,11 +543,11 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
     BigOut e;
     int iter = 1, lsfail = 0;
     while (true) {
-        big_eval<true>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+        big_eval<true, HL>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
         const BigOut e0 = e;
         last = e;
         ++iters;
-        const double dx = big_solve(M, w, t, ka, e.g);
+        const double dx = big_solve<HL>(M, w, t, ka, e.g);
         const double dxn2 = block_sum(dx * dx, t);
         if (!(dxn2 == dxn2)) { status |= 4; break; }
         if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }
@@ -645,7 +664,7 @@ __device__ bool big_reparam(const DevModel& M, const BigWs& w, const int t, int*
 }
 
 // simLoop of driverRedMaxBDF1.m:57-91 (INTEG 1) / driverRedMaxBDF2.m:57-125 (INTEG 2), all steps inside one launch
-template <int INTEG>
+template <int INTEG, bool HL>
 __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts o, const StepArgs a, double* wsbase, const size_t wsstride) {
     const int t = threadIdx.x, traj = blockIdx.x;
     const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
@@ -667,18 +686,18 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
         if (INTEG == 1) {
             const double q0 = q, qd0 = qd;
             const double xg = q0 + h * qd0;
-            const double x = big_newton(M, o, w, nc, t, id, xg, q0, xg, h, last, iters, halv, status, xlo);
+            const double x = big_newton<HL>(M, o, w, nc, t, id, xg, q0, xg, h, last, iters, halv, status, xlo);
             qd = ((x - q0) + xlo) / h;
             q = x;
         } else if (s == 0 && !started) {
             const double al = (2.0 - sqrt(2.0)) / 2.0;
             const double q0 = q, qd0 = qd;
-            const double qa = big_newton(M, o, w, nc, t, id, q0 + al * h * qd0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, xlo);
+            const double qa = big_newton<HL>(M, o, w, nc, t, id, q0 + al * h * qd0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, xlo);
             const double qda = (qa - q0) / (al * h);
             const double x10 = qa + (1.0 - al) * h * qda;
             const double qA = q0 + (1.0 - al) * h * qda;
             const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-            const double q1 = big_newton(M, o, w, nc, t, id, x10, qA, qB, al * h, last, iters, halv, status, xlo);
+            const double q1 = big_newton<HL>(M, o, w, nc, t, id, x10, qA, qB, al * h, last, iters, halv, status, xlo);
             qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
             q = q1;
             qp = q0;
@@ -688,7 +707,7 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
             const double x0 = q1 + h * qd1;
             const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
             const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-            const double q2 = big_newton(M, o, w, nc, t, id, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, xlo);
+            const double q2 = big_newton<HL>(M, o, w, nc, t, id, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, xlo);
             qp = q1;
             qdp = qd1;
             qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
@@ -732,7 +751,7 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
 }
 
 // Parity hook (rmx_eval): one residual (+ Hessian) evaluation per trajectory
-template <bool WANT_H>
+template <bool WANT_H, bool HL>
 __global__ void __launch_bounds__(BT) k_big_eval(const DevModel M, const double* __restrict__ q, const double* __restrict__ qA, const double* __restrict__ qB,
                                                  const double eta, double* __restrict__ g, double* __restrict__ H, const int* __restrict__ charts,
                                                  double* wsbase, const size_t wsstride) {
@@ -743,11 +762,11 @@ __global__ void __launch_bounds__(BT) k_big_eval(const DevModel M, const double*
     const double x = id >= 0 ? q[off] : 0.0, xa = id >= 0 ? qA[off] : 0.0, xb = id >= 0 ? qB[off] : 0.0;
     const NodeConsts nc = node_consts(M, t < M.n ? t : 0, M.nsph ? charts + (size_t)traj * M.nsph : nullptr);
     BigOut e;
-    big_eval<WANT_H>(M, w, nc, t, x, (x - xa) / eta, x - xb, eta, e);
+    big_eval<WANT_H, HL>(M, w, nc, t, x, (x - xa) / eta, x - xb, eta, e);
     if (id >= 0) g[off] = e.g;
     if (WANT_H) {
         const size_t nn = (size_t)M.nr * M.nr;
-        for (size_t i = t; i < nn; i += BT) H[(size_t)traj * nn + i] = w.H[i];
+        for (size_t i = t; i < nn; i += BT) H[(size_t)traj * nn + i] = hget<HL>(w.H, i);
     }
 }
 
@@ -772,15 +791,37 @@ __global__ void __launch_bounds__(BT) k_big_energy(const DevModel M, const doubl
 
 size_t big_ws_doubles(const rmx_model* m) { return big_ws_doubles_n(m->nr); }
 
+// H in LDS when nr x nr doubles fit the workgroup's LDS limit next to ~8 KB of static arrays
+static size_t big_dyn_lds(const rmx_model* m) {
+    const size_t need = (size_t)m->nr * m->nr * sizeof(double);
+    return need + 8192 <= (size_t)m->lds_limit ? need : 0;
+}
+template <typename K>
+static void big_allow_lds(K kernel, const size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 void launch_big_step(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(BT);
-    if (integ == INTEG_BDF1) k_big_step<1><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
-    else k_big_step<2><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
+    const size_t lds = big_dyn_lds(m);
+    if (lds) {
+        if (integ == INTEG_BDF1) { big_allow_lds(k_big_step<1, true>, lds); k_big_step<1, true><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
+        else { big_allow_lds(k_big_step<2, true>, lds); k_big_step<2, true><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
+    } else {
+        if (integ == INTEG_BDF1) k_big_step<1, false><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
+        else k_big_step<2, false><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
+    }
 }
 void launch_big_eval(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
     const dim3 grid(b->B), block(BT);
-    if (wantH) k_big_eval<true><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
-    else k_big_eval<false><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+    const size_t lds = wantH ? big_dyn_lds(m) : 0;
+    if (wantH && lds) {
+        big_allow_lds(k_big_eval<true, true>, lds);
+        k_big_eval<true, true><<<grid, block, lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+    } else if (wantH) {
+        k_big_eval<true, false><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+    } else {
+        k_big_eval<false, false><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+    }
 }
 void launch_big_energy(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(BT);

@@ -59,6 +59,7 @@ struct rmx_model {
     DevModel dm{};
     size_t smem_bytes = 0;
     int n_simd = 0;                 // SIMDs of the device (4 per CU)
+    int lds_limit = 0;              // LDS bytes one workgroup may hold (hipDeviceProp_t::sharedMemPerBlock); RMX_BIG_LDS_LIMIT overrides
     void* dgconst = nullptr;        // 64-lane plain models: the staged per-node constants in global memory (DevModel::gconst)
     int gconst_min_batch = 0;       // batches of at least this many rollouts run the global-constants kernels (0: never)
     bool big = false;               // more than 64 nodes: the one-workgroup-per-tree kernels of rmx_big.hip
