@@ -4,15 +4,17 @@
 // every multi-DOF joint counts one node per DOF (a JointFree3D body is 6 nodes).  The reference has no size limit.  These kernels
 // remove the limit with the SAME algebra - the world-frame recursive Newton-Euler with analytic derivatives of DESIGN.md section 3,
 // restated node by node in oracle/redmax_tensorfree.c - laid out for a workgroup instead of a wavefront:
-//   * root->node path products / sums : pointer jumping over the ancestor table (log2(depth) rounds), the per-node values in a
-//                                       global workspace (L2-resident), one workgroup barrier per round
-//   * node->leaves subtree sums       : a suffix scan over the depth-first order (Hillis-Steele, log2(n) rounds), subtree(j) =
+//   * root->node path products / sums : pointer jumping over the ancestor table (log2(depth) rounds), the per-node values in LDS
+//                                       ([component][n] rows of the dynamic array `dyn`), one workgroup barrier per round
+//   * node->leaves subtree sums       : a suffix scan over the depth-first order (Hillis-Steele in place, log2(n) rounds), subtree(j) =
 //                                       suffix(j) - suffix(end_j)
-//   * the nr x nr Hessian             : thread = row, a loop over the columns (ancestor test j < i < end_j), column-major in the workspace
+//   * the nr x nr Hessian             : thread = row, a loop over the columns (ancestor test j < i < end_j), column-major; in LDS
+//                                       when it fits next to the per-node rows (nr <= ~128), else in a global workspace
 //   * dx = -H\g                       : LU with partial pivoting (MATLAB mldivide, driverRedMaxBDF1.m:117; first maximum wins),
-//                                       thread = row, implicit row permutation, the pivot row read through the cache
+//                                       thread = (row, column group), implicit row permutation, pivot search on wave shuffles
 // Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
-// of newton_impl (rmx_device.h).  Nothing here is tuned: a 128-link chain costs ~100x a 32-link chain per step.  Covered: BDF1, BDF2
+// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts): a 72-link chain 1.9 ms per BDF1 step, a 128-link
+// chain 5.5 ms, a 256-link chain 114 ms (H in HBM); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered: BDF1, BDF2
 // (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching; not covered: ground
 // contact, the adjoint, matlab-simple Euler, rmx_eval_mfd (refused by the C ABI for such models).
 #include <hip/hip_runtime.h>
@@ -23,47 +25,48 @@ namespace {
 
 constexpr int BT = BIG_MAXN;          // threads per workgroup = node slots
 
-// Per-rollout workspace in global memory (doubles).  Rows of per-node data are [component][BT].
+// The per-node workspace lives in LDS (the dynamic array `dyn`, rows of per-node data are [component][n]); only H goes to global memory
+// when it does not fit next to it.  Offsets in doubles; region X is reused: E, V (path products / sums) -> the in-place suffix scan -> H.
 struct BigWs {
-    double* E[2];     // [12][BT] x 2  world transforms (R row-major 9, p 3), double-buffered for the pointer jumping
-    double* V[2];     // [6][BT] x 2   path sums (phi, beta)
-    double* S[2];     // [28][BT] x 2  body terms / suffix sums
-    double* cu;       // [6][BT]   y - z          (column i as seen from its strict ancestors)
-    double* cl;       // [12][BT]  m1, m2w, sw    (column i as seen from its strict descendants)
-    double* red;      // [BT]      block reductions / broadcasts
-    double* vec;      // [4][BT]   reduced-order vectors: b, x, scratch
-    double* H;        // [nr][nr]  column-major
+    double* H;        // [nr][nr] column-major, global memory (used when !HL)
+    int ns;           // stride of the per-node rows = number of nodes
+    int oE[2];        // [12][ns] x 2  world transforms (R row-major 9, p 3), double-buffered for the pointer jumping
+    int oV[2];        // [6][ns] x 2   path sums (phi, beta)
+    int oS;           // [28][ns]      body terms -> suffix sums (in place)
+    int ocu;          // [6][ns]       y - z          (column i as seen from its strict ancestors)
+    int ocl;          // [12][ns]      m1, m2w, sw    (column i as seen from its strict descendants)
 };
-__host__ __device__ constexpr size_t big_ws_doubles_n(const int nr) {
-    return (size_t)BT * (2 * 12 + 2 * 6 + 2 * 28 + 6 + 12 + 1 + 4) + (size_t)nr * nr;
+__host__ __device__ constexpr size_t big_ws_doubles_n(const int nr) { return (size_t)nr * nr; }
+// doubles of LDS: region X = max(E + V, scan, H if it is kept in LDS) + cu, cl
+__host__ __device__ constexpr size_t big_lds_doubles(const int n, const int nr, const bool hl) {
+    return ((hl && (size_t)nr * nr > (size_t)36 * n) ? (size_t)nr * nr : (size_t)36 * n) + (size_t)18 * n;
 }
-__device__ __forceinline__ BigWs big_ws(double* base, const int nr) {
+template <bool HL>
+__device__ __forceinline__ BigWs big_ws(double* base, const int n, const int nr) {
     BigWs w;
-    double* p = base;
-    w.E[0] = p; p += 12 * BT; w.E[1] = p; p += 12 * BT;
-    w.V[0] = p; p += 6 * BT;  w.V[1] = p; p += 6 * BT;
-    w.S[0] = p; p += 28 * BT; w.S[1] = p; p += 28 * BT;
-    w.cu = p; p += 6 * BT;
-    w.cl = p; p += 12 * BT;
-    w.red = p; p += BT;
-    w.vec = p; p += 4 * BT;
-    w.H = p;
-    (void)nr;
+    w.H = base;
+    w.ns = n;
+    w.oE[0] = 0; w.oE[1] = 12 * n;
+    w.oV[0] = 24 * n; w.oV[1] = 30 * n;
+    w.oS = 0;
+    const int xsz = (HL && nr * nr > 36 * n) ? nr * nr : 36 * n;
+    w.ocu = xsz;
+    w.ocl = xsz + 6 * n;
     return w;
 }
 
 // H in LDS (HL): up to ~136 reduced DOFs the nr x nr matrix fits the CU's 160 KB next to the small static arrays, and one pivot
 // step of the LU is a few LDS round trips instead of global ones (the solve is latency-bound: thread = row, a barrier per pivot).
 // The accesses name the LDS array itself: no generic pointer into LDS is ever formed (see block_sum).
-extern __shared__ double dynH[];
+extern __shared__ double dyn[];
 template <bool HL>
 __device__ __forceinline__ double hget(const double* __restrict__ Hg, const size_t i) {
-    if constexpr (HL) return dynH[i];
+    if constexpr (HL) return dyn[i];
     else return Hg[i];
 }
 template <bool HL>
 __device__ __forceinline__ void hput(double* __restrict__ Hg, const size_t i, const double v) {
-    if constexpr (HL) dynH[i] = v;
+    if constexpr (HL) dyn[i] = v;
     else Hg[i] = v;
 }
 
@@ -152,7 +155,7 @@ struct BigOut {
 template <bool WANT_H, bool HL = false>
 __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc, const int t, const double q, const double qd,
                          const double v, const double eta, BigOut& out) {
-    const int n = M.n, NS = M.stride;
+    const int n = M.n, NS = M.stride, LS = w.ns;      // NS: stride of the model's constant tables, LS: of the LDS rows
     const bool act = t < n;
     const int tj = act ? t : 0;
     const double e2 = eta * eta;
@@ -171,19 +174,21 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     }
     // ---- world transforms: pointer jumping, E_w,j = E_w,anc T_j...
     int cur = 0;
+    if (act) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) w.E[0][c * BT + t] = R[c];
+        for (int c = 0; c < 9; ++c) dyn[w.oE[0] + c * LS + t] = R[c];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) w.E[0][(9 + c) * BT + t] = p[c];
+        for (int c = 0; c < 3; ++c) dyn[w.oE[0] + (9 + c) * LS + t] = p[c];
+    }
     __syncthreads();
     for (int r = 0; r < M.rounds; ++r) {
         const int a = act ? M.anc[r * NS + tj] : -1;
         if (a >= 0) {
             double Ra[9], pa[3];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) Ra[c] = w.E[cur][c * BT + a];
+            for (int c = 0; c < 9; ++c) Ra[c] = dyn[w.oE[cur] + c * LS + a];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pa[c] = w.E[cur][(9 + c) * BT + a];
+            for (int c = 0; c < 3; ++c) pa[c] = dyn[w.oE[cur] + (9 + c) * LS + a];
             double Rn[9], pn[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -196,10 +201,12 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
 #pragma unroll
             for (int c = 0; c < 3; ++c) p[c] = pn[c];
         }
+        if (act) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) w.E[cur ^ 1][c * BT + t] = R[c];
+            for (int c = 0; c < 9; ++c) dyn[w.oE[cur ^ 1] + c * LS + t] = R[c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) w.E[cur ^ 1][(9 + c) * BT + t] = p[c];
+            for (int c = 0; c < 3; ++c) dyn[w.oE[cur ^ 1] + (9 + c) * LS + t] = p[c];
+        }
         cur ^= 1;
         __syncthreads();
     }
@@ -216,17 +223,22 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     // path sum of a 6-vector (own value in x6, result in x6)
     auto path_sum6 = [&](double (&x6)[6]) {
         int cv = 0;
+        __syncthreads();          // the previous pass (or the transforms) may still be reading this region
+        if (act) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) w.V[0][c * BT + t] = x6[c];
+            for (int c = 0; c < 6; ++c) dyn[w.oV[0] + c * LS + t] = x6[c];
+        }
         __syncthreads();
         for (int r = 0; r < M.rounds; ++r) {
             const int a = act ? M.anc[r * NS + tj] : -1;
             if (a >= 0) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) x6[c] += w.V[cv][c * BT + a];
+                for (int c = 0; c < 6; ++c) x6[c] += dyn[w.oV[cv] + c * LS + a];
             }
+            if (act) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) w.V[cv ^ 1][c * BT + t] = x6[c];
+                for (int c = 0; c < 6; ++c) dyn[w.oV[cv ^ 1] + c * LS + t] = x6[c];
+            }
             cv ^= 1;
             __syncthreads();
         }
@@ -338,28 +350,34 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
         }
         out.eV = eV;
     }
-    // ---- subtree sums: suffix scan over the depth-first order, subtree(j) = suffix(j) - suffix(end_j)
+    // ---- subtree sums: suffix scan over the depth-first order (Hillis-Steele, in place: read, barrier, write), subtree(j) =
+    // suffix(j) - suffix(end_j).  The region was E / V: every path product and sum is in registers by now.
     {
-        int cs = 0;
-#pragma unroll
-        for (int c = 0; c < 28; ++c) w.S[0][c * BT + t] = act ? S[c] : 0.0;
         __syncthreads();
-        for (int d = 1; d < BT; d <<= 1) {
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < 28; ++c) dyn[w.oS + c * LS + t] = S[c];
+        }
+        __syncthreads();
+        for (int d = 1; d < n; d <<= 1) {
             double add[28];
-            const bool on = t + d < BT;
+            const bool on = act && t + d < n;
 #pragma unroll
-            for (int c = 0; c < 28; ++c) add[c] = on ? w.S[cs][c * BT + t + d] : 0.0;
+            for (int c = 0; c < 28; ++c) add[c] = on ? dyn[w.oS + c * LS + t + d] : 0.0;
+            __syncthreads();
+            if (act) {
 #pragma unroll
-            for (int c = 0; c < 28; ++c) S[c] = (act ? S[c] : 0.0) + add[c];
-#pragma unroll
-            for (int c = 0; c < 28; ++c) w.S[cs ^ 1][c * BT + t] = S[c];
-            cs ^= 1;
+                for (int c = 0; c < 28; ++c) {
+                    S[c] += add[c];
+                    dyn[w.oS + c * LS + t] = S[c];
+                }
+            }
             __syncthreads();
         }
-        const int en = act ? M.end[tj] : BT;
-        if (en < BT) {
+        const int en = act ? M.end[tj] : n;
+        if (en < n) {
 #pragma unroll
-            for (int c = 0; c < 28; ++c) S[c] -= w.S[cs][c * BT + en];
+            for (int c = 0; c < 28; ++c) S[c] -= dyn[w.oS + c * LS + en];
         }
         __syncthreads();
     }
@@ -435,14 +453,16 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     cross3(gv, sv, b3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) rl[9 + c] = -e2 * (a3[c] - mS * b3[c]);
+    if (act) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        w.cu[c * BT + t] = yt[c] - zt[c];
-        w.cu[(3 + c) * BT + t] = yf[c] - zf[c];
-        w.cl[c * BT + t] = m1w[c];
-        w.cl[(3 + c) * BT + t] = m1v[c];
-        w.cl[(6 + c) * BT + t] = m2w[c];
-        w.cl[(9 + c) * BT + t] = sw[c];
+        for (int c = 0; c < 3; ++c) {
+            dyn[w.ocu + c * LS + t] = yt[c] - zt[c];
+            dyn[w.ocu + (3 + c) * LS + t] = yf[c] - zf[c];
+            dyn[w.ocl + c * LS + t] = m1w[c];
+            dyn[w.ocl + (3 + c) * LS + t] = m1v[c];
+            dyn[w.ocl + (6 + c) * LS + t] = m2w[c];
+            dyn[w.ocl + (9 + c) * LS + t] = sw[c];
+        }
     }
     __syncthreads();
     // ---- row of this node: H(a, i) = s_a . cu_i for a a strict ancestor of i, rl_a . cl_i for a strict descendant, Hdiag on the
@@ -451,8 +471,6 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     const int ka = act ? M.idx[tj] : -1;
     if (ka >= 0) {
         const int ea = M.end[tj];
-        const double* __restrict__ cu = w.cu;     // read-only here and distinct from H: lets the loads of later columns start
-        const double* __restrict__ cl = w.cl;     // before the stores of earlier ones
         double* __restrict__ Hw = w.H;
 #pragma unroll 4
         for (int i = 0; i < n; ++i) {
@@ -463,10 +481,10 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
                 h = Hdiag;
             } else if (t < i && i < ea) {          // this row's node is a strict ancestor of column node i
 #pragma unroll
-                for (int c = 0; c < 3; ++c) h += sw[c] * cu[c * BT + i] + sv[c] * cu[(3 + c) * BT + i];
+                for (int c = 0; c < 3; ++c) h += sw[c] * dyn[w.ocu + c * LS + i] + sv[c] * dyn[w.ocu + (3 + c) * LS + i];
             } else if (i < t && t < M.end[i]) {    // strict descendant
 #pragma unroll
-                for (int c = 0; c < 12; ++c) h += rl[c] * cl[c * BT + i];
+                for (int c = 0; c < 12; ++c) h += rl[c] * dyn[w.ocl + c * LS + i];
             }
             hput<HL>(Hw, (size_t)ki * nr + ka, h);
         }
@@ -594,23 +612,26 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
 // the workspace instead of v_readlane).  Returns true if a chart changed (the caller refreshes its NodeConsts).
 template <bool WITH_PREV>
 __device__ bool big_reparam(const DevModel& M, const BigWs& w, const int t, int* chart, double& q, double& qd, double& qp, double& qdp) {
-    double* sq = w.vec;          // [4][BT]: q, qd, qp, qdp per node
-    sq[t] = q;
-    sq[BT + t] = qd;
-    sq[2 * BT + t] = qp;
-    sq[3 * BT + t] = qdp;
+    const int LS = w.ns;         // q, qd, qp, qdp per node at the start of region X: [4][ns]
+    __syncthreads();
+    if (t < LS) {
+        dyn[t] = q;
+        dyn[LS + t] = qd;
+        dyn[2 * LS + t] = qp;
+        dyn[3 * LS + t] = qdp;
+    }
     __syncthreads();
     bool switched = false;
     for (int g = 0; g < M.nsph; ++g) {
         const int first = M.sph_first[g];
         const int c0 = chart[g];
-        const double qv[3] = {sq[first], sq[first + 1], sq[first + 2]};
+        const double qv[3] = {dyn[first], dyn[first + 1], dyn[first + 2]};
         double Told[9];
         const double detTold = euler_T(c0, qv, Told);
         if (fabs(detTold) > 0.5) continue;
-        const double qdv[3] = {sq[BT + first], sq[BT + first + 1], sq[BT + first + 2]};
-        const double q1v[3] = {sq[2 * BT + first], sq[2 * BT + first + 1], sq[2 * BT + first + 2]};
-        const double qd1v[3] = {sq[3 * BT + first], sq[3 * BT + first + 1], sq[3 * BT + first + 2]};
+        const double qdv[3] = {dyn[LS + first], dyn[LS + first + 1], dyn[LS + first + 2]};
+        const double q1v[3] = {dyn[2 * LS + first], dyn[2 * LS + first + 1], dyn[2 * LS + first + 2]};
+        const double qd1v[3] = {dyn[3 * LS + first], dyn[3 * LS + first + 1], dyn[3 * LS + first + 2]};
         double R[9], R1[9], Tt[9];
         euler_R(c0, qv, R);
         if (WITH_PREV) euler_R(c0, q1v, R1);
@@ -668,7 +689,7 @@ template <int INTEG, bool HL>
 __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts o, const StepArgs a, double* wsbase, const size_t wsstride) {
     const int t = threadIdx.x, traj = blockIdx.x;
     const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
-    const BigWs w = big_ws(wsbase + (size_t)traj * wsstride, M.nr);
+    const BigWs w = big_ws<HL>(wsbase + (size_t)traj * wsstride, M.n, M.nr);
     const int id = (t < M.n) ? M.idx[t] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     double q = id >= 0 ? a.q[off] : 0.0;
@@ -756,7 +777,7 @@ __global__ void __launch_bounds__(BT) k_big_eval(const DevModel M, const double*
                                                  const double eta, double* __restrict__ g, double* __restrict__ H, const int* __restrict__ charts,
                                                  double* wsbase, const size_t wsstride) {
     const int t = threadIdx.x, traj = blockIdx.x;
-    const BigWs w = big_ws(wsbase + (size_t)traj * wsstride, M.nr);
+    const BigWs w = big_ws<HL>(wsbase + (size_t)traj * wsstride, M.n, M.nr);
     const int id = (t < M.n) ? M.idx[t] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     const double x = id >= 0 ? q[off] : 0.0, xa = id >= 0 ? qA[off] : 0.0, xb = id >= 0 ? qB[off] : 0.0;
@@ -774,7 +795,7 @@ __global__ void __launch_bounds__(BT) k_big_eval(const DevModel M, const double*
 __global__ void __launch_bounds__(BT) k_big_energy(const DevModel M, const double* __restrict__ q, const double* __restrict__ qd, double* __restrict__ T,
                                                    double* __restrict__ V, const int* __restrict__ charts, double* wsbase, const size_t wsstride) {
     const int t = threadIdx.x, traj = blockIdx.x;
-    const BigWs w = big_ws(wsbase + (size_t)traj * wsstride, M.nr);
+    const BigWs w = big_ws<false>(wsbase + (size_t)traj * wsstride, M.n, M.nr);
     const int id = (t < M.n) ? M.idx[t] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     const NodeConsts nc = node_consts(M, t < M.n ? t : 0, M.nsph ? charts + (size_t)traj * M.nsph : nullptr);
@@ -791,39 +812,46 @@ __global__ void __launch_bounds__(BT) k_big_energy(const DevModel M, const doubl
 
 size_t big_ws_doubles(const rmx_model* m) { return big_ws_doubles_n(m->nr); }
 
-// H in LDS when nr x nr doubles fit the workgroup's LDS limit next to ~8 KB of static arrays
-static size_t big_dyn_lds(const rmx_model* m) {
-    const size_t need = (size_t)m->nr * m->nr * sizeof(double);
-    return need + 8192 <= (size_t)m->lds_limit ? need : 0;
+// Dynamic LDS of a launch: the per-node workspace, plus H when nr x nr doubles fit the workgroup's limit next to it and ~8 KB of
+// static arrays (hl)
+static bool big_hl(const rmx_model* m) {
+    return big_lds_doubles(m->n, m->nr, true) * sizeof(double) + 8192 <= (size_t)m->lds_limit;
 }
+static size_t big_dyn_lds(const rmx_model* m, const bool hl) { return big_lds_doubles(m->n, m->nr, hl) * sizeof(double); }
 template <typename K>
 static void big_allow_lds(K kernel, const size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 void launch_big_step(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(BT);
-    const size_t lds = big_dyn_lds(m);
-    if (lds) {
+    const bool hl = big_hl(m);
+    const size_t lds = big_dyn_lds(m, hl);
+    if (hl) {
         if (integ == INTEG_BDF1) { big_allow_lds(k_big_step<1, true>, lds); k_big_step<1, true><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
         else { big_allow_lds(k_big_step<2, true>, lds); k_big_step<2, true><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
     } else {
-        if (integ == INTEG_BDF1) k_big_step<1, false><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
-        else k_big_step<2, false><<<grid, block, 0, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
+        if (integ == INTEG_BDF1) { big_allow_lds(k_big_step<1, false>, lds); k_big_step<1, false><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
+        else { big_allow_lds(k_big_step<2, false>, lds); k_big_step<2, false><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
     }
 }
 void launch_big_eval(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
     const dim3 grid(b->B), block(BT);
-    const size_t lds = wantH ? big_dyn_lds(m) : 0;
-    if (wantH && lds) {
+    const bool hl = wantH && big_hl(m);
+    const size_t lds = big_dyn_lds(m, hl);
+    if (hl) {
         big_allow_lds(k_big_eval<true, true>, lds);
         k_big_eval<true, true><<<grid, block, lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
     } else if (wantH) {
-        k_big_eval<true, false><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+        big_allow_lds(k_big_eval<true, false>, lds);
+        k_big_eval<true, false><<<grid, block, lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
     } else {
-        k_big_eval<false, false><<<grid, block, 0, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+        big_allow_lds(k_big_eval<false, false>, lds);
+        k_big_eval<false, false><<<grid, block, lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
     }
 }
 void launch_big_energy(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(BT);
-    k_big_energy<<<grid, block, 0, b->stream>>>(m->dm, b->q, b->qd, dT, dV, b->chart, b->bigws, b->bigws_stride);
+    const size_t lds = big_dyn_lds(m, false);
+    big_allow_lds(k_big_energy, lds);
+    k_big_energy<<<grid, block, lds, b->stream>>>(m->dm, b->q, b->qd, dT, dV, b->chart, b->bigws, b->bigws_stride);
 }
