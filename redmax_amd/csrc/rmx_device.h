@@ -492,18 +492,34 @@ __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, 
 #pragma unroll
         for (int c = 0; c < (MODE == 1 ? 36 : 21); ++c) KD[c] = 0.0;
     }
-    bool touched = false;
-#pragma unroll 1     // unrolled, the scheduler interleaves the eight corners and their temporaries spill
+    // Which of the 8 corners (+-sides/2, ForceGroundCuboid.m:71-83, the reference's order: ic = 4 [x > 0] + 2 [y > 0] + [z > 0]) of THIS
+    // lane's body penetrate (:84-88).  The loop below then visits, per lane, only its own penetrating corners, lowest ic first: the
+    // trip count is the largest number of penetrating corners of any body of the tree (4 for a cuboid lying on a face, 2 on an edge)
+    // instead of the 8 that the union over 32 bodies in different orientations always came to - and every body still adds its
+    // corners in the reference's order, so the sums are the same bit for bit.
+    unsigned rem = 0u;
+#pragma unroll
     for (int ic = 0; ic < 8; ++ic) {
-        // the 8 corners (+-sides/2, ForceGroundCuboid.m:71-83); their order is irrelevant to the sums
         const double xl[3] = {(ic & 4 ? 0.5 : -0.5) * sd[0], (ic & 2 ? 0.5 : -0.5) * sd[1], (ic & 1 ? 0.5 : -0.5) * sd[2]};
         double x[3];
         mat3v(R, xl, x);
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] += p[c];
         const double d = n[0] * (x[0] - M.gx[0]) + n[1] * (x[1] - M.gx[1]) + n[2] * (x[2] - M.gx[2]);
-        const bool pen = con && !(d > 0.0);          // only penetrating corners act (:84-88)
-        if (!__any(pen)) continue;                   // wave-uniform skip
+        if (con && !(d > 0.0)) rem |= 1u << ic;
+    }
+    bool touched = false;
+#pragma unroll 1     // unrolled, the scheduler interleaves the corners and their temporaries spill
+    while (__any(rem != 0u)) {
+        const bool pen = rem != 0u;
+        const int ic = pen ? __builtin_ctz(rem) : 0;       // this lane's next penetrating corner
+        rem &= rem - 1u;
+        const double xl[3] = {(ic & 4 ? 0.5 : -0.5) * sd[0], (ic & 2 ? 0.5 : -0.5) * sd[1], (ic & 1 ? 0.5 : -0.5) * sd[2]};
+        double x[3];
+        mat3v(R, xl, x);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] += p[c];
+        const double d = n[0] * (x[0] - M.gx[0]) + n[1] * (x[1] - M.gx[1]) + n[2] * (x[2] - M.gx[2]);
         touched = true;
         if (pen) {
             if (MODE == 0) V += 0.5 * kn * d * d;    // (:176)
