@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 105
+#define RMX_VERSION 106
 
 enum {
     RMX_OK = 0,
@@ -157,6 +157,13 @@ typedef struct rmx_ground_contact {
     double kn, kt;           /* setStiffness(kn, kt)   :35-38 */
     double mu;               /* setFriction(mu)        :46-48 */
     double kd;               /* setDamping(kd)         :41-43 */
+    /* Every ForceGroundCuboid object holds its own E, kn, kt, mu, kd (:6-13): scenes whose force objects differ (a floor and a wall,
+     * a slippery patch) pass them per body, in listing order; NULL = the shared value above for every flagged body (ABI 106). */
+    const double* E_body;    /* [n][16] column-major 4x4 per body, or NULL */
+    const double* kn_body;   /* [n] or NULL */
+    const double* kt_body;   /* [n] or NULL */
+    const double* mu_body;   /* [n] or NULL */
+    const double* kd_body;   /* [n] or NULL */
 } rmx_ground_contact;
 int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc);
 

@@ -94,7 +94,9 @@ for i = 1 : n
 	desc.qLimD(i) = j.qLimD;
 end
 
-% scene.forces: ForceNull (nothing to do) or ForceGroundCuboid objects sharing one ground frame and one parameter set
+% scene.forces: ForceNull (nothing to do) or ForceGroundCuboid objects.  Every object holds its own E, kn, kt, mu, kd
+% (ForceGroundCuboid.m:6-13): they travel per body (groundE_body 16 x n, kn_body .. kd_body 1 x n); groundE, kn .. kd are those
+% of the first object (what a scene with one ground, like scene 11, needs).
 ground = [];
 for i = 1 : numel(scene.forces)
 	f = scene.forces{i};
@@ -107,8 +109,8 @@ for i = 1 : numel(scene.forces)
 				desc.sides = zeros(3,n);
 				desc.groundE = f.E;
 				desc.kn = f.kn; desc.kt = f.kt; desc.mu = f.mu; desc.kd = f.kd;
-			elseif ~isequal(f.E,ground.E) || f.kn ~= ground.kn || f.kt ~= ground.kt || f.mu ~= ground.mu || f.kd ~= ground.kd
-				error('redmax:hip','flattenScene: all ForceGroundCuboid objects of a scene must share one frame and one parameter set');
+				desc.groundE_body = repmat(reshape(f.E,16,1),1,n);
+				desc.kn_body = f.kn*ones(1,n); desc.kt_body = f.kt*ones(1,n); desc.mu_body = f.mu*ones(1,n); desc.kd_body = f.kd*ones(1,n);
 			end
 			hit = 0;
 			for k = 1 : n
@@ -121,6 +123,8 @@ for i = 1 : numel(scene.forces)
 			end
 			desc.contact(hit) = 1;
 			desc.sides(:,hit) = f.cuboid.sides(:);
+			desc.groundE_body(:,hit) = reshape(f.E,16,1);
+			desc.kn_body(hit) = f.kn; desc.kt_body(hit) = f.kt; desc.mu_body(hit) = f.mu; desc.kd_body(hit) = f.kd;
 		otherwise
 			error('redmax:hip','flattenScene: force class %s is outside the HIP path (ForceNull and ForceGroundCuboid are in)',class(f));
 	end

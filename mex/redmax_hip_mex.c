@@ -163,6 +163,12 @@ static void cmd_create(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[
         gc.kt = scalar_field(s, "kt", 0.0);
         gc.mu = scalar_field(s, "mu", 0.0);
         gc.kd = scalar_field(s, "kd", 0.0);
+        /* one frame / parameter set per force object (ForceGroundCuboid.m:6-13); absent: the shared values above */
+        if (field(s, "groundE_body", 0)) gc.E_body = f64(s, "groundE_body", 16 * n, 1);
+        if (field(s, "kn_body", 0)) gc.kn_body = f64(s, "kn_body", n, 1);
+        if (field(s, "kt_body", 0)) gc.kt_body = f64(s, "kt_body", n, 1);
+        if (field(s, "mu_body", 0)) gc.mu_body = f64(s, "mu_body", n, 1);
+        if (field(s, "kd_body", 0)) gc.kd_body = f64(s, "kd_body", n, 1);
     }
     const int slot = live_slot(NULL);
     if (slot < 0) die("too many live handles (destroy some first)");

@@ -94,6 +94,7 @@ def lib():
         L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
         L.orc_set_ls_fail_limit.argtypes = [C.c_int]
         L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_set_ground_contact_body.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
         L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
         L.orc_adjoint_bdf1.restype = C.c_double
         L.orc_adjoint_bdf2.argtypes = L.orc_adjoint_bdf1.argtypes
@@ -200,6 +201,7 @@ def lower_composite(d):
                 out[key].append(d[key][L])
             out["contact"].append(int(d["contact"][L]) if (has_contact and final) else 0)
             out["sides"].append(np.asarray(d["sides"][L]) if (has_contact and final) else np.zeros(3))
+            out.setdefault("gL", []).append(L)        # listing entry of this node (per-body ground frames follow the body)
         last[L] = len(out["type"]) - 1
     low = {"njoints": len(out["type"]), "grav": d["grav"], "idx": np.array(out["idx"], dtype=np.int32), "last_of_listing": last,
            "sph_first": np.array(sph_first, dtype=np.int32)}
@@ -213,6 +215,9 @@ def lower_composite(d):
         low["contact"] = np.array(out["contact"], dtype=np.int32)
         low["sides"] = np.ascontiguousarray(np.stack(out["sides"]), dtype=np.float64)
         low["ground"] = d["ground"]
+        if d.get("ground_body") is not None:      # one frame / set of constants per ForceGroundCuboid object, listing order -> node order
+            gb = d["ground_body"]
+            low["ground_body"] = {k: np.ascontiguousarray(np.asarray(gb[k], dtype=np.float64)[out["gL"]]) for k in ("E", "kn", "kt", "mu", "kd")}
     return low
 
 
@@ -243,8 +248,15 @@ class Oracle:
             self._cflags = np.ascontiguousarray(desc_dict["contact"], dtype=np.int32)
             self._csides = np.ascontiguousarray(desc_dict["sides"], dtype=np.float64)
             self._cE = np.ascontiguousarray(np.asarray(g["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
-            self._L.orc_set_ground_contact(self._h, self._cflags.ctypes.data_as(_ip), _p(self._csides), _p(self._cE),
-                                           float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"]))
+            gb = desc_dict.get("ground_body")
+            if gb is None:
+                self._L.orc_set_ground_contact(self._h, self._cflags.ctypes.data_as(_ip), _p(self._csides), _p(self._cE),
+                                               float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"]))
+            else:                                     # [n][4][4] row-major -> [n][16] column-major
+                self._cEb = np.ascontiguousarray(np.asarray(gb["E"], dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1).reshape(-1, 16))
+                self._ck = [np.ascontiguousarray(gb[k], dtype=np.float64) for k in ("kn", "kt", "mu", "kd")]
+                self._L.orc_set_ground_contact_body(self._h, self._cflags.ctypes.data_as(_ip), _p(self._csides), _p(self._cEb), 1,
+                                                    _p(self._ck[0]), _p(self._ck[1]), _p(self._ck[2]), _p(self._ck[3]), 1)
 
     def __del__(self):
         try:

@@ -175,7 +175,7 @@ struct orc_scene {
     /* ForceGroundCuboid (one per flagged body, shared parameters) */
     int* contact;                        /* [n] flag */
     double* sides;                       /* [n][3]   */
-    m4 groundE; double kn, kt, mu, kd;
+    struct ogf { m4 E; double kn, kt, mu, kd; } *gf;      /* [n] the ground frame and constants of each body's ForceGroundCuboid */
     /* JointSpherical groups (three consecutive revolute nodes each) and their Euler charts */
     int nsph; int* sph_first; int* sph_chart; int* sph_chart1;
 };
@@ -395,7 +395,7 @@ void orc_destroy(orc_scene* s) {
     free(s->nd); free(s->qInit); free(s->qdotInit);
     free(s->J); free(s->Jdot); free(s->dJdq); free(s->dJdotdq);
     free(s->Mm); free(s->Km); free(s->Dm); free(s->fm); free(s->fr); free(s->Kr); free(s->Dr);
-    free(s->contact); free(s->sides);
+    free(s->contact); free(s->sides); free(s->gf);
     free(s->sph_first); free(s->sph_chart); free(s->sph_chart1);
     free(s);
 }
@@ -553,14 +553,17 @@ static void add_Gt_X(double* Blk, double sign, const double G[3][6], const doubl
 }
 static void compute_ground_contact(orc_scene* s, int deriv) {
     if (!s->contact) return;
-    double xg[3], ng[3], N[3][3], T[3][3];
-    for (int a = 0; a < 3; a++) { xg[a] = s->groundE[a][3]; ng[a] = s->groundE[a][2]; }
-    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { N[a][b] = ng[a] * ng[b]; T[a][b] = (a == b) - N[a][b]; }
     double eb[3][3][3];
     for (int c = 0; c < 3; c++) { double e[3] = { 0, 0, 0 }; e[c] = 1.0; se3_brac3(eb[c], e); }
     for (int ib = 0; ib < s->n; ib++) {
         if (!s->contact[ib]) continue;
         onode* j = &s->nd[ib];
+        /* every force object holds its own E, kn, kt, mu, kd (ForceGroundCuboid.m:6-13, 56-57) */
+        const struct ogf* gf = &s->gf[ib];
+        const double kn = gf->kn, kt = gf->kt, mu = gf->mu, kd = gf->kd;
+        double xg[3], ng[3], N[3][3], T[3][3];
+        for (int a = 0; a < 3; a++) { xg[a] = gf->E[a][3]; ng[a] = gf->E[a][2]; }
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { N[a][b] = ng[a] * ng[b]; T[a][b] = (a == b) - N[a][b]; }
         double* fm = s->fm + j->idxM; double* Kb = s->Km + 36 * ib; double* Db = s->Dm + 36 * ib;
         double R[3][3], Rt[3][3], p[3], RNR[3][3], RtN[3][3], B[3][3], RtT[3][3], pxgtmp[3][3], tv[3];
         for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) { R[a][b] = j->E_wi[a][b]; Rt[b][a] = R[a][b]; } p[a] = j->E_wi[a][3]; }
@@ -583,7 +586,7 @@ static void compute_ground_contact(orc_scene* s, int deriv) {
             /* fc = -kn*ng*d - kd*N*vwi ; fm += G'*R'*fc */
             double Nv[3]; m33_mulv(Nv, N, vwi);
             double fc[3], Rtf[3];
-            for (int a = 0; a < 3; a++) fc[a] = -s->kn * ng[a] * d - s->kd * Nv[a];
+            for (int a = 0; a < 3; a++) fc[a] = -kn * ng[a] * d - kd * Nv[a];
             m33_mulv(Rtf, Rt, fc);
             for (int a = 0; a < 6; a++) { double t = 0; for (int k = 0; k < 3; k++) t += G[k][a] * Rtf[k]; fm[a] += t; }
             if (deriv) {
@@ -596,7 +599,7 @@ static void compute_ground_contact(orc_scene* s, int deriv) {
                     X[a][c] = -ec - t33[a][c] + pxgtmp[a][c];
                     X[a][3 + c] = RNR[a][c];
                 }
-                add_Gt_X(Kb, -s->kn, G, X);
+                add_Gt_X(Kb, -kn, G, X);
                 /* tmp2 = -[e1b*RNRGphi,...] - RNR*Gphibrac ; Km -= kd*G'*[tmp2 0] */
                 m33_mul(t33, RNR, Gpb);
                 for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) {
@@ -604,24 +607,24 @@ static void compute_ground_contact(orc_scene* s, int deriv) {
                     X[a][c] = -ec - t33[a][c];
                     X[a][3 + c] = 0.0;
                 }
-                add_Gt_X(Kb, -s->kd, G, X);
+                add_Gt_X(Kb, -kd, G, X);
                 /* Dm -= kd*G'*RNR*G */
                 for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 3; k++) t += RNR[a][k] * G[k][c]; X[a][c] = t; }
-                add_Gt_X(Db, -s->kd, G, X);
+                add_Gt_X(Db, -kd, G, X);
             }
-            if (s->mu == 0) continue;
+            if (mu == 0) continue;
             /* friction: a = T*xwdot, xwdot = R*G*phi */
             double av[3]; m33_mulv(av, T, vwi);
             double anorm = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
-            if (s->mu * fabs(s->kn * d) > s->kt * anorm) {      /* static friction: fs = -kt*a */
-                double fs[3] = { -s->kt * av[0], -s->kt * av[1], -s->kt * av[2] };
+            if (mu * fabs(kn * d) > kt * anorm) {      /* static friction: fs = -kt*a */
+                double fs[3] = { -kt * av[0], -kt * av[1], -kt * av[2] };
                 m33_mulv(Rtf, Rt, fs);
                 for (int a = 0; a < 6; a++) { double t = 0; for (int k = 0; k < 3; k++) t += G[k][a] * Rtf[k]; fm[a] += t; }
                 if (deriv) {
                     double X[3][6];
                     /* D = -kt*G'*R'*T*R*G = -kt*G'*B*G */
                     for (int a = 0; a < 3; a++) for (int c = 0; c < 6; c++) { double t = 0; for (int k = 0; k < 3; k++) t += B[a][k] * G[k][c]; X[a][c] = t; }
-                    add_Gt_X(Db, -s->kt, G, X);
+                    add_Gt_X(Db, -kt, G, X);
                     /* K = -kt*G'*[(B*e1b-e1b*B)*Gphi, (B*e2b-e2b*B)*Gphi, (B*e3b-e3b*B)*Gphi, Z] */
                     for (int c = 0; c < 3; c++) {
                         double Be[3][3], eB[3][3], col[3];
@@ -630,10 +633,10 @@ static void compute_ground_contact(orc_scene* s, int deriv) {
                         m33_mulv(col, Be, Gphi);
                         for (int a = 0; a < 3; a++) { X[a][c] = col[a]; X[a][3 + c] = 0.0; }
                     }
-                    add_Gt_X(Kb, -s->kt, G, X);
+                    add_Gt_X(Kb, -kt, G, X);
                 }
             } else {                                            /* dynamic friction: fd = -mu*kn*d*t */
-                const double mukn = s->mu * s->kn;
+                const double mukn = mu * kn;
                 double tt[3] = { av[0] / anorm, av[1] / anorm, av[2] / anorm };
                 double fd[3] = { -mukn * d * tt[0], -mukn * d * tt[1], -mukn * d * tt[2] };
                 m33_mulv(Rtf, Rt, fd);
@@ -680,10 +683,10 @@ static double ground_contact_energy(const orc_scene* s) {
             double d = 0;
             for (int a = 0; a < 3; a++) {
                 double xw = j->E_wi[a][0] * xli[0] + j->E_wi[a][1] * xli[1] + j->E_wi[a][2] * xli[2] + j->E_wi[a][3];
-                d += s->groundE[a][2] * (xw - s->groundE[a][3]);
+                d += s->gf[ib].E[a][2] * (xw - s->gf[ib].E[a][3]);
             }
             if (d > 0) continue;
-            v += 0.5 * s->kn * (d * d);
+            v += 0.5 * s->gf[ib].kn * (d * d);
         }
     }
     return v;
@@ -691,13 +694,23 @@ static double ground_contact_energy(const orc_scene* s) {
 /* Attach ForceGroundCuboid to the flagged bodies (scenesRedMax.m:307-311 style: setTransform, setStiffness, setDamping,
  * setFriction).  E16 column-major. */
 void orc_set_ground_contact(orc_scene* s, const int* flags, const double* sides, const double* E16, double kn, double kt, double mu, double kd) {
-    free(s->contact); free(s->sides);
+    orc_set_ground_contact_body(s, flags, sides, E16, 0, &kn, &kt, &mu, &kd, 0);
+}
+/* One force object per flagged body, each with its own frame and constants (ForceGroundCuboid.m:28-47).  E16: [n][16] column-major
+ * when E_per_body, else one frame for all; kn..kd: [n] when k_per_body, else one value each. */
+void orc_set_ground_contact_body(orc_scene* s, const int* flags, const double* sides, const double* E16, int E_per_body,
+                                 const double* kn, const double* kt, const double* mu, const double* kd, int k_per_body) {
+    free(s->contact); free(s->sides); free(s->gf);
     s->contact = (int*)malloc(sizeof(int) * (size_t)s->n);
     s->sides = (double*)malloc(sizeof(double) * 3 * (size_t)s->n);
+    s->gf = (struct ogf*)calloc((size_t)s->n, sizeof(struct ogf));
     memcpy(s->contact, flags, sizeof(int) * (size_t)s->n);
     memcpy(s->sides, sides, sizeof(double) * 3 * (size_t)s->n);
-    cm16_to_m4(s->groundE, E16);
-    s->kn = kn; s->kt = kt; s->mu = mu; s->kd = kd;
+    for (int i = 0; i < s->n; i++) {
+        cm16_to_m4(s->gf[i].E, E16 + (E_per_body ? 16 * (size_t)i : 0));
+        const int k = k_per_body ? i : 0;
+        s->gf[i].kn = kn[k]; s->gf[i].kt = kt[k]; s->gf[i].mu = mu[k]; s->gf[i].kd = kd[k];
+    }
     orc_reset(s);
 }
 

@@ -75,6 +75,10 @@ void orc_energy(const orc_scene* s, double* T, double* V);          /* Joint.com
  * setDamping(kd).  Pinned by Hexpected of scene 11 (scenesRedMax.m:292-293) with JointFree2D emulated by a
  * prismatic-x / prismatic-y / revolute-z chain of massless links (same reduced coordinates, JointFree2D.m:20-33). */
 void orc_set_ground_contact(orc_scene* s, const int* flags, const double* sides, const double* E16, double kn, double kt, double mu, double kd);
+/* the same with one frame / one set of constants PER BODY (every ForceGroundCuboid object holds its own E, kn, kt, mu, kd):
+ * E16 [n][16] if E_per_body else [16]; kn..kd [n] if k_per_body else [1] */
+void orc_set_ground_contact_body(orc_scene* s, const int* flags, const double* sides, const double* E16, int E_per_body,
+                                 const double* kn, const double* kt, const double* mu, const double* kd, int k_per_body);
 
 /* Joint.computeJacobian at the current state; any pointer may be NULL.
  * J,Jdot: nm x nr column-major; dJdq,dJdotdq: nm x nr x nr (MATLAB layout). */

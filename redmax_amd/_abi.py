@@ -57,7 +57,8 @@ class TaskPointPos(C.Structure):
 
 class GroundContact(C.Structure):
     _fields_ = [("flags", _ip), ("sides", _dp), ("E", C.c_double * 16), ("kn", C.c_double), ("kt", C.c_double),
-                ("mu", C.c_double), ("kd", C.c_double)]
+                ("mu", C.c_double), ("kd", C.c_double), ("E_body", _dp), ("kn_body", _dp), ("kt_body", _dp), ("mu_body", _dp),
+                ("kd_body", _dp)]
 
 
 class History(C.Structure):

@@ -31,6 +31,13 @@ class BatchSim:
             gc.flags, gc.sides = _abi.iptr(self._keep["contact"]), _abi.dptr(self._keep["sides"])
             gc.E[:] = list(np.asarray(g["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
             gc.kn, gc.kt, gc.mu, gc.kd = float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"])
+            gb = d.get("ground_body")
+            if gb is not None:        # force objects with their own frames / constants, listing order; [n][4][4] row-major -> column-major
+                self._keep["gE"] = np.ascontiguousarray(np.asarray(gb["E"], dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1).reshape(-1, 16))
+                gc.E_body = _abi.dptr(self._keep["gE"])
+                for k in ("kn", "kt", "mu", "kd"):
+                    self._keep["g" + k] = np.ascontiguousarray(gb[k], dtype=np.float64)
+                    setattr(gc, k + "_body", _abi.dptr(self._keep["g" + k]))
             _abi.check(self._L.rmx_model_set_ground_contact(self._model, C.byref(gc)), "rmx_model_set_ground_contact")
         self.nsph = self._L.rmx_model_nsph(self._model)
         self.B = int(batch)

@@ -333,7 +333,9 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     m->node_of_listing = pos;
     m->NP = n <= 4 ? 4 : n <= 8 ? 8 : n <= 16 ? 16 : n <= 32 ? 32 : n <= 64 ? 64 : BIG_MAXN;
     m->big = big;
-    m->smem_bytes = big ? 0 : sizeof(double) * ((size_t)acc_doubles(n, m->NP) + (size_t)NCONST * cstride(m->NP));
+    // per-node constants + the rows of the per-body ground frames (con_setup; present in every launch so that attaching a
+    // ForceGroundCuboid later does not change the layout)
+    m->smem_bytes = big ? 0 : sizeof(double) * ((size_t)acc_doubles(n, m->NP) + (size_t)(NCONST + NGROUND) * cstride(m->NP));
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -518,19 +520,32 @@ extern "C" void rmx_model_destroy(rmx_model* m) {
 }
 
 // scene.forces{end+1} = ForceGroundCuboid(body); setTransform / setStiffness / setDamping / setFriction
-// (scenesRedMax.m:303-309, ForceGroundCuboid.m:18-48) for every flagged body, one ground frame per scene.
+// (scenesRedMax.m:303-309, ForceGroundCuboid.m:18-48) for every flagged body, each with its own ground frame and constants.
 extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc) {
     if (!m || !gc || !gc->flags || !gc->sides) return fail(RMX_E_INVALID, "null argument");
     if (!(gc->kn >= 0) || !(gc->kt >= 0) || !(gc->mu >= 0) || !(gc->kd >= 0)) return fail(RMX_E_INVALID, "contact constants must be >= 0");
     if (m->big) return fail(RMX_E_INVALID, "rmx_model_set_ground_contact: trees of more than 64 nodes have no contact kernels");
     HIPCHK(hipSetDevice(m->device));
-    std::vector<double> con(4 * MAXN, 0.0);
+    std::vector<double> con((size_t)NCON * MAXN, 0.0);
     bool any = false;
     for (int L = 0; L < m->nlist; ++L) {
         const int k = m->node_of_listing[L];
         con[k] = gc->flags[L] ? 1.0 : 0.0;
         any = any || gc->flags[L];
         for (int c = 0; c < 3; ++c) con[(1 + c) * MAXN + k] = gc->sides[3 * L + c];
+        // this body's force object: its ground frame (ng = E(1:3,3), xg = E(1:3,4): ForceGroundCuboid.m:56-57) and constants
+        const M4 E = from_cm(gc->E_body ? gc->E_body + 16 * (size_t)L : gc->E);
+        const double kn = gc->kn_body ? gc->kn_body[L] : gc->kn, kt = gc->kt_body ? gc->kt_body[L] : gc->kt;
+        const double mu = gc->mu_body ? gc->mu_body[L] : gc->mu, kd = gc->kd_body ? gc->kd_body[L] : gc->kd;
+        if (gc->flags[L] && (!(kn >= 0) || !(kt >= 0) || !(mu >= 0) || !(kd >= 0))) return fail(RMX_E_INVALID, "contact constants must be >= 0");
+        for (int c = 0; c < 3; ++c) {
+            con[(4 + c) * MAXN + k] = E.a[c][2];
+            con[(7 + c) * MAXN + k] = E.a[c][3];
+        }
+        con[10 * MAXN + k] = kn;
+        con[11 * MAXN + k] = kt;
+        con[12 * MAXN + k] = mu;
+        con[13 * MAXN + k] = kd;
     }
     // the new table is uploaded first and swapped in only on success; kernels of existing batches that may still read the
     // old one (rmx_step_bdf1_async) are drained before it is freed
@@ -550,13 +565,6 @@ extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_conta
     if (m->dcon) (void)hipFree(m->dcon);
     m->dcon = fresh;
     m->dm.con = (const double*)fresh;
-    if (!any) return RMX_OK;
-    const M4 E = from_cm(gc->E);
-    for (int c = 0; c < 3; ++c) {
-        m->dm.gn[c] = E.a[c][2];      // ng = E(1:3,3)   ForceGroundCuboid.m:70
-        m->dm.gx[c] = E.a[c][3];      // xg = E(1:3,4)   :69
-    }
-    m->dm.kn = gc->kn; m->dm.kt = gc->kt; m->dm.mu = gc->mu; m->dm.kdc = gc->kd;
     return RMX_OK;
 }
 extern "C" int rmx_model_nr(const rmx_model* m) { return m ? m->nr : RMX_E_INVALID; }

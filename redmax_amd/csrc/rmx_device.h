@@ -47,6 +47,8 @@ constexpr int ACC_STRIDE = 29;    // odd stride: conflict-free lane=node LDS wri
 constexpr int NCOL = 18;          // column-side Hessian vectors per node (yz6, m1 6, m2w3, sw3)
 constexpr int COL_STRIDE = 19;
 constexpr int MAXROUNDS = 6;      // log2(MAXN)
+constexpr int NCON = 14;          // rows of DevModel::con
+constexpr int NGROUND = 10;       // of which per-body ground frame and constants (GroundC)
 constexpr int NCONST = 68;        // per-node constants staged in LDS: K(36) sb(6) I4(4) prm(8) type(1) rel(2) anc(6) end(1) contact(1) sides(3)
 constexpr int MAXSPH = 21;        // spherical joints per tree (three nodes each)
 constexpr int SPH_ROWS = 42;      // per-node constants that depend on a spherical node's axis: K(36) + sb(6), the first LDS rows
@@ -93,10 +95,10 @@ struct DevModel {
     const int* anc;   // [MAXROUNDS][MAXN] ancestor 2^r levels up, or -1
     const unsigned long long* rel;  // [2][MAXN] bit i of rel[j]: node i is a strict ancestor of j; of rel[MAXN+j]: strict descendant
     double grav[3];
-    // ForceGroundCuboid: one ground plane per scene, per-body flags (null con: no contact forces in the scene)
-    const double* con;   // [4][MAXN]  contact flag, cuboid sides(3)
-    double gn[3], gx[3]; // plane normal (Z axis of the ground frame) and origin   ForceGroundCuboid.m:56-57
-    double kn, kt, mu, kdc;   // setStiffness(kn, kt), setFriction(mu), setDamping(kd)
+    // ForceGroundCuboid: every flagged body carries its own force object (null con: no contact forces in the scene)
+    const double* con;   // [NCON][MAXN]  contact flag, cuboid sides(3) | per body: plane normal (Z axis of ITS ground frame) (3) and origin
+                         // (3) ForceGroundCuboid.m:56-57, kn, kt (setStiffness), mu (setFriction), kd (setDamping).  Rows 0..3 travel with
+                         // the per-node constants (NCONST), rows 4..13 are staged behind them by con_setup in the contact-capable kernels
     // JointSpherical / JointFree3D: group g = nodes sph_first[g] .. +2 (revolute about the axes of the group's Euler chart)
     const double* gconst;   // [NCONST][cstride(NP)] the per-node constants as smem_setup stages them, in global memory (RMX_GLOBAL_CONSTS)
     int nsph;
@@ -478,12 +480,33 @@ __host__ __device__ constexpr int sym21(const int r, const int c) { return r * 6
 // MODE 2: the damping block Dw = sum Gw' Y Gw, symmetric because N, T and AT are: its 21 upper-triangle entries, rows first
 // (00..05, 11..15, 22..25, 33..35, 44, 45, 55).  The two derivative passes each repeat the corner geometry; keeping both blocks
 // (72 accumulators) live at once is what pushed the Hessian stage of the contact kernels into scratch.
+// The ground frame and constants of this lane's ForceGroundCuboid object (every object holds its own E, kn, kt, mu, kd:
+// ForceGroundCuboid.m:6-13), from the rows con_setup stages behind the per-node constants.
+struct GroundC {
+    double n[3], gx[3], kn, kt, mu, kdc;
+};
+template <int NP>
+__device__ __forceinline__ GroundC ground_of(const DevModel& M, const double* __restrict__ sAcc, const int jc) {
+    constexpr int CS = cstride(NP);
+    const double* g = RMX_CONSTS(sAcc, M.n, NP) + NCONST * CS + jc;
+    GroundC G;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        G.n[c] = g[c * CS];
+        G.gx[c] = g[(3 + c) * CS];
+    }
+    G.kn = g[6 * CS];
+    G.kt = g[7 * CS];
+    G.mu = g[8 * CS];
+    G.kdc = g[9 * CS];
+    return G;
+}
 template <int MODE>
-__device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, const double sd[3], const double R[9],
+__device__ __forceinline__ bool contact_body(const GroundC& G, const bool con, const double sd[3], const double R[9],
                                              const double p[3], const double phw[3], const double phv[3], double (&F)[6],
                                              double (&KD)[36], double& V) {
-    const double n[3] = {M.gn[0], M.gn[1], M.gn[2]};
-    const double kn = M.kn, kt = M.kt, mu = M.mu, kdc = M.kdc;
+    const double n[3] = {G.n[0], G.n[1], G.n[2]};
+    const double kn = G.kn, kt = G.kt, mu = G.mu, kdc = G.kdc;
     if (MODE == 0) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) F[c] = 0.0;
@@ -505,7 +528,7 @@ __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, 
         mat3v(R, xl, x);
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] += p[c];
-        const double d = n[0] * (x[0] - M.gx[0]) + n[1] * (x[1] - M.gx[1]) + n[2] * (x[2] - M.gx[2]);
+        const double d = n[0] * (x[0] - G.gx[0]) + n[1] * (x[1] - G.gx[1]) + n[2] * (x[2] - G.gx[2]);
         if (con && !(d > 0.0)) rem |= 1u << ic;
     }
     bool touched = false;
@@ -519,7 +542,7 @@ __device__ __forceinline__ bool contact_body(const DevModel& M, const bool con, 
         mat3v(R, xl, x);
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] += p[c];
-        const double d = n[0] * (x[0] - M.gx[0]) + n[1] * (x[1] - M.gx[1]) + n[2] * (x[2] - M.gx[2]);
+        const double d = n[0] * (x[0] - G.gx[0]) + n[1] * (x[1] - G.gx[1]) + n[2] * (x[2] - G.gx[2]);
         touched = true;
         if (pen) {
             if (MODE == 0) V += 0.5 * kn * d * d;    // (:176)
@@ -947,16 +970,17 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         // only this test runs and its outcome is reported in fs.touched; the caller leaves the lean path when it is set.
         const bool con = cCon[jc] != 0.0;
         const double sd[3] = {cCon[CS + jc], cCon[2 * CS + jc], cCon[3 * CS + jc]};
-        const double dc = M.gn[0] * (p[0] - M.gx[0]) + M.gn[1] * (p[1] - M.gx[1]) + M.gn[2] * (p[2] - M.gx[2]);
-        const double reach = 0.5 * (fabs(M.gn[0] * R[0] + M.gn[1] * R[3] + M.gn[2] * R[6]) * sd[0] +
-                                    fabs(M.gn[0] * R[1] + M.gn[1] * R[4] + M.gn[2] * R[7]) * sd[1] +
-                                    fabs(M.gn[0] * R[2] + M.gn[1] * R[5] + M.gn[2] * R[8]) * sd[2]);
+        const GroundC G = ground_of<NP>(M, sAcc, jc);
+        const double dc = G.n[0] * (p[0] - G.gx[0]) + G.n[1] * (p[1] - G.gx[1]) + G.n[2] * (p[2] - G.gx[2]);
+        const double reach = 0.5 * (fabs(G.n[0] * R[0] + G.n[1] * R[3] + G.n[2] * R[6]) * sd[0] +
+                                    fabs(G.n[0] * R[1] + G.n[1] * R[4] + G.n[2] * R[7]) * sd[1] +
+                                    fabs(G.n[0] * R[2] + G.n[1] * R[5] + G.n[2] * R[8]) * sd[2]);
         const bool near = __any(con && !(dc - reach > 1e-9 * (fabs(dc) + reach)));
         if constexpr (!CT) {
             fs.touched = near;
         } else if (near) {
             double Fc[6], k1[36];
-            fs.touched = contact_body<0>(M, con, sd, R, p, phw, phv, Fc, k1, eVc);
+            fs.touched = contact_body<0>(G, con, sd, R, p, phw, phv, Fc, k1, eVc);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 wt[c] -= e2 * Fc[c];
@@ -1422,6 +1446,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             const double* cCon = cEnd + CS;
             const bool con = act && cCon[jj] != 0.0;
             const double sd[3] = {cCon[CS + jj], cCon[2 * CS + jj], cCon[3 * CS + jj]};
+            const GroundC G = ground_of<NP>(M, sAcc, jj);
             const double s6[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
             double m26[6];
 #pragma unroll
@@ -1432,7 +1457,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             double Fc[6], eVc;
             {   // stiffness block: 36 numbers = two passes of the 28-wide scan
                 double Kx[36];
-                contact_body<1>(M, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Kx, eVc);
+                contact_body<1>(G, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Kx, eVc);
                 lds_subtree_sum<NP, 28>(M, sAcc, cEnd, lane, act, jj, &Kx[0]);
                 lds_subtree_sum<NP, 8>(M, sAcc, cEnd, lane, act, jj, &Kx[28]);
 #pragma unroll
@@ -1449,7 +1474,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             }
             {   // damping block, symmetric: 21 numbers, one pass
                 double Dx[36];
-                contact_body<2>(M, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Dx, eVc);
+                contact_body<2>(G, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Dx, eVc);
                 lds_subtree_sum<NP, 21>(M, sAcc, cEnd, lane, act, jj, &Dx[0]);
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {

@@ -57,6 +57,19 @@ __device__ __forceinline__ void smem_setup(const DevModel& M, double*& sAcc, dou
     __syncthreads();
 }
 
+// The contact-capable kernels: every body's own ground frame and constants (DevModel::con rows 4..13, GroundC) behind the per-node
+// constants.  Ends with a barrier.
+template <int NP>
+__device__ __forceinline__ void con_setup(const DevModel& M, double* __restrict__ sCol) {
+    constexpr int CS = cstride(NP);
+    if (M.con && threadIdx.x < CS) {
+        const int j = threadIdx.x;
+        const bool in = j < M.n;
+        for (int r = 0; r < NGROUND; ++r) sCol[(NCONST + r) * CS + j] = in ? M.con[(4 + r) * MAXN + j] : 0.0;
+    }
+    __syncthreads();
+}
+
 template <int NP>
 __global__ void __launch_bounds__(64) k_stage_consts(const DevModel M, double* __restrict__ dst) {
     stage_consts<NP>(M, dst);
@@ -101,6 +114,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevO
     PivotPolicy piv;
     int* const chart = (CT && M.nsph) ? a.chart + (size_t)traj * M.nsph : nullptr;
     if constexpr (CT) {
+        con_setup<NP>(M, sCol);
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
     }
     int stop = a.nsteps;
@@ -172,6 +186,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevO
     PivotPolicy piv;
     int* const chart = (CT && M.nsph) ? a.chart + (size_t)traj * M.nsph : nullptr;
     if constexpr (CT) {
+        con_setup<NP>(M, sCol);
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
     }
     int stop = a.nsteps;
@@ -571,6 +586,7 @@ __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, cons
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x, traj = blockIdx.x;
     if constexpr (CT) {
+        con_setup<NP>(M, sCol);
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart + (size_t)traj * M.nsph);
     }
     const int id = (lane < M.n) ? M.idx[lane] : -1;
@@ -637,6 +653,7 @@ __global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, co
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     if constexpr (CT) {
+        con_setup<NP>(M, sCol);
         if (M.nsph) sph_setup<NP>(M, sCol, threadIdx.x, chart + (size_t)blockIdx.x * M.nsph);
     }
     const int lane = threadIdx.x, traj = blockIdx.x;

@@ -317,8 +317,8 @@ class Scene:
                 raise NotImplementedError("only ForceNull and ForceGroundCuboid are in scope (SURVEY.md §2 row 10)")
             if not isinstance(f.cuboid, BodyCuboid) or f.cuboid not in self.bodies:
                 raise ValueError("ForceGroundCuboid needs a BodyCuboid of this scene")
-        if len({f.params() for f in self.forces}) > 1:
-            raise NotImplementedError("all ForceGroundCuboid instances of a scene must share one ground frame and one parameter set")
+        if len({id(f.cuboid) for f in self.forces}) != len(self.forces):
+            raise NotImplementedError("one ForceGroundCuboid per body (several grounds under one body are outside the HIP path)")
         nr = 0
         nm = 0
         for j in reversed(joints):                   # leaf-to-root numbering
@@ -400,6 +400,14 @@ class Scene:
             d["contact"] = np.array([1 if id(j.body) in touched else 0 for j in joints], dtype=np.int32)
             d["sides"] = np.ascontiguousarray(np.stack([getattr(j.body, "sides", np.zeros(3)) for j in joints]), dtype=np.float64)
             d["ground"] = {"E": f0.E.copy(), "kn": f0.kn, "kt": f0.kt, "mu": f0.mu, "kd": f0.kd}
+            # every ForceGroundCuboid object holds its own E, kn, kt, mu, kd (ForceGroundCuboid.m:6-13): per body when they differ
+            same = all(np.array_equal(f.E, f0.E) and (f.kn, f.kt, f.mu, f.kd) == (f0.kn, f0.kt, f0.mu, f0.kd) for f in self.forces)
+            if not same:
+                of = {id(f.cuboid): f for f in self.forces}
+                fb = [of.get(id(j.body), f0) for j in joints]
+                d["ground_body"] = {"E": np.stack([np.asarray(f.E, dtype=np.float64) for f in fb]),
+                                    "kn": np.array([f.kn for f in fb], dtype=np.float64), "kt": np.array([f.kt for f in fb], dtype=np.float64),
+                                    "mu": np.array([f.mu for f in fb], dtype=np.float64), "kd": np.array([f.kd for f in fb], dtype=np.float64)}
         self._desc = d
         return d
 

@@ -305,6 +305,32 @@ def sceneChainGround(n=32, ground_z=-2.0, q0=0.0):
     return scene
 
 
+def sceneChainTwoGrounds(n=8, ground_z=-1.0):
+    """sceneChainGround with TWO kinds of ForceGroundCuboid objects, which the reference allows (every object holds its own E, kn, kt,
+    mu, kd: ForceGroundCuboid.m:6-13): even bodies over the z-up floor at ground_z with scene 11's constants, odd bodies over a plane
+    tilted by 0.3 rad about y through (0, 0, ground_z - 0.5), softer, more damped and nearly frictionless."""
+    scene = sceneChain(n)
+    scene.name = "%d-link chain over two grounds" % n
+    scene.h = 5e-4
+    scene.tEnd = 0.1
+    c, s = math.cos(0.3), math.sin(0.3)
+    tilted = np.array([[c, 0, s, 0.0], [0, 1, 0, 0.0], [-s, 0, c, ground_z - 0.5], [0, 0, 0, 1.0]])
+    for i, b in enumerate(scene.bodies):
+        f = ForceGroundCuboid(b)
+        if i % 2 == 0:
+            f.setTransform(_T([0, 0, ground_z]))
+            f.setStiffness(1e5, 1e2)
+            f.setDamping(3e1)
+            f.setFriction(0.5)
+        else:
+            f.setTransform(tilted)
+            f.setStiffness(4e4, 5e1)
+            f.setDamping(6e1)
+            f.setFriction(0.05)
+        scene.forces.append(f)
+    return scene
+
+
 def sceneTree(n=64):
     """Config 3: ~n-DOF branching tree following scene 2's pattern (scenesRedMax.m:101-130):
     binary tree in depth-first order, 1-DOF joints alternating by depth parity between revolute

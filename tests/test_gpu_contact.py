@@ -309,3 +309,55 @@ def test_contact_free_scene_takes_the_plain_kernels(oracle_lib):
     go, Ho = o.eval_bdf1((q0 + sc.h * qd0)[0], q0[0], qd0[0], sc.h)
     assert _rel(g[0], go) <= 1e-11 and _rel(H[0], Ho) <= 1e-11
     sim.close()
+
+
+@pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
+def test_force_objects_with_their_own_ground_frames(oracle_lib, integ):
+    """Every ForceGroundCuboid object holds its own E, kn, kt, mu, kd (ForceGroundCuboid.m:6-13).  An 8-link chain whose even bodies
+    meet a floor and whose odd bodies meet a tilted, softer, nearly frictionless plane: g, H at penetrating states (1e-11) and a
+    rollout through the contact (1e-6 |q|) against the oracle; and per-body copies of ONE frame reproduce the shared-frame results
+    bit for bit."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainTwoGrounds
+    sc = sceneChainTwoGrounds(8, ground_z=-1.0)
+    sc.init()
+    d = sc.desc()
+    assert d.get("ground_body") is not None
+    B = 4
+    rng = np.random.default_rng(11)
+    nr, h = sc.nr, sc.h
+    q0, qd0, q1 = _penetrating_states("chain8two", nr, h, B, rng)
+    sim = BatchSim(sc, batch=B)
+    o = oracle_lib.Oracle(d)
+    o_shared = oracle_lib.Oracle(dict(d, ground_body=None))
+    differs = 0
+    g, H = sim.eval_residual(q1, q0, q0 + 0.5 * h * qd0, h)
+    for b in range(B):
+        go, Ho = o.eval_residual(q1[b], q0[b], q0[b] + 0.5 * h * qd0[b], h)
+        assert _rel(g[b], go) <= 1e-11 and _rel(H[b], Ho) <= 1e-11
+        differs += _rel(o_shared.eval_residual(q1[b], q0[b], q0[b] + 0.5 * h * qd0[b], h)[0], go) > 1e-6
+    assert differs >= 2                                    # the second plane really is in play
+    K = 60
+    sim.set_state(q1, qd0)
+    out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(K, h=h, stats=True)
+    q, qd = sim.get_state()
+    for b in range(B):
+        ob = oracle_lib.Oracle(d)
+        ob.set_state(q1[b], qd0[b])
+        (ob.step_bdf1 if integ == "bdf1" else ob.step_bdf2)(h, K)
+        qo, qdo = ob.get_state()
+        assert _rel(q[b], qo) <= 1e-6 and _rel(qd[b], qdo) <= 1e-4
+    sim.close()
+    # n copies of one frame = the shared frame, bit for bit
+    sg = sceneChainGround(8, ground_z=-1.0)
+    sg.init()
+    dg = sg.desc()
+    n = len(dg["contact"])
+    gg = dg["ground"]
+    sims = []
+    for gb in (None, {"E": np.stack([gg["E"]] * n), "kn": np.full(n, gg["kn"]), "kt": np.full(n, gg["kt"]), "mu": np.full(n, gg["mu"]),
+                      "kd": np.full(n, gg["kd"])}):
+        s2 = BatchSim(dict(dg, ground_body=gb), batch=B)
+        sims.append(s2.eval_residual(q1, q0, q0 + 0.5 * h * qd0, h))
+        s2.close()
+    assert np.array_equal(sims[0][0], sims[1][0]) and np.array_equal(sims[0][1], sims[1][1])

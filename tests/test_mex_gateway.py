@@ -135,11 +135,16 @@ def flatten(scene):
         g = d["ground"]
         out.update(contact=d["contact"].astype(np.int32), sides=d["sides"].T, groundE=np.asarray(g["E"], dtype=np.float64).reshape(4, 4),
                    kn=g["kn"], kt=g["kt"], mu=g["mu"], kd=g["kd"])
+        gb = d.get("ground_body") or {"E": np.stack([np.asarray(g["E"], dtype=np.float64)] * n), "kn": np.full(n, g["kn"]),
+                                      "kt": np.full(n, g["kt"]), "mu": np.full(n, g["mu"]), "kd": np.full(n, g["kd"])}
+        out.update(groundE_body=np.stack([np.asarray(E, dtype=np.float64).reshape(4, 4).T.reshape(16) for E in gb["E"]]).T,
+                   kn_body=np.asarray(gb["kn"], dtype=np.float64).reshape(1, n), kt_body=np.asarray(gb["kt"], dtype=np.float64).reshape(1, n),
+                   mu_body=np.asarray(gb["mu"], dtype=np.float64).reshape(1, n), kd_body=np.asarray(gb["kd"], dtype=np.float64).reshape(1, n))
     return out
 
 
 def test_gateway_builds_warning_free_and_answers_version(gw):
-    assert gw.call(1, "version") == 105
+    assert gw.call(1, "version") == 106
 
 
 def test_gateway_reports_errors_the_matlab_way(gw):

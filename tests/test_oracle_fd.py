@@ -82,11 +82,15 @@ def test_newton_hessian_is_jacobian_of_g(oracle_lib):
     assert _err(H_, H) < 1e-6
 
 
-def test_ground_contact_fd(oracle_lib):
+@pytest.mark.parametrize("two", [False, True])
+def test_ground_contact_fd(oracle_lib, two):
     """ForceGroundCuboid's K and D against central differences of f (Scene.test K/D checks, Scene.m:343-376) on a chain
-    whose corners penetrate the ground, plus H = dg/dq1 of the BDF1 residual through contact."""
-    sc = sceneChainGround(4, ground_z=-1.0)
+    whose corners penetrate the ground, plus H = dg/dq1 of the BDF1 residual through contact.  two: force objects with different
+    frames and constants (a floor for the even bodies, a tilted softer plane for the odd ones)."""
+    from redmax_amd.scenes import sceneChainTwoGrounds
+    sc = sceneChainTwoGrounds(4, ground_z=-1.0) if two else sceneChainGround(4, ground_z=-1.0)
     sc.init()
+    assert (sc.desc().get("ground_body") is not None) == two
     o = oracle_lib.Oracle(sc.desc())
     rng = np.random.default_rng(8)
     nr, h = o.nr, sc.h
@@ -119,3 +123,22 @@ def test_ground_contact_fd(oracle_lib):
             gp.append(o.eval_bdf1(x, q, qd, h, want_H=False))
         H_[:, i] = (gp[0] - gp[1]) / 2e-7
     assert _err(H_, H) < 1e-6
+
+
+def test_per_body_ground_frames_equal_the_shared_frame_when_they_are_the_same(oracle_lib):
+    """orc_set_ground_contact_body with n copies of one frame / parameter set = orc_set_ground_contact, bit for bit."""
+    sc = sceneChainGround(5, ground_z=-1.0)
+    sc.init()
+    d = sc.desc()
+    n = len(d["contact"])
+    g = d["ground"]
+    d2 = dict(d, ground_body={"E": np.stack([g["E"]] * n), "kn": np.full(n, g["kn"]), "kt": np.full(n, g["kt"]), "mu": np.full(n, g["mu"]),
+                              "kd": np.full(n, g["kd"])})
+    rng = np.random.default_rng(3)
+    q = rng.uniform(0.1, 0.4, sc.nr)
+    qd = rng.uniform(-3, 3, sc.nr)
+    out = []
+    for dd in (d, d2):
+        o = oracle_lib.Oracle(dd)
+        out.append(o.eval_bdf1(q + sc.h * qd, q, qd, sc.h))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
