@@ -280,6 +280,22 @@ __device__ __forceinline__ double recip(double x) {
     return fma(r, fma(e, e, e), r);
 }
 
+// an = sqrt(a2) and ian = 1 / sqrt(a2) from ONE v_rsq_f64 (good to ~2^-24): a cubic step r (1 + u/2 + 3 u^2/8), u = 1 - a2 r^2,
+// leaves u^3 ~ 2^-72 before rounding; sqrt = a2 r with one residual correction.  10 instructions for both against the 22 + 14 of
+// the library sqrt (range scaling, class test) and the IEEE division - per penetrating corner of the ground contact, on the path
+// of every line-search trial.  a2 = 0: an = 0, ian = NaN (the caller's 0 * ian is NaN like its 0 * (1/0) was).
+__device__ __forceinline__ void sqrt_rcp(const double a2, double& an, double& ian) {
+    const double r0 = __builtin_amdgcn_rsq(a2);
+    const double t = a2 * r0;
+    const double u = fma(-t, r0, 1.0);
+    const double r = fma(r0, u * fma(0.375, u, 0.5), r0);
+    const double s = a2 * r;
+    const double e = fma(-s, s, a2);
+    const double sq = fma(0.5 * e, r, s);
+    an = a2 > 0.0 ? sq : 0.0;
+    ian = r;
+}
+
 // s + e = a + b exactly (Knuth's TwoSum, no ordering assumption; six additions that must not be re-associated)
 __device__ __forceinline__ void two_sum(const double a, const double b, double& s, double& e) {
     s = a + b;
@@ -554,13 +570,14 @@ __device__ __forceinline__ bool contact_body(const GroundC& G, const bool con, c
             double a[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) a[c] = vw[c] - n[c] * nv;            // T vw
-            const double an = sqrt(dot3(a, a));
+            double an, ian;
+            sqrt_rcp(dot3(a, a), an, ian);
             const bool fric = mu != 0.0;
             const bool stat = fric && (mu * fabs(kn * d) > kt * an);   // (:112)
             const double mukn = mu * kn;
             double tt[3] = {0.0, 0.0, 0.0};
             if (fric && !stat) {
-                const double ia = 1.0 / an;
+                const double ia = ian;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) tt[c] = a[c] * ia;
             }
@@ -606,7 +623,7 @@ __device__ __forceinline__ bool contact_body(const GroundC& G, const bool con, c
                             for (int k = 0; k < 3; ++k)
                                 XL[3 * i + k] -= kt * (Sk[3 * i + k] - (Sv[3 * i + k] - n[i] * nxv[k]));
                     } else {
-                        const double ia = 1.0 / an, ia3 = ia * ia * ia, a2 = an * an;
+                        const double ia = ian, ia3 = ia * ia * ia, a2 = an * an;
                         double AT[9], ATS[9];
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
@@ -643,7 +660,7 @@ __device__ __forceinline__ bool contact_body(const GroundC& G, const bool con, c
 #pragma unroll
                             for (int k = 0; k < 3; ++k) Y[3 * i + k] -= kt * ((i == k ? 1.0 : 0.0) - n[i] * n[k]);
                     } else {
-                        const double ia = 1.0 / an, ia3 = ia * ia * ia, a2 = an * an;
+                        const double ia = ian, ia3 = ia * ia * ia, a2 = an * an;
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
