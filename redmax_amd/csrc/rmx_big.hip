@@ -519,16 +519,28 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
         if (r == pr) mystep = k;
         if (row && mystep < 0) {
             const double l = hget<HL>(H, ck + r) / hget<HL>(H, ck + pr);
-            const size_t st = (size_t)ncg * nr;
             int c = k + 1 + cg;
-            for (; c + 3 * ncg < nr; c += 4 * ncg) {       // four columns in flight: loads first, then the stores
-                const size_t c0 = (size_t)c * nr, c1 = c0 + st, c2 = c1 + st, c3 = c2 + st;
-                const double p0 = hget<HL>(H, c0 + pr), p1 = hget<HL>(H, c1 + pr), p2 = hget<HL>(H, c2 + pr), p3 = hget<HL>(H, c3 + pr);
-                const double a0 = hget<HL>(H, c0 + r), a1 = hget<HL>(H, c1 + r), a2 = hget<HL>(H, c2 + r), a3 = hget<HL>(H, c3 + r);
-                hput<HL>(H, c0 + r, a0 - l * p0);
-                hput<HL>(H, c1 + r, a1 - l * p1);
-                hput<HL>(H, c2 + r, a2 - l * p2);
-                hput<HL>(H, c3 + r, a3 - l * p3);
+            // UF columns in flight (loads first, then the stores): 4 when H is in LDS, 16 when every access is a trip to HBM / L2
+            constexpr int UF = HL ? 4 : 16;
+            for (; c + (UF - 1) * ncg < nr; c += UF * ncg) {
+                double pv[UF], av[UF];
+#pragma unroll
+                for (int u = 0; u < UF; ++u) pv[u] = hget<HL>(H, (size_t)(c + u * ncg) * nr + pr);
+#pragma unroll
+                for (int u = 0; u < UF; ++u) av[u] = hget<HL>(H, (size_t)(c + u * ncg) * nr + r);
+#pragma unroll
+                for (int u = 0; u < UF; ++u) hput<HL>(H, (size_t)(c + u * ncg) * nr + r, av[u] - l * pv[u]);
+            }
+            if constexpr (!HL) {          // remainder of the wide unroll, four at a time
+                for (; c + 3 * ncg < nr; c += 4 * ncg) {
+                    double pv[4], av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pv[u] = hget<HL>(H, (size_t)(c + u * ncg) * nr + pr);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = hget<HL>(H, (size_t)(c + u * ncg) * nr + r);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) hput<HL>(H, (size_t)(c + u * ncg) * nr + r, av[u] - l * pv[u]);
+                }
             }
             for (; c < nr; c += ncg) {
                 const size_t cc = (size_t)c * nr;
