@@ -14,7 +14,7 @@
 //                                       thread = (row, column group), implicit row permutation, pivot search on wave shuffles
 // Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
 // of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts): a 72-link chain 1.9 ms per BDF1 step, a 128-link
-// chain 5.5 ms, a 256-link chain 114 ms (H in HBM); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered: BDF1, BDF2
+// chain 5.4 ms, a 256-link chain 61 ms (H in HBM, blocked LU); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered: BDF1, BDF2
 // (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching; not covered: ground
 // contact, the adjoint, matlab-simple Euler, rmx_eval_mfd (refused by the C ABI for such models).
 #include <hip/hip_runtime.h>
@@ -38,8 +38,14 @@ struct BigWs {
 };
 __host__ __device__ constexpr size_t big_ws_doubles_n(const int nr) { return (size_t)nr * nr; }
 // doubles of LDS: region X = max(E + V, scan, H if it is kept in LDS) + cu, cl
+constexpr int LU_NB = 32;             // panel width of the blocked LU (H in HBM)
 __host__ __device__ constexpr size_t big_lds_doubles(const int n, const int nr, const bool hl) {
-    return ((hl && (size_t)nr * nr > (size_t)36 * n) ? (size_t)nr * nr : (size_t)36 * n) + (size_t)18 * n;
+    // region X: E + V (36 n) | the scan (28 n) | H (hl) or the LU panel [LU_NB][nr] + its U12 block [LU_NB][BT] (!hl); then cu, cl
+    // (H in LDS is formed while cu, cl are read: behind them; the LU panel is only used after H is complete: over everything)
+    const size_t x0 = (size_t)36 * n;
+    if (hl) return ((size_t)nr * nr > x0 ? (size_t)nr * nr : x0) + (size_t)18 * n;
+    const size_t lu = (size_t)LU_NB * nr + (size_t)LU_NB * BT;
+    return lu > x0 + (size_t)18 * n ? lu : x0 + (size_t)18 * n;
 }
 template <bool HL>
 __device__ __forceinline__ BigWs big_ws(double* base, const int n, const int nr) {
@@ -495,8 +501,128 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
 // dx = -H\g: LU with partial pivoting on the workspace copy of H (column-major nr x nr), thread = reduced row.  The permutation is
 // implicit (rows are never moved): piv[r] = the step at which row r served as the pivot row, or -1.  First maximum wins (dgetf2).
 // bneg: this node's -g (nodes without a DOF: ignored).  Returns this node's dx.
+#ifdef RMX_BIG_PROFILE
+__device__ unsigned long long g_prof[8];
+#define PROF_T0() const unsigned long long p0_ = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(i) do { if (t == 0 && blockIdx.x == 0) g_prof[i] += __builtin_amdgcn_s_memtime() - p0_; } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(i) do {} while (0)
+#endif
+// dx = -H\g with H in HBM (nr > ~128): right-looking BLOCKED LU with partial pivoting, thread = row, implicit permutation as in
+// big_solve.  Unblocked, every pivot streams the whole trailing matrix through the CU (nr^3/3 x 16 B = 89 MB per solve at 256 DOFs:
+// the launch was HBM-bound).  Here a panel of LU_NB columns is factored in LDS, the LU_NB pivot rows of every trailing column are
+// forward-substituted (thread = column, U12 kept in LDS), and the trailing matrix is read and written ONCE per panel with the
+// rank-LU_NB update a(r,c) -= sum_j L(r,j) U(j,c) (L(r,:) in registers, U from LDS).  Same pivots, same operations per entry as the
+// unblocked loop up to the order of the subtractions.
+__device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
+    __shared__ int spiv[BT];
+    __shared__ double b[BT];
+    __shared__ double xs[BT];
+    constexpr int NB = LU_NB;
+    const int nr = M.nr;
+    double* __restrict__ H = w.H;
+    const int oU = NB * nr;            // dyn[j * nr + r]: panel column j, row r;  dyn[oU + j * BT + c]: U12(j, c-th column of the pass)
+    if (ka >= 0) b[ka] = -g;
+    __syncthreads();
+    const int r = t;
+    const bool row = r < nr;
+    int mystep = -1;
+    for (int kb = 0; kb < nr; kb += NB) {
+        const int nb = nr - kb < NB ? nr - kb : NB;
+        PROF_T0();
+        if (row) {
+            for (int j = 0; j < nb; ++j) dyn[j * nr + r] = H[(size_t)(kb + j) * nr + r];
+        }
+        __syncthreads();
+        // the panel, pivot by pivot, in LDS; the multipliers stay in place
+        for (int j = 0; j < nb; ++j) {
+            const double cand = (row && mystep < 0) ? fabs(dyn[j * nr + r]) : -1.0;
+            const int pr = block_argmax(cand, r, t);
+            if (t == 0) spiv[kb + j] = pr;
+            if (r == pr) mystep = kb + j;
+            if (row && mystep < 0) {
+                const double l = dyn[j * nr + r] / dyn[j * nr + pr];
+                dyn[j * nr + r] = l;
+                for (int jj = j + 1; jj < nb; ++jj) dyn[jj * nr + r] -= l * dyn[jj * nr + pr];
+                b[r] -= l * b[pr];
+            }
+            __syncthreads();
+        }
+        if (row) {       // U (pivot rows) for the back substitution; the multipliers of the other rows are never read from H again
+            for (int j = 0; j < nb; ++j) H[(size_t)(kb + j) * nr + r] = dyn[j * nr + r];
+        }
+        PROF_ADD(3);
+        // trailing columns, BT per pass
+        for (int c0 = kb + nb; c0 < nr; c0 += BT) {
+            PROF_T0();
+            const int c = c0 + t;
+            if (c < nr) {          // thread = column: U12(:, c) = L11^-1 A12(pivot rows, c)
+                double u[NB];
+                double* col = H + (size_t)c * nr;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    double a = 0.0;
+                    if (j < nb) {
+                        const int pj = spiv[kb + j];
+                        a = col[pj];
+#pragma unroll
+                        for (int i = 0; i < j; ++i) a -= dyn[i * nr + pj] * u[i];
+                        col[pj] = a;
+                    }
+                    u[j] = a;
+                    dyn[oU + j * BT + t] = a;
+                }
+            }
+            __syncthreads();
+            PROF_ADD(4);
+            if (row && mystep < 0) {       // thread = row: the rank-nb update of its trailing entries
+                double L[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) L[j] = j < nb ? dyn[j * nr + r] : 0.0;
+                const int ncol = nr - c0 < BT ? nr - c0 : BT;
+                int cc = 0;
+                for (; cc + 7 < ncol; cc += 8) {           // eight columns in flight
+                    double a[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = H[(size_t)(c0 + cc + q) * nr + r];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a[q] -= L[j] * dyn[oU + j * BT + cc + q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) H[(size_t)(c0 + cc + q) * nr + r] = a[q];
+                }
+                for (; cc < ncol; ++cc) {
+                    double a = H[(size_t)(c0 + cc) * nr + r];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) a -= L[j] * dyn[oU + j * BT + cc];
+                    H[(size_t)(c0 + cc) * nr + r] = a;
+                }
+            }
+            __syncthreads();
+            PROF_ADD(5);
+        }
+    }
+    // back substitution on the implicitly permuted upper triangle
+    PROF_T0();
+    for (int k = nr - 1; k >= 0; --k) {
+        const int pr = spiv[k];
+        if (r == pr) xs[k] = b[r] / H[(size_t)k * nr + r];
+        __syncthreads();
+        if (row && mystep < k) b[r] -= H[(size_t)k * nr + r] * xs[k];
+        __syncthreads();
+    }
+    PROF_ADD(6);
+    const double dx = ka >= 0 ? xs[ka] : 0.0;
+    __syncthreads();
+    return dx;
+}
+
 template <bool HL>
 __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
+    if constexpr (!HL) return big_solve_blocked(M, w, t, ka, g);
     __shared__ int spiv[BT];         // pivot row of step k
     __shared__ double b[BT];         // right-hand side, reduced order
     __shared__ double xs[BT];        // solution, reduced order
@@ -573,11 +699,12 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
     BigOut e;
     int iter = 1, lsfail = 0;
     while (true) {
-        big_eval<true, HL>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+        { PROF_T0(); big_eval<true, HL>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(0); }
         const BigOut e0 = e;
         last = e;
         ++iters;
-        const double dx = big_solve<HL>(M, w, t, ka, e.g);
+        double dx;
+        { PROF_T0(); dx = big_solve<HL>(M, w, t, ka, e.g); PROF_ADD(1); }
         const double dxn2 = block_sum(dx * dx, t);
         if (!(dxn2 == dxn2)) { status |= 4; break; }
         if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }
@@ -597,7 +724,7 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
                 e = e0;
                 break;
             }
-            big_eval<false>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+            { PROF_T0(); big_eval<false>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(2); }
             gn2 = block_sum(e.g * e.g, t);
             if (0.5 * gn2 < f0) break;
             if (iterLs >= o.iterLsMax) break;
@@ -781,6 +908,11 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
         a.status[traj] |= status;
     }
     if (t == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;
+#ifdef RMX_BIG_PROFILE
+    if (t == 0 && traj == 0)
+        printf("big profile (ticks, block 0): eval+H %llu solve %llu trial eval %llu | panel %llu U12 %llu trailing %llu backsub %llu | total %llu\n",
+               g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], __builtin_amdgcn_s_memtime() - tick0);
+#endif
 }
 
 // Parity hook (rmx_eval): one residual (+ Hessian) evaluation per trajectory
