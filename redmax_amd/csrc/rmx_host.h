@@ -102,6 +102,7 @@ struct rmx_batch {
     void RMX_CAT(launch_step_fullchain_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 // 64-lane plain step kernels reading the per-node constants from global memory (rmx_kernels.hip RMX_PART 3) and the staging kernel
 void launch_step_gconst_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
+void launch_step_fulln_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream);
 // rmx_big.hip: trees of 65..BIG_MAXN nodes, one workgroup per rollout
 size_t big_ws_doubles(const rmx_model* m);

@@ -85,21 +85,26 @@ __global__ void __launch_bounds__(64) k_stage_consts(const DevModel M, double* _
 // FULLCHAIN: an instantiation for serial chains that fill every node slot (is_chain && n == NP, decided by the launcher): the two
 // model facts are compile-time constants there, so the tree paths (pointer jumping, relation masks, subtree ranges) and the
 // per-row bounds of partly filled sizes are not even compiled in - fewer live masks, a smaller loop body.
-template <int NP, bool FULLCHAIN>
+// TAG >= TAG_FULLN: a tree (not necessarily a chain) that fills every node slot: n == NP at compile time, so the per-row bounds of partly
+// filled sizes go (the 64-joint tree of BASELINE.json configs[2]).
+constexpr int TAG_FULLN = 4;
+template <int NP, bool FULLCHAIN, int TAG = 0>
 __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
     DevModel M = Min;
     if constexpr (FULLCHAIN) {
         M.n = NP;
         M.is_chain = 1;
     }
+    if constexpr (TAG >= TAG_FULLN) M.n = NP;
     return M;
 }
 
-// TAG: unused, it keeps the kernel names of a translation unit compiled with other macros (RMX_GLOBAL_CONSTS) distinct
+// TAG: keeps the kernel names of a translation unit compiled with other macros (RMX_GLOBAL_CONSTS) distinct (0, 3); TAG_FULLN, TAG_FULLN + 1:
+// the n == NP instantiations of the two
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
 __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
-    const DevModel M = model_view<NP, FULLCHAIN>(Min);
+    const DevModel M = model_view<NP, FULLCHAIN, TAG>(Min);
     const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
     const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
     if (s0 >= a.nsteps) return;                    // the lean launch took this trajectory all the way
@@ -167,7 +172,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevO
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
 __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
-    const DevModel M = model_view<NP, FULLCHAIN>(Min);
+    const DevModel M = model_view<NP, FULLCHAIN, TAG>(Min);
     const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
     const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
     if (s0 >= a.nsteps) return;
@@ -742,6 +747,11 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
 void RMX_CAT(launch_step_gconst_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
     const size_t bytes = sizeof(double) * (size_t)acc_doubles(m->n, RMX_NP);
+    if (m->dm.n == RMX_NP) {          // every node slot in use: the n == NP instantiation
+        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_FULLN + 1>), grid, block, bytes, b->stream, m->dm, o, a);
+        else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_FULLN + 1>), grid, block, bytes, b->stream, m->dm, o, a);
+        return;
+    }
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, 3>), grid, block, bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, 3>), grid, block, bytes, b->stream, m->dm, o, a);
 }
@@ -753,6 +763,14 @@ void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
+#if RMX_NP == 64
+// a tree that fills all 64 node slots (n == NP at compile time; LDS-resident constants)
+void launch_step_fulln_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_FULLN>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_FULLN>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+}
+#endif
 
 #elif RMX_PART == 1
 
@@ -796,6 +814,9 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     // More than two rollouts per CU: the kernels that read the per-node constants from global memory (33.8 KB of LDS per wavefront
     // instead of 68.6 KB: four wavefronts per CU instead of two).  Up to two per CU the LDS-resident constants are faster (-7 %).
     if (m->dm.gconst && m->gconst_min_batch > 0 && b->B >= m->gconst_min_batch) return launch_step_gconst_64(m, b, integ, o, a);
+#if !defined(RMX_NO_FULLCHAIN)
+    if (m->dm.n == RMX_NP) return launch_step_fulln_64(m, b, integ, o, a);
+#endif
 #endif
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
