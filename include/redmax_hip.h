@@ -202,7 +202,7 @@ int rmx_eval(rmx_batch* b, const double* q, const double* qA, const double* qB, 
  * M = J'MmJ (:212), the force vector f = fr + J'(fm - Mm Jdot qdot) (:215-216) and D = df/dqdot (:227-237).  q, qdot, f: host
  * [batch][nr]; M, D: host [batch][nr*nr] column-major.  K = df/dq is not returned on its own: it only exists folded into H
  * (rmx_eval gives H = M - eta D - eta^2 K + dMdq dqtmp).  Spherical joints: in the coordinates of the batch's current Euler charts
- * (rmx_get_charts).  Models with ground contact are refused.
+ * (rmx_get_charts).  ForceGroundCuboid: its wrench is part of f, its damping block J' Dm J part of D (ForceGroundCuboid.m:104-106).
  * Does not change state. */
 int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, double* M, double* f, double* D);
 

@@ -718,7 +718,6 @@ extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const d
 extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, double* M, double* f, double* D) {
     if (!b || !q || !qdot || !M || !f || !D) return fail(RMX_E_INVALID, "null argument");
     rmx_model* m = b->m;
-    if (m->dm.con) return fail(RMX_E_INVALID, "rmx_eval_mfd: models with ground contact are outside this hook (the contact K/D blocks only exist inside H)");
     if (m->big) return fail(RMX_E_INVALID, "rmx_eval_mfd: trees of more than 64 nodes are outside this hook");
     HIPCHK(hipSetDevice(m->device));
     if (int rc = pending_error_check(b, "rmx_eval_mfd")) return rc;

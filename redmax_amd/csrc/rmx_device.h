@@ -1214,10 +1214,11 @@ __device__ __forceinline__ void eval_mass(const DevModel& M, const int lane, con
 //                              = (Bc_a' s_a).s_i - 2 (Ic_a s_a).xi_i  a strict descendant ;  + Dr on the diagonal.
 // Idle rows/columns: identity in M, zero in D.
 // Column I (and on) of M and D for trees of up to 16 nodes (eval_MD's loop with the column broadcast fused into the FMAs).
-template <int NP, int I>
+template <int NP, int I, bool CD = false>
 __device__ __forceinline__ void md_columns_dpp(const double (&cv)[24], const double (&sw)[3], const double (&sv)[3], const double (&r1)[6],
-                                               const double (&r2w)[3], const unsigned long long desc_m, const unsigned long long anc_m,
-                                               const int lane, const double mdiag, const double ddiag, double (&Mrow)[NP], double (&Drow)[NP]) {
+                                               const double (&r2w)[3], const double (&r2v)[3], const unsigned long long desc_m,
+                                               const unsigned long long anc_m, const int lane, const double mdiag, const double ddiag,
+                                               double (&Mrow)[NP], double (&Drow)[NP]) {
     if constexpr (I < NP) {
         double m_lo = 0.0, m_up = 0.0, d_a = 0.0, d_b = 0.0, d_up = 0.0;
 #pragma unroll
@@ -1232,18 +1233,52 @@ __device__ __forceinline__ void md_columns_dpp(const double (&cv)[24], const dou
             fmadd_rowbcast<I>(d_up, cv[18 + c], sw[c]);
             fmadd_rowbcast<I>(m_up, cv[15 + c], sv[c]);
             fmadd_rowbcast<I>(d_up, cv[21 + c], sv[c]);
+            if constexpr (CD) fmadd_rowbcast<I>(d_a, cv[3 + c], r2v[c]);      // ground contact: (Dc_a s_a)_v . sv_i
         }
         const double d_lo = d_a - 2.0 * d_b;
         const double mu = (double)(unsigned)((desc_m >> I) & 1ull);
         const double ml = (double)(unsigned)((anc_m >> I) & 1ull);
         Mrow[I] = (I == lane) ? mdiag : (mu * m_up + ml * m_lo);
         Drow[I] = (I == lane) ? ddiag : (mu * d_up + ml * d_lo);
-        md_columns_dpp<NP, I + 1>(cv, sw, sv, r1, r2w, desc_m, anc_m, lane, mdiag, ddiag, Mrow, Drow);
+        md_columns_dpp<NP, I + 1, CD>(cv, sw, sv, r1, r2w, r2v, desc_m, anc_m, lane, mdiag, ddiag, Mrow, Drow);
     }
 }
 
+// yc = Dc s for eval_MD<.., CD>: the contact damping blocks of the bodies (contact_body<2>, 21 numbers each) summed over the subtree
+// through the LDS scan, times this node's screw.  Zero while no corner of the tree penetrates (fs.touched, wave-uniform).
 template <int NP>
-__device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const FrontState& fs, double (&Mrow)[NP], double (&Drow)[NP]) {
+__device__ __forceinline__ void contact_damping_fold(const DevModel& M, double* __restrict__ sAcc, const int lane, const FrontState& fs,
+                                                     double (&yc)[6]) {
+    constexpr int CS = cstride(NP);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) yc[c] = 0.0;
+    if (!fs.touched) return;
+    const bool act = fs.act;
+    const int jj = act ? lane : 0;
+    const double* cEnd = RMX_CONSTS(sAcc, M.n, NP) + (NCONST - 5) * CS;
+    const double* cCon = cEnd + CS;
+    const bool con = act && cCon[jj] != 0.0;
+    const double sd[3] = {cCon[CS + jj], cCon[2 * CS + jj], cCon[3 * CS + jj]};
+    const GroundC G = ground_of<NP>(M, sAcc, jj);
+    const double s6[6] = {fs.sw[0], fs.sw[1], fs.sw[2], fs.sv[0], fs.sv[1], fs.sv[2]};
+    double Fc[6], eVc, Dx[36];
+    contact_body<2>(G, con, sd, fs.Rw, fs.pw, fs.phw, fs.phv, Fc, Dx, eVc);
+    lds_subtree_sum<NP, 21>(M, sAcc, cEnd, lane, act, jj, &Dx[0]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a += Dx[r <= c ? sym21(r, c) : sym21(c, r)] * s6[c];
+        yc[r] = a;
+    }
+}
+
+// CD: models with ground contact.  yc = Dc s of this node, Dc = the contact damping blocks Dw = sum Gw' Y Gw of the bodies of its subtree
+// (contact_damping_fold): D gains  s_a . (Dc_i s_i)  for i a descendant of a,  (Dc_a s_a) . s_i  for an ancestor,  s_a . Dc_a s_a  on the
+// diagonal - the same places the Coriolis block Bc occupies, so yc joins y (Bc s) and its transpose-side twin r2.
+template <int NP, bool CD = false>
+__device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const FrontState& fs, double (&Mrow)[NP], double (&Drow)[NP],
+                                        const double* yc = nullptr) {
     const bool act = fs.act;
     const int jj = act ? lane : 0;
     const double mS = fs.S[6];
@@ -1276,6 +1311,16 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
     cross3(hfS, fs.sv, b3);                   // r2w = (Bc' s)_w = TL' sw - 2 hf x sv
 #pragma unroll
     for (int c = 0; c < 3; ++c) r2w[c] = TL[c] * fs.sw[0] + TL[3 + c] * fs.sw[1] + TL[6 + c] * fs.sw[2] - 2.0 * b3[c];
+    double r2v[3] = {0.0, 0.0, 0.0};
+    if constexpr (CD) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            yD[c] += yc[c];
+            yD[3 + c] += yc[3 + c];
+            r2w[c] += yc[c];          // Dc is symmetric: Dc' s = Dc s
+            r2v[c] = yc[3 + c];
+        }
+    }
     double cv[24];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -1296,7 +1341,7 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
     const double ddiag = fs.dof ? (syD - fs.dd) : 0.0;
     if constexpr (NP <= 16) {     // one DPP row holds the tree: broadcasts fused into the FMAs (see eval_hess)
         dpp_settle(cv);
-        md_columns_dpp<NP, 0>(cv, fs.sw, fs.sv, r1, r2w, desc_m, anc_m, lane, mdiag, ddiag, Mrow, Drow);
+        md_columns_dpp<NP, 0, CD>(cv, fs.sw, fs.sv, r1, r2w, r2v, desc_m, anc_m, lane, mdiag, ddiag, Mrow, Drow);
         return;
     }
 #pragma unroll
@@ -1306,8 +1351,9 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
         for (int c = 0; c < 24; ++c) Ci[c] = readlane_d(cv[c], i);
         const double m_lo = r1[0] * Ci[0] + r1[1] * Ci[1] + r1[2] * Ci[2] + r1[3] * Ci[3] + r1[4] * Ci[4] + r1[5] * Ci[5];
         const double m_up = fs.sw[0] * Ci[12] + fs.sw[1] * Ci[13] + fs.sw[2] * Ci[14] + fs.sv[0] * Ci[15] + fs.sv[1] * Ci[16] + fs.sv[2] * Ci[17];
-        const double d_lo = r2w[0] * Ci[0] + r2w[1] * Ci[1] + r2w[2] * Ci[2] -
-                            2.0 * (r1[0] * Ci[6] + r1[1] * Ci[7] + r1[2] * Ci[8] + r1[3] * Ci[9] + r1[4] * Ci[10] + r1[5] * Ci[11]);
+        double d_lo = r2w[0] * Ci[0] + r2w[1] * Ci[1] + r2w[2] * Ci[2] -
+                      2.0 * (r1[0] * Ci[6] + r1[1] * Ci[7] + r1[2] * Ci[8] + r1[3] * Ci[9] + r1[4] * Ci[10] + r1[5] * Ci[11]);
+        if constexpr (CD) d_lo += r2v[0] * Ci[3] + r2v[1] * Ci[4] + r2v[2] * Ci[5];
         const double d_up = fs.sw[0] * Ci[18] + fs.sw[1] * Ci[19] + fs.sw[2] * Ci[20] + fs.sv[0] * Ci[21] + fs.sv[1] * Ci[22] + fs.sv[2] * Ci[23];
         const double mu = (double)(unsigned)((desc_m >> i) & 1ull);
         const double ml = (double)(unsigned)((anc_m >> i) & 1ull);

@@ -96,6 +96,7 @@ struct rmx_batch {
     void RMX_CAT(launch_adjoint_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const AdjArgs& a); \
     void RMX_CAT(launch_phase_, NPV)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d); \
     void RMX_CAT(launch_mfd_, NPV)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD); \
+    void RMX_CAT(launch_mfd_ct_, NPV)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD); \
     void RMX_CAT(launch_eval_ct_, NPV)(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH); \
     void RMX_CAT(launch_step_ct_, NPV)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a); \
     void RMX_CAT(launch_energy_ct_, NPV)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV); \

@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(64) k_eval(const DevModel M, const int B, cons
 // Parity hook for computeValues itself (driverRedMaxBDF1.m:190-243): M = J'MmJ (:212), f = fr + J'(fm - Mm Jdot qdot) (:215-216)
 // and D = df/dqdot (:227-237) at (q, qdot), results to HBM (column-major per trajectory).  f is the residual with v = 0 and
 // e2 = 1 (g = M v - e2 f = -f); M and D rows come from the subtree sums the same front pass leaves behind (eval_MD).
-template <int NP>
+template <int NP, bool CT = false>
 __global__ void __launch_bounds__(64) k_eval_mfd(const DevModel M, const int B, const double* __restrict__ q, const double* __restrict__ qd,
                                                  double* __restrict__ Mo, double* __restrict__ fo, double* __restrict__ Do,
                                                  const int* __restrict__ chart) {
@@ -626,15 +626,22 @@ __global__ void __launch_bounds__(64) k_eval_mfd(const DevModel M, const int B, 
     smem_setup<NP>(M, sAcc, sCol);
     // JointSpherical / JointFree3D: the group's three revolute nodes about the axes of the trajectory's Euler chart ARE the joint in
     // the chart's coordinates (S = T of JointSpherical.m:298-303), so M, f, D come out in those coordinates with no further term
+    if constexpr (CT) con_setup<NP>(M, sCol);
     if (M.nsph) sph_setup<NP>(M, sCol, threadIdx.x, chart + (size_t)blockIdx.x * M.nsph);
     const int lane = threadIdx.x, traj = blockIdx.x;
     const int id = (lane < M.n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     FrontState fs;
     NodeOut e;
-    eval_front_e2<NP, true>(M, sAcc, lane, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, 1.0, e, fs);
+    eval_front_e2<NP, true, false, CT>(M, sAcc, lane, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, 1.0, e, fs);
     double Mrow[NP], Drow[NP];
-    eval_MD<NP>(M, lane, fs, Mrow, Drow);
+    if constexpr (CT) {       // ForceGroundCuboid: its wrench is in f (the front), its damping blocks go into D here
+        double yc[6];
+        contact_damping_fold<NP>(M, sAcc, lane, fs, yc);
+        eval_MD<NP, true>(M, lane, fs, Mrow, Drow, yc);
+    } else {
+        eval_MD<NP>(M, lane, fs, Mrow, Drow);
+    }
     if (id >= 0) fo[off] = -e.g;
     double* Mt = Mo + (size_t)traj * M.nr * M.nr;
     double* Dt = Do + (size_t)traj * M.nr * M.nr;
@@ -779,6 +786,10 @@ void RMX_CAT(launch_eval_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bo
     if (wantH) RMX_LAUNCH((k_eval<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
     else RMX_LAUNCH((k_eval<RMX_NP, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart);
 }
+void RMX_CAT(launch_mfd_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD) {
+    const dim3 grid(b->B), block(64);
+    RMX_LAUNCH((k_eval_mfd<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD, b->chart);
+}
 void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
     // every trajectory as far as it stays clear of the ground (all the way in scenes without ForceGroundCuboid) ...
@@ -845,6 +856,7 @@ void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
 }
 
 void RMX_CAT(launch_mfd_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dM, double* df, double* dD) {
+    if (m->dm.con) return RMX_CAT(launch_mfd_ct_, RMX_NP)(m, b, dM, df, dD);
     const dim3 grid(b->B), block(64);
     RMX_LAUNCH((k_eval_mfd<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, b->B, b->tmpA, b->tmpB, dM, df, dD, b->chart);
 }

@@ -361,3 +361,35 @@ def test_force_objects_with_their_own_ground_frames(oracle_lib, integ):
         sims.append(s2.eval_residual(q1, q0, q0 + 0.5 * h * qd0, h))
         s2.close()
     assert np.array_equal(sims[0][0], sims[1][0]) and np.array_equal(sims[0][1], sims[1][1])
+
+
+@pytest.mark.parametrize("name", ["chain6ground", "chain32ground", "chain8two", "11"])
+def test_compute_values_hook_with_ground_contact(oracle_lib, name):
+    """rmx_eval_mfd on scenes with ForceGroundCuboid: the contact wrench is part of f, its damping block J' Dm J part of D
+    (ForceGroundCuboid.m:104-106, 135-150), both friction branches; M, f, D vs the oracle's computeValues at penetrating states."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainTwoGrounds
+    if name == "11":
+        sc = scenesRedMax(11)
+    elif name == "chain8two":
+        sc = sceneChainTwoGrounds(8, ground_z=-1.0)
+    else:
+        sc = sceneChainGround(6 if name == "chain6ground" else 32, ground_z=-1.0)
+    sc.init()
+    B = 6
+    rng = np.random.default_rng(21)
+    _, qd, q = _penetrating_states(name, sc.nr, sc.h, B, rng)
+    sim = BatchSim(sc, batch=B)
+    M, f, D = sim.eval_mfd(q, qd)
+    o_free = oracle_lib.Oracle(dict(sc.desc(), contact=None))
+    touched = 0
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        Mo, fo, _, _, Do = o.compute_values(deriv=True)
+        assert _rel(M[b], Mo) <= 1e-11 and _rel(f[b], fo) <= 1e-11, (name, b, _rel(M[b], Mo), _rel(f[b], fo))
+        assert _rel(D[b], Do) <= 1e-11, (name, b, _rel(D[b], Do))
+        o_free.set_state(q[b], qd[b])
+        touched += _rel(o_free.compute_values(deriv=True)[4], Do) > 1e-6
+    assert touched >= 1                                   # the contact damping really was in D
+    sim.close()
