@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 106
+#define RMX_VERSION 107
 
 enum {
     RMX_OK = 0,
@@ -172,7 +172,8 @@ int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc);
  * constructed in CHART_XYZ.  rmx_step_bdf1/bdf2 run reparam_ after every step per trajectory (status bit RMX_ST_CHART when a
  * chart changed), so q/qdot returned by rmx_get_state are coordinates in the charts rmx_get_charts reports.  rmx_set_state
  * puts every joint back to CHART_XYZ; rmx_set_charts (after it) declares other charts for the given coordinates.
- * charts: host [batch][nsph], spherical joints in listing order.  rmx_step_euler / rmx_adjoint_bdf1 refuse such models. */
+ * charts: host [batch][nsph], spherical joints in listing order.  rmx_step_euler / rmx_adjoint_bdf1 refuse such models.  A scene may
+ * hold at most 21 JointSpherical / JointFree3D joints (rmx_model_create refuses more), whatever its node count. */
 int rmx_model_nsph(const rmx_model* m);
 int rmx_get_charts(rmx_batch* b, int* charts);
 int rmx_set_charts(rmx_batch* b, const int* charts);
@@ -287,11 +288,61 @@ double rmx_last_step_ms(const rmx_batch* b);
 /* The HIP stream the batch's kernels are enqueued on (as void*), for callers that order other work
  * (e.g. a torch.distributed gather) after it. */
 void* rmx_batch_stream(const rmx_batch* b);
-/* Asynchronous variant used by bench.py: enqueue the nsteps kernel and return without synchronising.
- * rmx_sync() waits for the stream. */
+/* ---- Asynchronous stepping: one host thread (MATLAB has one) driving several batches / devices at once (ABI 107).
+ * simLoop (driverRedMaxBDF1.m:57-91, driverRedMaxBDF2.m:57-125) of a batch is ONE kernel launch on the batch's own stream; the
+ * *_async entries enqueue it and return without waiting, so a host loop over batches that live on different devices (or on one
+ * device) has all of them running before it blocks on the first rmx_sync().  Rules: between an *_async call and rmx_sync() on the
+ * same batch only *_async / rmx_sync / rmx_stats_reset may be called on it; other batches are free.  The per-trajectory counters
+ * accumulate on the device (rmx_stats_reset before, rmx_stats_read after the sync).
+ *   rmx_step_bdf1_async / rmx_step_bdf2_async   nsteps steps, no per-step record
+ *   rmx_step_history_async                      integrator 1 | 2 as rmx_step_history; `record` chooses what Scene.saveHistory
+ *                                               (Scene.m:134-161) keeps ON THE DEVICE for every step: RMX_REC_ENERGY (T, V),
+ *                                               RMX_REC_STATE (q, qdot), RMX_REC_CHARTS (Euler charts), OR-ed together
+ *   rmx_sync                                    waits for the batch's stream; reports a failed launch
+ *   rmx_history_read                            after rmx_sync: copies the record of the last rmx_step_history_async into host arrays
+ *                                               shaped as in rmx_history (any pointer whose part was not recorded must be NULL);
+ *                                               the record stays readable until the next step call on the batch */
+enum { RMX_REC_ENERGY = 1, RMX_REC_STATE = 2, RMX_REC_CHARTS = 4 };
 int rmx_step_bdf1_async(rmx_batch* b, const rmx_opts* opts, int nsteps);
+int rmx_step_bdf2_async(rmx_batch* b, const rmx_opts* opts, int nsteps);
+int rmx_step_history_async(rmx_batch* b, const rmx_opts* opts, int nsteps, int integrator, int record);
 int rmx_sync(rmx_batch* b);
-/* The async variant accumulates the per-trajectory counters on the device: reset before, read after. */
+int rmx_history_read(rmx_batch* b, const rmx_history* hist);
+
+/* ---- Multi-device groups (ABI 107): BASELINE.json's north_star shards the batch axis across GPUs and names MATLAB as the host.
+ * A group owns one model + one batch per listed device (a device may be listed more than once: its shards then share it, each on
+ * its own stream) and splits `batch` trajectories into contiguous shards whose sizes differ by at most one, in device-list order
+ * (the "strong" plan of redmax_amd/sharding.py).  Every array argument is the WHOLE batch, shaped exactly as for a single rmx_batch;
+ * the group scatters / gathers the shards' slices.  rmx_group_step is simLoop for the whole batch: it launches every shard's
+ * kernel asynchronously, then waits for all of them and gathers the counters and the per-step record into the caller's arrays -
+ * the one "collective" of the path, here a set of device-to-host copies (no RCCL: the host array is the destination).
+ * gc may be NULL (no ForceGroundCuboid).  devices == NULL: devices 0 .. ndevices-1. */
+typedef struct rmx_group rmx_group;
+int rmx_group_create(const rmx_model_desc* desc, const rmx_ground_contact* gc, int batch, const int* devices, int ndevices,
+                     rmx_group** out);
+void rmx_group_destroy(rmx_group* g);
+int rmx_group_batch_size(const rmx_group* g);
+int rmx_group_nshards(const rmx_group* g);
+/* shard s: its device, the index of its first trajectory in the whole batch and its trajectory count (any pointer may be NULL) */
+int rmx_group_shard(const rmx_group* g, int s, int* device, int* first, int* count);
+/* the shard's own batch / model, for the hooks that have no group form (rmx_eval, rmx_eval_mfd, rmx_adjoint_*, rmx_step_euler,
+ * rmx_get_charts ...): call them per shard with the array pointers advanced to the shard's first trajectory */
+rmx_batch* rmx_group_shard_batch(rmx_group* g, int s);
+rmx_model* rmx_group_shard_model(rmx_group* g, int s);
+int rmx_group_set_state(rmx_group* g, const double* q, const double* qdot);     /* [batch][nr], as rmx_set_state */
+int rmx_group_get_state(rmx_group* g, double* q, double* qdot);
+/* stats, hist: as rmx_step_history, arrays for the whole batch; hist (and any of its members) may be NULL */
+int rmx_group_step(rmx_group* g, const rmx_opts* opts, int nsteps, int integrator, rmx_stats* stats, const rmx_history* hist);
+/* the two halves of rmx_group_step for hosts that overlap their own work with the devices: launch all shards (record: RMX_REC_*),
+ * then wait and gather (stats / hist as above; hist members outside `record` must be NULL) */
+int rmx_group_step_async(rmx_group* g, const rmx_opts* opts, int nsteps, int integrator, int record);
+int rmx_group_sync(rmx_group* g, rmx_stats* stats, const rmx_history* hist);
+int rmx_group_energy(rmx_group* g, double* T, double* V);                      /* [batch], as rmx_energy */
+/* Timing of the last rmx_group_step / rmx_group_step_async + rmx_group_sync: wall_ms = host wall clock from the first launch to
+ * the last shard's completion; per shard (arrays [nshards], any may be NULL) kernel_ms = HIP-event time of its launch, start_ms /
+ * end_ms = when its launch began / ended relative to the start of the FIRST shard on the same device (HIP events of one device
+ * share a clock; 0 / kernel_ms for that first shard).  Shards run concurrently when start_ms of one lies before end_ms of another. */
+int rmx_group_timing(rmx_group* g, double* wall_ms, double* kernel_ms, double* start_ms, double* end_ms);
 /* Profiling hook: mean shader-clock cycles per wavefront of {residual evaluation, residual+Hessian evaluation,
  * LU solve, the two norm reductions} of one Newton iteration at the current state (reps repetitions per trajectory)
  * in cycles16[0..3]; cycles16[4..15] split the residual+Hessian evaluation into its 12 stages (rmx_device.h RMX_STAMP). */

@@ -1,9 +1,12 @@
 classdef HipSim < handle
-	%HipSim  B independent rollouts of one redmax.Scene on one MI355X (libredmax_hip.so through redmax_hip_mex).
+	%HipSim  B independent rollouts of one redmax.Scene on one or several MI355X (libredmax_hip.so through redmax_hip_mex).
 	%
-	%   sim = redmax.HipSim(scene, batch, device)   scene: an initialised redmax.Scene (or a desc struct)
+	%   sim = redmax.HipSim(scene, batch, devices)  scene: an initialised redmax.Scene (or a desc struct); devices: a device
+	%                                               index or a VECTOR of them, e.g. 0:7 - the batch is split into one contiguous
+	%                                               shard per entry, every array below stays the whole batch
 	%   sim.setState(q, qdot)                       nr x batch, the DOF order of Joint.getQ
-	%   [T,V,stats,Q,Qdot] = sim.step(itype, h, nsteps, opts)   itype 1: BDF1, 2: SDIRK2 + BDF2
+	%   [T,V,stats,Q,Qdot] = sim.step(itype, h, nsteps, opts)   itype 1: BDF1, 2: SDIRK2 + BDF2; all devices step concurrently
+	%   sim.stepAsync(itype, h, nsteps, opts, record);  ...  [T,V,stats,Q,Qdot] = sim.sync();   the same, MATLAB free in between
 	%   [q, qdot] = sim.getState()
 	%   delete(sim)
 	%
@@ -17,20 +20,24 @@ classdef HipSim < handle
 		nsph   % spherical joints (Euler charts live on the device, see getCharts)
 		batch  % trajectories
 		idxR   % 0-based reduced index of every listed joint's first DOF (-1: fixed)
+		devices      % device of every shard
+		shardFirst   % 0-based index of every shard's first trajectory
+		shardCount   % trajectories per shard
 	end
 
 	methods
-		function this = HipSim(scene, batch, device)
+		function this = HipSim(scene, batch, devices)
 			if nargin < 2, batch = 1; end
-			if nargin < 3, device = 0; end
+			if nargin < 3, devices = 0; end
 			if isstruct(scene)
 				desc = scene;
 			else
 				desc = redmax.flattenScene(scene);
 			end
-			this.h = redmax_hip_mex('create', desc, batch, device);
+			this.h = redmax_hip_mex('create', desc, batch, double(devices(:)'));
 			info = redmax_hip_mex('info', this.h);
 			this.nr = info.nr; this.nm = info.nm; this.nsph = info.nsph; this.batch = info.batch; this.idxR = info.idxR;
+			this.devices = info.devices; this.shardFirst = info.shard_first; this.shardCount = info.shard_count;
 		end
 
 		function delete(this)
@@ -55,6 +62,28 @@ classdef HipSim < handle
 		function varargout = step(this, itype, hstep, nsteps, opts)
 			if nargin < 5, opts = struct(); end
 			[varargout{1:max(nargout,1)}] = redmax_hip_mex('step', this.h, itype, hstep, nsteps, opts);
+		end
+
+		function stepAsync(this, itype, hstep, nsteps, opts, record)
+			% launch simLoop on every device and return; record: 1 = T, V (default), +2 = Q, Qdot, +4 = charts
+			if nargin < 5 || isempty(opts), opts = struct(); end
+			if nargin < 6, record = 1; end
+			redmax_hip_mex('step_async', this.h, itype, hstep, nsteps, opts, record);
+		end
+
+		function varargout = sync(this)
+			% wait for the launches of stepAsync and gather: [T, V, stats, Q, Qdot, C] as step
+			[varargout{1:max(nargout,1)}] = redmax_hip_mex('sync', this.h);
+		end
+
+		function [wall, kernel, t0, t1] = timing(this)
+			% wall clock ms of the last step and, per shard, kernel ms and launch start / end (rmx_group_timing)
+			[wall, kernel, t0, t1] = redmax_hip_mex('timing', this.h);
+		end
+
+		function t = ticks(this)
+			% shader-clock ticks every rollout's wavefront spent in the last step launch (rmx_step_ticks)
+			t = redmax_hip_mex('ticks', this.h);
 		end
 
 		function [T, V] = euler(this, hstep, nsteps)

@@ -121,6 +121,11 @@ for i = 1 : numel(scene.forces)
 			if hit == 0
 				error('redmax:hip','flattenScene: ForceGroundCuboid on a body that is not in the scene');
 			end
+			if desc.contact(hit)
+				% a floor and a wall on one cuboid: the device tables hold one force object per body; overwriting the first
+				% silently would drop its contact (redmax_amd/redmax.py Scene.desc raises for the same case)
+				error('redmax:hip','flattenScene: one ForceGroundCuboid per body (body %d carries two)',hit);
+			end
 			desc.contact(hit) = 1;
 			desc.sides(:,hit) = f.cuboid.sides(:);
 			desc.groundE_body(:,hit) = reshape(f.E,16,1);

@@ -18,9 +18,13 @@
  *
  *   v            = redmax_hip_mex('version')
  *   n            = redmax_hip_mex('devices')
- *   h            = redmax_hip_mex('create', desc, batch [, device])     desc: struct, see read_desc() below
+ *   h            = redmax_hip_mex('create', desc, batch [, devices])    desc: struct, see cmd_create() below.  devices: a device index
+ *                  or a VECTOR of them (default 0).  The batch is split into one contiguous shard per listed device (sizes differ by at
+ *                  most one; a device may be listed twice); every array below is the WHOLE batch, the gateway scatters / gathers
+ *                  (rmx_group_*).  BASELINE.json north_star: "the batch axis shards across GPUs", host = MATLAB.
  *                  redmax_hip_mex('destroy', h)
- *   info         = redmax_hip_mex('info', h)                            struct nr, nm, nsph, batch, idxR (0-based, -1 fixed)
+ *   info         = redmax_hip_mex('info', h)                            struct nr, nm, nsph, batch, idxR (0-based, -1 fixed),
+ *                                                                       nshards, devices, shard_first (0-based), shard_count
  *                  redmax_hip_mex('set', h, q, qdot)                     nr x B each          Joint.setQ   (Joint.m:231-292)
  *   [q, qdot]    = redmax_hip_mex('get', h)                                                   Joint.getQ   (Joint.m:173-229)
  *   [T,V,st,Q,Qd,C]= redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])
@@ -29,6 +33,14 @@
  *                  Q, Qd (only when requested): nr x B x nsteps, the full Scene.saveHistory record (Scene.m:134-161);
  *                  C (only when requested): nsph x B x nsteps int32, the Euler chart of every spherical joint after each step.
  *                  opts: struct with any of tol, dxMax, iterMaxPerDof, iterLsMax, lu_mode, compensated, ls_fail_limit (driverRedMaxBDF1.m:95-98).
+ *                  All shards' kernels are launched before the first one is waited for: N devices run concurrently.
+ *                  redmax_hip_mex('step_async', h, itype, hstep, nsteps [, opts [, record]])
+ *                  the same launch without the wait: MATLAB gets control back while the devices step (several handles can be in
+ *                  flight).  record: bit mask of what Scene.saveHistory keeps on the device, 1 = T, V (default), 2 = Q, Qdot, 4 = C.
+ *   [T,V,st,Q,Qd,C]= redmax_hip_mex('sync', h)
+ *                  waits for the launches of the last 'step_async' and gathers; outputs beyond what `record` asked for are an error.
+ *   [wall,k,t0,t1] = redmax_hip_mex('timing', h)                         rmx_group_timing of the last step: wall clock ms, and per shard
+ *                  (1 x nshards) kernel ms, start and end of its launch relative to the first shard on the same device
  *   [T, V]       = redmax_hip_mex('euler', h, hstep, nsteps)             matlab-simple/testRedMax.m:67-109
  *   [g, H]       = redmax_hip_mex('eval', h, q, qA, qB, eta)             evalBDF1 & co (driverRedMaxBDF1.m:160-187); H: nr x nr x B
  *   [T, V]       = redmax_hip_mex('energy', h)                           Joint/Body.computeEnergies
@@ -48,15 +60,19 @@
 
 typedef struct {
     uint64_t magic;
-    rmx_model* m;
-    rmx_batch* b;
+    rmx_group* g;          /* one model + batch per listed device */
+    int nshards;
     int nr, nm, nsph, B, njoints;
+    int pending_nsteps;    /* 'step_async' in flight: its nsteps and record mask ('sync' shapes its outputs from them) */
+    int pending_record;
+    int pending;
 } handle_t;
 
 #define HANDLE_MAGIC 0x726d78686970ull /* "rmxhip" */
 /* live handles: a handle value that MATLAB passes back is only dereferenced when it is in this table, so a stale or
  * made-up uint64 is an error message, not a crash */
 #define MAX_LIVE 256
+#define MAX_SHARDS 64
 static handle_t* g_live[MAX_LIVE];
 static int live_slot(const handle_t* h) {
     for (int i = 0; i < MAX_LIVE; ++i)
@@ -104,6 +120,13 @@ static const double* state_arg(const mxArray* a, const handle_t* h, const char* 
     return mxGetPr(a);
 }
 static mxArray* new_i32(size_t r, size_t c) { return mxCreateNumericMatrix(r, c, mxINT32_CLASS, mxREAL); }
+/* the hooks without a group form run shard by shard, every array advanced to the shard's first trajectory */
+static rmx_batch* shard(const handle_t* h, int s, size_t* first) {
+    int f = 0;
+    if (rmx_group_shard(h->g, s, NULL, &f, NULL)) die_rmx("rmx_group_shard");
+    *first = (size_t)f;
+    return rmx_group_shard_batch(h->g, s);
+}
 
 /* Scene.init() (Scene.m:59-119) -> rmx_model_create.  desc fields, joints in the scene's listing order (N = njoints):
  *   njoints; parent int32 1xN (0-based, -1 root); type int32 1xN (RMX_JOINT_*); axis 3xN; E0_pj, E0_ji 4x4xN; I_i 6xN;
@@ -112,11 +135,19 @@ static mxArray* new_i32(size_t r, size_t c) { return mxCreateNumericMatrix(r, c,
  *   ground contact (optional, ForceGroundCuboid): contact int32 1xN, sides 3xN, groundE 4x4, kn, kt, mu, kd */
 static void cmd_create(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     (void)nlhs;
-    if (nrhs < 3) die("usage: h = redmax_hip_mex('create', desc, batch [, device])");
+    if (nrhs < 3) die("usage: h = redmax_hip_mex('create', desc, batch [, devices])");
     const mxArray* s = prhs[1];
     if (!mxIsStruct(s)) die("desc must be a struct (redmax.flattenScene)");
     const int batch = (int)mxGetScalar(prhs[2]);
-    const int device = nrhs > 3 ? (int)mxGetScalar(prhs[3]) : 0;
+    int devices[MAX_SHARDS] = {0};
+    int ndev = 1;
+    if (nrhs > 3 && !mxIsEmpty(prhs[3])) {     /* a device index or a vector of them: one shard per entry */
+        if (!mxIsDouble(prhs[3]) || mxIsComplex(prhs[3])) die("devices must be a real double scalar or vector");
+        const size_t nd = mxGetNumberOfElements(prhs[3]);
+        if (nd > MAX_SHARDS) die("too many devices listed");
+        ndev = (int)nd;
+        for (int i = 0; i < ndev; ++i) devices[i] = (int)mxGetPr(prhs[3])[i];
+    }
     rmx_model_desc d;
     memset(&d, 0, sizeof d);
     d.njoints = (int)scalar_field(s, "njoints", 0);
@@ -174,14 +205,13 @@ static void cmd_create(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[
     if (slot < 0) die("too many live handles (destroy some first)");
     handle_t* h = (handle_t*)mxCalloc(1, sizeof *h);
     mexMakeMemoryPersistent(h);
-    if (rmx_model_create(&d, device, &h->m)) { mxFree(h); die_rmx("rmx_model_create"); }
-    if (has_contact && rmx_model_set_ground_contact(h->m, &gc)) { rmx_model_destroy(h->m); mxFree(h); die_rmx("rmx_model_set_ground_contact"); }
-    h->nr = rmx_model_nr(h->m);
-    h->nm = rmx_model_nm(h->m);
-    h->nsph = rmx_model_nsph(h->m);
+    if (rmx_group_create(&d, has_contact ? &gc : NULL, batch, devices, ndev, &h->g)) { mxFree(h); die_rmx("rmx_group_create"); }
+    h->nshards = rmx_group_nshards(h->g);
+    h->nr = rmx_model_nr(rmx_group_shard_model(h->g, 0));
+    h->nm = rmx_model_nm(rmx_group_shard_model(h->g, 0));
+    h->nsph = rmx_model_nsph(rmx_group_shard_model(h->g, 0));
     h->B = batch;
     h->njoints = d.njoints;
-    if (rmx_batch_create(h->m, batch, &h->b)) { rmx_model_destroy(h->m); mxFree(h); die_rmx("rmx_batch_create"); }
     h->magic = HANDLE_MAGIC;
     g_live[slot] = h;
     plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
@@ -191,23 +221,34 @@ static void cmd_create(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[
 static void cmd_destroy(int nrhs, const mxArray* prhs[]) {
     handle_t* h = get_handle(nrhs, prhs);
     g_live[live_slot(h)] = NULL;
-    rmx_batch_destroy(h->b);
-    rmx_model_destroy(h->m);
+    rmx_group_destroy(h->g);
     h->magic = 0;
     mxFree(h);
 }
 
 static void cmd_info(mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     handle_t* h = get_handle(nrhs, prhs);
-    static const char* names[] = {"nr", "nm", "nsph", "batch", "idxR"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 5, names);
+    static const char* names[] = {"nr", "nm", "nsph", "batch", "idxR", "nshards", "devices", "shard_first", "shard_count"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 9, names);
     mxSetField(plhs[0], 0, "nr", mxCreateDoubleScalar(h->nr));
     mxSetField(plhs[0], 0, "nm", mxCreateDoubleScalar(h->nm));
     mxSetField(plhs[0], 0, "nsph", mxCreateDoubleScalar(h->nsph));
     mxSetField(plhs[0], 0, "batch", mxCreateDoubleScalar(h->B));
     mxArray* idx = new_i32(1, (size_t)h->njoints);
-    if (rmx_model_idxR(h->m, (int*)mxGetData(idx))) die_rmx("rmx_model_idxR");
+    if (rmx_model_idxR(rmx_group_shard_model(h->g, 0), (int*)mxGetData(idx))) die_rmx("rmx_model_idxR");
     mxSetField(plhs[0], 0, "idxR", idx);
+    mxSetField(plhs[0], 0, "nshards", mxCreateDoubleScalar(h->nshards));
+    mxArray* dv = mxCreateDoubleMatrix(1, (size_t)h->nshards, mxREAL);
+    mxArray* sf = mxCreateDoubleMatrix(1, (size_t)h->nshards, mxREAL);
+    mxArray* sc = mxCreateDoubleMatrix(1, (size_t)h->nshards, mxREAL);
+    for (int i = 0; i < h->nshards; ++i) {
+        int dev = 0, first = 0, count = 0;
+        if (rmx_group_shard(h->g, i, &dev, &first, &count)) die_rmx("rmx_group_shard");
+        mxGetPr(dv)[i] = dev; mxGetPr(sf)[i] = first; mxGetPr(sc)[i] = count;
+    }
+    mxSetField(plhs[0], 0, "devices", dv);
+    mxSetField(plhs[0], 0, "shard_first", sf);
+    mxSetField(plhs[0], 0, "shard_count", sc);
 }
 
 static void read_opts(const mxArray* s, rmx_opts* o) {
@@ -222,51 +263,98 @@ static void read_opts(const mxArray* s, rmx_opts* o) {
     o->compensated = (int)scalar_field(s, "compensated", o->compensated);
 }
 
+/* the outputs of 'step' / 'sync' for nsteps steps: T, V (B x K), st (B x 3 int32), and, when asked for, Q, Qd (nr x B x K) and
+ * C (nsph x B x K int32); fills the rmx_stats / rmx_history that point into them */
+typedef struct { mxArray *T, *V, *st, *Q, *Qd, *C; rmx_stats stats; rmx_history hist; } step_out_t;
+static void step_outputs(const handle_t* h, int nsteps, int want_energy, int want_state, int want_charts, step_out_t* o) {
+    const size_t B = (size_t)h->B, K = (size_t)nsteps;
+    memset(o, 0, sizeof *o);
+    o->T = mxCreateDoubleMatrix(B, want_energy ? K : 0, mxREAL);
+    o->V = mxCreateDoubleMatrix(B, want_energy ? K : 0, mxREAL);
+    o->st = new_i32(B, 3);
+    int* sp = (int*)mxGetData(o->st);
+    o->stats.newton_iters = sp;
+    o->stats.ls_halvings = sp + B;
+    o->stats.status = sp + 2 * B;
+    o->hist.T = (K && want_energy) ? mxGetPr(o->T) : NULL;
+    o->hist.V = (K && want_energy) ? mxGetPr(o->V) : NULL;
+    if (want_state) {   /* the full Scene.saveHistory record */
+        const mwSize dims[3] = {(mwSize)h->nr, (mwSize)B, (mwSize)K};
+        o->Q = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+        o->Qd = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+        if (K && h->nr) { o->hist.q = mxGetPr(o->Q); o->hist.qdot = mxGetPr(o->Qd); }
+    }
+    if (want_charts) {   /* JointSpherical.chart after every step: nsph x B x nsteps int32 */
+        const mwSize dims[3] = {(mwSize)h->nsph, (mwSize)B, (mwSize)K};
+        o->C = mxCreateNumericArray(3, dims, mxINT32_CLASS, mxREAL);
+        if (K && h->nsph) o->hist.charts = (int*)mxGetData(o->C);
+    }
+}
+static void step_return(int nlhs, mxArray* plhs[], const step_out_t* o) {
+    plhs[0] = o->T;
+    if (nlhs > 1) plhs[1] = o->V;
+    if (nlhs > 2) plhs[2] = o->st;
+    if (nlhs > 3) plhs[3] = o->Q;
+    if (nlhs > 4) plhs[4] = o->Qd;
+    if (nlhs > 5) plhs[5] = o->C;
+}
+static int step_args(int nrhs, const mxArray* prhs[], const char* usage, int* itype, rmx_opts* o) {
+    if (nrhs < 5) die(usage);
+    *itype = (int)mxGetScalar(prhs[2]);
+    const int nsteps = (int)mxGetScalar(prhs[4]);
+    if (*itype != 1 && *itype != 2) die("itype must be 1 (BDF1) or 2 (BDF2)");
+    if (nsteps < 0) die("nsteps < 0");
+    rmx_opts_default(o);
+    o->h = mxGetScalar(prhs[3]);
+    if (nrhs > 5) read_opts(prhs[5], o);
+    return nsteps;
+}
+
 static void cmd_step(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     handle_t* h = get_handle(nrhs, prhs);
-    if (nrhs < 5) die("usage: [T,V,stats,Q,Qdot,C] = redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])");
-    const int itype = (int)mxGetScalar(prhs[2]);
-    const int nsteps = (int)mxGetScalar(prhs[4]);
-    if (itype != 1 && itype != 2) die("itype must be 1 (BDF1) or 2 (BDF2)");
-    if (nsteps < 0) die("nsteps < 0");
+    int itype;
     rmx_opts o;
-    rmx_opts_default(&o);
-    o.h = mxGetScalar(prhs[3]);
-    if (nrhs > 5) read_opts(prhs[5], &o);
-    const size_t B = (size_t)h->B, K = (size_t)nsteps;
-    mxArray* T = mxCreateDoubleMatrix(B, K, mxREAL);
-    mxArray* V = mxCreateDoubleMatrix(B, K, mxREAL);
-    mxArray* st = new_i32(B, 3);
-    int* sp = (int*)mxGetData(st);
-    rmx_stats stats;
-    stats.newton_iters = sp;
-    stats.ls_halvings = sp + B;
-    stats.status = sp + 2 * B;
-    mxArray *Q = NULL, *Qd = NULL;
-    rmx_history hist;
-    hist.T = K ? mxGetPr(T) : NULL;
-    hist.V = K ? mxGetPr(V) : NULL;
-    hist.q = hist.qdot = NULL;
-    hist.charts = NULL;
-    mxArray* C = NULL;
-    if (nlhs > 3) {   /* the full Scene.saveHistory record */
-        const mwSize dims[3] = {(mwSize)h->nr, (mwSize)B, (mwSize)K};
-        Q = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
-        Qd = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
-        if (K && h->nr) { hist.q = mxGetPr(Q); hist.qdot = mxGetPr(Qd); }
+    const int nsteps = step_args(nrhs, prhs, "usage: [T,V,stats,Q,Qdot,C] = redmax_hip_mex('step', h, itype, hstep, nsteps [, opts])", &itype, &o);
+    if (h->pending) die("a 'step_async' of this handle is in flight: 'sync' first");
+    step_out_t out;
+    step_outputs(h, nsteps, 1, nlhs > 3, nlhs > 5, &out);
+    /* simLoop of the whole batch: every shard's launch goes out before the first is waited for (rmx_group_step) */
+    if (rmx_group_step(h->g, &o, nsteps, itype, &out.stats, &out.hist)) die_rmx("rmx_group_step");
+    step_return(nlhs, plhs, &out);
+}
+
+/* redmax_hip_mex('step_async', h, itype, hstep, nsteps [, opts [, record]]): launch and return */
+static void cmd_step_async(int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    int itype;
+    rmx_opts o;
+    const int nsteps = step_args(nrhs, prhs, "usage: redmax_hip_mex('step_async', h, itype, hstep, nsteps [, opts [, record]])", &itype, &o);
+    if (h->pending) die("a 'step_async' of this handle is already in flight: 'sync' first");
+    const int record = nrhs > 6 ? (int)mxGetScalar(prhs[6]) : RMX_REC_ENERGY;
+    if (rmx_group_step_async(h->g, &o, nsteps, itype, record)) {
+        char msg[512];
+        strncpy(msg, rmx_last_error(), sizeof msg - 1);
+        msg[sizeof msg - 1] = 0;
+        rmx_group_sync(h->g, NULL, NULL);      /* drain the shards that did start */
+        mexErrMsgIdAndTxt("redmax:hip", "rmx_group_step_async: %s", msg);
     }
-    if (nlhs > 5) {   // JointSpherical.chart after every step: nsph x B x nsteps int32
-        const mwSize dims[3] = {(mwSize)h->nsph, (mwSize)B, (mwSize)K};
-        C = mxCreateNumericArray(3, dims, mxINT32_CLASS, mxREAL);
-        if (K && h->nsph) hist.charts = (int*)mxGetData(C);
-    }
-    if (rmx_step_history(h->b, &o, nsteps, itype, &stats, &hist)) die_rmx("rmx_step_history");
-    plhs[0] = T;
-    if (nlhs > 1) plhs[1] = V;
-    if (nlhs > 2) plhs[2] = st;
-    if (nlhs > 3) plhs[3] = Q;
-    if (nlhs > 4) plhs[4] = Qd;
-    if (nlhs > 5) plhs[5] = C;
+    h->pending = 1;
+    h->pending_nsteps = nsteps;
+    h->pending_record = record;
+}
+
+/* [T,V,st,Q,Qd,C] = redmax_hip_mex('sync', h): wait for the launches of 'step_async' and gather */
+static void cmd_sync(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    if (!h->pending) die("'sync' without a 'step_async' in flight");
+    const int rec = h->pending_record;
+    if (nlhs > 3 && !(rec & RMX_REC_STATE)) die("'sync': Q, Qdot were not recorded (record bit 2 of 'step_async')");
+    if (nlhs > 5 && !(rec & RMX_REC_CHARTS)) die("'sync': the charts were not recorded (record bit 4 of 'step_async')");
+    step_out_t out;
+    step_outputs(h, h->pending_nsteps, rec & RMX_REC_ENERGY, nlhs > 3, nlhs > 5, &out);
+    h->pending = 0;
+    if (rmx_group_sync(h->g, &out.stats, &out.hist)) die_rmx("rmx_group_sync");
+    step_return(nlhs, plhs, &out);
 }
 
 static void cmd_euler(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
@@ -276,7 +364,25 @@ static void cmd_euler(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]
     if (nsteps < 0) die("nsteps < 0");
     mxArray* T = mxCreateDoubleMatrix((size_t)h->B, (size_t)nsteps, mxREAL);
     mxArray* V = mxCreateDoubleMatrix((size_t)h->B, (size_t)nsteps, mxREAL);
-    if (rmx_step_euler(h->b, mxGetScalar(prhs[2]), nsteps, nsteps ? mxGetPr(T) : NULL, nsteps ? mxGetPr(V) : NULL)) die_rmx("rmx_step_euler");
+    if (h->nshards == 1) {
+        size_t f;
+        if (rmx_step_euler(shard(h, 0, &f), mxGetScalar(prhs[2]), nsteps, nsteps ? mxGetPr(T) : NULL, nsteps ? mxGetPr(V) : NULL)) die_rmx("rmx_step_euler");
+    } else {      /* rmx_step_euler writes dense [nsteps][shard] arrays: per shard into a scratch matrix, then into the columns */
+        for (int s = 0; s < h->nshards; ++s) {
+            size_t f;
+            int cnt = 0;
+            rmx_batch* b = shard(h, s, &f);
+            rmx_group_shard(h->g, s, NULL, NULL, &cnt);
+            double* tmp = (double*)mxCalloc(2 * (size_t)cnt * (size_t)nsteps + 1, sizeof(double));
+            double* tv = tmp + (size_t)cnt * (size_t)nsteps;
+            if (rmx_step_euler(b, mxGetScalar(prhs[2]), nsteps, nsteps ? tmp : NULL, nsteps ? tv : NULL)) { mxFree(tmp); die_rmx("rmx_step_euler"); }
+            for (int k = 0; k < nsteps; ++k) {
+                memcpy(mxGetPr(T) + (size_t)k * (size_t)h->B + f, tmp + (size_t)k * (size_t)cnt, sizeof(double) * (size_t)cnt);
+                memcpy(mxGetPr(V) + (size_t)k * (size_t)h->B + f, tv + (size_t)k * (size_t)cnt, sizeof(double) * (size_t)cnt);
+            }
+            mxFree(tmp);
+        }
+    }
     plhs[0] = T;
     if (nlhs > 1) plhs[1] = V;
 }
@@ -293,7 +399,12 @@ static void cmd_eval(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
         const mwSize dims[3] = {(mwSize)h->nr, (mwSize)h->nr, (mwSize)h->B};
         H = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
     }
-    if (rmx_eval(h->b, q, qA, qB, mxGetScalar(prhs[5]), mxGetPr(g), H ? mxGetPr(H) : NULL)) die_rmx("rmx_eval");
+    for (int s = 0; s < h->nshards; ++s) {
+        size_t f;
+        rmx_batch* b = shard(h, s, &f);
+        const size_t o = f * (size_t)h->nr;
+        if (rmx_eval(b, q + o, qA + o, qB + o, mxGetScalar(prhs[5]), mxGetPr(g) + o, H ? mxGetPr(H) + o * (size_t)h->nr : NULL)) die_rmx("rmx_eval");
+    }
     plhs[0] = g;
     if (nlhs > 1) plhs[1] = H;
 }
@@ -332,8 +443,17 @@ static void cmd_adjoint(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs
     /* optional 7th argument: the integrator, 1 = BDF1 (driverRedMaxAdjointBDF1.m, default), 2 = BDF2 (driverRedMaxAdjointBDF2.m) */
     const int integ = nrhs > 6 ? (int)mxGetScalar(prhs[6]) : 1;
     if (integ != 1 && integ != 2) die("adjoint: the integrator must be 1 (BDF1) or 2 (BDF2)");
-    if ((integ == 1 ? rmx_adjoint_bdf1 : rmx_adjoint_bdf2)(h->b, &o, nsteps, &task, p, mxGetPr(P), mxGetPr(dPdp), &stats))
-        die_rmx(integ == 1 ? "rmx_adjoint_bdf1" : "rmx_adjoint_bdf2");
+    for (int s = 0; s < h->nshards; ++s) {     /* shard by shard (the adjoint has no asynchronous entry: its outputs are per-call host buffers) */
+        size_t f;
+        rmx_batch* b = shard(h, s, &f);
+        rmx_stats st_s;
+        st_s.newton_iters = stats.newton_iters + f;
+        st_s.ls_halvings = NULL;
+        st_s.status = stats.status + f;
+        if ((integ == 1 ? rmx_adjoint_bdf1 : rmx_adjoint_bdf2)(b, &o, nsteps, &task, p + f * (size_t)h->nr, mxGetPr(P) + f,
+                                                                mxGetPr(dPdp) + f * (size_t)h->nr, &st_s))
+            die_rmx(integ == 1 ? "rmx_adjoint_bdf1" : "rmx_adjoint_bdf2");
+    }
     plhs[0] = P;
     if (nlhs > 1) plhs[1] = dPdp;
     if (nlhs > 2) plhs[2] = st;
@@ -343,8 +463,7 @@ static void cmd_adjoint(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs
 static void at_exit(void) {
     for (int i = 0; i < MAX_LIVE; ++i)
         if (g_live[i]) {
-            rmx_batch_destroy(g_live[i]->b);
-            rmx_model_destroy(g_live[i]->m);
+            rmx_group_destroy(g_live[i]->g);
             mxFree(g_live[i]);
             g_live[i] = NULL;
         }
@@ -356,7 +475,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         mexAtExit(at_exit);
         registered = 1;
     }
-    char cmd[24];
+    char cmd[24];      /* the command table: tests/test_mex_gateway.py checks that matlab/+redmax/HipSim.m uses these and only these */
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) die("first argument must be a command string");
     if (!strcmp(cmd, "version")) {
         plhs[0] = mxCreateDoubleScalar((double)rmx_version());
@@ -371,16 +490,31 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     } else if (!strcmp(cmd, "set")) {
         handle_t* h = get_handle(nrhs, prhs);
         if (nrhs < 4) die("usage: redmax_hip_mex('set', h, q, qdot)");
-        if (rmx_set_state(h->b, state_arg(prhs[2], h, "q"), state_arg(prhs[3], h, "qdot"))) die_rmx("rmx_set_state");
+        if (rmx_group_set_state(h->g, state_arg(prhs[2], h, "q"), state_arg(prhs[3], h, "qdot"))) die_rmx("rmx_group_set_state");
     } else if (!strcmp(cmd, "get")) {
         handle_t* h = get_handle(nrhs, prhs);
         mxArray* q = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
         mxArray* qd = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
-        if (rmx_get_state(h->b, mxGetPr(q), mxGetPr(qd))) die_rmx("rmx_get_state");
+        if (rmx_group_get_state(h->g, mxGetPr(q), mxGetPr(qd))) die_rmx("rmx_group_get_state");
         plhs[0] = q;
         if (nlhs > 1) plhs[1] = qd;
     } else if (!strcmp(cmd, "step")) {
         cmd_step(nlhs, plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "step_async")) {
+        cmd_step_async(nrhs, prhs);
+    } else if (!strcmp(cmd, "sync")) {
+        cmd_sync(nlhs, plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "timing")) {
+        handle_t* h = get_handle(nrhs, prhs);
+        mxArray* k = mxCreateDoubleMatrix(1, (size_t)h->nshards, mxREAL);
+        mxArray* t0 = mxCreateDoubleMatrix(1, (size_t)h->nshards, mxREAL);
+        mxArray* t1 = mxCreateDoubleMatrix(1, (size_t)h->nshards, mxREAL);
+        double wall = 0.0;
+        if (rmx_group_timing(h->g, &wall, mxGetPr(k), mxGetPr(t0), mxGetPr(t1))) die_rmx("rmx_group_timing");
+        plhs[0] = mxCreateDoubleScalar(wall);
+        if (nlhs > 1) plhs[1] = k;
+        if (nlhs > 2) plhs[2] = t0;
+        if (nlhs > 3) plhs[3] = t1;
     } else if (!strcmp(cmd, "euler")) {
         cmd_euler(nlhs, plhs, nrhs, prhs);
     } else if (!strcmp(cmd, "eval")) {
@@ -389,23 +523,35 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         handle_t* h = get_handle(nrhs, prhs);
         mxArray* T = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);
         mxArray* V = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);
-        if (rmx_energy(h->b, mxGetPr(T), mxGetPr(V))) die_rmx("rmx_energy");
+        if (rmx_group_energy(h->g, mxGetPr(T), mxGetPr(V))) die_rmx("rmx_group_energy");
         plhs[0] = T;
         if (nlhs > 1) plhs[1] = V;
     } else if (!strcmp(cmd, "getcharts")) {
         handle_t* h = get_handle(nrhs, prhs);
         mxArray* c = new_i32((size_t)h->nsph, (size_t)h->B);
-        if (h->nsph && rmx_get_charts(h->b, (int*)mxGetData(c))) die_rmx("rmx_get_charts");
+        for (int s = 0; s < h->nshards && h->nsph; ++s) {
+            size_t f;
+            rmx_batch* b = shard(h, s, &f);
+            if (rmx_get_charts(b, (int*)mxGetData(c) + f * (size_t)h->nsph)) die_rmx("rmx_get_charts");
+        }
         plhs[0] = c;
     } else if (!strcmp(cmd, "setcharts")) {
         handle_t* h = get_handle(nrhs, prhs);
         if (nrhs < 3 || !mxIsInt32(prhs[2]) || mxGetNumberOfElements(prhs[2]) != (size_t)h->nsph * (size_t)h->B)
             die("charts must be an int32 nsph x batch array");
-        if (h->nsph && rmx_set_charts(h->b, (const int*)mxGetData(prhs[2]))) die_rmx("rmx_set_charts");
+        for (int s = 0; s < h->nshards && h->nsph; ++s) {
+            size_t f;
+            rmx_batch* b = shard(h, s, &f);
+            if (rmx_set_charts(b, (const int*)mxGetData(prhs[2]) + f * (size_t)h->nsph)) die_rmx("rmx_set_charts");
+        }
     } else if (!strcmp(cmd, "ticks")) {      /* t = redmax_hip_mex('ticks', h): per-rollout share of the last step launch (rmx_step_ticks) */
         handle_t* h = get_handle(nrhs, prhs);
         unsigned long long* t = (unsigned long long*)mxCalloc((size_t)h->B, sizeof *t);
-        if (rmx_step_ticks(h->b, t)) { mxFree(t); die_rmx("rmx_step_ticks"); }
+        for (int s = 0; s < h->nshards; ++s) {
+            size_t f;
+            rmx_batch* b = shard(h, s, &f);
+            if (rmx_step_ticks(b, t + f)) { mxFree(t); die_rmx("rmx_step_ticks"); }
+        }
         mxArray* out = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);
         for (int i = 0; i < h->B; ++i) mxGetPr(out)[i] = (double)t[i];
         mxFree(t);

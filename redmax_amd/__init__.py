@@ -7,7 +7,7 @@ from . import se3  # noqa: F401
 from .redmax import (Body, BodyCuboid, ForceGroundCuboid, Joint, JointFixed, JointPrismatic, JointRevolute, Scene)  # noqa: F401
 from .scenes import (IN_SCOPE_SCENES, sceneAdjointChain, sceneChain, sceneChainGround, scenesRedMax, sceneTree,  # noqa: F401
                      syntheticStates)
-from .batch import BatchSim  # noqa: F401
+from .batch import BatchSim, GroupSim  # noqa: F401
 from .driver import (driverRedMaxAdjointBDF1, driverRedMaxAdjointBDF2, driverRedMaxBDF1, driverRedMaxBDF2, simLoop, taskObjective,  # noqa: F401
                      testRedMax)
 from ._abi import RedMaxHipError  # noqa: F401

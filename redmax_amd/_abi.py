@@ -24,9 +24,13 @@ SYMBOLS = (
     "rmx_batch_create", "rmx_batch_destroy", "rmx_batch_size",
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
     "rmx_eval", "rmx_eval_mfd", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_history", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_adjoint_bdf2", "rmx_energy",
-    "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_sync",
-    "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases", "rmx_step_ticks",
+    "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_step_bdf2_async", "rmx_step_history_async", "rmx_sync",
+    "rmx_history_read", "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases", "rmx_step_ticks",
+    "rmx_group_create", "rmx_group_destroy", "rmx_group_batch_size", "rmx_group_nshards", "rmx_group_shard", "rmx_group_shard_batch",
+    "rmx_group_shard_model", "rmx_group_set_state", "rmx_group_get_state", "rmx_group_step", "rmx_group_step_async", "rmx_group_sync",
+    "rmx_group_energy", "rmx_group_timing",
 )
+REC_ENERGY, REC_STATE, REC_CHARTS = 1, 2, 4      # RMX_REC_*
 
 
 class RedMaxHipError(RuntimeError):
@@ -119,6 +123,25 @@ def lib():
     L.rmx_batch_stream.restype = vp
     L.rmx_step_bdf1_async.argtypes = [vp, C.POINTER(Opts), C.c_int]
     L.rmx_sync.argtypes = [vp]
+    L.rmx_step_bdf2_async.argtypes = [vp, C.POINTER(Opts), C.c_int]
+    L.rmx_step_history_async.argtypes = [vp, C.POINTER(Opts), C.c_int, C.c_int, C.c_int]
+    L.rmx_history_read.argtypes = [vp, C.POINTER(History)]
+    L.rmx_group_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(GroundContact), C.c_int, _ip, C.c_int, C.POINTER(vp)]
+    L.rmx_group_destroy.argtypes = [vp]
+    L.rmx_group_batch_size.argtypes = [vp]
+    L.rmx_group_nshards.argtypes = [vp]
+    L.rmx_group_shard.argtypes = [vp, C.c_int, _ip, _ip, _ip]
+    L.rmx_group_shard_batch.argtypes = [vp, C.c_int]
+    L.rmx_group_shard_batch.restype = vp
+    L.rmx_group_shard_model.argtypes = [vp, C.c_int]
+    L.rmx_group_shard_model.restype = vp
+    L.rmx_group_set_state.argtypes = [vp, _dp, _dp]
+    L.rmx_group_get_state.argtypes = [vp, _dp, _dp]
+    L.rmx_group_step.argtypes = [vp, C.POINTER(Opts), C.c_int, C.c_int, C.POINTER(Stats), C.POINTER(History)]
+    L.rmx_group_step_async.argtypes = [vp, C.POINTER(Opts), C.c_int, C.c_int, C.c_int]
+    L.rmx_group_sync.argtypes = [vp, C.POINTER(Stats), C.POINTER(History)]
+    L.rmx_group_energy.argtypes = [vp, _dp, _dp]
+    L.rmx_group_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.rmx_stats_reset.argtypes = [vp]
     L.rmx_profile_phases.argtypes = [vp, C.c_int, C.c_double, _dp]
     L.rmx_stats_read.argtypes = [vp, C.POINTER(Stats)]
@@ -138,6 +161,27 @@ def dptr(a):
 
 def iptr(a):
     return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def make_ground_contact(d, keep):
+    """scene.forces (ForceGroundCuboid objects) of a Scene.desc() dict -> GroundContact, or None when the scene has none."""
+    if d.get("contact") is None or not np.any(d["contact"]):
+        return None
+    g = d["ground"]
+    gc = GroundContact()
+    keep["contact"] = np.ascontiguousarray(d["contact"], dtype=np.int32)
+    keep["sides"] = np.ascontiguousarray(d["sides"], dtype=np.float64)
+    gc.flags, gc.sides = iptr(keep["contact"]), dptr(keep["sides"])
+    gc.E[:] = list(np.asarray(g["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
+    gc.kn, gc.kt, gc.mu, gc.kd = float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"])
+    gb = d.get("ground_body")
+    if gb is not None:        # force objects with their own frames / constants, listing order; [n][4][4] row-major -> column-major
+        keep["gE"] = np.ascontiguousarray(np.asarray(gb["E"], dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1).reshape(-1, 16))
+        gc.E_body = dptr(keep["gE"])
+        for k in ("kn", "kt", "mu", "kd"):
+            keep["g" + k] = np.ascontiguousarray(gb[k], dtype=np.float64)
+            setattr(gc, k + "_body", dptr(keep["g" + k]))
+    return gc
 
 
 def make_desc(d):

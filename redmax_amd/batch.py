@@ -23,21 +23,8 @@ class BatchSim:
         _abi.check(self._L.rmx_model_create(C.byref(self._desc), int(device), C.byref(self._model)), "rmx_model_create")
         self.nr = self._L.rmx_model_nr(self._model)
         self.nm = self._L.rmx_model_nm(self._model)
-        if d.get("contact") is not None and np.any(d["contact"]):     # scene.forces: ForceGroundCuboid
-            g = d["ground"]
-            gc = _abi.GroundContact()
-            self._keep["contact"] = np.ascontiguousarray(d["contact"], dtype=np.int32)
-            self._keep["sides"] = np.ascontiguousarray(d["sides"], dtype=np.float64)
-            gc.flags, gc.sides = _abi.iptr(self._keep["contact"]), _abi.dptr(self._keep["sides"])
-            gc.E[:] = list(np.asarray(g["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
-            gc.kn, gc.kt, gc.mu, gc.kd = float(g["kn"]), float(g["kt"]), float(g["mu"]), float(g["kd"])
-            gb = d.get("ground_body")
-            if gb is not None:        # force objects with their own frames / constants, listing order; [n][4][4] row-major -> column-major
-                self._keep["gE"] = np.ascontiguousarray(np.asarray(gb["E"], dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1).reshape(-1, 16))
-                gc.E_body = _abi.dptr(self._keep["gE"])
-                for k in ("kn", "kt", "mu", "kd"):
-                    self._keep["g" + k] = np.ascontiguousarray(gb[k], dtype=np.float64)
-                    setattr(gc, k + "_body", _abi.dptr(self._keep["g" + k]))
+        gc = _abi.make_ground_contact(d, self._keep)      # scene.forces: ForceGroundCuboid
+        if gc is not None:
             _abi.check(self._L.rmx_model_set_ground_contact(self._model, C.byref(gc)), "rmx_model_set_ground_contact")
         self.nsph = self._L.rmx_model_nsph(self._model)
         self.B = int(batch)
@@ -221,6 +208,35 @@ class BatchSim:
             self.opts.h = float(h)
         _abi.check(self._L.rmx_step_bdf1_async(self._batch, C.byref(self.opts), int(nsteps)), "rmx_step_bdf1_async")
 
+    def step_bdf2_async(self, nsteps, h=None):
+        if h is not None:
+            self.opts.h = float(h)
+        _abi.check(self._L.rmx_step_bdf2_async(self._batch, C.byref(self.opts), int(nsteps)), "rmx_step_bdf2_async")
+
+    def step_history_async(self, nsteps, integrator=1, record=_abi.REC_ENERGY | _abi.REC_STATE, h=None):
+        """simLoop enqueued, nothing waited for; `record` (REC_ENERGY | REC_STATE | REC_CHARTS) stays on the device until
+        history_read() (after sync())."""
+        if h is not None:
+            self.opts.h = float(h)
+        self._async = (int(nsteps), int(record))
+        _abi.check(self._L.rmx_step_history_async(self._batch, C.byref(self.opts), int(nsteps), int(integrator), int(record)), "rmx_step_history_async")
+
+    def history_read(self):
+        nsteps, record = self._async
+        out = {}
+        hist = _abi.History()
+        if record & _abi.REC_ENERGY:
+            out["T"], out["V"] = np.empty((nsteps, self.B)), np.empty((nsteps, self.B))
+            hist.T, hist.V = _abi.dptr(out["T"]), _abi.dptr(out["V"])
+        if record & _abi.REC_STATE:
+            out["q"], out["qdot"] = np.empty((nsteps, self.B, self.nr)), np.empty((nsteps, self.B, self.nr))
+            hist.q, hist.qdot = _abi.dptr(out["q"]), _abi.dptr(out["qdot"])
+        if record & _abi.REC_CHARTS and self.nsph:
+            out["charts"] = np.full((nsteps, self.B, self.nsph), 7, dtype=np.int32)
+            hist.charts = _abi.iptr(out["charts"])
+        _abi.check(self._L.rmx_history_read(self._batch, C.byref(hist)), "rmx_history_read")
+        return out
+
     def sync(self):
         _abi.check(self._L.rmx_sync(self._batch), "rmx_sync")
         return self._L.rmx_last_step_ms(self._batch)
@@ -248,3 +264,104 @@ class BatchSim:
         V = np.empty(self.B)
         _abi.check(self._L.rmx_energy(self._batch, _abi.dptr(T), _abi.dptr(V)), "rmx_energy")
         return T, V
+
+
+class GroupSim:
+    """The whole batch over a LIST of devices (rmx_group_*, include/redmax_hip.h): one model + batch per listed device, contiguous
+    shards, every array the whole batch.  ``step`` launches all shards before it waits for the first - the multi-device simLoop a
+    single host thread (MATLAB: matlab/+redmax/HipSim.m with a device vector) can drive; a device may be listed more than once."""
+
+    def __init__(self, scene_or_desc, batch, devices=(0,)):
+        d = scene_or_desc.desc() if hasattr(scene_or_desc, "desc") else scene_or_desc
+        self._L = _abi.lib()
+        self._desc, self._keep = _abi.make_desc(d)
+        gc = _abi.make_ground_contact(d, self._keep)
+        dev = np.ascontiguousarray(list(devices), dtype=np.int32)
+        self._g = C.c_void_p()
+        _abi.check(self._L.rmx_group_create(C.byref(self._desc), C.byref(gc) if gc is not None else None, int(batch), _abi.iptr(dev),
+                                            len(dev), C.byref(self._g)), "rmx_group_create")
+        self.B = int(batch)
+        self.nshards = self._L.rmx_group_nshards(self._g)
+        m0 = self._L.rmx_group_shard_model(self._g, 0)
+        self.nr, self.nsph = self._L.rmx_model_nr(m0), self._L.rmx_model_nsph(m0)
+        self.shards = []
+        for s in range(self.nshards):
+            dv, f, c = C.c_int(), C.c_int(), C.c_int()
+            _abi.check(self._L.rmx_group_shard(self._g, s, C.byref(dv), C.byref(f), C.byref(c)), "rmx_group_shard")
+            self.shards.append((dv.value, f.value, c.value))
+        self.opts = _abi.Opts()
+        self._L.rmx_opts_default(C.byref(self.opts))
+        self._async = None
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._L.rmx_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _arr(self, a):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.B, self.nr)))
+
+    def set_state(self, q, qdot):
+        q, qdot = self._arr(q), self._arr(qdot)
+        _abi.check(self._L.rmx_group_set_state(self._g, _abi.dptr(q), _abi.dptr(qdot)), "rmx_group_set_state")
+
+    def get_state(self):
+        q, qd = np.empty((self.B, self.nr)), np.empty((self.B, self.nr))
+        _abi.check(self._L.rmx_group_get_state(self._g, _abi.dptr(q), _abi.dptr(qd)), "rmx_group_get_state")
+        return q, qd
+
+    def _outputs(self, nsteps, record):
+        out = {k: np.zeros(self.B, dtype=np.int32) for k in ("newton_iters", "ls_halvings", "status")}
+        st = _abi.Stats(_abi.iptr(out["newton_iters"]), _abi.iptr(out["ls_halvings"]), _abi.iptr(out["status"]))
+        hist = _abi.History()
+        if record & _abi.REC_ENERGY:
+            out["T"], out["V"] = np.empty((nsteps, self.B)), np.empty((nsteps, self.B))
+            hist.T, hist.V = _abi.dptr(out["T"]), _abi.dptr(out["V"])
+        if record & _abi.REC_STATE:
+            out["q"], out["qdot"] = np.empty((nsteps, self.B, self.nr)), np.empty((nsteps, self.B, self.nr))
+            hist.q, hist.qdot = _abi.dptr(out["q"]), _abi.dptr(out["qdot"])
+        if record & _abi.REC_CHARTS and self.nsph:
+            out["charts"] = np.full((nsteps, self.B, self.nsph), 7, dtype=np.int32)
+            hist.charts = _abi.iptr(out["charts"])
+        return out, st, hist
+
+    def step(self, nsteps, integrator=1, h=None, record=0):
+        """simLoop of the whole batch (rmx_group_step); returns counters + the recorded per-step arrays + timing."""
+        if h is not None:
+            self.opts.h = float(h)
+        out, st, hist = self._outputs(int(nsteps), int(record))
+        _abi.check(self._L.rmx_group_step(self._g, C.byref(self.opts), int(nsteps), int(integrator), C.byref(st), C.byref(hist)), "rmx_group_step")
+        out.update(self.timing())
+        return out
+
+    def step_async(self, nsteps, integrator=1, h=None, record=0):
+        if h is not None:
+            self.opts.h = float(h)
+        self._async = (int(nsteps), int(record))
+        _abi.check(self._L.rmx_group_step_async(self._g, C.byref(self.opts), int(nsteps), int(integrator), int(record)), "rmx_group_step_async")
+
+    def sync(self):
+        nsteps, record = self._async
+        out, st, hist = self._outputs(nsteps, record)
+        _abi.check(self._L.rmx_group_sync(self._g, C.byref(st), C.byref(hist)), "rmx_group_sync")
+        out.update(self.timing())
+        return out
+
+    def energy(self):
+        T, V = np.empty(self.B), np.empty(self.B)
+        _abi.check(self._L.rmx_group_energy(self._g, _abi.dptr(T), _abi.dptr(V)), "rmx_group_energy")
+        return T, V
+
+    def timing(self):
+        """wall_ms of the last step and, per shard, kernel ms and the start / end of its launch relative to the first shard on the
+        same device (rmx_group_timing)."""
+        w = C.c_double()
+        k, t0, t1 = np.zeros(self.nshards), np.zeros(self.nshards), np.zeros(self.nshards)
+        _abi.check(self._L.rmx_group_timing(self._g, C.cast(C.byref(w), _abi._dp), _abi.dptr(k), _abi.dptr(t0), _abi.dptr(t1)), "rmx_group_timing")
+        return {"wall_ms": w.value, "kernel_ms": k, "start_ms": t0, "end_ms": t1}

@@ -32,6 +32,7 @@ static int fail(int code, const std::string& msg) {
 
 
 extern "C" const char* rmx_last_error(void) { return g_err.c_str(); }
+static void hist_free(rmx_batch* b);
 
 // An error already pending in this thread's HIP state when an entry point is about to launch.  If this batch still has an
 // asynchronous launch of its own that nobody waited for (rmx_step_bdf1_async without rmx_sync), the error is reported as that
@@ -312,7 +313,7 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
 
     // axis variants of the spherical group nodes: chart switches (JointSpherical.reparam_) swap them into LDS on the device
     const int nsph = sph_first ? (int)sph_first->size() : 0;
-    if (nsph > MAXSPH) return fail(RMX_E_INVALID, "too many spherical joints");
+    if (nsph > MAXSPH) return fail(RMX_E_INVALID, "too many spherical joints: a scene may hold at most " + std::to_string(MAXSPH) + " JointSpherical / JointFree3D joints (their Euler-chart tables are sized for that)");
     std::vector<double> sphV((size_t)nsph * 9 * SPH_ROWS + 1, 0.0);
     for (int g = 0; g < nsph; ++g)
         for (int k = 0; k < 3; ++k)
@@ -548,19 +549,20 @@ extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_conta
         con[13 * MAXN + k] = kd;
     }
     // the new table is uploaded first and swapped in only on success; kernels of existing batches that may still read the
-    // old one (rmx_step_bdf1_async) are drained before it is freed
+    // old one (rmx_step_*_async) are drained before it is freed
     void* fresh = nullptr;
     if (any) {
         HIPCHK(hipMalloc(&fresh, con.size() * sizeof(double)));
         const hipError_t e = hipMemcpy(fresh, con.data(), con.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(fresh); return fail(RMX_E_HIP, std::string("hipMemcpy(contact): ") + hipGetErrorString(e)); }
     }
-    {
-        const hipError_t es = hipDeviceSynchronize();
+    for (rmx_batch* bb : m->batches) {      // only this model's batches can be reading the old table: other models' streams run on
+        const hipError_t es = hipStreamSynchronize(bb->stream);
         if (es != hipSuccess) {
             if (fresh) (void)hipFree(fresh);
-            return fail(RMX_E_HIP, std::string("hipDeviceSynchronize: ") + hipGetErrorString(es));
+            return fail(RMX_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(es));
         }
+        bb->async_pending = false;
     }
     if (m->dcon) (void)hipFree(m->dcon);
     m->dcon = fresh;
@@ -608,6 +610,7 @@ extern "C" int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out) {
         rmx_batch_destroy(b);
         return fail(RMX_E_HIP, msg);
     }
+    m->batches.push_back(b);
     *out = b;
     return RMX_OK;
 }
@@ -615,7 +618,9 @@ extern "C" int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out) {
 extern "C" void rmx_batch_destroy(rmx_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->m->device);
+    b->m->batches.erase(std::remove(b->m->batches.begin(), b->m->batches.end(), b), b->m->batches.end());
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    hist_free(b);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
                     (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
         if (p) (void)hipFree(p);
@@ -647,6 +652,7 @@ static int copy_state(rmx_batch* b, const double* q, const double* qd, hipMemcpy
         if (qd) HIPCHK(hipMemcpyAsync((void*)qd, b->qd, nb, kind, b->stream));
     }
     HIPCHK(hipStreamSynchronize(b->stream));
+    b->async_pending = false;      // the batch's stream has been waited for
     return RMX_OK;
 }
 extern "C" int rmx_model_nsph(const rmx_model* m) { return m ? m->dm.nsph : RMX_E_INVALID; }
@@ -790,6 +796,77 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     return RMX_OK;
 }
 
+// ---- the per-step record of a step call (Scene.saveHistory, Scene.m:134-161), in device buffers that live on the batch
+static void hist_free(rmx_batch* b) {
+    for (void* p : {(void*)b->hist.T, (void*)b->hist.V, (void*)b->hist.Q, (void*)b->hist.Qd, (void*)b->hist.C})
+        if (p) (void)hipFree(p);
+    b->hist = rmx_batch::Hist{};
+}
+static int hist_alloc(rmx_batch* b, int nsteps, int record) {
+    hist_free(b);
+    const rmx_model* m = b->m;
+    const size_t nh = (size_t)nsteps * b->B, nq = nh * m->nr, nc = nh * (size_t)m->dm.nsph;
+    hipError_t e = hipSuccess;
+    if ((record & RMX_REC_ENERGY) && nh) {
+        e = hipMalloc((void**)&b->hist.T, nh * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->hist.V, nh * sizeof(double));
+    }
+    if (e == hipSuccess && (record & RMX_REC_STATE) && nq) {
+        e = hipMalloc((void**)&b->hist.Q, nq * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->hist.Qd, nq * sizeof(double));
+    }
+    // models with spherical joints run the extended (CT) step kernels, which record the chart after every step
+    if (e == hipSuccess && (record & RMX_REC_CHARTS) && nc) e = hipMalloc((void**)&b->hist.C, nc * sizeof(int));
+    if (e != hipSuccess) {
+        hist_free(b);
+        (void)hipGetLastError();      // the failed allocation must not be taken for a failed launch later on
+        return fail(RMX_E_NOMEM, std::string("hipMalloc(per-step record): ") + hipGetErrorString(e));
+    }
+    b->hist.nsteps = nsteps;
+    return RMX_OK;
+}
+// rows of `width` bytes, `rows` of them: device (dense) -> host array whose rows are `dpitch` bytes apart
+static hipError_t rows_out(void* dst, size_t dpitch, const void* src, size_t width, size_t rows, hipStream_t st) {
+    if (!width || !rows) return hipSuccess;
+    if (dpitch == width) return hipMemcpyAsync(dst, src, width * rows, hipMemcpyDeviceToHost, st);
+    return hipMemcpy2DAsync(dst, dpitch, src, width, width, rows, hipMemcpyDeviceToHost, st);
+}
+// Enqueue the copies of the record into host arrays laid out for `pitchB` trajectories per step, this batch's first trajectory
+// being number `first` of them (pitchB = B, first = 0 for a batch on its own; a shard of an rmx_group otherwise).
+static int hist_copy_out(rmx_batch* b, const rmx_history* h, size_t pitchB, size_t first) {
+    if (!h) return RMX_OK;
+    const rmx_model* m = b->m;
+    const size_t K = (size_t)b->hist.nsteps, B = (size_t)b->B, nr = (size_t)m->nr, ns = (size_t)m->dm.nsph;
+    if ((h->T == nullptr) != (h->V == nullptr)) return fail(RMX_E_INVALID, "history T and V must be given together");
+    if ((h->q == nullptr) != (h->qdot == nullptr)) return fail(RMX_E_INVALID, "history q and qdot must be given together");
+    if (K && B && ((h->T && !b->hist.T) || (h->q && nr && !b->hist.Q) || (h->charts && ns && !b->hist.C)))
+        return fail(RMX_E_INVALID, "this part of the per-step record was not recorded by the step call (RMX_REC_*)");
+    hipError_t e = hipSuccess;
+    if (h->T) {
+        e = rows_out(h->T + first, pitchB * 8, b->hist.T, B * 8, K, b->stream);
+        if (e == hipSuccess) e = rows_out(h->V + first, pitchB * 8, b->hist.V, B * 8, K, b->stream);
+    }
+    if (e == hipSuccess && h->q && nr) {
+        e = rows_out(h->q + first * nr, pitchB * nr * 8, b->hist.Q, B * nr * 8, K, b->stream);
+        if (e == hipSuccess) e = rows_out(h->qdot + first * nr, pitchB * nr * 8, b->hist.Qd, B * nr * 8, K, b->stream);
+    }
+    if (e == hipSuccess && h->charts && ns) e = rows_out(h->charts + first * ns, pitchB * ns * 4, b->hist.C, B * ns * 4, K, b->stream);
+    if (e != hipSuccess) return fail(RMX_E_HIP, std::string("copying the per-step record: ") + hipGetErrorString(e));
+    return RMX_OK;
+}
+static hipError_t stats_copy_out(rmx_batch* b, const rmx_stats* st) {
+    hipError_t e = hipSuccess;
+    if (!st) return e;
+    if (st->newton_iters) e = hipMemcpyAsync(st->newton_iters, b->it, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess && st->ls_halvings) e = hipMemcpyAsync(st->ls_halvings, b->ls, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess && st->status) e = hipMemcpyAsync(st->status, b->status, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
+    return e;
+}
+static void take_event_time(rmx_batch* b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
+}
+
 static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* st, double* hT, double* hV, int integ,
                      double* hQ = nullptr, double* hQd = nullptr, int* hC = nullptr) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
@@ -799,67 +876,29 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
     rmx_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
     if (nsteps == 0 || m->nr == 0) return RMX_OK;
-    double *dT = nullptr, *dV = nullptr, *dQ = nullptr, *dQd = nullptr;
-    const size_t nh = (size_t)nsteps * b->B, nq = nh * m->nr;
-    if (hT) {
-        HIPCHK(hipMalloc((void**)&dT, nh * sizeof(double)));
-        hipError_t e = hipMalloc((void**)&dV, nh * sizeof(double));
-        if (e != hipSuccess) { (void)hipFree(dT); return fail(RMX_E_NOMEM, "hipMalloc(hist)"); }
-    }
-    if (hQ) {
-        hipError_t e = hipMalloc((void**)&dQ, nq * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void**)&dQd, nq * sizeof(double));
-        if (e != hipSuccess) {
-            if (dT) (void)hipFree(dT);
-            if (dV) (void)hipFree(dV);
-            if (dQ) (void)hipFree(dQ);
-            return fail(RMX_E_NOMEM, "hipMalloc(state history)");
-        }
-    }
-    int* dC = nullptr;
-    const size_t nc = nh * (size_t)m->dm.nsph;
-    if (hC && nc) {      // models with spherical joints run the extended (CT) step kernels, which record the chart after every step
-        hipError_t e = hipMalloc((void**)&dC, nc * sizeof(int));
-        if (e != hipSuccess) {
-            for (void* p : {(void*)dT, (void*)dV, (void*)dQ, (void*)dQd})
-                if (p) (void)hipFree(p);
-            return fail(RMX_E_NOMEM, "hipMalloc(chart history)");
-        }
-    }
+    int rc = hist_alloc(b, nsteps, (hT ? RMX_REC_ENERGY : 0) | (hQ ? RMX_REC_STATE : 0) | (hC ? RMX_REC_CHARTS : 0));
+    if (rc) return rc;
     const bool ws = st != nullptr;
     if (ws) {
         (void)hipMemsetAsync(b->it, 0, sizeof(int) * b->B, b->stream);
         (void)hipMemsetAsync(b->ls, 0, sizeof(int) * b->B, b->stream);
         (void)hipMemsetAsync(b->status, 0, sizeof(int) * b->B, b->stream);
     }
-    int rc = launch_step(b, opts, nsteps, integ, ws, dT, dV, dQ, dQd, dC);
+    rc = launch_step(b, opts, nsteps, integ, ws, b->hist.T, b->hist.V, b->hist.Q, b->hist.Qd, b->hist.C);
     hipError_t e = hipSuccess;
     if (rc == RMX_OK) {
-        if (hT) {
-            e = hipMemcpyAsync(hT, dT, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hV, dV, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
-        }
-        if (e == hipSuccess && hQ) {
-            e = hipMemcpyAsync(hQ, dQ, nq * sizeof(double), hipMemcpyDeviceToHost, b->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hQd, dQd, nq * sizeof(double), hipMemcpyDeviceToHost, b->stream);
-        }
-        if (e == hipSuccess && dC) e = hipMemcpyAsync(hC, dC, nc * sizeof(int), hipMemcpyDeviceToHost, b->stream);
-        if (e == hipSuccess && ws) {
-            if (st->newton_iters) e = hipMemcpyAsync(st->newton_iters, b->it, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
-            if (e == hipSuccess && st->ls_halvings) e = hipMemcpyAsync(st->ls_halvings, b->ls, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
-            if (e == hipSuccess && st->status) e = hipMemcpyAsync(st->status, b->status, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-        if (e == hipSuccess) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
+        const rmx_history h{hT, hV, hQ, hQd, hC};
+        rc = hist_copy_out(b, &h, (size_t)b->B, 0);
+        if (rc == RMX_OK) {
+            if (ws) e = stats_copy_out(b, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+            if (e == hipSuccess) {
+                take_event_time(b);
+                b->async_pending = false;      // the stream has been waited for: nothing of this batch is in flight any more
+            }
         }
     }
-    if (dT) (void)hipFree(dT);
-    if (dV) (void)hipFree(dV);
-    if (dQ) (void)hipFree(dQ);
-    if (dQd) (void)hipFree(dQd);
-    if (dC) (void)hipFree(dC);
+    hist_free(b);                               // a synchronous call has delivered its record: nothing to keep
     if (rc) return rc;
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_step: ") + hipGetErrorString(e));
     return RMX_OK;
@@ -955,12 +994,23 @@ static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rm
             total += (sizes[i] + 255) & ~(size_t)255;
         }
         if (total > b->adjws_bytes) {
-            if (b->adjws) (void)hipFree(b->adjws);
-            b->adjws = nullptr;
-            b->adjws_bytes = 0;
-            e = hipMalloc(&b->adjws, total);
-            if (e == hipSuccess) b->adjws_bytes = total;
-            else b->adjws = nullptr;
+            void* fresh = nullptr;
+            e = hipMalloc(&fresh, total);      // the new buffer first: a failed regrow keeps the old workspace usable
+            if (e != hipSuccess && b->adjws) {      // ... unless old + new do not fit side by side: then the old one has to go first
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(b->stream);
+                (void)hipFree(b->adjws);
+                b->adjws = nullptr;
+                b->adjws_bytes = 0;
+                e = hipMalloc(&fresh, total);
+            }
+            if (e == hipSuccess) {
+                if (b->adjws) { (void)hipStreamSynchronize(b->stream); (void)hipFree(b->adjws); }
+                b->adjws = fresh;
+                b->adjws_bytes = total;
+            } else {
+                (void)hipGetLastError();       // an out-of-memory here must not be taken for a failed launch by the next call
+            }
         }
         if (e == hipSuccess)
             for (int i = 0; i < 6; ++i) bufs[i] = (char*)b->adjws + offs[i];
@@ -1002,14 +1052,43 @@ extern "C" int rmx_adjoint_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, 
     return adjoint_impl(b, opts, nsteps, task, p, P, dPdp, stats, INTEG_BDF2);
 }
 
-extern "C" int rmx_step_bdf1_async(rmx_batch* b, const rmx_opts* opts, int nsteps) {
+// simLoop of one batch enqueued on its stream, nothing waited for (include/redmax_hip.h "Asynchronous stepping")
+static int step_async(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ, int record) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
-    if (nsteps <= 0 || b->m->nr == 0) return RMX_OK;
+    if (nsteps < 0) return fail(RMX_E_INVALID, "nsteps < 0");
+    if (record & ~(RMX_REC_ENERGY | RMX_REC_STATE | RMX_REC_CHARTS)) return fail(RMX_E_INVALID, "record: unknown RMX_REC_* bits");
     HIPCHK(hipSetDevice(b->m->device));
-    const int rc = launch_step(b, opts, nsteps, INTEG_BDF1, true, nullptr, nullptr);   // counters accumulate on the device
+    if (b->async_pending && (b->hist.T || b->hist.Q || b->hist.C)) {
+        // the launch in flight writes the record that is about to be replaced: wait for it (stacked async steps without a record
+        // need no wait - the stream orders them)
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    int rc = hist_alloc(b, nsteps, record);
+    if (rc) return rc;
+    if (nsteps == 0 || b->m->nr == 0) return RMX_OK;
+    rc = launch_step(b, opts, nsteps, integ, true, b->hist.T, b->hist.V, b->hist.Q, b->hist.Qd, b->hist.C);   // counters accumulate on the device
     if (rc == RMX_OK) b->async_pending = true;      // until rmx_sync (or any synchronous call on this batch) has waited for it
     return rc;
 }
+extern "C" int rmx_step_bdf1_async(rmx_batch* b, const rmx_opts* opts, int nsteps) { return step_async(b, opts, nsteps, INTEG_BDF1, 0); }
+extern "C" int rmx_step_bdf2_async(rmx_batch* b, const rmx_opts* opts, int nsteps) { return step_async(b, opts, nsteps, INTEG_BDF2, 0); }
+extern "C" int rmx_step_history_async(rmx_batch* b, const rmx_opts* opts, int nsteps, int integrator, int record) {
+    if (integrator != 1 && integrator != 2) return fail(RMX_E_INVALID, "integrator must be 1 (BDF1) or 2 (BDF2)");
+    return step_async(b, opts, nsteps, integrator == 1 ? INTEG_BDF1 : INTEG_BDF2, record);
+}
+static int history_read(rmx_batch* b, const rmx_history* hist, size_t pitchB, size_t first) {
+    if (!b || !hist) return fail(RMX_E_INVALID, "null argument");
+    HIPCHK(hipSetDevice(b->m->device));
+    if (b->async_pending) {
+        const int rc = rmx_sync(b);
+        if (rc) return rc;
+    }
+    const int rc = hist_copy_out(b, hist, pitchB, first);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RMX_OK;
+}
+extern "C" int rmx_history_read(rmx_batch* b, const rmx_history* hist) { return history_read(b, hist, b ? (size_t)b->B : 0, 0); }
 extern "C" int rmx_stats_reset(rmx_batch* b) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     HIPCHK(hipSetDevice(b->m->device));
@@ -1025,6 +1104,7 @@ extern "C" int rmx_stats_read(rmx_batch* b, rmx_stats* st) {
     if (st->ls_halvings) HIPCHK(hipMemcpyAsync(st->ls_halvings, b->ls, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream));
     if (st->status) HIPCHK(hipMemcpyAsync(st->status, b->status, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    b->async_pending = false;
     return RMX_OK;
 }
 // How the time of the last rmx_step_* launch was spread over the rollouts: shader-clock ticks (s_memtime) every rollout's wavefront
@@ -1034,6 +1114,7 @@ extern "C" int rmx_step_ticks(rmx_batch* b, unsigned long long* ticks) {
     HIPCHK(hipSetDevice(b->m->device));
     HIPCHK(hipMemcpyAsync(ticks, b->ticks, sizeof(unsigned long long) * b->B, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    b->async_pending = false;
     return RMX_OK;
 }
 
@@ -1043,8 +1124,7 @@ extern "C" int rmx_sync(rmx_batch* b) {
     const hipError_t es = hipStreamSynchronize(b->stream);
     b->async_pending = false;
     if (es != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_sync: the asynchronous launch failed: ") + hipGetErrorString(es));
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
+    take_event_time(b);
     return RMX_OK;
 }
 
@@ -1089,5 +1169,174 @@ extern "C" int rmx_energy(rmx_batch* b, double* T, double* V) {
     (void)hipFree(dT);
     (void)hipFree(dV);
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_energy: ") + hipGetErrorString(e));
+    return RMX_OK;
+}
+
+
+// ============================================================================ multi-device groups (include/redmax_hip.h, ABI 107)
+#include <chrono>
+
+struct rmx_group {
+    int B = 0, nr = 0;
+    std::vector<rmx_model*> models;
+    std::vector<rmx_batch*> batches;
+    std::vector<int> device, first, count;
+    std::chrono::steady_clock::time_point t0;
+    double wall_ms = 0.0;
+    bool in_flight = false;
+};
+
+extern "C" void rmx_group_destroy(rmx_group* g) {
+    if (!g) return;
+    for (rmx_batch* b : g->batches) rmx_batch_destroy(b);
+    for (rmx_model* m : g->models) rmx_model_destroy(m);
+    delete g;
+}
+
+extern "C" int rmx_group_create(const rmx_model_desc* desc, const rmx_ground_contact* gc, int batch, const int* devices, int ndevices,
+                                rmx_group** out) {
+    if (!desc || !out) return fail(RMX_E_INVALID, "null argument");
+    *out = nullptr;
+    if (batch < 1) return fail(RMX_E_INVALID, "batch must be >= 1");
+    if (ndevices < 1) return fail(RMX_E_INVALID, "ndevices must be >= 1");
+    if (ndevices > batch) return fail(RMX_E_INVALID, "more shards than trajectories");
+    rmx_group* g = new rmx_group();
+    g->B = batch;
+    // contiguous shards in device-list order, sizes differing by at most one (sharding.plan(..., "strong"))
+    const int base = batch / ndevices, extra = batch % ndevices;
+    int at = 0;
+    for (int s = 0; s < ndevices; ++s) {
+        const int cnt = base + (s < extra ? 1 : 0);
+        rmx_model* m = nullptr;
+        rmx_batch* b = nullptr;
+        int rc = rmx_model_create(desc, devices ? devices[s] : s, &m);
+        if (rc == RMX_OK) {
+            g->models.push_back(m);
+            if (gc) rc = rmx_model_set_ground_contact(m, gc);
+        }
+        if (rc == RMX_OK) rc = rmx_batch_create(m, cnt, &b);
+        if (rc != RMX_OK) {
+            const std::string msg = "rmx_group_create, shard " + std::to_string(s) + ": " + g_err;
+            rmx_group_destroy(g);
+            return fail(rc, msg);
+        }
+        g->batches.push_back(b);
+        g->device.push_back(m->device);
+        g->first.push_back(at);
+        g->count.push_back(cnt);
+        at += cnt;
+    }
+    g->nr = g->models[0]->nr;
+    *out = g;
+    return RMX_OK;
+}
+extern "C" int rmx_group_batch_size(const rmx_group* g) { return g ? g->B : RMX_E_INVALID; }
+extern "C" int rmx_group_nshards(const rmx_group* g) { return g ? (int)g->batches.size() : RMX_E_INVALID; }
+extern "C" int rmx_group_shard(const rmx_group* g, int s, int* device, int* first, int* count) {
+    if (!g || s < 0 || s >= (int)g->batches.size()) return fail(RMX_E_INVALID, "rmx_group_shard: bad argument");
+    if (device) *device = g->device[s];
+    if (first) *first = g->first[s];
+    if (count) *count = g->count[s];
+    return RMX_OK;
+}
+extern "C" rmx_batch* rmx_group_shard_batch(rmx_group* g, int s) { return (g && s >= 0 && s < (int)g->batches.size()) ? g->batches[s] : nullptr; }
+extern "C" rmx_model* rmx_group_shard_model(rmx_group* g, int s) { return (g && s >= 0 && s < (int)g->models.size()) ? g->models[s] : nullptr; }
+
+extern "C" int rmx_group_set_state(rmx_group* g, const double* q, const double* qdot) {
+    if (!g) return fail(RMX_E_INVALID, "null group");
+    for (size_t s = 0; s < g->batches.size(); ++s) {
+        const size_t off = (size_t)g->first[s] * g->nr;
+        if (int rc = rmx_set_state(g->batches[s], q ? q + off : nullptr, qdot ? qdot + off : nullptr)) return rc;
+    }
+    return RMX_OK;
+}
+extern "C" int rmx_group_get_state(rmx_group* g, double* q, double* qdot) {
+    if (!g) return fail(RMX_E_INVALID, "null group");
+    for (size_t s = 0; s < g->batches.size(); ++s) {
+        const size_t off = (size_t)g->first[s] * g->nr;
+        if (int rc = rmx_get_state(g->batches[s], q ? q + off : nullptr, qdot ? qdot + off : nullptr)) return rc;
+    }
+    return RMX_OK;
+}
+extern "C" int rmx_group_energy(rmx_group* g, double* T, double* V) {
+    if (!g || !T || !V) return fail(RMX_E_INVALID, "null argument");
+    for (size_t s = 0; s < g->batches.size(); ++s)
+        if (int rc = rmx_energy(g->batches[s], T + g->first[s], V + g->first[s])) return rc;
+    return RMX_OK;
+}
+
+// simLoop of the whole batch, first half: every shard's launch is in flight when this returns
+extern "C" int rmx_group_step_async(rmx_group* g, const rmx_opts* opts, int nsteps, int integrator, int record) {
+    if (!g) return fail(RMX_E_INVALID, "null group");
+    if (integrator != 1 && integrator != 2) return fail(RMX_E_INVALID, "integrator must be 1 (BDF1) or 2 (BDF2)");
+    for (rmx_batch* b : g->batches)
+        if (int rc = rmx_stats_reset(b)) return rc;          // (enqueued on the shard's stream ahead of its launch)
+    g->t0 = std::chrono::steady_clock::now();
+    g->in_flight = true;
+    for (rmx_batch* b : g->batches)
+        if (int rc = rmx_step_history_async(b, opts, nsteps, integrator, record)) return rc;
+    return RMX_OK;
+}
+// second half: wait for every shard, then the gather - each shard's slice of the counters and of the per-step record goes straight
+// into its place in the caller's whole-batch arrays
+extern "C" int rmx_group_sync(rmx_group* g, rmx_stats* stats, const rmx_history* hist) {
+    if (!g) return fail(RMX_E_INVALID, "null group");
+    int rc = RMX_OK;
+    std::string first_err;
+    for (rmx_batch* b : g->batches) {
+        const int r = rmx_sync(b);          // wait for ALL of them even when one has failed: nothing may stay in flight
+        if (r && !rc) { rc = r; first_err = g_err; }
+    }
+    if (g->in_flight) {
+        g->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g->t0).count();
+        g->in_flight = false;
+    }
+    if (rc) return fail(rc, first_err);
+    for (size_t s = 0; s < g->batches.size(); ++s) {
+        rmx_batch* b = g->batches[s];
+        const size_t f = (size_t)g->first[s];
+        if (hist && b->hist.nsteps > 0)
+            if (int r = history_read(b, hist, (size_t)g->B, f)) return r;
+        if (stats) {
+            rmx_stats st{stats->newton_iters ? stats->newton_iters + f : nullptr, stats->ls_halvings ? stats->ls_halvings + f : nullptr,
+                         stats->status ? stats->status + f : nullptr};
+            if (int r = rmx_stats_read(b, &st)) return r;
+        }
+    }
+    return RMX_OK;
+}
+extern "C" int rmx_group_step(rmx_group* g, const rmx_opts* opts, int nsteps, int integrator, rmx_stats* stats, const rmx_history* hist) {
+    if (!g) return fail(RMX_E_INVALID, "null group");
+    if (nsteps < 0) return fail(RMX_E_INVALID, "nsteps < 0");
+    int record = 0;
+    if (hist) {
+        if ((hist->T == nullptr) != (hist->V == nullptr)) return fail(RMX_E_INVALID, "history T and V must be given together");
+        if ((hist->q == nullptr) != (hist->qdot == nullptr)) return fail(RMX_E_INVALID, "history q and qdot must be given together");
+        record = (hist->T ? RMX_REC_ENERGY : 0) | (hist->q ? RMX_REC_STATE : 0) | (hist->charts ? RMX_REC_CHARTS : 0);
+    }
+    const int rc = rmx_group_step_async(g, opts, nsteps, integrator, record);
+    const int rs = rmx_group_sync(g, rc ? nullptr : stats, rc ? nullptr : hist);     // (also after a failed launch: drain what did start)
+    return rc ? rc : rs;
+}
+extern "C" int rmx_group_timing(rmx_group* g, double* wall_ms, double* kernel_ms, double* start_ms, double* end_ms) {
+    if (!g) return fail(RMX_E_INVALID, "null group");
+    if (wall_ms) *wall_ms = g->wall_ms;
+    for (size_t s = 0; s < g->batches.size(); ++s) {
+        rmx_batch* b = g->batches[s];
+        if (kernel_ms) kernel_ms[s] = b->last_ms;
+        size_t ref = s;
+        for (size_t r = 0; r < s; ++r)
+            if (g->device[r] == g->device[s]) { ref = r; break; }
+        float t0 = 0.f, t1 = (float)b->last_ms;
+        if (ref != s) {
+            HIPCHK(hipSetDevice(g->device[s]));
+            if (hipEventElapsedTime(&t0, g->batches[ref]->ev0, b->ev0) != hipSuccess || hipEventElapsedTime(&t1, g->batches[ref]->ev0, b->ev1) != hipSuccess) {
+                (void)hipGetLastError();
+                t0 = 0.f; t1 = (float)b->last_ms;
+            }
+        }
+        if (start_ms) start_ms[s] = t0;
+        if (end_ms) end_ms[s] = t1;
+    }
     return RMX_OK;
 }

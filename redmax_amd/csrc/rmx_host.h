@@ -63,6 +63,7 @@ struct rmx_model {
     void* dgconst = nullptr;        // 64-lane plain models: the staged per-node constants in global memory (DevModel::gconst)
     int gconst_min_batch = 0;       // batches of at least this many rollouts run the global-constants kernels (0: never)
     bool big = false;               // more than 64 nodes: the one-workgroup-per-tree kernels of rmx_big.hip
+    std::vector<struct rmx_batch*> batches;   // live batches of this model (rmx_model_set_ground_contact drains their streams only)
 };
 
 struct rmx_batch {
@@ -82,7 +83,15 @@ struct rmx_batch {
     void* adjws = nullptr;          // rmx_adjoint_*: H, M, D of every step and rollout, dP/dq, P, dP/dp - one allocation that is kept
     size_t adjws_bytes = 0;         // between calls and only ever grows (hipMalloc + hipFree of 3 x 20 MB cost more than the kernels)
     double last_ms = 0.0;
-    bool async_pending = false;     // an rmx_step_bdf1_async launch nobody has waited for yet (see pending_error_check)
+    bool async_pending = false;     // an rmx_step_*_async launch nobody has waited for yet (see pending_error_check)
+    // per-step record of the last step call (Scene.saveHistory): device buffers, kept until the next step call so that an
+    // asynchronous launch can be read back after rmx_sync (rmx_history_read)
+    struct Hist {
+        double *T = nullptr, *V = nullptr;      // [nsteps][B]
+        double *Q = nullptr, *Qd = nullptr;     // [nsteps][B][nr]
+        int* C = nullptr;                       // [nsteps][B][nsph]
+        int nsteps = 0;
+    } hist;
 };
 
 // launchers defined by rmx_kernels.hip for one RMX_NP each

@@ -97,7 +97,8 @@ class Gateway:
         nd = L.rmxstub_ndim(m)
         shape = tuple(L.rmxstub_dim(m, i) for i in range(nd))
         if cls == 2:          # struct: only the fields the gateway's 'info' returns
-            return {k: self.from_mx(L.mxGetField(m, 0, k.encode())) for k in ("nr", "nm", "nsph", "batch", "idxR")}
+            return {k: self.from_mx(L.mxGetField(m, 0, k.encode())) for k in ("nr", "nm", "nsph", "batch", "idxR", "nshards", "devices",
+                                                                               "shard_first", "shard_count")}
         dt = {mxDOUBLE: np.float64, mxINT32: np.int32, mxUINT64: np.uint64}[cls]
         n = int(np.prod(shape))
         buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(L.mxGetData(m)) if n else b""
@@ -144,7 +145,7 @@ def flatten(scene):
 
 
 def test_gateway_builds_warning_free_and_answers_version(gw):
-    assert gw.call(1, "version") == 106
+    assert gw.call(1, "version") == 107
 
 
 def test_gateway_reports_errors_the_matlab_way(gw):
@@ -185,7 +186,34 @@ def test_matlab_shims_do_not_copy_reference_files():
     """The MATLAB side adds files to the reference (package functions, a wrapper class, drivers); it must not carry any of
     the reference's classes (Scene.m, Joint.m ...), which stay the reference's own."""
     names = set(os.listdir(os.path.join(ROOT, "matlab", "+redmax")))
-    assert names == {"flattenScene.m", "HipSim.m", "simLoopHip.m", "runDriverHip.m"}
+    assert names == {"flattenScene.m", "HipSim.m", "simLoopHip.m", "simLoopBatchHip.m", "runDriverHip.m"}
+
+
+def test_command_table_matches_the_matlab_callers():
+    """Every command string matlab/ passes to redmax_hip_mex exists in the gateway's dispatch, and every command of the gateway
+    except the two process-level queries is reachable from redmax.HipSim (the MATLAB class a user holds)."""
+    src = open(MEX_C).read()
+    table = set(re.findall(r'!strcmp\(cmd, "(\w+)"\)', src[src.index("void mexFunction"):]))
+    used, hipsim = set(), set()
+    for root, _, files in os.walk(os.path.join(ROOT, "matlab")):
+        for f in files:
+            if f.endswith(".m"):
+                cmds = set(re.findall(r"redmax_hip_mex\('(\w+)'", open(os.path.join(root, f)).read()))
+                used |= cmds
+                if f == "HipSim.m":
+                    hipsim = cmds
+    assert used <= table, sorted(used - table)
+    assert table - hipsim == {"version", "devices"}, sorted(table - hipsim)
+    assert {"step_async", "sync", "timing"} <= hipsim          # the multi-device / asynchronous commands (ABI 107)
+
+
+def test_flattenScene_refuses_two_force_objects_on_one_body():
+    """a floor and a wall on one cuboid must raise in the MATLAB path as it does in redmax.py (the device tables
+    hold one ForceGroundCuboid per body) - the .m file cannot be executed here, so the guard is checked to sit before the writes."""
+    m = open(os.path.join(ROOT, "matlab", "+redmax", "flattenScene.m")).read()
+    guard = m.index("if desc.contact(hit)")
+    assert "error('redmax:hip','flattenScene: one ForceGroundCuboid per body" in m[guard:guard + 400]
+    assert guard < m.index("desc.contact(hit) = 1;")
 
 
 @pytest.mark.gpu
@@ -243,3 +271,39 @@ def test_batched_eval_and_state_layout_through_the_gateway(gw, oracle_lib):
         go, Ho = o.eval_bdf1(q[b], q[b], qd[b], sc.h)
         assert np.linalg.norm(g[:, b] - go) <= 1e-11 * np.linalg.norm(go)
         assert np.linalg.norm(H[:, :, b] - Ho) <= 1e-11 * np.linalg.norm(Ho)
+
+
+@pytest.mark.gpu
+def test_two_shards_through_the_gateway_async_and_sync(gw):
+    """ABI 107, the MATLAB half: 'create' with a device VECTOR shards the batch (here two shards on device 0), 'step' runs them
+    concurrently and gathers, 'step_async' + 'sync' is the same launch split in two calls.  Results must equal the one-shard
+    handle bit for bit, in every output (T, V, stats, Q, Qdot), and 'timing' must show the two launches overlapping."""
+    from redmax_amd.scenes import sceneChain, syntheticStates
+    sc = sceneChain(32)
+    sc.init()
+    B, K = 2048, 20
+    q, qd = syntheticStates(sc.nr, B)
+    d = flatten(sc)
+    outs = []
+    for devs, use_async in ((np.array([0.0]), False), (np.array([0.0, 0.0]), False), (np.array([0.0, 0.0]), True)):
+        h = gw.call(1, "create", d, float(B), devs)
+        info = gw.call(1, "info", h)
+        assert int(info["nshards"][0, 0]) == devs.size and info["shard_count"].sum() == B
+        gw.call(0, "set", h, q.T, qd.T)
+        if use_async:
+            gw.call(0, "step_async", h, 1.0, 1e-2, float(K), {}, 3.0)
+            with pytest.raises(MexError, match="in flight"):
+                gw.call(1, "step", h, 1.0, 1e-2, 1.0)
+            T, V, st, Q, Qd = gw.call(5, "sync", h)
+        else:
+            T, V, st, Q, Qd = gw.call(5, "step", h, 1.0, 1e-2, float(K))
+        q1, qd1 = gw.call(2, "get", h)
+        wall, k, t0, t1 = gw.call(4, "timing", h)
+        gw.call(0, "destroy", h)
+        outs.append((T, V, st, Q, Qd, q1, qd1))
+        if devs.size == 2:
+            assert t0[0, 1] < t1[0, 0], ("the second shard's launch did not start before the first one ended", t0, t1)
+            assert wall[0, 0] < k.sum(), (wall, k)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
