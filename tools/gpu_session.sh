@@ -25,23 +25,32 @@ BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-side
 if has prof; then
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- $BENCH > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
+  find $OUT/prof -name "*.db" -delete 2>/dev/null
   cd $ROOT
 fi
 if has pmc; then
+  # counter passes for every bench workload (tools/roofline_from_pmc.py reads them): separate rocprofv3 runs, --kernel-trace only
   cd /tmp
-  rocprofv3 -L 2>/dev/null | grep -o "SQ_INSTS_VALU[A-Z0-9_]*\|SQ_[A-Z_]*F64[A-Z_]*" | sort -u > $OUT/counters_valu.txt
-  P() { name=$1; shift; timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -- $BENCH $EXTRA > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err; echo "pmc $name rc=$?"; }
-  EXTRA=""
-  P f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES
-  P sq SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_F64 SQ_WAVES
-  P fetch FETCH_SIZE
-  P write WRITE_SIZE
-  EXTRA="--tol 1e-3"       # another iterations-per-step mix for the two-parameter calibration
-  P f64_tol3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES
-  EXTRA=""
-  BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-legs --repeats 0"
-  P fetch_k20 FETCH_SIZE
-  P write_k20 WRITE_SIZE
+  P() { wl=$1; name=$2; shift 2; timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${wl}_$name -- $BENCH $EXTRA > $OUT/pmc_${wl}_$name.json 2> $OUT/pmc_${wl}_$name.err; echo "pmc $wl $name rc=$?"; find $OUT/pmc_${wl}_$name -name "*.db" -delete 2>/dev/null; }
+  F64="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+  SQ="SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES"
+  COMMON="--no-cpu-baseline --no-side-legs --repeats 0"
+  for wl in ${PMC_WORKLOADS:-chain tree64 tree64x ground adjoint chain128}; do
+    case $wl in
+      chain)    BENCH="python $ROOT/bench.py --steps 100 --warmup 10 $COMMON";;
+      tree64)   BENCH="python $ROOT/bench.py --workload tree64 $COMMON";;
+      tree64x)  BENCH="python $ROOT/bench.py --workload tree64 --batch 1024 $COMMON";;
+      ground)   BENCH="python $ROOT/bench.py --workload ground $COMMON";;
+      adjoint)  BENCH="python $ROOT/bench.py --workload adjoint $COMMON";;
+      chain128) BENCH="python $ROOT/bench.py --workload chain --links 128 --batch 256 --steps 10 --warmup 2 --burn-in 0 $COMMON";;
+    esac
+    EXTRA=""
+    P $wl f64 $F64
+    P $wl sq $SQ
+    P $wl fetch FETCH_SIZE
+    P $wl write WRITE_SIZE
+    case $wl in chain|tree64|tree64x) EXTRA="--tol 1e-3"; P $wl f64_tol3 $F64; EXTRA="";; esac   # another iterations-per-step mix: the two-parameter model
+  done
   cd $ROOT
 fi
 if has extra; then

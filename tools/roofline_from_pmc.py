@@ -1,94 +1,148 @@
-"""Executed-work calibration of k_step_bdf1<32,false> from rocprofv3 PMC passes (what bench.py's EXEC table holds).
+"""Executed-work calibration of every bench workload from rocprofv3 PMC passes (what bench.py's `roofline` objects are built from).
 
     python tools/roofline_from_pmc.py gpurun_out/<tag>  [out.json]        (out.json: profiles/roofline_calibration.json, what bench.py loads)
 
-Inputs (written by tools/gpu_session.sh): pmc_f64/ and pmc_f64_tol3/ = counter_collection.csv of the bench command at two Newton
-tolerances (different iterations-per-step mixes) with SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, SQ_INSTS_VALU_MFMA_MOPS_F64,
-SQ_INSTS_VALU, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, plus the bench JSON line of each pass (measured iteration / halving counts).
-Model: counter(launch) = front_evals * FRONT + newton_iters * NEWTON (+ nothing else: q/qdot load/store is ~10 instructions per
-step), with front_evals = rollout-steps + newton_iters + ls_halvings.  Two launches (the 100-step timed ones) give the 2x2
-system per counter; the 10-step warm-up launches of the same passes are the cross-check.
-flops = 64 x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 512 x MFMA_MOPS_F64  (wave-instructions x 64 lanes; one MOP = 512 flops)."""
+Inputs (written by tools/gpu_session.sh <tag> pmc): for every workload WL in chain, tree64, tree64x (1024 rollouts: the kernels that
+read the constants from global memory), ground, adjoint, chain128 (one workgroup per tree) the directories pmc_WL_<pass>/ with the
+counter_collection.csv of `python bench.py --workload ... --repeats 0 --no-side-legs --no-cpu-baseline` and pmc_WL_<pass>.json,
+the bench line of that very run (measured evaluation / iteration counts).  Passes (separate runs: 8 SQ slots, FETCH_SIZE and
+WRITE_SIZE do not fit one pass; --kernel-trace only, as the pool requires):
+    f64     SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64  SQ_INSTS_VALU_MFMA_MOPS_F64  SQ_INSTS_VALU  SQ_WAVE_CYCLES  SQ_BUSY_CYCLES
+    sq      SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES
+    fetch   FETCH_SIZE        write   WRITE_SIZE
+    f64_tol3  (chain, tree64, tree64x) the f64 pass at --tol 1e-3: another iterations-per-step mix
+
+What is stored per workload:
+  launch     the counter TOTALS of the timed launch (the last step call of the run: with --repeats 0 nothing follows it) together with
+             its signature (steps, warm-up, batch, tol) and its measured Newton iteration / evaluation counts.  The workloads are
+             deterministic, so a bench run with the same signature reproduces the iteration count exactly and bench.py uses the totals
+             as they are (no model): flops = 64 x (ADD + MUL + 2 FMA) + 512 x MFMA_MOPS, every wave-wide instruction counted with all
+             64 lanes.
+  per_wave   where the instruction counts per stage are static (chain, tree64, tree64x): counter = front_evals * FRONT +
+             newton_iters * NEWTON solved from the two tolerance passes (the solution comes out integral to 3 digits: the static
+             instruction counts of the two code paths).  Valid for any --steps / --warmup of that workload.
+  fingerprints  opcode hashes of the kernels the workload launched (redmax_amd/kernel_fingerprint.json of the library the session
+             ran): bench.py refuses the entry when the built kernels differ.
+"""
 import csv
 import glob
 import json
+import os
 import sys
 
 import numpy as np
 
-COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
-            "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
+F64 = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+       "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
+
+# kernels of the timed step call, per workload: name fragments as rocprofv3 prints them (demangled)
+KERNELS = {
+    "chain": ("k_step_bdf1<32",), "tree64": ("k_step_bdf1<64",), "tree64x": ("k_step_bdf1<64",), "ground": ("k_step_bdf2<32",),
+    "adjoint": ("k_adjoint_fwd<16", "k_adjoint_bwd<16"), "chain128": ("k_big_step",),
+}
 
 
-def read_pass(root, name):
-    f = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, name))[0]
-    per = {}
-    for r in csv.DictReader(open(f)):
-        if "k_step_bdf1" not in r["Kernel_Name"]:      # (k_step_bdf1<32,false,false,true>, the FULLCHAIN instantiation, for the 32-chain)
+def read_pass(root, wl, name):
+    """(counter totals of the timed call {counter: value}, kernel names of that call, bench JSON) or None"""
+    files = glob.glob("%s/pmc_%s_%s/*/*counter_collection.csv" % (root, wl, name))
+    jf = "%s/pmc_%s_%s.json" % (root, wl, name)
+    if not files or not os.path.exists(jf):
+        return None
+    lines = [ln for ln in open(jf) if ln.startswith("{")]
+    if not lines:
+        return None
+    per, names = {}, {}
+    for r in csv.DictReader(open(files[0])):
+        if not any(k in r["Kernel_Name"] for k in KERNELS[wl]):
             continue
-        per.setdefault(int(r["Dispatch_Id"]), {}).setdefault(r["Counter_Name"], 0.0)
-        per[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        d = int(r["Dispatch_Id"])
+        per.setdefault(d, {}).setdefault(r["Counter_Name"], 0.0)
+        per[d][r["Counter_Name"]] += float(r["Counter_Value"])
+        names[d] = r["Kernel_Name"]
+    if not per:
+        return None
     ids = sorted(per)
-    line = json.loads([ln for ln in open("%s/pmc_%s.json" % (root, name)) if ln.startswith("{")][0])
-    return per[ids[0]], per[ids[-1]], line          # warm-up launch, timed launch, bench JSON
+    # the timed call = the trailing dispatches with pairwise different kernels (chain: 1; ground: lean + contact kernel; adjoint: forward +
+    # backward), as long as the same sequence of kernels also ended the call before it
+    take = [ids[-1]]
+    for d in reversed(ids[:-1]):
+        if names[d] in [names[t] for t in take]:
+            break
+        take.append(d)
+    tot = {}
+    for d in take:
+        for k, v in per[d].items():
+            tot[k] = tot.get(k, 0.0) + v
+    return tot, sorted(set(names[d] for d in take)), json.loads(lines[0])
 
 
 def flops(c):
     return 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2.0 * c["SQ_INSTS_VALU_FMA_F64"]) + 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
 
 
+def signature(line):
+    c = line["config"]
+    return {"steps": line["steps"], "warmup": line["warmup"], "batch": c["batch_per_gpu"], "tol": c.get("newton_tol"), "links": c.get("links")}
+
+
+def counts(line):
+    """(front evaluations, Newton iterations) of the timed launch as the bench line reports them"""
+    r = line.get("roofline") or {}
+    return r.get("front_evals"), r.get("newton_iters")
+
+
 def main():
     root = sys.argv[1]
-    rows, rhs = [], {k: [] for k in COUNTERS + ("flops",)}
-    info = []
-    for name in ("f64", "f64_tol3"):
-        warm, timed, line = read_pass(root, name)
-        B, K = line["config"]["batch_per_gpu"], line["steps"]
-        r = line["roofline"]
-        iters = r["newton_iters"]
-        halv = r["ls_halvings_per_step"] * B * K
-        # MFMA_MOPS is exact per iteration (15 MFMAs x 4 MOPS): use it to recover the integer iteration count of the profiled launch
-        iters_pmc = timed["SQ_INSTS_VALU_MFMA_MOPS_F64"] / 60.0
-        fronts = B * K + iters_pmc + halv
-        rows.append([fronts, iters_pmc])
-        for k in COUNTERS:
-            rhs[k].append(timed[k])
-        rhs["flops"].append(flops(timed))
-        info.append({"pass": name, "tol": line["config"]["newton_tol"], "newton_iters_bench": iters, "newton_iters_from_mfma_mops": iters_pmc,
-                     "ls_halvings": halv, "front_evals": fronts, "kernel_ms_profiled_run": r["kernel_ms"], "flops_timed_launch": flops(timed),
-                     "warmup_launch_flops": flops(warm)})
-    A = np.array(rows)
-    out = {"model": "counter = front_evals * FRONT + newton_iters * NEWTON, per wavefront-instruction totals over the launch", "passes": info,
-           "condition_number": float(np.linalg.cond(A)), "per_wave": {}}
-    for k, v in rhs.items():
-        x = np.linalg.solve(A, np.array(v))
-        out["per_wave"][k] = {"front": float(x[0]), "newton": float(x[1])}
-    t = info[0]
-    sec = t["kernel_ms_profiled_run"] * 1e-3
-    out["timed_launch"] = {
-        "executed_tflops": t["flops_timed_launch"] / sec / 1e12, "frac_of_78.6": t["flops_timed_launch"] / sec / 78.6e12,
-        "valu_insts_per_wave": rhs["SQ_INSTS_VALU"][0] / 1024.0, "wave_cycles_per_wave_counter_units": rhs["SQ_WAVE_CYCLES"][0] / 1024.0,
-        "valu_per_newton_iter_incl_front": rhs["SQ_INSTS_VALU"][0] / t["newton_iters_from_mfma_mops"]}
-    # HBM bytes per launch (separate FETCH_SIZE / WRITE_SIZE passes, KB as rocprofv3 reports them), the fingerprint of the kernel the
-    # library of this session was built with, and where the numbers come from
-    import os
-
-    def kb(name, counter):
-        f = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, name))
-        if not f:
-            return None
-        per = {}
-        for r in csv.DictReader(open(f[0])):
-            if "k_step_bdf1" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                per[int(r["Dispatch_Id"])] = per.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
-        return per[max(per)] if per else None
-    fe, wr = kb("fetch", "FETCH_SIZE"), kb("write", "WRITE_SIZE")
-    if fe is not None and wr is not None:
-        out["hbm_kb_per_launch"] = {"fetch": fe, "write": wr, "fetch_k20": kb("fetch_k20", "FETCH_SIZE"), "write_k20": kb("write_k20", "WRITE_SIZE")}
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out["fingerprint"] = json.load(open(os.path.join(here, "redmax_amd", "kernel_fingerprint.json")))
-    out["source"] = "tools/roofline_from_pmc.py %s" % root
-    print(json.dumps(out, indent=1))
+    fp_all = json.load(open(os.path.join(here, "redmax_amd", "kernel_fingerprint.json")))
+    by_name = {v["name"]: (k, v) for k, v in fp_all.items()}
+    out = {"schema": 2, "source": "tools/roofline_from_pmc.py %s" % root, "workloads": {}}
+    for wl in KERNELS:
+        p = read_pass(root, wl, "f64")
+        if p is None:
+            continue
+        tot, knames, line = p
+        fronts, iters = counts(line)
+        ent = {"kernels": knames, "signature": signature(line), "front_evals": fronts, "newton_iters": iters,
+               "kernel_ms_profiled_run": (line.get("roofline") or {}).get("kernel_ms"),
+               "launch": {k: tot[k] for k in F64 if k in tot}}
+        ent["launch"]["flops"] = flops(tot)
+        sq = read_pass(root, wl, "sq")
+        if sq is not None:
+            ent["launch_sq"] = sq[0]
+        for nm, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            q = read_pass(root, wl, nm)
+            if q is not None and ctr in q[0]:
+                ent.setdefault("hbm_kb_per_launch", {})[nm] = q[0][ctr]
+        # fingerprints of the kernels this workload launched: demangled rocprof names -> symbols of the library
+        fps = {}
+        for kn in knames:
+            base = kn.split("(")[0].replace("void ", "").strip()
+            hit = [(s, v) for n, (s, v) in by_name.items() if n.split("(")[0].replace("void ", "").strip().replace("(anonymous namespace)::", "") == base.replace("(anonymous namespace)::", "")]
+            for s, v in hit:
+                fps[s] = v["opcode_sha16"]
+        ent["fingerprints"] = fps
+        p3 = read_pass(root, wl, "f64_tol3")
+        if p3 is not None and fronts and iters:
+            tot3, _, line3 = p3
+            f3, i3 = counts(line3)
+            A = np.array([[fronts, iters], [f3, i3]], dtype=float)
+            ent["model_condition_number"] = float(np.linalg.cond(A))
+            ent["model_passes"] = [{"tol": signature(line)["tol"], "front_evals": fronts, "newton_iters": iters},
+                                   {"tol": signature(line3)["tol"], "front_evals": f3, "newton_iters": i3}]
+            pw = {}
+            for k in F64:
+                x = np.linalg.solve(A, np.array([tot[k], tot3[k]]))
+                pw[k] = {"front": float(x[0]), "newton": float(x[1])}
+            x = np.linalg.solve(A, np.array([flops(tot), flops(tot3)]))
+            pw["flops"] = {"front": float(x[0]), "newton": float(x[1])}
+            ent["per_wave"] = pw
+        out["workloads"][wl] = ent
+        ms = ent["kernel_ms_profiled_run"]
+        print("%-9s %-40s flops/launch %.4g  VALU/wave %.0f%s" % (wl, ",".join(k.split("(")[0][-40:] for k in knames)[:40], ent["launch"]["flops"],
+              tot["SQ_INSTS_VALU"] / max(signature(line)["batch"], 1),
+              ("  executed %.2f TF in the profiled run" % (ent["launch"]["flops"] / (ms * 1e-3) / 1e12)) if ms else ""))
+    print(json.dumps({k: v.get("per_wave", {}).get("SQ_INSTS_VALU") for k, v in out["workloads"].items()}, indent=1))
     if len(sys.argv) > 2:
         json.dump(out, open(sys.argv[2], "w"), indent=1)
 
