@@ -454,8 +454,8 @@ def roofline(kernel_ms, iters_rank, halv_rank, steps_rank, K, W, B_local, n, wl,
     if sq and sq.get("SQ_ACTIVE_INST_VALU"):
         out["lane_occupancy_counter"] = {
             "SQ_THREAD_CYCLES_VALU": sq.get("SQ_THREAD_CYCLES_VALU"), "SQ_ACTIVE_INST_VALU": sq.get("SQ_ACTIVE_INST_VALU"),
-            "active_lanes_per_valu_cycle": round(sq.get("SQ_THREAD_CYCLES_VALU", 0.0) / sq["SQ_ACTIVE_INST_VALU"] / 4.0, 2),
-            "note": "EXEC-mask occupancy of the calibrated launch (thread-cycles / (quad-)cycles with a VALU instruction active).  Idle lanes of "
+            "active_lanes_per_valu_cycle": round(sq.get("SQ_THREAD_CYCLES_VALU", 0.0) / sq["SQ_ACTIVE_INST_VALU"], 2),
+            "note": "EXEC-mask occupancy of the calibrated launch: lanes enabled per cycle with a VALU instruction active, of 64.  Idle lanes of "
                     "a partly filled wave mostly run UNMASKED on an identity / zero column (rmx_device.h), so this counter does not see them: "
                     "useful_frac, not this ratio, is the lane-honest figure"}
     return out

@@ -1169,6 +1169,247 @@ __device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict
     eval_front_e2<NP, FULL, TIMED, CT, NEARCHK>(M, sAcc, lane, xq, xqd, xv, eta, eta * eta, out, fs, stamps);
 }
 
+// ----------------------------------------------------------------------------- two line-search points per evaluation (n <= 32)
+//
+// A tree of at most 32 nodes leaves lanes 32..63 idle in every lane = node stage of the front.  The trial points of newton()'s
+// backtracking line search (driverRedMaxBDF1.m:124-138: x0 + alpha dx for alpha = 1, 1/2, 1/4 ... until 0.5 |g|^2 decreases, at most
+// iterLsMax of them) do not depend on each other, only the DECISION which one is taken does.  eval_front_dual evaluates the residual
+// at TWO iterates in one pass: lanes 0..31 carry trial point a, lanes 32..63 trial point b = the next halving, node = lane & 31 in
+// both halves, for the instruction count of one evaluation (every stage is lane-local or stays inside 16-lane DPP rows; the
+// hand-over from the first to the second row of a half is one row_bcast:15 for both halves at once).  The caller takes a if it is
+// accepted, else b, else goes on with the next pair: the reference's decisions in the reference's order, half the evaluations.
+// Residual only (6 subtree sums, by the register scan): the accepted point is evaluated once more by the full front, whose state
+// the Hessian stage needs.  Serial chains only (the callers fall back to one point per evaluation for branching trees).
+// What it is for: BASELINE.json configs[4] - at a stick / slip kink of the ground contact the reference's line search runs out its
+// 20 trials (or accepts 2^-13 of the step) on every one of the 320 iterations of a step, ~4300 trial evaluations for one step of one
+// rollout, and the launch of the whole batch waits for it.
+//
+// lane 15 of every 16-lane row -> all lanes of the NEXT row, rows 1 and 3 only (row_mask 0xA); the other rows receive 0
+__device__ __forceinline__ double dpp_bcast15_odd_rows(const double v) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xA, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xA, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sums along the chain, two chains of 32 nodes side by side (lanes 0..31 and 32..63)
+__device__ __forceinline__ void chain_scan_sum6_dual(double (&a)[3], double (&b)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a[c] += dpp_shr0<1>(a[c]); b[c] += dpp_shr0<1>(b[c]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a[c] += dpp_shr0<2>(a[c]); b[c] += dpp_shr0<2>(b[c]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a[c] += dpp_shr0<4>(a[c]); b[c] += dpp_shr0<4>(b[c]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a[c] += dpp_shr0<8>(a[c]); b[c] += dpp_shr0<8>(b[c]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {      // rows 1 and 3 add the complete total of lane 15 / 47
+        a[c] += dpp_bcast15_odd_rows(a[c]);
+        b[c] += dpp_bcast15_odd_rows(b[c]);
+    }
+}
+__device__ __forceinline__ void chain_scan_transform_dual(const int lane, double (&R)[9], double (&p)[3]) {
+    chain_compose_step<1>(lane, R, p);
+    chain_compose_step<2>(lane, R, p);
+    chain_compose_step<4>(lane, R, p);
+    chain_compose_step<8>(lane, R, p);
+    double Ra[9], pa[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ra[c] = dpp_bcast15_odd_rows(R[c]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pa[c] = dpp_bcast15_odd_rows(p[c]);
+    if (lane & 16) {
+        double Rn[9], pn[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Rn[3 * i + k] = Ra[3 * i] * R[k] + Ra[3 * i + 1] * R[3 + k] + Ra[3 * i + 2] * R[6 + k];
+            pn[i] = Ra[3 * i] * p[0] + Ra[3 * i + 1] * p[1] + Ra[3 * i + 2] * p[2] + pa[i];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = pn[c];
+    }
+}
+// suffix sums of 6 numbers per node along the two chains: row_shl scans, then rows 0 and 2 add the total of lane 16 / 48
+__device__ __forceinline__ void chain_suffix_sum6_dual(const int lane, double (&S)[6]) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[c] += dpp_shl0<1>(S[c]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[c] += dpp_shl0<2>(S[c]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[c] += dpp_shl0<4>(S[c]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[c] += dpp_shl0<8>(S[c]);
+    const double w0 = ((lane >> 4) == 0) ? 1.0 : 0.0, w2 = ((lane >> 4) == 2) ? 1.0 : 0.0;
+    double t0[6], t2[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        t0[c] = readlane_d(S[c], 16);
+        t2[c] = readlane_d(S[c], 48);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) S[c] = fma(w2, t2[c], fma(w0, t0[c], S[c]));
+}
+// the two halves' sums over their 32 lanes, each bitwise what wave_sum gives for a wave whose other half holds zeros
+__device__ __forceinline__ void wave_sum_dual(double v, double& sa, double& sb) {
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HALF_MIRROR>(v);
+    v += dpp_d<DPP_MIRROR>(v);
+    sa = (readlane_d(v, 0) + readlane_d(v, 16)) + 0.0;
+    sb = (readlane_d(v, 32) + readlane_d(v, 48)) + 0.0;
+}
+
+// g of two iterates of a serial chain of n <= 32 nodes (see above).  xq, xqd, xv: the coordinates of node lane & 31 at trial point
+// lane >> 5, zeros where the node has no DOF.  Same formulas, in the same order, as eval_front_e2<32, false, false, CT>.
+#ifndef RMX_DUAL_INLINE
+#define RMX_DUAL_INLINE 1          // 0: eval_front_dual as an out-of-line function with scalar arguments only (build variants)
+#endif
+#if RMX_DUAL_INLINE
+#define RMX_DUAL_FN __device__ __forceinline__
+#else
+#define RMX_DUAL_FN __device__ __attribute__((noinline))
+#endif
+struct Grav3 { double x, y, z; };
+template <bool CT>
+RMX_DUAL_FN double eval_front_dual(const double* __restrict__ cK, const Grav3 grav, const int lane, const double xq,
+                                   const double xqd, const double xv, const double eta, const double tau_add) {
+    constexpr int NP = 32;
+    constexpr int CS = cstride(NP);
+    const double e2 = eta * eta;
+    const int jc = lane & 31;
+    const double* cSb = cK + 36 * CS;
+    const double* cI4 = cSb + 6 * CS;
+    const double* cPrm = cI4 + 4 * CS;
+    const double* cTyp = cPrm + 8 * CS;
+    const double* cCon = cTyp + CS + 2 * CS + MAXROUNDS * CS + CS;
+    const int type = (int)cTyp[jc];
+    const bool dof = type != 0;
+    const double q = xq, qd = xqd, v = xv;
+    double u = 0.0, w = 0.0;
+    if (type == 1) {
+        sincos(q, &u, &w);
+    } else if (type == 2) {
+        u = q;
+    }
+    double R[9], p[3];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[c] = cK[c * CS + jc] + u * cK[(12 + c) * CS + jc] + w * cK[(24 + c) * CS + jc];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = cK[(9 + c) * CS + jc] + u * cK[(21 + c) * CS + jc] + w * cK[(33 + c) * CS + jc];
+    chain_scan_transform_dual(lane, R, p);
+    double sbw[3], sbv[3], t3[3], sw[3], sv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sbw[c] = cSb[c * CS + jc];
+        sbv[c] = cSb[(3 + c) * CS + jc];
+    }
+    mat3v(R, sbw, sw);
+    mat3v(R, sbv, sv);
+    cross3(p, sw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sv[c] += t3[c];
+    double phw[3], phv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        phw[c] = sw[c] * qd;
+        phv[c] = sv[c] * qd;
+    }
+    chain_scan_sum6_dual(phw, phv);
+    double xiw[3], xiv[3], bw[3], bv[3];
+    cross3(phw, sw, xiw);
+    cross3(phv, sw, xiv);
+    cross3(phw, sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xiv[c] += t3[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        bw[c] = sw[c] * v + e2 * qd * xiw[c];
+        bv[c] = sv[c] * v + e2 * qd * xiv[c];
+    }
+    chain_scan_sum6_dual(bw, bv);
+    const double I1 = cI4[0 * CS + jc], I2 = cI4[1 * CS + jc];
+    const double I3 = cI4[2 * CS + jc], ms = cI4[3 * CS + jc];
+    double mc[3], Ib[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mc[c] = ms * p[c];
+    {
+        const double cc = dot3(p, p);
+        Ib[0] = I1 * R[0] * R[0] + I2 * R[1] * R[1] + I3 * R[2] * R[2] + ms * (cc - p[0] * p[0]);
+        Ib[1] = I1 * R[0] * R[3] + I2 * R[1] * R[4] + I3 * R[2] * R[5] - ms * p[0] * p[1];
+        Ib[2] = I1 * R[0] * R[6] + I2 * R[1] * R[7] + I3 * R[2] * R[8] - ms * p[0] * p[2];
+        Ib[3] = I1 * R[3] * R[3] + I2 * R[4] * R[4] + I3 * R[5] * R[5] + ms * (cc - p[1] * p[1]);
+        Ib[4] = I1 * R[3] * R[6] + I2 * R[4] * R[7] + I3 * R[5] * R[8] - ms * p[1] * p[2];
+        Ib[5] = I1 * R[6] * R[6] + I2 * R[7] * R[7] + I3 * R[8] * R[8] + ms * (cc - p[2] * p[2]);
+    }
+    double ht[3], hf[3], bt[3], bf[3];
+    sym3v(Ib, phw, ht);
+    cross3(mc, phv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ht[c] += t3[c];
+    cross3(mc, phw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) hf[c] = ms * phv[c] - t3[c];
+    sym3v(Ib, bw, bt);
+    cross3(mc, bv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bt[c] += t3[c];
+    cross3(mc, bw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bf[c] = ms * bv[c] - t3[c];
+    double fct[3], fcf[3], a3[3], b3[3];
+    cross3(phw, ht, a3);
+    cross3(phv, hf, b3);
+    cross3(phw, hf, fcf);
+    const double gv[3] = {grav.x, grav.y, grav.z};
+    double fgt[3];
+    cross3(mc, gv, fgt);
+    double S[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        fct[c] = -a3[c] - b3[c];
+        S[c] = bt[c] - e2 * (fct[c] + fgt[c]);
+        S[3 + c] = bf[c] - e2 * (-fcf[c] + ms * gv[c]);
+    }
+    if constexpr (CT) {
+        const bool con = cCon[jc] != 0.0;
+        const double sd[3] = {cCon[CS + jc], cCon[2 * CS + jc], cCon[3 * CS + jc]};
+        GroundC G;
+        {
+            const double* gr = cK + NCONST * CS + jc;      // ground_of
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                G.n[c] = gr[c * CS];
+                G.gx[c] = gr[(3 + c) * CS];
+            }
+            G.kn = gr[6 * CS];
+            G.kt = gr[7 * CS];
+            G.mu = gr[8 * CS];
+            G.kdc = gr[9 * CS];
+        }
+        const double dc = G.n[0] * (p[0] - G.gx[0]) + G.n[1] * (p[1] - G.gx[1]) + G.n[2] * (p[2] - G.gx[2]);
+        const double reach = 0.5 * (fabs(G.n[0] * R[0] + G.n[1] * R[3] + G.n[2] * R[6]) * sd[0] +
+                                    fabs(G.n[0] * R[1] + G.n[1] * R[4] + G.n[2] * R[7]) * sd[1] +
+                                    fabs(G.n[0] * R[2] + G.n[1] * R[5] + G.n[2] * R[8]) * sd[2]);
+        const bool near = __any(con && !(dc - reach > 1e-9 * (fabs(dc) + reach)));
+        if (near) {
+            double Fc[6], k1[36], eVc;
+            contact_body<0>(G, con, sd, R, p, phw, phv, Fc, k1, eVc);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[c] -= e2 * Fc[c];
+        }
+    }
+    chain_suffix_sum6_dual(lane, S);
+    const double stiff = cPrm[1 * CS + jc], damp = cPrm[2 * CS + jc];
+    const double tau = cPrm[0 * CS + jc], qRest = cPrm[3 * CS + jc];
+    const double qLimL = cPrm[4 * CS + jc], qLimU = cPrm[5 * CS + jc];
+    const double qLimK = cPrm[6 * CS + jc], qLimD = cPrm[7 * CS + jc];
+    const double hitL = (dof && q < qLimL) ? 1.0 : 0.0, hitU = (dof && q > qLimU) ? 1.0 : 0.0;
+    const double fr = (tau + tau_add) + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
+                      hitU * (qLimK * (qLimU - q) - qLimD * qd);
+    return dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
+}
+
 // Reduced mass matrix row M(a,:) = (J' Mm J)(a,:) of this node from the subtree inertias (computeValues :212;
 // matlab-simple euler :86-87): M(a,i) = (Ic_a s_a).s_i if i is an ancestor-or-self of a, s_a.(Ic_i s_i) if a descendant.
 template <int NP>
@@ -2814,6 +3055,9 @@ __device__ __forceinline__ void pivot_policy_update(PivotPolicy& piv) {   // aft
 // comes near the ground; the first one that does ends the solve with status bit 64 and the caller redoes it with CT = true.
 constexpr int ST_LEFT_LEAN = 64;
 constexpr int ST_LS_CUT = 128;     // RMX_ST_LS_CUT
+#ifndef RMX_DUAL_LS
+#define RMX_DUAL_LS 1              // two line-search points per evaluation (eval_front_dual); 0: one (build variants, measurements)
+#endif
 template <int NP, bool PIVOT_ONLY, bool CT = false, bool LEAN = false>
 __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
@@ -2889,7 +3133,63 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         int iterLs = 1;
         double gn2 = g0n2;
         bool stalled = false;
+        // chains of at most 32 nodes in the kernels with the contact terms: from the second trial on the line search evaluates its
+        // points two at a time (eval_front_dual) - same points, same order of decisions
+        constexpr bool DUAL_LS = CT && !LEAN && NP == 32 && RMX_DUAL_LS;
         while (true) {
+            if constexpr (DUAL_LS) {
+                if (iterLs >= 2 && M.is_chain) {
+                    // trial iterLs at alpha (lanes 0..31) and trial iterLs + 1 at alpha / 2 (lanes 32..63), node = lane & 31
+                    const double x0d = dup_lo(x0), lo0d = dup_lo(lo0), dxd = dup_lo(dx), qAd = dup_lo(qA), qBd = dup_lo(qB);
+                    const bool hiH = lane >= 32;
+                    const double al = hiH ? 0.5 * alpha : alpha;
+                    double xl, lol;
+                    two_sum(x0d, fma(al, dxd, lo0d), xl, lol);
+                    lol *= o.comp;
+                    const unsigned long long same = __ballot(xl == x0d && lol == lo0d);
+                    const bool stall_a = (unsigned)same == 0xffffffffu, stall_b = (unsigned)(same >> 32) == 0xffffffffu;
+                    int take = -1;                         // 0: trial point a ends the search, 1: b
+                    if (stall_a) {                         // (see the one-point path below)
+                        stalled = true;
+                        iterLs = o.iterLsMax;
+                        e = e0;
+                        x = x0;
+                        lo = lo0;
+                        break;
+                    }
+                    const double gd = eval_front_dual<CT>(RMX_CONSTS(sAcc, M.n, NP), Grav3{M.grav[0], M.grav[1], M.grav[2]}, lane, xl,
+                                                          ((xl - qAd) + lol) / eta, (xl - qBd) + lol, eta, dup_lo(fs.tau_add));
+                    double ga2, gb2;
+                    wave_sum_dual(gd * gd, ga2, gb2);
+                    if (0.5 * ga2 < f0 || iterLs >= o.iterLsMax) {
+                        take = 0;
+                    } else {
+                        ++iterLs;                          // trial point b
+                        if (stall_b) {
+                            stalled = true;
+                            iterLs = o.iterLsMax;
+                            e = e0;
+                            x = x0;
+                            lo = lo0;
+                            break;
+                        }
+                        if (0.5 * gb2 < f0 || iterLs >= o.iterLsMax) take = 1;
+                    }
+                    if (take >= 0) {
+                        // the point that ends the search: the full front there (the state the Hessian stage needs; its |g|^2 is the
+                        // one carried on, as in the one-point path)
+                        const double xs = take ? take_hi(xl) : xl, ls = take ? take_hi(lol) : lol;
+                        x = hiH ? x0 : xs;
+                        lo = hiH ? lo0 : ls;
+                        eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, fs);
+                        gn2 = wave_sum(e.g * e.g);
+                        break;
+                    }
+                    alpha *= 0.25;
+                    ++iterLs;
+                    continue;
+                }
+            }
             two_sum(x0, fma(alpha, dx, lo0), x, lo);       // x + lo = x0 + (lo0 + alpha dx)
             lo *= o.comp;
             if (__all(x == x0 && lo == lo0)) {

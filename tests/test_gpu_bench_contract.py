@@ -39,6 +39,9 @@ def test_default_workload_line():
     # the reference-tolerance line, the tensor-free CPU baseline, Newton-count agreement and the repeated launches
     assert 0 < r["frac"] <= 1 and r["traffic"] > 0 and 0 < r["issue_bound"]["frac"] <= 1.05
     assert r["algorithmic_equiv_tflops"] > r["achieved"]
+    # round 4: the lane-honest fraction (flops of the scalar algorithm, tests/flop_count.py) beside the 64-lane one
+    assert 0 < r["useful_frac"] < r["frac"] and "calibration_stale" not in r
+    assert d["value_without_rollout_0"]["value"] > d["value"]
     # round 3: the headline runs the reference's own tol; the side measurements run the reference's 100 steps whatever --steps is
     assert d["config"]["newton_tol"] == 1e-9 == d["config"]["reference_newton_tol"]
     t = d["value_plain_iterate"]
@@ -75,14 +78,30 @@ def test_two_ranks_on_one_gpu_self_launch():
 @pytest.mark.parametrize("wl", ["tree64", "ground"])
 def test_extra_workload_lines(wl):
     d = _run("--workload", wl, "--steps", "10", "--warmup", "2", "--batch", "64")
-    assert d["value"] > 0 and d["roofline"] is None and "cpu_baseline" not in d
+    assert d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["batch_per_gpu"] == 64 and d["config"]["all_finite"]
+    # round 4: every workload line carries an executed-work roofline (a non-default signature uses the per-stage model or the scaled
+    # totals of the calibrated launch) and the lane-honest fraction
+    r = d["roofline"]
+    assert r["bound"] == "valu-issue" and r["unit"] == "TFLOP/s" and "calibration_stale" not in r
+    assert 0 < r["useful_frac"] <= r["frac"] <= 1 and r["kernel_ms"] > 0
+
+
+def test_extra_workload_default_signature_uses_the_counter_totals():
+    """At the calibrated signature the launch repeats the calibrated launch's Newton iterations exactly (deterministic workload), and the
+    roofline uses the counter totals of that very launch."""
+    d = _run("--workload", "tree64", "--no-side-legs", "--repeats", "0")
+    r = d["roofline"]
+    assert "counter totals of this very launch" in r["executed_flops_from"], r["executed_flops_from"]
+    assert 0 < r["useful_frac"] < r["frac"] <= 1
 
 
 def test_adjoint_workload_line():
-    """BASELINE.json configs[3] at config size: 16-DOF chain, 512 rollouts, forward + backward sweep, HBM roofline."""
+    """BASELINE.json configs[3] at config size: 16-DOF chain, 512 rollouts, forward + backward sweep: issue-bound roofline (round 4; the
+    HBM figure of rounds 1-3 stays as a side object - the path is not bound by it)."""
     d = _run("--workload", "adjoint", "--repeats", "2")
     assert d["steps"] == 20 and d["config"]["batch_per_gpu"] == 512 and d["value"] > 0
     assert d["config"]["all_finite"] and d["config"]["not_converged_trajectories"] == 0
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] <= 1 and r["kernel_ms"] > 0
+    assert r["bound"] == "valu-issue" and r["unit"] == "TFLOP/s" and 0 < r["useful_frac"] <= r["frac"] <= 1 and r["kernel_ms"] > 0
+    assert "calibration_stale" not in r and 0 < r["hbm"]["frac_of_8TBps"] < 0.1

@@ -27,11 +27,13 @@ from isa_blocks import cls  # noqa: E402
 
 
 def demangle(names):
-    try:
-        out = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt")] + list(names), capture_output=True, text=True, check=True).stdout.split("\n")
-        return dict(zip(names, out))
-    except (OSError, subprocess.CalledProcessError):
-        return {n: n for n in names}
+    for tool in (os.path.join(LLVM, "llvm-cxxfilt"), "c++filt"):
+        try:
+            out = subprocess.run([tool] + list(names), capture_output=True, text=True, check=True).stdout.split("\n")
+            return dict(zip(names, out))
+        except (OSError, subprocess.CalledProcessError):
+            continue
+    return {n: n for n in names}
 
 
 def code_objects(lib, workdir):

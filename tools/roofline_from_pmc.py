@@ -116,11 +116,15 @@ def main():
                 ent.setdefault("hbm_kb_per_launch", {})[nm] = q[0][ctr]
         # fingerprints of the kernels this workload launched: demangled rocprof names -> symbols of the library
         fps = {}
+
+        def base(nm):      # "void (anonymous namespace)::k<1, true>(args)" -> "k<1, true>"
+            return nm.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
         for kn in knames:
-            base = kn.split("(")[0].replace("void ", "").strip()
-            hit = [(s, v) for n, (s, v) in by_name.items() if n.split("(")[0].replace("void ", "").strip().replace("(anonymous namespace)::", "") == base.replace("(anonymous namespace)::", "")]
-            for s, v in hit:
-                fps[s] = v["opcode_sha16"]
+            for n, (s, v) in by_name.items():
+                if base(n) == base(kn):
+                    fps[s] = v["opcode_sha16"]
+        if len(fps) != len(knames):
+            print("WARNING: %s: %d kernels launched, %d matched in kernel_fingerprint.json" % (wl, len(knames), len(fps)))
         ent["fingerprints"] = fps
         p3 = read_pass(root, wl, "f64_tol3")
         if p3 is not None and fronts and iters:
@@ -139,7 +143,8 @@ def main():
             ent["per_wave"] = pw
         out["workloads"][wl] = ent
         ms = ent["kernel_ms_profiled_run"]
-        print("%-9s %-40s flops/launch %.4g  VALU/wave %.0f%s" % (wl, ",".join(k.split("(")[0][-40:] for k in knames)[:40], ent["launch"]["flops"],
+        ent["kernels"] = [base(k) for k in knames]
+        print("%-9s %-40s flops/launch %.4g  VALU/wave %.0f%s" % (wl, ",".join(ent["kernels"])[:40], ent["launch"]["flops"],
               tot["SQ_INSTS_VALU"] / max(signature(line)["batch"], 1),
               ("  executed %.2f TF in the profiled run" % (ent["launch"]["flops"] / (ms * 1e-3) / 1e12)) if ms else ""))
     print(json.dumps({k: v.get("per_wave", {}).get("SQ_INSTS_VALU") for k, v in out["workloads"].items()}, indent=1))
