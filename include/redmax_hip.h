@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 107
+#define RMX_VERSION 108
 
 enum {
     RMX_OK = 0,
@@ -206,6 +206,21 @@ int rmx_eval(rmx_batch* b, const double* q, const double* qA, const double* qB, 
  * (rmx_get_charts).  ForceGroundCuboid: its wrench is part of f, its damping block J' Dm J part of D (ForceGroundCuboid.m:104-106).
  * Does not change state. */
 int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, double* M, double* f, double* D);
+
+/* computeValues' FULL output, [M, f, dMdq, K, D] (driverRedMaxBDF1.m:188-243), at (q, qdot) for every trajectory, for trees of ANY
+ * size the library takes (ABI 108).  Every output may be NULL.
+ *   M, D, K : [batch][nr*nr] column-major;  K = df/dq (:239-243: Kr + J'KmJ + Kqvv + the dJdq terms), D = df/dqdot, M = J'MmJ
+ *   f       : [batch][nr]
+ *   dMv     : [batch][nr*nr] column-major, column i = dMdq(:,:,i) v for the caller's v [batch][nr] - the form in which evalBDF1
+ *             consumes the tensor (:181-184, v = dqtmp); needs v
+ *   dMdq    : the tensor itself, [batch][nr*nr*nr], entry (r, c, i) at r + nr (c + nr i)  (nr evaluations: a test hook)
+ * The world-frame kernels never form K, D or the tensor on their own: H(eta; v) = M + dMdq v - eta D - eta^2 K is what
+ * they evaluate, exactly, for any eta and v.  This hook takes the pieces apart on the host from a few such evaluations at the SAME
+ * (q, qdot) (qA = q - eta qdot): v = 0 at eta = 1 (and 2, 1/2 for trees of more than 64 nodes, where M and D have no kernel of their
+ * own) gives M, D, K; one more with the caller's v gives dMv = H(1; v) - H(1; 0).  Same conventions as rmx_eval_mfd for Euler
+ * charts and ForceGroundCuboid.  Does not change state. */
+int rmx_compute_values(rmx_batch* b, const double* q, const double* qdot, const double* v,
+                       double* M, double* f, double* D, double* K, double* dMv, double* dMdq);
 
 /* Per-trajectory counters of one rmx_step_* call (host arrays [batch], any may be NULL). */
 typedef struct rmx_stats {

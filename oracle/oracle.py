@@ -32,7 +32,8 @@ class _Desc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("newton_iters", C.c_int), ("ls_halvings", C.c_int), ("residual_evals", C.c_int),
-                ("hessian_evals", C.c_int), ("diverged", C.c_int), ("not_converged", C.c_int), ("chart_switches", C.c_int)]
+                ("hessian_evals", C.c_int), ("diverged", C.c_int), ("not_converged", C.c_int), ("chart_switches", C.c_int),
+                ("worst_exit_g", C.c_double)]
 
 
 class TaskPointPos(C.Structure):
@@ -85,6 +86,8 @@ def lib():
         L.orc_batch_step_bdf1.restype = C.c_long
         L.orc_batch_step_bdf1_ex.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, _ip, _ip, _ip]
         L.orc_batch_step_bdf1_ex.restype = C.c_long
+        L.orc_batch_step_bdf1_ex2.argtypes = [C.POINTER(_Desc), C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp]
+        L.orc_batch_step_bdf1_ex2.restype = C.c_long
         L.otf_nr.argtypes = [C.POINTER(_Desc)]
         L.otf_eval.argtypes = [C.POINTER(_Desc), _dp, _dp, _dp, C.c_double, _dp, _dp]
         L.otf_eval_lo.argtypes = [C.POINTER(_Desc), _dp, _dp, _dp, _dp, C.c_double, _dp, _dp]
@@ -419,9 +422,10 @@ def batch_step_bdf1(desc_dict, q, qdot, h, nsteps, nthreads=0, counters=False):
     # qRest: the batch helper takes it from the descriptor's q (model constant)
     if not counters:
         return int(L.orc_batch_step_bdf1(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads)))
-    out = {k: np.zeros(q.shape[0], dtype=np.int32) for k in ("newton_iters", "ls_halvings", "bad")}
-    L.orc_batch_step_bdf1_ex(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads),
-                             *[out[k].ctypes.data_as(_ip) for k in ("newton_iters", "ls_halvings", "bad")])
+    out = {k: np.zeros(q.shape[0], dtype=np.int32) for k in ("newton_iters", "ls_halvings", "bad", "diverged")}
+    out["worst_exit_g"] = np.zeros(q.shape[0])
+    L.orc_batch_step_bdf1_ex2(C.byref(d), int(q.shape[0]), _p(q), _p(qdot), float(h), int(nsteps), int(nthreads),
+                              *[out[k].ctypes.data_as(_ip) for k in ("newton_iters", "ls_halvings", "bad", "diverged")], _p(out["worst_exit_g"]))
     return out
 
 

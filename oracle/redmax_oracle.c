@@ -961,7 +961,7 @@ static void newton(orc_scene* s, double* x, const double* qA, const double* qB, 
         }
         if (st) st->ls_halvings += iterLs - 1;
         if (vnorm(nr, g) < tol) break;
-        if (iter >= iterMax) { if (st) st->not_converged++; break; }
+        if (iter >= iterMax) { if (st) { st->not_converged++; if (vnorm(nr, g) > st->worst_exit_g) st->worst_exit_g = vnorm(nr, g); } break; }
         lsfail += decreased ? 0 : 1;
         if (g_lsFailLimit > 0 && lsfail >= g_lsFailLimit) { if (st) st->not_converged++; break; }     /* orc_set_ls_fail_limit */
         iter++;
@@ -1584,12 +1584,18 @@ double orc_adjoint_bdf2(orc_scene* s, double h, int nsteps, const orc_task_point
 
 /* -------------------------------------------------- batch CPU baseline */
 
-long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad);
+long orc_batch_step_bdf1_ex2(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad,
+                             int* diverged, double* worst_exit_g);
+long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad) {
+    return orc_batch_step_bdf1_ex2(d, B, q, qdot, h, nsteps, nthreads, iters, halvings, bad, NULL, NULL);
+}
 long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads) {
     return orc_batch_step_bdf1_ex(d, B, q, qdot, h, nsteps, nthreads, NULL, NULL, NULL);
 }
 /* the same with per-rollout counters: Newton iterations, line-search halvings, diverged + not-converged steps ([B] or NULL) */
-long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad) {
+/* diverged: "Newton diverged" steps alone ([B] or NULL); worst_exit_g: the largest |g| a not-converged step of the rollout ended with */
+long orc_batch_step_bdf1_ex2(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads, int* iters, int* halvings, int* bad,
+                             int* diverged, double* worst_exit_g) {
     long total = 0;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -1613,6 +1619,8 @@ long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, d
             if (iters) iters[b] = st.newton_iters;
             if (halvings) halvings[b] = st.ls_halvings;
             if (bad) bad[b] = st.diverged + st.not_converged;
+            if (diverged) diverged[b] = st.diverged;
+            if (worst_exit_g) worst_exit_g[b] = st.worst_exit_g;
         }
         free(qrest);
         orc_destroy(s);

@@ -102,6 +102,8 @@ typedef struct orc_stats {
     int diverged;         /* steps that hit "Newton diverged"                         */
     int not_converged;    /* steps that hit iterMax                                   */
     int chart_switches;   /* JointSpherical.reparam_ chart changes                    */
+    double worst_exit_g;  /* largest |g| a "did not converge" step ended with (0 if none): tells a stall at the resolution of
+                             doubles (|g| ~ tol) from a step that is really lost                                           */
 } orc_stats;
 
 /* Newton constants used by every orc_step_* call (process-global).  Defaults = the reference's hard-coded
@@ -146,6 +148,10 @@ long orc_batch_step_bdf1(const orc_desc* d, int B, double* q, double* qdot, doub
  * number of steps that ended in "Newton diverged" / "did not converge" */
 long orc_batch_step_bdf1_ex(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads,
                             int* iters, int* halvings, int* bad);
+/* ... and, separately, the "Newton diverged" steps alone and the largest |g| a "did not converge" step of the rollout ended with
+ * (tools/max_valid_amplitude.py: which initial-state ranges the reference algorithm itself survives) */
+long orc_batch_step_bdf1_ex2(const orc_desc* d, int B, double* q, double* qdot, double h, int nsteps, int nthreads,
+                             int* iters, int* halvings, int* bad, int* diverged, double* worst_exit_g);
 
 /* ---- redmax_tensorfree.c: the tensor-free CPU baseline ("Baseline B"): the algorithm the HIP kernels
  * execute (world-frame recursive Newton-Euler + analytic derivatives), scalar C, same Newton, OpenMP over rollouts.

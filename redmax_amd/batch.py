@@ -113,6 +113,31 @@ class BatchSim:
         sh = (self.B, self.nr, self.nr)
         return M.reshape(sh).transpose(0, 2, 1), f, D.reshape(sh).transpose(0, 2, 1)      # column-major -> [b][row][col]
 
+    def compute_values(self, q, qdot, v=None, tensor=False):
+        """computeValues' full output (driverRedMaxBDF1.m:188-243) at (q, qdot), any tree size: dict with M, D, K [B][nr][nr], f [B][nr],
+        dMv (with v: column i = dMdq(:,:,i) v) and, with tensor=True, dMdq [B][nr][nr][nr] indexed [b][r][c][i]."""
+        q, qdot = self._arr(q), self._arr(qdot)
+        nr, B = self.nr, self.B
+        out = {k: np.empty((B, nr * nr)) for k in ("M", "D", "K")}
+        out["f"] = np.empty((B, nr))
+        vv = None
+        if v is not None:
+            vv = self._arr(v)
+            out["dMv"] = np.empty((B, nr * nr))
+        if tensor:
+            out["dMdq"] = np.empty((B, nr * nr * nr))
+        _abi.check(self._L.rmx_compute_values(self._batch, _abi.dptr(q), _abi.dptr(qdot), _abi.dptr(vv) if vv is not None else None,
+                                              _abi.dptr(out["M"]), _abi.dptr(out["f"]), _abi.dptr(out["D"]), _abi.dptr(out["K"]),
+                                              _abi.dptr(out["dMv"]) if vv is not None else None,
+                                              _abi.dptr(out["dMdq"]) if tensor else None), "rmx_compute_values")
+        sh = (B, nr, nr)
+        for k in ("M", "D", "K", "dMv"):
+            if k in out:
+                out[k] = out[k].reshape(sh).transpose(0, 2, 1)          # column-major -> [b][row][col]
+        if tensor:
+            out["dMdq"] = out["dMdq"].reshape((B, nr, nr, nr)).transpose(0, 3, 2, 1)    # (i, c, r) storage order -> [b][r][c][i]
+        return out
+
     # ---- stepping ----
     def _step(self, fn, nsteps, h, stats, history):
         if h is not None:

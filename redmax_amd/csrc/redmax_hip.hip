@@ -525,8 +525,8 @@ extern "C" void rmx_model_destroy(rmx_model* m) {
 extern "C" int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc) {
     if (!m || !gc || !gc->flags || !gc->sides) return fail(RMX_E_INVALID, "null argument");
     if (!(gc->kn >= 0) || !(gc->kt >= 0) || !(gc->mu >= 0) || !(gc->kd >= 0)) return fail(RMX_E_INVALID, "contact constants must be >= 0");
-    if (m->big) return fail(RMX_E_INVALID, "rmx_model_set_ground_contact: trees of more than 64 nodes have no contact kernels");
     HIPCHK(hipSetDevice(m->device));
+    const int MAXN = m->dm.stride;        // node stride of the table: rmx::MAXN, or BIG_MAXN for the one-workgroup kernels (rmx_big.hip)
     std::vector<double> con((size_t)NCON * MAXN, 0.0);
     bool any = false;
     for (int L = 0; L < m->nlist; ++L) {
@@ -724,7 +724,7 @@ extern "C" int rmx_eval(rmx_batch* b, const double* q, const double* qA, const d
 extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, double* M, double* f, double* D) {
     if (!b || !q || !qdot || !M || !f || !D) return fail(RMX_E_INVALID, "null argument");
     rmx_model* m = b->m;
-    if (m->big) return fail(RMX_E_INVALID, "rmx_eval_mfd: trees of more than 64 nodes are outside this hook");
+    if (m->big) return rmx_compute_values(b, q, qdot, nullptr, M, f, D, nullptr, nullptr, nullptr);   // no M / D kernel of their own: from H
     HIPCHK(hipSetDevice(m->device));
     if (int rc = pending_error_check(b, "rmx_eval_mfd")) return rc;
     const size_t nv = (size_t)b->B * m->nr, nn = nv * m->nr;
@@ -745,6 +745,63 @@ extern "C" int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, d
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     (void)hipFree(buf);
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_eval_mfd: ") + hipGetErrorString(e));
+    return RMX_OK;
+}
+
+// computeValues' full output from evaluations of H(eta; v) = M + dMdq v - eta D - eta^2 K at fixed (q, qdot): see include/redmax_hip.h
+extern "C" int rmx_compute_values(rmx_batch* b, const double* q, const double* qdot, const double* v, double* M, double* f, double* D,
+                                  double* K, double* dMv, double* dMdq) {
+    if (!b || !q || !qdot) return fail(RMX_E_INVALID, "null argument");
+    if (dMv && !v) return fail(RMX_E_INVALID, "rmx_compute_values: dMv needs v");
+    rmx_model* m = b->m;
+    const size_t nr = (size_t)m->nr, nv = (size_t)b->B * nr, nn = nv * nr;
+    if (nv == 0) return RMX_OK;
+    std::vector<double> qA(nv), qB(nv), g(nv), H1(nn), Mt, Dt, ft;
+    auto eval_at = [&](const double eta, const double* vv, std::vector<double>& Hout) -> int {
+        for (size_t i = 0; i < nv; ++i) {
+            qA[i] = q[i] - eta * qdot[i];
+            qB[i] = vv ? q[i] - vv[i] : q[i];
+        }
+        return rmx_eval(b, q, qA.data(), qB.data(), eta, g.data(), Hout.data());
+    };
+    if (int rc = eval_at(1.0, nullptr, H1)) return rc;           // H1 = M - D - K ; g = -f
+    if (f) for (size_t i = 0; i < nv; ++i) f[i] = -g[i];
+    if (M || D || K) {
+        if (!M) { Mt.resize(nn); M = Mt.data(); }
+        if (!D) { Dt.resize(nn); D = Dt.data(); }
+        if (!m->big) {
+            ft.resize(nv);
+            if (int rc = rmx_eval_mfd(b, q, qdot, M, ft.data(), D)) return rc;
+            if (K) for (size_t i = 0; i < nn; ++i) K[i] = (M[i] - D[i]) - H1[i];
+        } else {
+            std::vector<double> H2(nn), Hh(nn);
+            if (int rc = eval_at(2.0, nullptr, H2)) return rc;   // M - 2 D - 4 K
+            if (int rc = eval_at(0.5, nullptr, Hh)) return rc;   // M - D / 2 - K / 4
+            for (size_t i = 0; i < nn; ++i) {
+                const double k = (3.0 * H1[i] - H2[i] - 2.0 * Hh[i]) * (2.0 / 3.0);
+                const double d = (H1[i] - H2[i]) - 3.0 * k;
+                M[i] = H1[i] + d + k;
+                D[i] = d;
+                if (K) K[i] = k;
+            }
+        }
+    }
+    if (dMv) {
+        std::vector<double> Hv(nn);
+        if (int rc = eval_at(1.0, v, Hv)) return rc;
+        for (size_t i = 0; i < nn; ++i) dMv[i] = Hv[i] - H1[i];
+    }
+    if (dMdq) {
+        std::vector<double> Hk(nn), ek(nv);
+        for (size_t k = 0; k < nr; ++k) {
+            for (size_t i = 0; i < nv; ++i) ek[i] = (i % nr == k) ? 1.0 : 0.0;
+            if (int rc = eval_at(1.0, ek.data(), Hk)) return rc;
+            for (size_t t = 0; t < (size_t)b->B; ++t)
+                for (size_t i = 0; i < nr; ++i)
+                    for (size_t r = 0; r < nr; ++r)      // dMdq(r, k, i) = (dMdq(:,:,i) e_k)(r) = column i of H(e_k) - H(0)
+                        dMdq[t * nr * nr * nr + r + nr * (k + nr * i)] = Hk[t * nr * nr + i * nr + r] - H1[t * nr * nr + i * nr + r];
+        }
+    }
     return RMX_OK;
 }
 

@@ -19,6 +19,8 @@
 // contact, the adjoint, matlab-simple Euler, rmx_eval_mfd (refused by the C ABI for such models).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rmx_host.h"
 
 namespace {
@@ -34,21 +36,22 @@ struct BigWs {
     int oV[2];        // [6][ns] x 2   path sums (phi, beta)
     int oS;           // [28][ns]      body terms -> suffix sums (in place)
     int ocu;          // [6][ns]       y - z          (column i as seen from its strict ancestors)
-    int ocl;          // [12][ns]      m1, m2w, sw    (column i as seen from its strict descendants)
+    int ocl;          // [12][ns]      m1, m2w, sw    (column i as seen from its strict descendants); [18][ns] with ground contact: + m2v, sv
+    int ncl;          // 12 or 18
 };
 __host__ __device__ constexpr size_t big_ws_doubles_n(const int nr) { return (size_t)nr * nr; }
 // doubles of LDS: region X = max(E + V, scan, H if it is kept in LDS) + cu, cl
 constexpr int LU_NB = 32;             // panel width of the blocked LU (H in HBM)
-__host__ __device__ constexpr size_t big_lds_doubles(const int n, const int nr, const bool hl) {
+__host__ __device__ constexpr size_t big_lds_doubles(const int n, const int nr, const bool hl, const bool ct) {
     // region X: E + V (36 n) | the scan (28 n) | H (hl) or the LU panel [LU_NB][nr] + its U12 block [LU_NB][BT] (!hl); then cu, cl
     // (H in LDS is formed while cu, cl are read: behind them; the LU panel is only used after H is complete: over everything)
-    const size_t x0 = (size_t)36 * n;
-    if (hl) return ((size_t)nr * nr > x0 ? (size_t)nr * nr : x0) + (size_t)18 * n;
+    const size_t x0 = (size_t)36 * n, cc = (size_t)(ct ? 24 : 18) * n;
+    if (hl) return ((size_t)nr * nr > x0 ? (size_t)nr * nr : x0) + cc;
     const size_t lu = (size_t)LU_NB * nr + (size_t)LU_NB * BT;
-    return lu > x0 + (size_t)18 * n ? lu : x0 + (size_t)18 * n;
+    return lu > x0 + cc ? lu : x0 + cc;
 }
 template <bool HL>
-__device__ __forceinline__ BigWs big_ws(double* base, const int n, const int nr) {
+__device__ __forceinline__ BigWs big_ws(double* base, const int n, const int nr, const bool ct = false) {
     BigWs w;
     w.H = base;
     w.ns = n;
@@ -58,6 +61,7 @@ __device__ __forceinline__ BigWs big_ws(double* base, const int n, const int nr)
     const int xsz = (HL && nr * nr > 36 * n) ? nr * nr : 36 * n;
     w.ocu = xsz;
     w.ocl = xsz + 6 * n;
+    w.ncl = ct ? 18 : 12;
     return w;
 }
 
@@ -130,6 +134,17 @@ __device__ __forceinline__ int block_all(const bool v, const int t) {
     return r;
 }
 
+__device__ __forceinline__ int block_any(const bool v, const int t) {
+    __shared__ int sany;
+    if (t == 0) sany = 0;
+    __syncthreads();
+    if (v) sany = 1;          // benign race: every writer stores 1
+    __syncthreads();
+    const int r = sany;
+    __syncthreads();
+    return r;
+}
+
 // This node's constants: the model's arrays, or - for a node of a JointSpherical group - the variant of the group's current chart
 struct NodeConsts {
     const double* K;   int ks;     // K[r * ks], r = 0..35
@@ -158,7 +173,7 @@ struct BigOut {
 
 // evalBDF1 / computeValues for the generic implicit residual (see eval_front_e2 / eval_hess in rmx_device.h for the wavefront form and
 // oracle/redmax_tensorfree.c tf_eval for the node-by-node restatement this follows).  Thread t = node t; q, qd, v are this node's.
-template <bool WANT_H, bool HL = false>
+template <bool WANT_H, bool HL = false, bool CT = false>
 __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc, const int t, const double q, const double qd,
                          const double v, const double eta, BigOut& out) {
     const int n = M.n, NS = M.stride, LS = w.ns;      // NS: stride of the model's constant tables, LS: of the LDS rows
@@ -340,6 +355,29 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) S[25 + c] = hf[c];
+    // ---- ground contact (ForceGroundCuboid.m:54-153; contact_body in rmx_device.h, the world-frame form of DESIGN.md section 3): the
+    // wrench of this body's penetrating corners goes into w_b; its K / D blocks are formed in the Hessian part below
+    GroundC G;
+    bool con = false, touched = false;
+    double sd[3] = {0.0, 0.0, 0.0}, eVc = 0.0;
+    if constexpr (CT) {
+        con = act && M.con[tj] != 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sd[c] = M.con[(1 + c) * NS + tj];
+            G.n[c] = M.con[(4 + c) * NS + tj];
+            G.gx[c] = M.con[(7 + c) * NS + tj];
+        }
+        G.kn = M.con[10 * NS + tj];
+        G.kt = M.con[11 * NS + tj];
+        G.mu = M.con[12 * NS + tj];
+        G.kdc = M.con[13 * NS + tj];
+        double Fc[6], k1[36];
+        const bool tw = contact_body<0>(G, con, sd, R, p, phw, phv, Fc, k1, eVc);      // wave-uniform: some corner of this wave's bodies
+#pragma unroll
+        for (int c = 0; c < 6; ++c) S[c] -= e2 * Fc[c];
+        if (WANT_H) touched = block_any(tw, t) != 0;
+    }
     // energies (Body.computeEnergies, Joint.computeEnergies)
     const double stiff = act ? M.prm[1 * NS + tj] : 0.0, damp = act ? M.prm[2 * NS + tj] : 0.0;
     const double tau = act ? M.prm[0 * NS + tj] : 0.0, qRest = act ? M.prm[3 * NS + tj] : 0.0;
@@ -354,28 +392,29 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
             const double dqL = hitL * (qLimL - q), dqU = hitU * (qLimU - q);
             eV += 0.5 * stiff * (dq * dq) + 0.5 * qLimK * (dqL * dqL + dqU * dqU);
         }
-        out.eV = eV;
+        out.eV = eV + eVc;
     }
     // ---- subtree sums: suffix scan over the depth-first order (Hillis-Steele, in place: read, barrier, write), subtree(j) =
     // suffix(j) - suffix(end_j).  The region was E / V: every path product and sum is in registers by now.
-    {
+    auto subtree_sum = [&](double* X, auto ncTag) {
+        constexpr int NC = decltype(ncTag)::value;
         __syncthreads();
         if (act) {
 #pragma unroll
-            for (int c = 0; c < 28; ++c) dyn[w.oS + c * LS + t] = S[c];
+            for (int c = 0; c < NC; ++c) dyn[w.oS + c * LS + t] = X[c];
         }
         __syncthreads();
         for (int d = 1; d < n; d <<= 1) {
-            double add[28];
+            double add[NC];
             const bool on = act && t + d < n;
 #pragma unroll
-            for (int c = 0; c < 28; ++c) add[c] = on ? dyn[w.oS + c * LS + t + d] : 0.0;
+            for (int c = 0; c < NC; ++c) add[c] = on ? dyn[w.oS + c * LS + t + d] : 0.0;
             __syncthreads();
             if (act) {
 #pragma unroll
-                for (int c = 0; c < 28; ++c) {
-                    S[c] += add[c];
-                    dyn[w.oS + c * LS + t] = S[c];
+                for (int c = 0; c < NC; ++c) {
+                    X[c] += add[c];
+                    dyn[w.oS + c * LS + t] = X[c];
                 }
             }
             __syncthreads();
@@ -383,10 +422,11 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
         const int en = act ? M.end[tj] : n;
         if (en < n) {
 #pragma unroll
-            for (int c = 0; c < 28; ++c) S[c] -= dyn[w.oS + c * LS + en];
+            for (int c = 0; c < NC; ++c) X[c] -= dyn[w.oS + c * LS + en];
         }
         __syncthreads();
-    }
+    };
+    subtree_sum(S, std::integral_constant<int, 28>{});
     // ---- residual  g_j = s_j . W_j - eta^2 fr_j
     const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) + hitU * (qLimK * (qLimU - q) - qLimD * qd);
     out.g = dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
@@ -417,6 +457,53 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
         m1v[c] = sv[c] + 2.0 * eta * xiv[c] + zv[c];
         m2w[c] = eta * sw[c] + e2 * xiw[c];
     }
+    // ground contact: K / D blocks of this body at this state, summed over the subtree (36 + 21 numbers through the scan above) and
+    // folded into cxy = Dxc m2 + eta^2 Kxc s, cxr2 = Dxc' s, cxr3 = eta^2 Kxc' s (eval_hess in rmx_device.h); skipped while no
+    // corner of the tree penetrates (workgroup-uniform)
+    double cxy[6] = {0, 0, 0, 0, 0, 0}, cxr2[6] = {0, 0, 0, 0, 0, 0}, cxr3[6] = {0, 0, 0, 0, 0, 0};
+    if (CT && touched) {
+        const double s6[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
+        double m26[6], Fc[6], ev2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m26[c] = eta * sw[c] + e2 * xiw[c];
+            m26[3 + c] = eta * sv[c] + e2 * xiv[c];
+        }
+        {
+            double Kx[36];
+            contact_body<1>(G, con, sd, R, p, phw, phv, Fc, Kx, ev2);
+            subtree_sum(&Kx[0], std::integral_constant<int, 28>{});
+            subtree_sum(&Kx[28], std::integral_constant<int, 8>{});
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double ay = 0.0, a3k = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    ay += Kx[6 * r + c] * s6[c];
+                    a3k += Kx[6 * c + r] * s6[c];
+                }
+                cxy[r] = e2 * ay;
+                cxr3[r] = e2 * a3k;
+            }
+        }
+        {
+            double Dx[36];
+            contact_body<2>(G, con, sd, R, p, phw, phv, Fc, Dx, ev2);
+            subtree_sum(&Dx[0], std::integral_constant<int, 21>{});
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double ay = 0.0, a2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double drc = Dx[r <= c ? sym21(r, c) : sym21(c, r)];
+                    ay += drc * m26[c];
+                    a2 += drc * s6[c];
+                }
+                cxy[r] += ay;
+                cxr2[r] = a2;
+            }
+        }
+    }
     double yt[3], yf[3], gxs[3], kt[3];
     sym3v(IbS, m1w, yt);
     cross3(mcS, m1v, t3);
@@ -431,8 +518,8 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     cross3(mcS, gxs, kt);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        yt[c] -= a3[c] + e2 * kt[c];
-        yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c];
+        yt[c] -= a3[c] + e2 * kt[c] + cxy[c];
+        yf[c] -= 2.0 * b3[c] + e2 * mS * gxs[c] + cxy[3 + c];
     }
     double zt[3], zf[3];
     cross3(sw, Wt, a3);
@@ -444,7 +531,7 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
         zf[c] = -zf[c];
     }
     const double Hdiag = dof ? (dot3(sw, yt) + dot3(sv, yf) + eta * dd + e2 * kd) : 1.0;
-    double rl[12];          // r1, -r2w, -r3w
+    double rl[18];          // r1, -r2w, -r3w [, -cxr2(4:6), -cxr3(4:6): the ground contact's rows against m2v, sv]
     sym3v(IbS, sw, rl);
     cross3(mcS, sv, t3);
 #pragma unroll
@@ -454,11 +541,16 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     for (int c = 0; c < 3; ++c) rl[3 + c] = mS * sv[c] - t3[c];
     cross3(hfS, sv, b3);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rl[6 + c] = -(TL[c] * sw[0] + TL[3 + c] * sw[1] + TL[6 + c] * sw[2] - 2.0 * b3[c]);
+    for (int c = 0; c < 3; ++c) rl[6 + c] = -(TL[c] * sw[0] + TL[3 + c] * sw[1] + TL[6 + c] * sw[2] - 2.0 * b3[c]) - cxr2[c];
     cross3(gv, t3, a3);
     cross3(gv, sv, b3);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rl[9 + c] = -e2 * (a3[c] - mS * b3[c]);
+    for (int c = 0; c < 3; ++c) {
+        rl[9 + c] = -e2 * (a3[c] - mS * b3[c]) - cxr3[c];
+        rl[12 + c] = -cxr2[3 + c];
+        rl[15 + c] = -cxr3[3 + c];
+    }
+    const int ncl = (CT && touched) ? 18 : 12;  // workgroup-uniform (CT implies the 18-row layout: w.ncl == 18)
     if (act) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -468,6 +560,10 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
             dyn[w.ocl + (3 + c) * LS + t] = m1v[c];
             dyn[w.ocl + (6 + c) * LS + t] = m2w[c];
             dyn[w.ocl + (9 + c) * LS + t] = sw[c];
+            if (CT && touched) {
+                dyn[w.ocl + (12 + c) * LS + t] = eta * sv[c] + e2 * xiv[c];
+                dyn[w.ocl + (15 + c) * LS + t] = sv[c];
+            }
         }
     }
     __syncthreads();
@@ -491,6 +587,10 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
             } else if (i < t && t < M.end[i]) {    // strict descendant
 #pragma unroll
                 for (int c = 0; c < 12; ++c) h += rl[c] * dyn[w.ocl + c * LS + i];
+                if (CT && ncl == 18) {
+#pragma unroll
+                    for (int c = 12; c < 18; ++c) h += rl[c] * dyn[w.ocl + c * LS + i];
+                }
             }
             hput<HL>(Hw, (size_t)ki * nr + ka, h);
         }
@@ -691,7 +791,7 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
 
 // newton (driverRedMaxBDF1.m:94-157) for one implicit solve; see newton_impl (rmx_device.h) for the stall shortcut and the
 // compensated iterate x + lo.  Every decision is workgroup-uniform (norms come out of block_sum identical in all threads).
-template <bool HL>
+template <bool HL, bool CT>
 __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w, const NodeConsts& nc, const int t,
                              const int ka, double x, const double qA, const double qB, const double eta, BigOut& last, int& iters,
                              int& halvings, int& status, double& xlo) {
@@ -699,7 +799,7 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
     BigOut e;
     int iter = 1, lsfail = 0;
     while (true) {
-        { PROF_T0(); big_eval<true, HL>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(0); }
+        { PROF_T0(); big_eval<true, HL, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(0); }
         const BigOut e0 = e;
         last = e;
         ++iters;
@@ -724,7 +824,7 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
                 e = e0;
                 break;
             }
-            { PROF_T0(); big_eval<false>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(2); }
+            { PROF_T0(); big_eval<false, false, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(2); }
             gn2 = block_sum(e.g * e.g, t);
             if (0.5 * gn2 < f0) break;
             if (iterLs >= o.iterLsMax) break;
@@ -824,11 +924,11 @@ __device__ bool big_reparam(const DevModel& M, const BigWs& w, const int t, int*
 }
 
 // simLoop of driverRedMaxBDF1.m:57-91 (INTEG 1) / driverRedMaxBDF2.m:57-125 (INTEG 2), all steps inside one launch
-template <int INTEG, bool HL>
+template <int INTEG, bool HL, bool CT>
 __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts o, const StepArgs a, double* wsbase, const size_t wsstride) {
     const int t = threadIdx.x, traj = blockIdx.x;
     const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
-    const BigWs w = big_ws<HL>(wsbase + (size_t)traj * wsstride, M.n, M.nr);
+    const BigWs w = big_ws<HL>(wsbase + (size_t)traj * wsstride, M.n, M.nr, M.con != nullptr);
     const int id = (t < M.n) ? M.idx[t] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     double q = id >= 0 ? a.q[off] : 0.0;
@@ -846,18 +946,18 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
         if (INTEG == 1) {
             const double q0 = q, qd0 = qd;
             const double xg = q0 + h * qd0;
-            const double x = big_newton<HL>(M, o, w, nc, t, id, xg, q0, xg, h, last, iters, halv, status, xlo);
+            const double x = big_newton<HL, CT>(M, o, w, nc, t, id, xg, q0, xg, h, last, iters, halv, status, xlo);
             qd = ((x - q0) + xlo) / h;
             q = x;
         } else if (s == 0 && !started) {
             const double al = (2.0 - sqrt(2.0)) / 2.0;
             const double q0 = q, qd0 = qd;
-            const double qa = big_newton<HL>(M, o, w, nc, t, id, q0 + al * h * qd0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, xlo);
+            const double qa = big_newton<HL, CT>(M, o, w, nc, t, id, q0 + al * h * qd0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, xlo);
             const double qda = (qa - q0) / (al * h);
             const double x10 = qa + (1.0 - al) * h * qda;
             const double qA = q0 + (1.0 - al) * h * qda;
             const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-            const double q1 = big_newton<HL>(M, o, w, nc, t, id, x10, qA, qB, al * h, last, iters, halv, status, xlo);
+            const double q1 = big_newton<HL, CT>(M, o, w, nc, t, id, x10, qA, qB, al * h, last, iters, halv, status, xlo);
             qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
             q = q1;
             qp = q0;
@@ -867,7 +967,7 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
             const double x0 = q1 + h * qd1;
             const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
             const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-            const double q2 = big_newton<HL>(M, o, w, nc, t, id, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, xlo);
+            const double q2 = big_newton<HL, CT>(M, o, w, nc, t, id, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, xlo);
             qp = q1;
             qdp = qd1;
             qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
@@ -916,18 +1016,18 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
 }
 
 // Parity hook (rmx_eval): one residual (+ Hessian) evaluation per trajectory
-template <bool WANT_H, bool HL>
+template <bool WANT_H, bool HL, bool CT>
 __global__ void __launch_bounds__(BT) k_big_eval(const DevModel M, const double* __restrict__ q, const double* __restrict__ qA, const double* __restrict__ qB,
                                                  const double eta, double* __restrict__ g, double* __restrict__ H, const int* __restrict__ charts,
                                                  double* wsbase, const size_t wsstride) {
     const int t = threadIdx.x, traj = blockIdx.x;
-    const BigWs w = big_ws<HL>(wsbase + (size_t)traj * wsstride, M.n, M.nr);
+    const BigWs w = big_ws<HL>(wsbase + (size_t)traj * wsstride, M.n, M.nr, M.con != nullptr);
     const int id = (t < M.n) ? M.idx[t] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     const double x = id >= 0 ? q[off] : 0.0, xa = id >= 0 ? qA[off] : 0.0, xb = id >= 0 ? qB[off] : 0.0;
     const NodeConsts nc = node_consts(M, t < M.n ? t : 0, M.nsph ? charts + (size_t)traj * M.nsph : nullptr);
     BigOut e;
-    big_eval<WANT_H, HL>(M, w, nc, t, x, (x - xa) / eta, x - xb, eta, e);
+    big_eval<WANT_H, HL, CT>(M, w, nc, t, x, (x - xa) / eta, x - xb, eta, e);
     if (id >= 0) g[off] = e.g;
     if (WANT_H) {
         const size_t nn = (size_t)M.nr * M.nr;
@@ -939,12 +1039,13 @@ __global__ void __launch_bounds__(BT) k_big_eval(const DevModel M, const double*
 __global__ void __launch_bounds__(BT) k_big_energy(const DevModel M, const double* __restrict__ q, const double* __restrict__ qd, double* __restrict__ T,
                                                    double* __restrict__ V, const int* __restrict__ charts, double* wsbase, const size_t wsstride) {
     const int t = threadIdx.x, traj = blockIdx.x;
-    const BigWs w = big_ws<false>(wsbase + (size_t)traj * wsstride, M.n, M.nr);
+    const BigWs w = big_ws<false>(wsbase + (size_t)traj * wsstride, M.n, M.nr, M.con != nullptr);
     const int id = (t < M.n) ? M.idx[t] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     const NodeConsts nc = node_consts(M, t < M.n ? t : 0, M.nsph ? charts + (size_t)traj * M.nsph : nullptr);
     BigOut e;
-    big_eval<false>(M, w, nc, t, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, e);
+    if (M.con) big_eval<false, false, true>(M, w, nc, t, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, e);
+    else big_eval<false>(M, w, nc, t, id >= 0 ? q[off] : 0.0, id >= 0 ? qd[off] : 0.0, 0.0, 1.0, e);
     const double tt = block_sum(e.eT, t), vv = block_sum(e.eV, t);
     if (t == 0) {
         T[traj] = tt;
@@ -959,38 +1060,45 @@ size_t big_ws_doubles(const rmx_model* m) { return big_ws_doubles_n(m->nr); }
 // Dynamic LDS of a launch: the per-node workspace, plus H when nr x nr doubles fit the workgroup's limit next to it and ~8 KB of
 // static arrays (hl)
 static bool big_hl(const rmx_model* m) {
-    return big_lds_doubles(m->n, m->nr, true) * sizeof(double) + 8192 <= (size_t)m->lds_limit;
+    return big_lds_doubles(m->n, m->nr, true, m->dm.con != nullptr) * sizeof(double) + 8192 <= (size_t)m->lds_limit;
 }
-static size_t big_dyn_lds(const rmx_model* m, const bool hl) { return big_lds_doubles(m->n, m->nr, hl) * sizeof(double); }
+static size_t big_dyn_lds(const rmx_model* m, const bool hl) { return big_lds_doubles(m->n, m->nr, hl, m->dm.con != nullptr) * sizeof(double); }
 template <typename K>
 static void big_allow_lds(K kernel, const size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+template <int INTEG, bool HL, bool CT>
+static void big_step_launch(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a, const size_t lds) {
+    big_allow_lds(k_big_step<INTEG, HL, CT>, lds);
+    k_big_step<INTEG, HL, CT><<<dim3(b->B), dim3(BT), lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
+}
 void launch_big_step(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
-    const dim3 grid(b->B), block(BT);
-    const bool hl = big_hl(m);
+    const bool hl = big_hl(m), ct = m->dm.con != nullptr, b1 = integ == INTEG_BDF1;
     const size_t lds = big_dyn_lds(m, hl);
-    if (hl) {
-        if (integ == INTEG_BDF1) { big_allow_lds(k_big_step<1, true>, lds); k_big_step<1, true><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
-        else { big_allow_lds(k_big_step<2, true>, lds); k_big_step<2, true><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
+    if (ct) {
+        if (hl) { if (b1) big_step_launch<1, true, true>(m, b, o, a, lds); else big_step_launch<2, true, true>(m, b, o, a, lds); }
+        else { if (b1) big_step_launch<1, false, true>(m, b, o, a, lds); else big_step_launch<2, false, true>(m, b, o, a, lds); }
     } else {
-        if (integ == INTEG_BDF1) { big_allow_lds(k_big_step<1, false>, lds); k_big_step<1, false><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
-        else { big_allow_lds(k_big_step<2, false>, lds); k_big_step<2, false><<<grid, block, lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride); }
+        if (hl) { if (b1) big_step_launch<1, true, false>(m, b, o, a, lds); else big_step_launch<2, true, false>(m, b, o, a, lds); }
+        else { if (b1) big_step_launch<1, false, false>(m, b, o, a, lds); else big_step_launch<2, false, false>(m, b, o, a, lds); }
     }
 }
+template <bool WANT_H, bool HL, bool CT>
+static void big_eval_launch(const rmx_model* m, const rmx_batch* b, double eta, double* dg, double* dH, const size_t lds) {
+    big_allow_lds(k_big_eval<WANT_H, HL, CT>, lds);
+    k_big_eval<WANT_H, HL, CT><<<dim3(b->B), dim3(BT), lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+}
 void launch_big_eval(const rmx_model* m, const rmx_batch* b, bool wantH, double eta, double* dg, double* dH) {
-    const dim3 grid(b->B), block(BT);
-    const bool hl = wantH && big_hl(m);
+    const bool hl = wantH && big_hl(m), ct = m->dm.con != nullptr;
     const size_t lds = big_dyn_lds(m, hl);
-    if (hl) {
-        big_allow_lds(k_big_eval<true, true>, lds);
-        k_big_eval<true, true><<<grid, block, lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
-    } else if (wantH) {
-        big_allow_lds(k_big_eval<true, false>, lds);
-        k_big_eval<true, false><<<grid, block, lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+    if (ct) {
+        if (hl) big_eval_launch<true, true, true>(m, b, eta, dg, dH, lds);
+        else if (wantH) big_eval_launch<true, false, true>(m, b, eta, dg, dH, lds);
+        else big_eval_launch<false, false, true>(m, b, eta, dg, dH, lds);
     } else {
-        big_allow_lds(k_big_eval<false, false>, lds);
-        k_big_eval<false, false><<<grid, block, lds, b->stream>>>(m->dm, b->tmpA, b->tmpB, b->tmpC, eta, dg, dH, b->chart, b->bigws, b->bigws_stride);
+        if (hl) big_eval_launch<true, true, false>(m, b, eta, dg, dH, lds);
+        else if (wantH) big_eval_launch<true, false, false>(m, b, eta, dg, dH, lds);
+        else big_eval_launch<false, false, false>(m, b, eta, dg, dH, lds);
     }
 }
 void launch_big_energy(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {

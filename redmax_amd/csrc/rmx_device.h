@@ -139,6 +139,12 @@ __device__ __forceinline__ void sym3v(const double S[6], const double x[3], doub
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
+// v_writelane_b32: lane l of the result takes the scalar s, the other lanes keep old.  (This clang has no __builtin_amdgcn_writelane;
+// the intrinsic is reached by its IR name, so the compiler still sees an ordinary instruction and adds the wait states after a
+// v_readlane that produced s.)
+extern "C" __device__ int rmx_llvm_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int writelane_i(const int s, const int l, const int old) { return rmx_llvm_writelane_i32(s, l, old); }
+
 __device__ __forceinline__ double readlane_d(double v, int l) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, l);
@@ -2531,6 +2537,72 @@ __device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, Grow
     }
 }
 
+// The same last 16 pivots with the reciprocal of the next pivot HAND-SCHEDULED between the trailing updates of the current one.  The
+// chain readlane -> v_rcp_f64 -> 3 FMAs -> multiplier -> select is eight dependent instructions; left to the scheduler it ends up
+// behind the step's DPP FMAs (volatile asm keeps ITS order, the plain arithmetic sinks below it) and a lone wavefront then waits
+// ~10 ticks per link where an independent FMA would have issued in 6.  Here two updates sit between consecutive links
+// (__builtin_amdgcn_sched_barrier pins the order) and the multiplier of step K + 1 is formed inside step K.  Same operations on the
+// same values: bit-identical to lu_diag_tail.  l: the multiplier of step K (0 on rows that are finished), formed by the caller.
+#ifndef RMX_RCP_STAGED
+#define RMX_RCP_STAGED 0            // 1: lu_diag_tail_staged (build variants; measured before it becomes the default)
+#endif
+// The links as volatile asm (volatile asm statements keep their order, plain arithmetic does not: the scheduler moved the builtin
+// forms of these four out from between __builtin_amdgcn_sched_barrier pairs).  The wait states are the caller's business: each link
+// is placed with two VALU instructions between it and the producer of its operands (v_readlane -> SGPR use: 2, v_rcp_f64 -> use: 1).
+__device__ __forceinline__ void rcp_link0(double& r, const double piv) { asm volatile("v_rcp_f64_e32 %0, %1" : "=v"(r) : "s"(piv)); }
+__device__ __forceinline__ void rcp_link1(double& e, const double piv, const double r) { asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "s"(piv), "v"(r)); }
+__device__ __forceinline__ void rcp_link2(double& e) { asm volatile("v_fmac_f64_e32 %0, %0, %0" : "+v"(e)); }
+__device__ __forceinline__ void rcp_link3(double& r, const double e) { asm volatile("v_fmac_f64_e32 %0, %0, %1" : "+v"(r) : "v"(e)); }
+__device__ __forceinline__ void mul_link(double& l, const double a, const double r) { asm volatile("v_mul_f64 %0, %1, %2" : "=v"(l) : "v"(a), "v"(r)); }
+// the pivot out of lane L of v into a scalar pair, as volatile asm so that it keeps its place (one update behind the write of v,
+// two updates ahead of the v_rcp_f64 that reads the pair: the wait states of both hazards)
+template <int L>
+__device__ __forceinline__ double readlane_pinned(const double v) {
+    int lo, hi;
+    asm volatile("v_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4" : "=s"(lo), "=s"(hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(L));
+    return __hiloint2double(hi, lo);
+}
+template <int NP, int K>
+__device__ __forceinline__ void lu_diag_tail_staged(double (&Hrow)[NP], double& b, GrowGuard& gmax, PivGuard& pg, double piv, double rinv,
+                                                    const double l, double (&rinvs)[NP], const int lv) {
+    if constexpr (K < NP) {
+        constexpr int N = K - (NP - 16);
+        rinvs[K] = rinv;
+        gmax.see(Hrow[K] * l);
+        pg.see(piv, rinv);
+        constexpr bool LAST = K + 2 >= NP;
+        constexpr bool MORE = K + 1 < NP;
+        constexpr int NF = (NP - (K + 2) > 0 ? NP - (K + 2) : 0) + 1;      // columns K+2 .. NP-1, then the right-hand side
+        constexpr int GAP = NF >= 12 ? 2 : (NF >= 8 ? 1 : 0);              // updates between consecutive links (the last link sits in
+                                                                           // front of update 3 + 4 GAP); 0: left to the compiler
+        constexpr bool HAND = MORE && GAP > 0;
+        if constexpr (MORE) fmsub_rowbcast<N, LAST>(Hrow[K + 1], Hrow[K + 1], l);
+        if constexpr (MORE && !HAND) piv = readlane_d(Hrow[K + 1], K + 1);
+        double r = 0.0, e = 0.0, ln = 0.0;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            if constexpr (HAND) {
+                if (i == 1) piv = readlane_pinned<K + 1>(Hrow[K + 1]);
+                if (i == 3) rcp_link0(r, piv);
+                if (i == 3 + GAP) rcp_link1(e, piv, r);
+                if (i == 3 + 2 * GAP) rcp_link2(e);
+                if (i == 3 + 3 * GAP) rcp_link3(r, e);
+                if (i == 3 + 4 * GAP) mul_link(ln, Hrow[K + 1], r);
+            }
+            if (i < NF - 1) fmsub_rowbcast<N>(Hrow[K + 2 + i], Hrow[K + 2 + i], l);
+            else fmsub_rowbcast<N, LAST>(b, b, l);
+        }
+        if constexpr (HAND) {
+            rinv = r;
+        } else if constexpr (MORE) {
+            rinv = recip(piv);
+            ln = Hrow[K + 1] * rinv;
+        }
+        if constexpr (MORE) ln = (lv > K + 1) ? ln : 0.0;
+        lu_diag_tail_staged<NP, K + 1>(Hrow, b, gmax, pg, piv, rinv, ln, rinvs, lv);
+    }
+}
+
 template <int NP>
 __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, const double diag_own,
                                                     bool& ok) {
@@ -2662,6 +2734,9 @@ __device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], do
     }
 }
 
+#ifndef RMX_BACKSUB32
+#define RMX_BACKSUB32 1            // 1: back substitution without lane conditions (v_writelane capture); 0: the select form (build variants)
+#endif
 __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lane, double* sAcc, const double g, bool& ok) {
     constexpr int NP = 32;
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -2729,15 +2804,42 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
     GrowGuard gmax;
     gmax.hi = rowsA ? gmaxA.hi : gmaxB.hi;
     const double lim = rowsA ? limA : limB;
+#if RMX_RCP_STAGED
+    {
+        const double l16 = (lv > 16) ? Hrow[16] * rinv : 0.0;
+        lu_diag_tail_staged<NP, 16>(Hrow, b, gmax, pg, piv, rinv, l16, rinvs, lv);
+    }
+#else
     double rinv_own = 0.0;
     lu_diag_tail<NP, 16>(Hrow, b, gmax, pg, piv, rinv, rinvs, rinv_own, lv);
+#endif
     double dx = 0.0;
+#if RMX_BACKSUB32 == 1
+    // x_k = b_k / U_kk is formed in every lane (lane k holds it), read out of lane k into a scalar pair and written into lane k of dx
+    // (v_writelane); the update b_i -= U_ik x_k then runs on ALL lanes: a lane i >= k is finished (its b_i was consumed at step i,
+    // k descends) and what it computes from its stale b_i is never read.  5-6 issue slots per step and no lane condition, against
+    // compare + wait state + two selects for the update and another compare + two selects for the capture of dx (the compiler sank
+    // the latter into a 134-instruction select chain behind the solve).  Same products, same sums: bit-identical.
+    {
+        int dlo = 0, dhi = 0;
+#pragma unroll
+        for (int k = NP - 1; k >= 0; --k) {
+            const double t = b * rinvs[k];
+            const int slo = __builtin_amdgcn_readlane(__double2loint(t), k), shi = __builtin_amdgcn_readlane(__double2hiint(t), k);
+            dlo = writelane_i(slo, k, dlo);
+            dhi = writelane_i(shi, k, dhi);
+            if (k > 0) b = fma(-Hrow[k], __hiloint2double(shi, slo), b);
+        }
+        dx = __hiloint2double(dhi, dlo);
+    }
+#else
 #pragma unroll
     for (int k = NP - 1; k >= 0; --k) {
         const double xk = readlane_d(b, k) * rinvs[k];
         if (lv == k) dx = xk;
         if (lv < k) b -= Hrow[k] * xk;
     }
+#endif
     ok = !__any(lane < NP && gmax.bad(lim)) && pg.ok();
     RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
     if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
@@ -3239,15 +3341,126 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
     return x;
 }
 
+// The same Newton with the loop ROTATED so that the kernel holds ONE call site of the front per instantiation: the evaluation at the
+// top of the loop body is the first evaluation of the solve on entry and a line-search trial point afterwards (`ls`, wave-uniform).
+// In newton_impl the state of the front (FrontState, ~70 doubles per lane) has two producers - the evaluation before the loop and the
+// one inside the line search - and the compiler reconciles their register assignments with blocks of pure moves on the loop's edges
+// (~180 v_mov / v_accvgpr per Newton iteration of the 32-link chain kernel, 5 % of its issue slots).  Same decisions in the same
+// order, same arithmetic: the results are bit-identical.  Plain kernels only (the contact-capable ones keep newton_impl with its
+// two-point line search and the lean exit).
+#ifndef RMX_NEWTON_ROT
+#define RMX_NEWTON_ROT 1
+#endif
+template <int NP, bool PIVOT_ONLY>
+__device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
+                                             double x, const double qA, const double qB, const double eta, NodeOut& last,
+                                             int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
+    (void)sCol;
+    double Hrow[NP];
+    FrontState fs;
+    NodeOut e, e0;
+    double lo = 0.0, dx = 0.0, alpha = 1.0, f0 = 0.0, g0n2 = 0.0, x0 = x, lo0 = 0.0;
+    int iter = 1, lsfail = 0, iterLs = 1;
+    bool ls = false;
+    e0.g = e0.eT = e0.eV = 0.0;
+    while (true) {
+        eval_front<NP, true, false, false, false>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, fs);
+        const double gn2 = wave_sum(e.g * e.g);
+        if (ls) {                                        // this was a trial point of the line search (:124-138)
+            if (!(0.5 * gn2 < f0) && iterLs < o.iterLsMax) {
+                alpha *= 0.5;
+                ++iterLs;
+                two_sum(x0, fma(alpha, dx, lo0), x, lo);
+                lo *= o.comp;
+                if (__all(x == x0 && lo == lo0)) {        // see newton_impl: every further halving re-evaluates g(x0)
+                    last = e0;
+                    halvings += o.iterLsMax - 1;
+                    if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+                    break;
+                }
+                continue;
+            }
+            last = e;
+            halvings += iterLs - 1;
+            if (sqrt(gn2) < o.tol) break;
+            if (iter >= o.iterMax) {
+                status |= 2;
+                break;
+            }
+            lsfail += (0.5 * gn2 < f0) ? 0 : 1;
+            if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) {
+                status |= 2 | ST_LS_CUT;
+                break;
+            }
+            ++iter;
+        }
+        const double hdiag = eval_hess<NP, false, false, PIVOT_ONLY>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
+        e0 = e;
+        last = e;
+        ++iters;
+        if (PIVOT_ONLY) {
+            dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+        } else {
+            bool lu_ok;
+            if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
+            else if constexpr (NP == 64 && LU_SPLIT64) {
+                if constexpr (HESS_MFMA64) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
+                else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
+            }
+            else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
+            if (lu_ok) {
+                piv.streak = 0;
+            } else {             // growth guard tripped: redo this solve with partial pivoting (see newton_impl)
+                ++piv.streak;
+                status |= 16;
+                NodeOut e2;
+                eval_front<NP, true, false, false, false>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e2, fs);
+                eval_hess<NP, false, false>(M, lane, fs, Hrow, nullptr, sAcc);
+                dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+            }
+        }
+        const double dxn2 = wave_sum(dx * dx);
+        if (!(dxn2 == dxn2)) {
+            status |= 4;
+            break;
+        }
+        if (sqrt(dxn2) > o.dxMax) {
+            status |= 1;
+            break;
+        }
+        alpha = 1.0;
+        g0n2 = gn2;
+        f0 = 0.5 * g0n2;
+        x0 = x;
+        lo0 = lo;
+        iterLs = 1;
+        two_sum(x0, fma(alpha, dx, lo0), x, lo);
+        lo *= o.comp;
+        if (__all(x == x0 && lo == lo0)) {
+            last = e0;
+            halvings += o.iterLsMax - 1;
+            if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+            break;
+        }
+        ls = true;
+    }
+    xlo = lo;
+    return x;
+}
+
 template <int NP, bool CT, bool LEAN>
 __device__ __forceinline__ double newton_policy(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                                 double x, const double qA, const double qB, const double eta, NodeOut& last,
                                                 int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
+    constexpr bool ROT = RMX_NEWTON_ROT && !CT && !LEAN;
     if (o.lu_mode != 0 || piv.hold > 0) {     // wave-uniform
         if (piv.hold > 0) --piv.hold;
-        return newton_impl<NP, true, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
+        if constexpr (ROT) return newton_rot<NP, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
+        else return newton_impl<NP, true, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
     }
-    const double r = newton_impl<NP, false, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
+    double r;
+    if constexpr (ROT) r = newton_rot<NP, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
+    else r = newton_impl<NP, false, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
     pivot_policy_update(piv);
     return r;
 }

@@ -207,14 +207,101 @@ def test_big_tree_refusals():
     sim = BatchSim(sc, batch=1)
     with pytest.raises(RedMaxHipError):
         sim.step_euler(1, 1e-2)
-    with pytest.raises(RedMaxHipError):
-        sim.eval_mfd(np.zeros((1, sc.nr)), np.zeros((1, sc.nr)))
     sim.close()
-    scg = sceneChainGround(100)
-    scg.init()
-    with pytest.raises(RedMaxHipError):
-        BatchSim(scg, batch=1)
     big = sceneChain(300)
     big.init()
     with pytest.raises(RedMaxHipError):
         BatchSim(big, batch=1)
+
+
+def test_compute_values_on_a_big_tree(oracle_lib):
+    """computeValues' full output (driverRedMaxBDF1.m:188-243) for a tree of more than 64 nodes: no M / D kernel exists at that size, so
+    rmx_compute_values (and rmx_eval_mfd through it) takes M, D, K apart from H(eta; v = 0) at eta = 1, 2, 1/2 and dMdq v from one more
+    evaluation.  72-link chain against the literal oracle (its dense tensor path), relative to |M| + |D| + |K|."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChain
+    sc = sceneChain(72)
+    for j in sc.joints:                      # some joint damping and stiffness, so that D and K have more in them than the Coriolis terms
+        j.setDamping(3.0e2)
+        j.setStiffness(2.0e3)
+    sc.init()
+    B = 2
+    q, qd = syntheticStates(sc.nr, B, first=3)
+    rng = np.random.default_rng(9)
+    v = rng.standard_normal((B, sc.nr)) * 1e-2
+    sim = BatchSim(sc, batch=B)
+    out = sim.compute_values(q, qd, v=v)
+    M2, f2, D2 = sim.eval_mfd(q, qd)
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        Mo, fo, dMo, Ko, Do = o.compute_values(deriv=True)
+        scale = np.linalg.norm(Mo) + np.linalg.norm(Do) + np.linalg.norm(Ko)
+        assert np.linalg.norm(out["M"][b] - Mo) <= 1e-10 * scale and np.linalg.norm(out["f"][b] - fo) <= 1e-10 * np.linalg.norm(fo)
+        assert np.linalg.norm(out["D"][b] - Do) <= 1e-10 * scale and np.linalg.norm(out["K"][b] - Ko) <= 1e-10 * scale
+        assert np.linalg.norm(out["dMv"][b] - np.einsum("rci,c->ri", dMo, v[b])) <= 1e-10 * scale
+        assert np.array_equal(M2[b], out["M"][b]) and np.array_equal(D2[b], out["D"][b]) and np.array_equal(f2[b], out["f"][b])
+    sim.close()
+
+
+def _ground_states(sc, B, rng, depth=0.6):
+    """States of a chain over the ground with bodies IN the ground: the chain lies along x at the joints' height, so a floor just below
+    z = 0 is penetrated by the lower corners of every cuboid; random joint angles and velocities on top."""
+    q = 0.02 * rng.standard_normal((B, sc.nr))
+    qd = 0.5 * rng.standard_normal((B, sc.nr))
+    return q, qd
+
+
+def test_ground_contact_on_a_big_tree_eval(oracle_lib):
+    """ForceGroundCuboid on a tree of more than 64 nodes (the reference has no size limit, ForceGroundCuboid.m:54-153): g and H of a
+    72-link chain whose bodies penetrate a frictional floor, both friction branches, against the literal oracle."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainGround
+    sc = sceneChainGround(72, ground_z=-0.3)
+    sc.init()
+    B = 2
+    rng = np.random.default_rng(4)
+    q0, qd0 = _ground_states(sc, B, rng)
+    h = sc.h
+    q1 = q0 + h * qd0 + 1e-4 * rng.standard_normal((B, sc.nr))
+    sim = BatchSim(sc, batch=B)
+    g, H = sim.eval_residual(q1, q0, q0 + h * qd0, h)
+    o_free = oracle_lib.Oracle(dict(sc.desc(), contact=None))
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        go, Ho = o.eval_residual(q1[b], q0[b], q0[b] + h * qd0[b], h)
+        assert _rel(g[b], go) <= 1e-10 and _rel(H[b], Ho) <= 1e-10, (b, _rel(g[b], go), _rel(H[b], Ho))
+        gf, Hf = o_free.eval_residual(q1[b], q0[b], q0[b] + h * qd0[b], h)
+        assert _rel(gf, go) > 1e-3 and _rel(Hf, Ho) > 1e-6          # the contact terms really are in g and H
+    sim.close()
+
+
+@pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
+def test_ground_contact_on_a_big_tree_rollout(oracle_lib, integ):
+    """A 72-link chain dropped onto the floor, a few steps of BDF1 / BDF2 (scene 11's step) through touch-down against the literal
+    oracle: final state, Newton counts."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainGround
+    sc = sceneChainGround(72, ground_z=-0.52)
+    sc.init()
+    B = 1
+    rng = np.random.default_rng(12)
+    q = 0.01 * rng.standard_normal((B, sc.nr))
+    qd = 0.2 * rng.standard_normal((B, sc.nr))
+    nsteps = 3
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(nsteps, h=sc.h, stats=True)
+    qg, qdg = sim.get_state()
+    sim.close()
+    o = oracle_lib.Oracle(sc.desc())
+    o.set_state(q[0], qd[0])
+    st = o.step_bdf1(sc.h, nsteps) if integ == "bdf1" else o.step_bdf2(sc.h, nsteps)
+    qo, qdo = o.get_state()
+    assert (out["status"] & 15 == 0).all()
+    assert _rel(qg[0], qo) <= 1e-8 and _rel(qdg[0], qdo) <= 1e-6, (_rel(qg[0], qo), _rel(qdg[0], qdo))
+    assert abs(int(out["newton_iters"][0]) - int(st.newton_iters)) <= 1
+    of = oracle_lib.Oracle(dict(sc.desc(), contact=None))
+    of.set_state(q[0], qd[0])
+    (of.step_bdf1 if integ == "bdf1" else of.step_bdf2)(sc.h, nsteps)
+    assert _rel(of.get_state()[1], qdo) > 1e-3                 # the floor really was felt

@@ -393,3 +393,39 @@ def test_compute_values_hook_with_ground_contact(oracle_lib, name):
         touched += _rel(o_free.compute_values(deriv=True)[4], Do) > 1e-6
     assert touched >= 1                                   # the contact damping really was in D
     sim.close()
+
+
+@pytest.mark.parametrize("name", ["chain6ground", "chain8two", "11"])
+def test_compute_values_full_output_with_ground_contact(oracle_lib, name):
+    """rmx_compute_values on scenes with ForceGroundCuboid at penetrating states: K carries J' Km J and the dJdq' fm term of the contact
+    wrench (driverRedMaxBDF1.m:239-243, ForceGroundCuboid.m:104-150), both friction branches; K, D, dMv vs the oracle."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainTwoGrounds
+    if name == "11":
+        sc = scenesRedMax(11)
+    elif name == "chain8two":
+        sc = sceneChainTwoGrounds(8, ground_z=-1.0)
+    else:
+        sc = sceneChainGround(6, ground_z=-1.0)
+    sc.init()
+    B = 6
+    rng = np.random.default_rng(22)
+    _, qd, q = _penetrating_states(name, sc.nr, sc.h, B, rng)
+    v = rng.standard_normal((B, sc.nr)) * 1e-2
+    sim = BatchSim(sc, batch=B)
+    out = sim.compute_values(q, qd, v=v)
+    o_free = oracle_lib.Oracle(dict(sc.desc(), contact=None))
+    touched = 0
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        Mo, fo, dMo, Ko, Do = o.compute_values(deriv=True)
+        scale = np.linalg.norm(Mo) + np.linalg.norm(Do) + np.linalg.norm(Ko)
+        assert _rel(out["M"][b], Mo) <= 1e-11 and _rel(out["f"][b], fo) <= 1e-11
+        assert np.linalg.norm(out["D"][b] - Do) <= 1e-11 * scale
+        assert np.linalg.norm(out["K"][b] - Ko) <= 1e-10 * scale, (name, b, np.linalg.norm(out["K"][b] - Ko) / scale)
+        assert np.linalg.norm(out["dMv"][b] - np.einsum("rci,c->ri", dMo, v[b])) <= 1e-10 * scale
+        o_free.set_state(q[b], qd[b])
+        touched += _rel(o_free.compute_values(deriv=True)[3], Ko) > 1e-6
+    assert touched >= 1                                   # the contact stiffness really was in K
+    sim.close()

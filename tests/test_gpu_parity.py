@@ -477,3 +477,37 @@ def test_compute_values_hook_matches_oracle(oracle_lib, name):
         assert _rel(f[b], fo) <= 1e-11, (name, b, _rel(f[b], fo))
         assert _rel(D[b], Do) <= 1e-11 or np.linalg.norm(D[b] - Do) <= 1e-11 * np.linalg.norm(Mo), (name, b, _rel(D[b], Do))
     sim.close()
+
+
+@pytest.mark.parametrize("name", ["0", "2", "14", "chain8skew", "tree15", "chain32", "7", "9"])
+def test_compute_values_full_output_matches_oracle(oracle_lib, name):
+    """rmx_compute_values = the FULL [M, f, dMdq, K, D] of computeValues (driverRedMaxBDF1.m:188-243) vs the oracle's literal dense
+    restatement: K = df/dq and the tensor contracted with a vector (dMv: column i = dMdq(:,:,i) v, the way evalBDF1 :181-184 uses
+    it) for every scene, the whole tensor for the small ones.  The hook separates the pieces of H(eta; v) on the host, so the bar is
+    relative to the size of the largest piece (|M| + |D| + |K|), 1e-10."""
+    from redmax_amd import BatchSim
+    sc = _scene(name)
+    sc.init()
+    B = 3
+    q, qd = syntheticStates(sc.nr, B, first=11)
+    s0, sd0 = sc.getQ()
+    q, qd = q + s0, qd + sd0
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((B, sc.nr)) * 1e-2
+    small = sc.nr <= 8
+    sim = BatchSim(sc, batch=B)
+    out = sim.compute_values(q, qd, v=v, tensor=small)
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        Mo, fo, dMo, Ko, Do = o.compute_values(deriv=True)
+        scale = np.linalg.norm(Mo) + np.linalg.norm(Do) + np.linalg.norm(Ko)
+        assert _rel(out["M"][b], Mo) <= 1e-11 and _rel(out["f"][b], fo) <= 1e-11
+        assert np.linalg.norm(out["D"][b] - Do) <= 1e-11 * scale
+        assert np.linalg.norm(out["K"][b] - Ko) <= 1e-10 * scale, (name, b, np.linalg.norm(out["K"][b] - Ko) / scale)
+        dMv = np.einsum("rci,c->ri", dMo, v[b])
+        assert np.linalg.norm(out["dMv"][b] - dMv) <= 1e-10 * scale * max(np.linalg.norm(v[b]), 1.0), (name, b)
+        assert np.linalg.norm(dMv) > 0 or sc.nr == 1
+        if small:
+            assert np.linalg.norm(out["dMdq"][b] - dMo) <= 1e-10 * scale, (name, b, np.linalg.norm(out["dMdq"][b] - dMo) / scale)
+    sim.close()
