@@ -20,6 +20,7 @@ Objects on the JSON line besides the driver's contract:
   repeat                   the K-step launch repeated from the same state: median / min / max kernel time
   value_plain_iterate      the same launch with the Newton iterate in plain doubles (rmx_opts.compensated = 0), 100 steps
   value_at_survey_init     the same launch from SURVEY 8(d)'s wide initial-state ranges, 100 steps
+  value_at_max_valid_init  the same launch at the largest initial-state amplitude the reference algorithm survives (measured: 0.1856)
   value_at_tol_1e-8        the tolerance rounds 1 and 2 ran the headline at
   strong_scaling           1024 rollouts in total over the N ranks
   cpu_baseline             the literal CPU restatement of the reference (oracle) on the host cores, bounded sample
@@ -494,7 +495,7 @@ def rank_main(args, make_stepper=None, backend=None):
     comp = 0 if args.plain_iterate else 1
     burn = args.burn_in if on_gpu else 0.0         # a clock ramp is a GPU matter: the CPU stand-ins of the tests skip it
     m = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, K, W, args.repeats, comp, burn)
-    plain = strong = wide = soft = cutleg = None
+    plain = strong = wide = soft = cutleg = maxv = None
     KR = args.ref_steps
     if wl == "ground" and on_gpu and not args.no_reference_tol:
         # the opt-in straggler policy (rmx_opts.ls_fail_limit, NOT reference behaviour): same launch, Newton loop of a step cut at its
@@ -507,6 +508,9 @@ def rank_main(args, make_stepper=None, backend=None):
             plain = measure(ctx, make_stepper, scene, gen, weak, h, args.tol, integ, KR, W, 0, 0, burn)
         from redmax_amd import syntheticStates
         wide = measure(ctx, make_stepper, scene, lambda first, count: syntheticStates(scene.nr, count, first=first, sq=np.pi / 4, sv=1.0),
+                       weak, h, args.tol, integ, KR, W, 0, comp, burn)
+        from redmax_amd.scenes import MAX_VALID_INIT_AMPLITUDE as AMAX
+        maxv = measure(ctx, make_stepper, scene, lambda first, count: syntheticStates(scene.nr, count, first=first, sq=AMAX, sv=AMAX),
                        weak, h, args.tol, integ, KR, W, 0, comp, burn)
         if args.tol != 1e-8:
             soft = measure(ctx, make_stepper, scene, gen, weak, h, 1e-8, integ, K, W, 0, comp, burn)
@@ -579,6 +583,18 @@ def rank_main(args, make_stepper=None, backend=None):
                         "reference algorithm itself (oracle) prints 'Newton diverged' within a few steps on 1-2 %% of these rollouts per step, "
                         "after which a rollout is not a valid simulation (DESIGN.md 5), so the headline uses U(-0.1,0.1); this is the same "
                         "launch on the wide states, failures counted, not hidden" % KR}
+        if maxv is not None:
+            from redmax_amd.scenes import MAX_VALID_INIT_AMPLITUDE as AMAX
+            out["value_at_max_valid_init"] = {
+                "init": "q,qdot~U(-%g,%g), rng(20240+global_index); traj 0: q=0.1,qdot=0" % (AMAX, AMAX), "newton_tol": args.tol, "steps": KR,
+                "value": round(maxv["rollouts"] * KR / maxv["elapsed"], 1), "unit": "rollout-steps/s", "kernel_ms": round(maxv["kernel_ms"], 4),
+                "newton_iters_per_step": round(maxv["iters"] / (maxv["rollouts"] * KR), 3),
+                "ls_halvings_per_step": round(maxv["halvings"] / (maxv["rollouts"] * KR), 3),
+                "not_converged_or_diverged_trajectories": maxv["bad"], "all_finite": maxv["finite"],
+                "note": "the largest initial-state amplitude at which the REFERENCE ALGORITHM (literal oracle) survives all 1024 x 100 "
+                        "trajectory-steps - found, not chosen: tools/max_valid_amplitude.py bisects [0.1, pi/4] on the full batch "
+                        "(profiles/r04_max_valid_amplitude.json; 0.1963 already loses rollouts to 'Newton diverged' within 5 steps).  "
+                        "GPU vs oracle at this amplitude: tests/test_gpu_full_size.py::test_max_valid_amplitude_sample"}
         if soft is not None:
             out["value_at_tol_1e-8"] = {
                 "newton_tol": 1e-8, "steps": K, "value": round(soft["rollouts"] * K / soft["elapsed"], 1), "unit": "rollout-steps/s",

@@ -103,9 +103,9 @@ typedef struct rmx_opts {
                               0 (default) eliminate on the diagonal under a growth guard (|multiplier| <= 8, i.e. threshold
                                 pivoting with tau = 1/8) and redo the solve with full partial pivoting when the guard trips;
                               1 always full partial pivoting (the reference behaviour, ~2x slower solve).  The pivot search compares
-                                the top 26 bits of |H(a,k)| (exponent + 14 mantissa bits), lowest row first among equals: exact
-                                ties resolve as LAPACK's first maximum, candidates within 2^-14 relative of each other may be
-                                taken in another order, so results agree with dgetrf to roundoff, not bit for bit  */
+                                |H(a,k)| as full doubles, lowest row first among equals: LAPACK's first maximum (idamax in dgetf2),
+                                in every kernel of the library (ABI 108; up to ABI 107 the one-wavefront kernels compared the top 26
+                                bits only); the elimination scales by the reciprocal of the pivot, as dgetf2 does  */
     int compensated;       /* the Newton iterate of newton() (driverRedMaxBDF1.m:94-157):
                               1 (default) carried as an unevaluated sum x + xlo, |xlo| <= ulp(x)/2; xlo enters the residual where x
                                 enters linearly with large coefficients (dqtmp = q1 - q0 - h qdot0 and qdot1 = (q1 - q0)/h,

@@ -95,6 +95,12 @@ classdef HipSim < handle
 			[varargout{1:max(nargout,1)}] = redmax_hip_mex('eval', this.h, q, qA, qB, eta);
 		end
 
+		function varargout = computeValues(this, q, qdot, varargin)
+			% [M,f,K,D,dMv] = computeValues(q, qdot [, v]): the full output of the reference's computeValues (driverRedMaxBDF1.m:188-243)
+			% at (q, qdot), per rollout; dMv(:,i,b) = dMdq(:,:,i) * v(:,b)
+			[varargout{1:max(nargout,1)}] = redmax_hip_mex('values', this.h, q, qdot, varargin{:});
+		end
+
 		function [T, V] = energy(this)
 			[T, V] = redmax_hip_mex('energy', this.h);
 		end

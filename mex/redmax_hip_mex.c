@@ -409,6 +409,35 @@ static void cmd_eval(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[])
     if (nlhs > 1) plhs[1] = H;
 }
 
+/* [M,f,K,D,dMv] = redmax_hip_mex('values', h, q, qdot [, v]) - computeValues' full output (driverRedMaxBDF1.m:188-243: [M,f,dMdq,K,D])
+ * at (q, qdot): M, K, D nr x nr x B, f nr x B; with v (nr x B) also dMv, whose column i is dMdq(:,:,i) v (evalBDF1 :181-184 uses the
+ * tensor in exactly this form, v = dqtmp).  rmx_compute_values, per shard. */
+static void cmd_values(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    handle_t* h = get_handle(nrhs, prhs);
+    if (nrhs < 4) die("usage: [M,f,K,D,dMv] = redmax_hip_mex('values', h, q, qdot [, v])");
+    const double* q = state_arg(prhs[2], h, "q");
+    const double* qd = state_arg(prhs[3], h, "qdot");
+    const double* v = nrhs > 4 ? state_arg(prhs[4], h, "v") : NULL;
+    if (nlhs > 4 && !v) die("values: the fifth output dMv needs v");
+    const mwSize dims[3] = {(mwSize)h->nr, (mwSize)h->nr, (mwSize)h->B};
+    mxArray* out[5] = {NULL, NULL, NULL, NULL, NULL};
+    out[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+    out[1] = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
+    if (nlhs > 2) out[2] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+    if (nlhs > 3) out[3] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+    if (nlhs > 4) out[4] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+    for (int s = 0; s < h->nshards; ++s) {
+        size_t f;
+        rmx_batch* b = shard(h, s, &f);
+        const size_t o = f * (size_t)h->nr, oo = o * (size_t)h->nr;
+        if (rmx_compute_values(b, q + o, qd + o, v ? v + o : NULL, mxGetPr(out[0]) + oo, mxGetPr(out[1]) + o,
+                               out[3] ? mxGetPr(out[3]) + oo : NULL, out[2] ? mxGetPr(out[2]) + oo : NULL,
+                               out[4] ? mxGetPr(out[4]) + oo : NULL, NULL))
+            die_rmx("rmx_compute_values");
+    }
+    for (int i = 0; i < 5 && (i == 0 || i < nlhs); ++i) plhs[i] = out[i];
+}
+
 static void cmd_adjoint(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     handle_t* h = get_handle(nrhs, prhs);
     if (nrhs < 6) die("usage: [P,dPdp,stats] = redmax_hip_mex('adjoint', h, hstep, nsteps, task, p [, integrator])");
@@ -519,6 +548,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         cmd_euler(nlhs, plhs, nrhs, prhs);
     } else if (!strcmp(cmd, "eval")) {
         cmd_eval(nlhs, plhs, nrhs, prhs);
+    } else if (!strcmp(cmd, "values")) {
+        cmd_values(nlhs, plhs, nrhs, prhs);
     } else if (!strcmp(cmd, "energy")) {
         handle_t* h = get_handle(nrhs, prhs);
         mxArray* T = mxCreateDoubleMatrix(1, (size_t)h->B, mxREAL);

@@ -10,16 +10,28 @@
 //                                       suffix(j) - suffix(end_j)
 //   * the nr x nr Hessian             : thread = row, a loop over the columns (ancestor test j < i < end_j), column-major; in LDS
 //                                       when it fits next to the per-node rows (nr <= ~128), else in a global workspace
-//   * dx = -H\g                       : LU with partial pivoting (MATLAB mldivide, driverRedMaxBDF1.m:117; first maximum wins),
-//                                       thread = (row, column group), implicit row permutation, pivot search on wave shuffles
+//   * dx = -H\g                       : LU with partial pivoting (MATLAB mldivide, driverRedMaxBDF1.m:117; first maximum wins; the pivot
+//                                       column scaled by the reciprocal of the pivot as dgetf2 does), implicit row permutation, pivot
+//                                       search on DPP butterflies.  H in LDS: thread = (row, column group).  H in HBM (nr > ~136):
+//                                       right-looking blocked LU, 32-column panel in LDS, the rank-32 trailing update on the fp64
+//                                       MATRIX CORES (v_mfma_f64_16x16x4_f64: the one contraction of this library that is large
+//                                       enough - up to 224 x 224 x 32 per panel)
 // Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
-// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts): a 72-link chain 1.9 ms per BDF1 step, a 128-link
-// chain 5.4 ms, a 256-link chain 61 ms (H in HBM, blocked LU); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered: BDF1, BDF2
-// (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching; not covered: ground
-// contact, the adjoint, matlab-simple Euler, rmx_eval_mfd (refused by the C ABI for such models).
+// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 1.8 ms per BDF1 step, a
+// 128-link chain 5.2 ms, a 256-link chain 35 ms (62 in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
+// BDF1, BDF2 (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching, ground contact
+// (ForceGroundCuboid, CT instantiations), rmx_eval_mfd / rmx_compute_values through rmx_eval; not covered: the adjoint, matlab-simple
+// Euler (refused by the C ABI for such models).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+
+// Fused multiply-adds only where the SOURCE writes a * b + c in one expression.  hipcc's default (-ffp-contract=fast) also lets the
+// backend fuse a multiply into a later add when the product has no other use - so the residual-only instantiation of big_eval (where
+// the Hessian's consumers of a product are compiled out) rounded a few sums differently from the full one, and rmx_eval's g depended on
+// whether H was asked for (tests/test_gpu_big_trees.py::test_big_tree_eval_matches_oracle compares the two bit for bit).  These kernels
+// are bound by LDS latency, not by the FMA count.
+#pragma clang fp contract(on)
 
 #include "rmx_host.h"
 
@@ -68,7 +80,7 @@ __device__ __forceinline__ BigWs big_ws(double* base, const int n, const int nr,
 // H in LDS (HL): up to ~136 reduced DOFs the nr x nr matrix fits the CU's 160 KB next to the small static arrays, and one pivot
 // step of the LU is a few LDS round trips instead of global ones (the solve is latency-bound: thread = row, a barrier per pivot).
 // The accesses name the LDS array itself: no generic pointer into LDS is ever formed (see block_sum).
-extern __shared__ double dyn[];
+extern __shared__ __attribute__((aligned(16))) double dyn[];
 template <bool HL>
 __device__ __forceinline__ double hget(const double* __restrict__ Hg, const size_t i) {
     if constexpr (HL) return dyn[i];
@@ -94,19 +106,33 @@ __device__ __forceinline__ double block_sum(double v, const int t) {
     __syncthreads();
     return r;
 }
-// index of the largest v over the workgroup, the lowest index among equals (dgetf2's first maximum); v >= -1, NaN never wins
+// (value, index) of the largest v over the WAVEFRONT, the lowest index among equals (dgetf2's first maximum), identical in every lane;
+// v >= -1, a NaN never wins.  Butterfly inside the 16-lane rows on DPP moves, the four row winners through v_readlane: ~60 VALU
+// instructions.  (The __shfl_xor form - six dependent ds_bpermute round trips of three values - was ~1.2 k ticks of every pivot's
+// serial path.)
+__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
+    auto take = [&](const double ov, const int oi) {
+        const bool w = ov > v || (ov == v && oi < idx);
+        v = w ? ov : v;
+        idx = w ? oi : idx;
+    };
+    take(dpp_d<DPP_XOR1>(v), dpp_i<DPP_XOR1>(idx));
+    take(dpp_d<DPP_XOR2>(v), dpp_i<DPP_XOR2>(idx));
+    take(dpp_d<DPP_HALF_MIRROR>(v), dpp_i<DPP_HALF_MIRROR>(idx));
+    take(dpp_d<DPP_MIRROR>(v), dpp_i<DPP_MIRROR>(idx));
+    const double v0 = readlane_d(v, 0), v1 = readlane_d(v, 16), v2 = readlane_d(v, 32), v3 = readlane_d(v, 48);
+    const int i0 = __builtin_amdgcn_readlane(idx, 0), i1 = __builtin_amdgcn_readlane(idx, 16), i2 = __builtin_amdgcn_readlane(idx, 32),
+              i3 = __builtin_amdgcn_readlane(idx, 48);
+    v = v0; idx = i0;
+    take(v1, i1);
+    take(v2, i2);
+    take(v3, i3);
+}
+// index of the largest v over the workgroup, the lowest index among equals; v >= -1, NaN never wins
 __device__ __forceinline__ int block_argmax(double v, int idx, const int t) {
     __shared__ double sv[BT / 64];
     __shared__ int si[BT / 64];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(idx, off);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
-    }
+    wave_argmax(v, idx);
     if ((t & 63) == 0) {
         sv[t >> 6] = v;
         si[t >> 6] = idx;
@@ -551,6 +577,9 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
         rl[15 + c] = -cxr3[3 + c];
     }
     const int ncl = (CT && touched) ? 18 : 12;  // workgroup-uniform (CT implies the 18-row layout: w.ncl == 18)
+    __shared__ short s_idx[BT], s_end[BT];      // reduced index and subtree end of every node: what the column loop below asks of node i
+    s_idx[t] = act ? (short)M.idx[tj] : (short)-1;
+    s_end[t] = act ? (short)M.end[tj] : (short)0;
     if (act) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -568,7 +597,10 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     }
     __syncthreads();
     // ---- row of this node: H(a, i) = s_a . cu_i for a a strict ancestor of i, rl_a . cl_i for a strict descendant, Hdiag on the
-    // diagonal, 0 otherwise.  Depth-first order: a is a strict ancestor of i iff a < i < end_a.
+    // diagonal, 0 otherwise.  Depth-first order: a is a strict ancestor of i iff a < i < end_a.  Both products are formed for every
+    // column and the relation selects: uniform control flow, so four columns' worth of (broadcast) LDS reads are in flight at a time.
+    // The branchy form - pick the product by relation, three divergent bodies per column behind two scalar loads of idx / end - cost
+    // ~1.7 k ticks per column (in-kernel timers, tools/big_profile.py), a fifth of a Newton iteration at 128 DOFs.
     const int nr = M.nr;
     const int ka = act ? M.idx[tj] : -1;
     if (ka >= 0) {
@@ -576,23 +608,19 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
         double* __restrict__ Hw = w.H;
 #pragma unroll 4
         for (int i = 0; i < n; ++i) {
-            const int ki = M.idx[i];
-            if (ki < 0) continue;
-            double h = 0.0;
-            if (i == t) {
-                h = Hdiag;
-            } else if (t < i && i < ea) {          // this row's node is a strict ancestor of column node i
+            const int ki = s_idx[i], ei = s_end[i];
+            double hu = 0.0, hl = 0.0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) h += sw[c] * dyn[w.ocu + c * LS + i] + sv[c] * dyn[w.ocu + (3 + c) * LS + i];
-            } else if (i < t && t < M.end[i]) {    // strict descendant
+            for (int c = 0; c < 3; ++c) hu += sw[c] * dyn[w.ocu + c * LS + i] + sv[c] * dyn[w.ocu + (3 + c) * LS + i];
 #pragma unroll
-                for (int c = 0; c < 12; ++c) h += rl[c] * dyn[w.ocl + c * LS + i];
-                if (CT && ncl == 18) {
+            for (int c = 0; c < 12; ++c) hl += rl[c] * dyn[w.ocl + c * LS + i];
+            if (CT && ncl == 18) {
 #pragma unroll
-                    for (int c = 12; c < 18; ++c) h += rl[c] * dyn[w.ocl + c * LS + i];
-                }
+                for (int c = 12; c < 18; ++c) hl += rl[c] * dyn[w.ocl + c * LS + i];
             }
-            hput<HL>(Hw, (size_t)ki * nr + ka, h);
+            const bool anc = t < i && i < ea, desc = i < t && t < ei;
+            const double h = (i == t) ? Hdiag : (anc ? hu : (desc ? hl : 0.0));
+            if (ki >= 0) hput<HL>(Hw, (size_t)ki * nr + ka, h);
         }
     }
     __syncthreads();
@@ -616,14 +644,17 @@ __device__ unsigned long long g_prof[8];
 // rank-LU_NB update a(r,c) -= sum_j L(r,j) U(j,c) (L(r,:) in registers, U from LDS).  Same pivots, same operations per entry as the
 // unblocked loop up to the order of the subtractions.
 __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
     __shared__ int spiv[BT];
+    __shared__ int sused[BT];          // sused[r] != 0: row r has served as a pivot row (its multipliers are 0 from then on)
     __shared__ double b[BT];
     __shared__ double xs[BT];
     constexpr int NB = LU_NB;
     const int nr = M.nr;
     double* __restrict__ H = w.H;
-    const int oU = NB * nr;            // dyn[j * nr + r]: panel column j, row r;  dyn[oU + j * BT + c]: U12(j, c-th column of the pass)
+    const int oU = NB * nr;            // dyn[j * nr + r]: panel column j, row r;  dyn[oU + j * BT + c]: -U12(j, c-th column of the pass)
     if (ka >= 0) b[ka] = -g;
+    sused[t] = 0;
     __syncthreads();
     const int r = t;
     const bool row = r < nr;
@@ -631,8 +662,14 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
     for (int kb = 0; kb < nr; kb += NB) {
         const int nb = nr - kb < NB ? nr - kb : NB;
         PROF_T0();
-        if (row) {
-            for (int j = 0; j < nb; ++j) dyn[j * nr + r] = H[(size_t)(kb + j) * nr + r];
+        if (row) {       // all NB loads in flight (a rolled loop is NB dependent trips to L2 / HBM)
+            double pc[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < nb) pc[j] = H[(size_t)(kb + j) * nr + r];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < nb) dyn[j * nr + r] = pc[j];
         }
         __syncthreads();
         // the panel, pivot by pivot, in LDS; the multipliers stay in place
@@ -640,21 +677,42 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
             const double cand = (row && mystep < 0) ? fabs(dyn[j * nr + r]) : -1.0;
             const int pr = block_argmax(cand, r, t);
             if (t == 0) spiv[kb + j] = pr;
-            if (r == pr) mystep = kb + j;
+            if (r == pr) {
+                mystep = kb + j;
+                sused[r] = 1;
+            }
             if (row && mystep < 0) {
-                const double l = dyn[j * nr + r] / dyn[j * nr + pr];
+                const double l = dyn[j * nr + r] * recip(dyn[j * nr + pr]);      // dgetf2 scales by the reciprocal of the pivot
                 dyn[j * nr + r] = l;
-                for (int jj = j + 1; jj < nb; ++jj) dyn[jj * nr + r] -= l * dyn[jj * nr + pr];
+                // the remaining panel columns eight at a time, loads first (a rolled loop is one LDS round trip per column, ~4.5 k ticks
+                // per pivot on average: the panel was 40 % of a 256-DOF solve).  Columns past the panel go to a dummy column - the
+                // first row of the U12 staging area behind the panel, dead until the panel is done - instead of being guarded.
+                for (int j0 = j + 1; j0 < nb; j0 += 8) {       // workgroup-uniform trip count
+                    int cj[8];
+                    double pv[8], av[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cj[u] = (j0 + u < nb ? j0 + u : NB) * nr;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pv[u] = dyn[cj[u] + pr];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) av[u] = dyn[cj[u] + r];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dyn[cj[u] + r] = av[u] - l * pv[u];
+                }
                 b[r] -= l * b[pr];
             }
             __syncthreads();
         }
         if (row) {       // U (pivot rows) for the back substitution; the multipliers of the other rows are never read from H again
-            for (int j = 0; j < nb; ++j) H[(size_t)(kb + j) * nr + r] = dyn[j * nr + r];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < nb) H[(size_t)(kb + j) * nr + r] = dyn[j * nr + r];
         }
         PROF_ADD(3);
-        // trailing columns, BT per pass
-        for (int c0 = kb + nb; c0 < nr; c0 += BT) {
+        // trailing columns (BT >= nr: one pass)
+        const int c0 = kb + nb;
+        const int ncol = nr - c0;
+        if (ncol > 0) {
             PROF_T0();
             const int c = c0 + t;
             if (c < nr) {          // thread = column: U12(:, c) = L11^-1 A12(pivot rows, c)
@@ -671,53 +729,99 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
                         col[pj] = a;
                     }
                     u[j] = a;
-                    dyn[oU + j * BT + t] = a;
+                    dyn[oU + j * BT + t] = -a;
                 }
             }
             __syncthreads();
             PROF_ADD(4);
-            if (row && mystep < 0) {       // thread = row: the rank-nb update of its trailing entries
-                double L[NB];
+            // The rank-nb update A22 -= L21 U12 on the fp64 matrix cores: north_star's "MFMA when ndof is large enough to be a real
+            // contraction" - up to 224 x 224 x 32 here, against K = 6 .. 12 in the 32-DOF Hessian.  Transposed form so that a lane's four
+            // results are four COLUMNS of one row block and a load / store instruction touches 16 consecutive rows of 4 columns (H is
+            // column-major): D'(col, row) = sum_k (-U12)(k, col) L21(row, k) + A22(row, col), v_mfma_f64_16x16x4_f64 with
+            //   A operand  lane (jj, gg) -> (-U12)(k = 4 kk + gg, col = 16 nbk + jj)      from the LDS copy the pass above wrote
+            //   B operand  lane (jj, gg) -> L21(row = 16 mb + jj, k = 4 kk + gg)          the panel in LDS; 0 for rows that have been pivots
+            //   C / D      element q     -> A22(row = 16 mb + jj, col = 16 nbk + 4 q + gg)
+            // Eight MFMAs per 16 x 16 tile (K = 32); a wavefront keeps the L fragments of a row block and walks the column blocks.
+            // The sum over k runs in the same order as the scalar loop it replaces (one fused multiply-add per k).
+            {
+                const int wave = t >> 6, lane = t & 63, jj = lane & 15, gg = lane >> 4;
+                const int MB = (nr + 15) >> 4, NBK = (ncol + 15) >> 4;
+                for (int mb = wave; mb < MB; mb += BT / 64) {
+                    const int arow = 16 * mb + jj;
+                    const bool aon = arow < nr && sused[arow < nr ? arow : 0] == 0;
+                    double lf[NB / 4];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) L[j] = j < nb ? dyn[j * nr + r] : 0.0;
-                const int ncol = nr - c0 < BT ? nr - c0 : BT;
-                int cc = 0;
-                for (; cc + 7 < ncol; cc += 8) {           // eight columns in flight
-                    double a[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) a[q] = H[(size_t)(c0 + cc + q) * nr + r];
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) a[q] -= L[j] * dyn[oU + j * BT + cc + q];
+                    for (int kk = 0; kk < NB / 4; ++kk) {
+                        const int k = 4 * kk + gg;
+                        lf[kk] = (aon && k < nb) ? dyn[k * nr + arow] : 0.0;
                     }
+                    v4d cn;                   // C of the tile about to be worked on, fetched one tile ahead
+                    size_t adn[4];
+                    bool okn[4];
+                    auto fetch = [&](const int nbk) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) H[(size_t)(c0 + cc + q) * nr + r] = a[q];
-                }
-                for (; cc < ncol; ++cc) {
-                    double a = H[(size_t)(c0 + cc) * nr + r];
+                        for (int q = 0; q < 4; ++q) {
+                            const int cc = 16 * nbk + 4 * q + gg;
+                            okn[q] = cc < ncol && arow < nr;
+                            adn[q] = (size_t)(c0 + (cc < ncol ? cc : 0)) * nr + (arow < nr ? arow : 0);
+                            cn[q] = okn[q] ? H[adn[q]] : 0.0;
+                        }
+                    };
+                    fetch(0);
+                    for (int nbk = 0; nbk < NBK; ++nbk) {
+                        const int cj = 16 * nbk + jj;                    // this lane's column of the A operand
+                        v4d acc = cn;
+                        size_t ad[4];
+                        bool ok[4];
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) a -= L[j] * dyn[oU + j * BT + cc];
-                    H[(size_t)(c0 + cc) * nr + r] = a;
+                        for (int q = 0; q < 4; ++q) {
+                            ad[q] = adn[q];
+                            ok[q] = okn[q];
+                        }
+                        double uf[NB / 4];
+#pragma unroll
+                        for (int kk = 0; kk < NB / 4; ++kk) {
+                            const int k = 4 * kk + gg;
+                            uf[kk] = (cj < ncol && k < nb) ? dyn[oU + k * BT + cj] : 0.0;
+                        }
+                        if (nbk + 1 < NBK) fetch(nbk + 1);               // in flight underneath the eight MFMAs
+#pragma unroll
+                        for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[kk], lf[kk], acc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (ok[q]) H[ad[q]] = acc[q];
+                    }
                 }
             }
             __syncthreads();
             PROF_ADD(5);
         }
     }
-    // back substitution on the implicitly permuted upper triangle
+    // back substitution on the implicitly permuted upper triangle.  x_k = b(p_k) / U(p_k, k) is formed by EVERY thread from two broadcast
+    // reads (the reciprocals of the pivots come from one parallel pass), so a step is one barrier instead of two and no thread waits for
+    // the pivot row's owner; the column entries U(r, k) of eight steps are fetched together (each step used to wait for its own trip to
+    // L2 / HBM).
     PROF_T0();
-    for (int k = nr - 1; k >= 0; --k) {
-        const int pr = spiv[k];
-        if (r == pr) xs[k] = b[r] / H[(size_t)k * nr + r];
-        __syncthreads();
-        if (row && mystep < k) b[r] -= H[(size_t)k * nr + r] * xs[k];
-        __syncthreads();
+    if (row) xs[r] = recip(H[(size_t)r * nr + spiv[r]]);          // 1 / U(p_k, k), k = r
+    __syncthreads();
+    double dxr = 0.0;
+    for (int k0 = nr - 1; k0 >= 0; k0 -= 8) {
+        double u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = (row && k0 - i >= 0) ? H[(size_t)(k0 - i) * nr + r] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 - i;
+            if (k >= 0) {        // workgroup-uniform
+                const double xk = b[spiv[k]] * xs[k];
+                if (k == ka) dxr = xk;
+                if (row && mystep < k) b[r] -= u[i] * xk;
+                __syncthreads();
+            }
+        }
     }
     PROF_ADD(6);
-    const double dx = ka >= 0 ? xs[ka] : 0.0;
-    __syncthreads();
-    return dx;
+    return dxr;
 }
 
 template <bool HL>
@@ -744,7 +848,7 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
         if (t == 0) spiv[k] = pr;
         if (r == pr) mystep = k;
         if (row && mystep < 0) {
-            const double l = hget<HL>(H, ck + r) / hget<HL>(H, ck + pr);
+            const double l = hget<HL>(H, ck + r) * recip(hget<HL>(H, ck + pr));      // dgetf2 scales by the reciprocal of the pivot
             int c = k + 1 + cg;
             // UF columns in flight (loads first, then the stores): 4 when H is in LDS, 16 when every access is a trip to HBM / L2
             constexpr int UF = HL ? 4 : 16;
@@ -776,17 +880,17 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
         }
         __syncthreads();
     }
-    // back substitution on the implicitly permuted upper triangle
+    // back substitution on the implicitly permuted upper triangle (one barrier per step: see big_solve_blocked)
+    if (t < nr) xs[t] = recip(hget<HL>(H, (size_t)t * nr + spiv[t]));
+    __syncthreads();
+    double dxr = 0.0;
     for (int k = nr - 1; k >= 0; --k) {
-        const int pr = spiv[k];
-        if (cg == 0 && r == pr) xs[k] = b[r] / hget<HL>(H, (size_t)k * nr + r);
-        __syncthreads();
-        if (row && cg == 0 && mystep < k) b[r] -= hget<HL>(H, (size_t)k * nr + r) * xs[k];
+        const double xk = b[spiv[k]] * xs[k];
+        if (k == ka) dxr = xk;
+        if (row && cg == 0 && mystep < k) b[r] -= hget<HL>(H, (size_t)k * nr + r) * xk;
         __syncthreads();
     }
-    const double dx = ka >= 0 ? xs[ka] : 0.0;
-    __syncthreads();
-    return dx;
+    return dxr;
 }
 
 // newton (driverRedMaxBDF1.m:94-157) for one implicit solve; see newton_impl (rmx_device.h) for the stall shortcut and the
@@ -1060,7 +1164,7 @@ size_t big_ws_doubles(const rmx_model* m) { return big_ws_doubles_n(m->nr); }
 // Dynamic LDS of a launch: the per-node workspace, plus H when nr x nr doubles fit the workgroup's limit next to it and ~8 KB of
 // static arrays (hl)
 static bool big_hl(const rmx_model* m) {
-    return big_lds_doubles(m->n, m->nr, true, m->dm.con != nullptr) * sizeof(double) + 8192 <= (size_t)m->lds_limit;
+    return big_lds_doubles(m->n, m->nr, true, m->dm.con != nullptr) * sizeof(double) + 8192 <= (size_t)m->lds_limit;      // the kernels hold 6.1 - 7.1 KB of static LDS
 }
 static size_t big_dyn_lds(const rmx_model* m, const bool hl) { return big_lds_doubles(m->n, m->nr, hl, m->dm.con != nullptr) * sizeof(double); }
 template <typename K>

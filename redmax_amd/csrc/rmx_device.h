@@ -232,6 +232,21 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_d<DPP_MIRROR>(v);
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
+// the same for a vector that is zero on the lanes past the padded tree size NP (residuals, Newton updates: idle lanes carry exact
+// zeros): only the 16-lane rows that can hold something are read out.  x + 0 = x, so the sum has the bits of wave_sum.
+template <int NP>
+__device__ __forceinline__ double wave_sum_np(double v) {
+    if constexpr (NP > 32) {
+        return wave_sum(v);
+    } else {
+        v += dpp_d<DPP_XOR1>(v);
+        v += dpp_d<DPP_XOR2>(v);
+        v += dpp_d<DPP_HALF_MIRROR>(v);
+        v += dpp_d<DPP_MIRROR>(v);
+        if constexpr (NP > 16) return readlane_d(v, 0) + readlane_d(v, 16);
+        else return readlane_d(v, 0);
+    }
+}
 __device__ __forceinline__ unsigned wave_umax(unsigned v) {
     unsigned t;
     t = (unsigned)dpp_i<DPP_XOR1>((int)v); v = t > v ? t : v;
@@ -2463,6 +2478,9 @@ __device__ __forceinline__ bool sph_reparam(const DevModel& M, double* __restric
 // raw multipliers are large for scaling reasons only.  If any step violates the guard (or is NaN) `ok` comes back false and
 // the caller redoes the solve with full partial pivoting (lu_solve_neg) on a re-assembled H: pivoting semantics are kept,
 // its cost is paid only when needed.
+#ifndef RMX_BACKSUB32
+#define RMX_BACKSUB32 1            // 1: back substitution without lane conditions (v_writelane capture); 0: the select form (build variants)
+#endif
 constexpr double LU_GROWTH_MAX = 8.0;
 constexpr int LU_BATCH = 8;
 // The positive-pivot half of the guard: every pivot must be positive, finite and non-zero.  It is tested on the reciprocals, which
@@ -2537,72 +2555,6 @@ __device__ __forceinline__ void lu_diag_tail(double (&Hrow)[NP], double& b, Grow
     }
 }
 
-// The same last 16 pivots with the reciprocal of the next pivot HAND-SCHEDULED between the trailing updates of the current one.  The
-// chain readlane -> v_rcp_f64 -> 3 FMAs -> multiplier -> select is eight dependent instructions; left to the scheduler it ends up
-// behind the step's DPP FMAs (volatile asm keeps ITS order, the plain arithmetic sinks below it) and a lone wavefront then waits
-// ~10 ticks per link where an independent FMA would have issued in 6.  Here two updates sit between consecutive links
-// (__builtin_amdgcn_sched_barrier pins the order) and the multiplier of step K + 1 is formed inside step K.  Same operations on the
-// same values: bit-identical to lu_diag_tail.  l: the multiplier of step K (0 on rows that are finished), formed by the caller.
-#ifndef RMX_RCP_STAGED
-#define RMX_RCP_STAGED 0            // 1: lu_diag_tail_staged (build variants; measured before it becomes the default)
-#endif
-// The links as volatile asm (volatile asm statements keep their order, plain arithmetic does not: the scheduler moved the builtin
-// forms of these four out from between __builtin_amdgcn_sched_barrier pairs).  The wait states are the caller's business: each link
-// is placed with two VALU instructions between it and the producer of its operands (v_readlane -> SGPR use: 2, v_rcp_f64 -> use: 1).
-__device__ __forceinline__ void rcp_link0(double& r, const double piv) { asm volatile("v_rcp_f64_e32 %0, %1" : "=v"(r) : "s"(piv)); }
-__device__ __forceinline__ void rcp_link1(double& e, const double piv, const double r) { asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(e) : "s"(piv), "v"(r)); }
-__device__ __forceinline__ void rcp_link2(double& e) { asm volatile("v_fmac_f64_e32 %0, %0, %0" : "+v"(e)); }
-__device__ __forceinline__ void rcp_link3(double& r, const double e) { asm volatile("v_fmac_f64_e32 %0, %0, %1" : "+v"(r) : "v"(e)); }
-__device__ __forceinline__ void mul_link(double& l, const double a, const double r) { asm volatile("v_mul_f64 %0, %1, %2" : "=v"(l) : "v"(a), "v"(r)); }
-// the pivot out of lane L of v into a scalar pair, as volatile asm so that it keeps its place (one update behind the write of v,
-// two updates ahead of the v_rcp_f64 that reads the pair: the wait states of both hazards)
-template <int L>
-__device__ __forceinline__ double readlane_pinned(const double v) {
-    int lo, hi;
-    asm volatile("v_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4" : "=s"(lo), "=s"(hi) : "v"(__double2loint(v)), "v"(__double2hiint(v)), "n"(L));
-    return __hiloint2double(hi, lo);
-}
-template <int NP, int K>
-__device__ __forceinline__ void lu_diag_tail_staged(double (&Hrow)[NP], double& b, GrowGuard& gmax, PivGuard& pg, double piv, double rinv,
-                                                    const double l, double (&rinvs)[NP], const int lv) {
-    if constexpr (K < NP) {
-        constexpr int N = K - (NP - 16);
-        rinvs[K] = rinv;
-        gmax.see(Hrow[K] * l);
-        pg.see(piv, rinv);
-        constexpr bool LAST = K + 2 >= NP;
-        constexpr bool MORE = K + 1 < NP;
-        constexpr int NF = (NP - (K + 2) > 0 ? NP - (K + 2) : 0) + 1;      // columns K+2 .. NP-1, then the right-hand side
-        constexpr int GAP = NF >= 12 ? 2 : (NF >= 8 ? 1 : 0);              // updates between consecutive links (the last link sits in
-                                                                           // front of update 3 + 4 GAP); 0: left to the compiler
-        constexpr bool HAND = MORE && GAP > 0;
-        if constexpr (MORE) fmsub_rowbcast<N, LAST>(Hrow[K + 1], Hrow[K + 1], l);
-        if constexpr (MORE && !HAND) piv = readlane_d(Hrow[K + 1], K + 1);
-        double r = 0.0, e = 0.0, ln = 0.0;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            if constexpr (HAND) {
-                if (i == 1) piv = readlane_pinned<K + 1>(Hrow[K + 1]);
-                if (i == 3) rcp_link0(r, piv);
-                if (i == 3 + GAP) rcp_link1(e, piv, r);
-                if (i == 3 + 2 * GAP) rcp_link2(e);
-                if (i == 3 + 3 * GAP) rcp_link3(r, e);
-                if (i == 3 + 4 * GAP) mul_link(ln, Hrow[K + 1], r);
-            }
-            if (i < NF - 1) fmsub_rowbcast<N>(Hrow[K + 2 + i], Hrow[K + 2 + i], l);
-            else fmsub_rowbcast<N, LAST>(b, b, l);
-        }
-        if constexpr (HAND) {
-            rinv = r;
-        } else if constexpr (MORE) {
-            rinv = recip(piv);
-            ln = Hrow[K + 1] * rinv;
-        }
-        if constexpr (MORE) ln = (lv > K + 1) ? ln : 0.0;
-        lu_diag_tail_staged<NP, K + 1>(Hrow, b, gmax, pg, piv, rinv, ln, rinvs, lv);
-    }
-}
-
 template <int NP>
 __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hrow)[NP], const double g, const double diag_own,
                                                     bool& ok) {
@@ -2670,13 +2622,27 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
     }
     if constexpr (KTAIL < NP) lu_diag_tail<NP, KTAIL>(Hrow, b, gmax, pg, piv, rinv, rinvs, rinv_own, lv);
     double dx = 0.0;
+    if constexpr (KEEP_ALL && RMX_BACKSUB32 == 1) {
+        // without lane conditions: see lu_solve_neg_diag32 (x_k written into lane k of dx, the update on all lanes)
+        int dlo = 0, dhi = 0;
 #pragma unroll
-    for (int k = NP - 1; k >= 0; --k) {
-        double xk;
-        if constexpr (KEEP_ALL) xk = readlane_d(b, k) * rinvs[k];
-        else xk = readlane_d(b * rinv_own, k);
-        if (lv == k) dx = xk;
-        if (lv < k) b -= Hrow[k] * xk;
+        for (int k = NP - 1; k >= 0; --k) {
+            const double t = b * rinvs[k];
+            const int slo = __builtin_amdgcn_readlane(__double2loint(t), k), shi = __builtin_amdgcn_readlane(__double2hiint(t), k);
+            dlo = writelane_i(slo, k, dlo);
+            dhi = writelane_i(shi, k, dhi);
+            if (k > 0) b = fma(-Hrow[k], __hiloint2double(shi, slo), b);
+        }
+        dx = __hiloint2double(dhi, dlo);
+    } else {
+#pragma unroll
+        for (int k = NP - 1; k >= 0; --k) {
+            double xk;
+            if constexpr (KEEP_ALL) xk = readlane_d(b, k) * rinvs[k];
+            else xk = readlane_d(b * rinv_own, k);
+            if (lv == k) dx = xk;
+            if (lv < k) b -= Hrow[k] * xk;
+        }
     }
     // lanes beyond the padded size may carry mirrored rows (eval_hess ZERO_IDLE = false): their guard is ignored
     ok = !__any(lane < NP && gmax.bad(lim)) && pg.ok();
@@ -2692,6 +2658,9 @@ __device__ __forceinline__ double lu_solve_neg_diag(const int lane, double (&Hro
 // return through LDS to row-per-lane (lane = row), which is exactly the state lu_solve_neg_diag has after 16 pivots: the last
 // 16 pivots (lu_diag_tail) and the back substitution are shared.  Same operations on the same values in the same order
 // per matrix entry: the results are bit-identical to lu_solve_neg_diag.
+#ifndef RMX_P1_BFIRST
+#define RMX_P1_BFIRST 1
+#endif
 template <int K>
 __device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], double (&B)[16], double (&BX)[4], double& bA,
                                             double& bB, GrowGuard& gmaxA, GrowGuard& gmaxB, PivGuard& pg, double& piv, double& rinv,
@@ -2708,13 +2677,41 @@ __device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], do
         gmaxA.pin();
         gmaxB.pin();
         pg.pin();
+#if RMX_P1_BFIRST
+        // Order inside a step: every update of set B (rows 16..31) reads the pivot row out of a set-A register (lane K, which the
+        // step's own set-A update leaves unchanged: its multiplier is 0), so B goes FIRST and A second.  With A first, each B
+        // update followed the asm statement that had just written its source register, and the compiler - which cannot see into
+        // the asm - put a wait state between every such pair (gfx950's conservative forwarding hazard for inline asm): ~4 s_nop
+        // per pivot, each a full issue slot of the lone wavefront.  The arithmetic per entry is the same either way.
         if constexpr (K + 1 < 16) {
             // the pivot columns are replicated in the four DPP rows: the next pivot is lane K + 1 of the lane's own row, one
             // v_mov_b64_dpp instead of two v_readlane plus the wait states of the scalar round trip (the reciprocal's operand)
+            fmsub_rowbcast<K>(B[K + 1], A[K + 1], lB);
             fmsub_rowbcast<K>(A[K + 1], A[K + 1], lA);
             piv = row_bcast<K + 1>(A[K + 1]);
             rinv = recip(piv);
         } else {                       // pivot 16 is row 16 (set B of lane 0), column 16 (first extra column of DPP row 0)
+            fmsub_rowbcast<K>(BX[0], AX[0], lB);
+            piv = readlane_d(BX[0], 0);
+            rinv = recip(piv);
+        }
+#pragma unroll
+        for (int c = K + 2; c < 16; ++c) fmsub_rowbcast<K>(B[c], A[c], lB);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (K + 1 < 16 || c > 0) fmsub_rowbcast<K>(BX[c], AX[c], lB);
+        fmsub_rowbcast<K>(bB, bA, lB);
+#pragma unroll
+        for (int c = K + 2; c < 16; ++c) fmsub_rowbcast<K>(A[c], A[c], lA);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fmsub_rowbcast<K>(AX[c], AX[c], lA);
+        fmsub_rowbcast<K>(bA, bA, lA);
+#else      // the order of rounds 1-3 (build variants)
+        if constexpr (K + 1 < 16) {
+            fmsub_rowbcast<K>(A[K + 1], A[K + 1], lA);
+            piv = row_bcast<K + 1>(A[K + 1]);
+            rinv = recip(piv);
+        } else {
             fmsub_rowbcast<K>(BX[0], AX[0], lB);
             piv = readlane_d(BX[0], 0);
             rinv = recip(piv);
@@ -2730,13 +2727,11 @@ __device__ __forceinline__ void lu32_phase1(double (&A)[16], double (&AX)[4], do
         }
         fmsub_rowbcast<K>(bB, bA, lB);
         fmsub_rowbcast<K>(bA, bA, lA);
+#endif
         lu32_phase1<K + 1>(A, AX, B, BX, bA, bB, gmaxA, gmaxB, pg, piv, rinv, rinvs, jv);
     }
 }
 
-#ifndef RMX_BACKSUB32
-#define RMX_BACKSUB32 1            // 1: back substitution without lane conditions (v_writelane capture); 0: the select form (build variants)
-#endif
 __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lane, double* sAcc, const double g, bool& ok) {
     constexpr int NP = 32;
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -2804,15 +2799,8 @@ __device__ __forceinline__ double lu_solve_neg_diag32(const int n, const int lan
     GrowGuard gmax;
     gmax.hi = rowsA ? gmaxA.hi : gmaxB.hi;
     const double lim = rowsA ? limA : limB;
-#if RMX_RCP_STAGED
-    {
-        const double l16 = (lv > 16) ? Hrow[16] * rinv : 0.0;
-        lu_diag_tail_staged<NP, 16>(Hrow, b, gmax, pg, piv, rinv, l16, rinvs, lv);
-    }
-#else
     double rinv_own = 0.0;
     lu_diag_tail<NP, 16>(Hrow, b, gmax, pg, piv, rinv, rinvs, rinv_own, lv);
-#endif
     double dx = 0.0;
 #if RMX_BACKSUB32 == 1
     // x_k = b_k / U_kk is formed in every lane (lane k holds it), read out of lane k into a scalar pair and written into lane k of dx
@@ -3076,15 +3064,21 @@ __device__ __forceinline__ double lu_solve_neg(const int n, const int lane, doub
     for (int k = 0; k < NP; ++k) {
         // every lane inverts its own candidate while the search runs (off the critical path)
         const double rinv_mine = recip(Hrow[k]);
-        // pivot search: max |H(a,k)| over unused rows.  The key is the top 26 bits of |H(a,k)| (exponent + 14 mantissa bits)
-        // with 63 - lane below it: candidates that agree to ~2^-14 relative count as equal and the LOWEST row wins, which is
-        // LAPACK's first-maximum rule for exact ties (dgetf2/idamax behind MATLAB's mldivide, driverRedMaxBDF1.m:117); rows
-        // whose magnitudes differ by less than 2^-14 may be taken in another order than LAPACK would (same growth bound up to
-        // that factor; stated in redmax_hip.h and DESIGN.md)
-        unsigned key = 0u;
-        if (pivstep < 0) key = ((unsigned)(__double2hiint(Hrow[k]) & 0x7fffffff) & ~63u) + 64u + (63u - (unsigned)lane);
+        // pivot search: max |H(a,k)| over unused rows on the FULL double, the lowest row among equals: LAPACK's first maximum (idamax in
+        // dgetf2 behind MATLAB's mldivide, driverRedMaxBDF1.m:117), the rule the large-tree kernels (rmx_big.hip) apply as well.  Three
+        // integer reductions: the high words of |H| (order-preserving for non-negative doubles), then the low words of the lanes that
+        // tie there, then the lane.  (Up to round 3 one reduction compared the top 26 bits only: rows closer than 2^-14 could be taken
+        // in another order than LAPACK's.)
+        const bool cand = pivstep < 0;
+        const unsigned hiw = (unsigned)__double2hiint(Hrow[k]) & 0x7fffffffu, low = (unsigned)__double2loint(Hrow[k]);
+        const unsigned k1 = cand ? (hiw | 0x80000000u) : 0u;
+        const unsigned m1 = (NP <= 32) ? wave_umax32(k1) : wave_umax(k1);
+        const bool t1 = cand && k1 == m1;
+        const unsigned k2 = t1 ? low : 0u;
+        const unsigned m2 = (NP <= 32) ? wave_umax32(k2) : wave_umax(k2);
+        unsigned key = (t1 && low == m2) ? (64u - (unsigned)lane) : 0u;      // lanes 0..63 -> 64..1: the lowest lane has the largest key
         key = (NP <= 32) ? wave_umax32(key) : wave_umax(key);
-        const int pl = 63 - (int)(key & 63u);
+        const int pl = 64 - (int)key;
         const double rinv = readlane_d(rinv_mine, pl);
         const bool elim = pivstep < 0 && lane != pl;
         if (lane == pl) {
@@ -3365,7 +3359,7 @@ __device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o
     e0.g = e0.eT = e0.eV = 0.0;
     while (true) {
         eval_front<NP, true, false, false, false>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, fs);
-        const double gn2 = wave_sum(e.g * e.g);
+        const double gn2 = wave_sum_np<NP>(e.g * e.g);
         if (ls) {                                        // this was a trial point of the line search (:124-138)
             if (!(0.5 * gn2 < f0) && iterLs < o.iterLsMax) {
                 alpha *= 0.5;
@@ -3419,7 +3413,7 @@ __device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o
                 dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
             }
         }
-        const double dxn2 = wave_sum(dx * dx);
+        const double dxn2 = wave_sum_np<NP>(dx * dx);
         if (!(dxn2 == dxn2)) {
             status |= 4;
             break;

@@ -381,6 +381,12 @@ def sceneTree(n=64):
     return scene
 
 
+# The largest a for which the reference algorithm itself (literal oracle, the reference's Newton constants) survives all 1024 x 100
+# trajectory-steps of the 32-link chain from q, qdot ~ U(-a, a): tools/max_valid_amplitude.py, profiles/r04_max_valid_amplitude.json
+# (0.1963 already loses rollouts to "Newton diverged" within 5 steps).  bench.py's side leg value_at_max_valid_init runs there.
+MAX_VALID_INIT_AMPLITUDE = 0.1856
+
+
 def syntheticStates(nr, batch, first=0, sq=0.1, sv=0.1):
     """Synthetic initial states of the benchmark configs: trajectory b has q~U(-sq,sq)^nr, qdot~U(-sv,sv)^nr
     from numpy.random.default_rng(20240+b); trajectory 0 is the deterministic state q=0.1, qdot=0 used in

@@ -218,7 +218,7 @@ def test_compute_values_on_a_big_tree(oracle_lib):
     """computeValues' full output (driverRedMaxBDF1.m:188-243) for a tree of more than 64 nodes: no M / D kernel exists at that size, so
     rmx_compute_values (and rmx_eval_mfd through it) takes M, D, K apart from H(eta; v = 0) at eta = 1, 2, 1/2 and dMdq v from one more
     evaluation.  72-link chain against the literal oracle (its dense tensor path), relative to |M| + |D| + |K|."""
-    from redmax_amd import BatchSim
+    from redmax_amd import BatchSim, syntheticStates
     from redmax_amd.scenes import sceneChain
     sc = sceneChain(72)
     for j in sc.joints:                      # some joint damping and stiffness, so that D and K have more in them than the Coriolis terms

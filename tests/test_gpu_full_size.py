@@ -196,3 +196,31 @@ def test_tree64_global_constants_kernels(oracle_lib, monkeypatch):
         st = o.step_bdf1(1e-2, K)
         qo, _ = o.get_state()
         assert _rel(qb[b], qo) <= 1e-8 and int(ob["newton_iters"][b]) == st.newton_iters
+
+
+def test_max_valid_amplitude_sample(oracle_lib):
+    """The headline workload at the LARGEST initial-state amplitude the reference algorithm survives (q, qdot ~ U(-0.1856, 0.1856):
+    found by tools/max_valid_amplitude.py on the literal oracle, profiles/r04_max_valid_amplitude.json): 1024 rollouts x 100 BDF1
+    steps on the GPU - no rollout diverges -, and a 64-rollout sample of the same batch against the literal oracle over the whole
+    rollout: final q to 1e-8 (SURVEY.md 8(d)'s rollout tolerance)."""
+    import os
+    from redmax_amd import BatchSim, sceneChain, syntheticStates
+    from redmax_amd.scenes import MAX_VALID_INIT_AMPLITUDE as A
+    sc = sceneChain(32)
+    sc.init()
+    B, K, NS = 1024, 100, 64
+    q, qd = syntheticStates(sc.nr, B, sq=A, sv=A)
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(K, h=sc.h, stats=True)
+    qg, qdg = sim.get_state()
+    sim.close()
+    assert np.isfinite(qg).all() and (out["status"] & 1 == 0).all()            # nothing diverged
+    assert (out["status"] & 15 != 0).mean() <= 0.01                              # the compensated iterate converges (nearly) everywhere
+    idx = np.linspace(0, B - 1, NS).astype(int)
+    qo, qdo = np.ascontiguousarray(q[idx]), np.ascontiguousarray(qd[idx])
+    oracle_lib.set_newton()
+    cnt = oracle_lib.batch_step_bdf1(sc.desc(), qo, qdo, sc.h, K, nthreads=os.cpu_count(), counters=True)
+    assert int(cnt["diverged"].sum()) == 0 and float(cnt["worst_exit_g"].max()) < 1e-6
+    eq = np.linalg.norm(qg[idx] - qo, axis=1) / np.linalg.norm(qo, axis=1)
+    assert eq.max() <= 1e-8, eq.max()

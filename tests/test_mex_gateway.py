@@ -265,12 +265,20 @@ def test_batched_eval_and_state_layout_through_the_gateway(gw, oracle_lib):
     q2, qd2 = gw.call(2, "get", h)
     assert np.array_equal(q2, q.T) and np.array_equal(qd2, qd.T)
     g, H = gw.call(2, "eval", h, q.T, q.T, (q + sc.h * qd).T, sc.h)
+    v = 1e-2 * np.random.default_rng(8).standard_normal((B, sc.nr))
+    M, f, K, D, dMv = gw.call(5, "values", h, q.T, qd.T, v.T)          # computeValues' full output through the gateway
     gw.call(0, "destroy", h)
     for b in range(B):
         o = oracle_lib.Oracle(sc.desc())
         go, Ho = o.eval_bdf1(q[b], q[b], qd[b], sc.h)
         assert np.linalg.norm(g[:, b] - go) <= 1e-11 * np.linalg.norm(go)
         assert np.linalg.norm(H[:, :, b] - Ho) <= 1e-11 * np.linalg.norm(Ho)
+        o.set_state(q[b], qd[b])
+        Mo, fo, dMo, Ko, Do = o.compute_values(deriv=True)
+        scale = np.linalg.norm(Mo) + np.linalg.norm(Do) + np.linalg.norm(Ko)
+        assert np.linalg.norm(M[:, :, b] - Mo) <= 1e-11 * scale and np.linalg.norm(f[:, b] - fo) <= 1e-11 * np.linalg.norm(fo)
+        assert np.linalg.norm(K[:, :, b] - Ko) <= 1e-10 * scale and np.linalg.norm(D[:, :, b] - Do) <= 1e-11 * scale
+        assert np.linalg.norm(dMv[:, :, b] - np.einsum("rci,c->ri", dMo, v[b])) <= 1e-10 * scale
 
 
 @pytest.mark.gpu
