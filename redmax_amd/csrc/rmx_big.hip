@@ -647,6 +647,8 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
     typedef double v4d __attribute__((ext_vector_type(4)));
     __shared__ int spiv[BT];
     __shared__ int sused[BT];          // sused[r] != 0: row r has served as a pivot row (its multipliers are 0 from then on)
+    __shared__ double spv[2][BT / 64];  // per-wavefront pivot candidates of the next panel column
+    __shared__ int spi[2][BT / 64];
     __shared__ double b[BT];
     __shared__ double xs[BT];
     constexpr int NB = LU_NB;
@@ -672,22 +674,49 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
                 if (j < nb) dyn[j * nr + r] = pc[j];
         }
         __syncthreads();
-        // the panel, pivot by pivot, in LDS; the multipliers stay in place
+        // The panel, pivot by pivot, in LDS; the multipliers stay in place.  ONE barrier per pivot: the search for pivot j + 1 rides inside
+        // step j - its column is updated first, every wavefront reduces its rows' candidates on DPP butterflies while the remaining
+        // panel columns are being updated, and the four per-wavefront winners cross in LDS (double-buffered by the parity of j) at the
+        // barrier that ends the step.  (Search, two barriers, then update and a third barrier: 4.6 k ticks per pivot for ~600 ticks of
+        // work, in-kernel timers.)  Same candidates, same comparisons (|a|, lowest row among equals), same multipliers.
+        {
+            double cv = (row && mystep < 0) ? fabs(dyn[r]) : -1.0;
+            int ci = r;
+            wave_argmax(cv, ci);
+            if ((t & 63) == 0) { spv[0][t >> 6] = cv; spi[0][t >> 6] = ci; }
+        }
+        __syncthreads();
         for (int j = 0; j < nb; ++j) {
-            const double cand = (row && mystep < 0) ? fabs(dyn[j * nr + r]) : -1.0;
-            const int pr = block_argmax(cand, r, t);
+            const int par = j & 1;
+            double bv = spv[par][0];
+            int pr = spi[par][0];
+#pragma unroll
+            for (int q = 1; q < BT / 64; ++q)
+                if (spv[par][q] > bv || (spv[par][q] == bv && spi[par][q] < pr)) { bv = spv[par][q]; pr = spi[par][q]; }
             if (t == 0) spiv[kb + j] = pr;
             if (r == pr) {
                 mystep = kb + j;
                 sused[r] = 1;
             }
-            if (row && mystep < 0) {
-                const double l = dyn[j * nr + r] * recip(dyn[j * nr + pr]);      // dgetf2 scales by the reciprocal of the pivot
+            const bool elim = row && mystep < 0;
+            double l = 0.0, cv = -1.0;
+            int ci = r;
+            if (elim) {
+                l = dyn[j * nr + r] * recip(dyn[j * nr + pr]);      // dgetf2 scales by the reciprocal of the pivot
                 dyn[j * nr + r] = l;
-                // the remaining panel columns eight at a time, loads first (a rolled loop is one LDS round trip per column, ~4.5 k ticks
-                // per pivot on average: the panel was 40 % of a 256-DOF solve).  Columns past the panel go to a dummy column - the
-                // first row of the U12 staging area behind the panel, dead until the panel is done - instead of being guarded.
-                for (int j0 = j + 1; j0 < nb; j0 += 8) {       // workgroup-uniform trip count
+                if (j + 1 < nb) {                                  // the look-ahead column and this row's candidate for pivot j + 1
+                    const double a1 = dyn[(j + 1) * nr + r] - l * dyn[(j + 1) * nr + pr];
+                    dyn[(j + 1) * nr + r] = a1;
+                    cv = fabs(a1);
+                }
+            }
+            wave_argmax(cv, ci);                                   // every lane takes part (finished rows and idle threads carry -1)
+            if ((t & 63) == 0) { spv[par ^ 1][t >> 6] = cv; spi[par ^ 1][t >> 6] = ci; }
+            if (elim) {
+                // the remaining panel columns eight at a time, loads first (a rolled loop is one LDS round trip per column).  Columns past
+                // the panel go to a dummy column - the first row of the U12 staging area behind the panel, dead until the panel is done -
+                // instead of being guarded.
+                for (int j0 = j + 2; j0 < nb; j0 += 8) {       // workgroup-uniform trip count
                     int cj[8];
                     double pv[8], av[8];
 #pragma unroll

@@ -41,7 +41,8 @@ def test_default_workload_line():
     assert r["algorithmic_equiv_tflops"] > r["achieved"]
     # round 4: the lane-honest fraction (flops of the scalar algorithm, tests/flop_count.py) beside the 64-lane one
     assert 0 < r["useful_frac"] < r["frac"] and "calibration_stale" not in r
-    assert d["value_without_rollout_0"]["value"] > d["value"]
+    if d["rollout_ms"]["slowest_rollout"] == 0:       # reported when the launch ends with rollout 0 (it does over 100 steps; a short --steps
+        assert d["value_without_rollout_0"]["value"] > d["value"]      # window can end with another rollout)
     # round 3: the headline runs the reference's own tol; the side measurements run the reference's 100 steps whatever --steps is
     assert d["config"]["newton_tol"] == 1e-9 == d["config"]["reference_newton_tol"]
     t = d["value_plain_iterate"]
