@@ -167,6 +167,37 @@ def test_chain72_bdf2_matches_literal_oracle(oracle_lib):
     assert abs(int(out["newton_iters"][0]) - st.newton_iters) <= 1
 
 
+def test_chain72_bdf1_rollout_matches_literal_oracle(oracle_lib):
+    """The BDF1 rollout of a tree of more than 64 nodes against the LITERAL oracle (the tensor-free code of the test above is the
+    kernels' own algorithm): 72-link chain, 6 steps of the reference's simLoop, 2 rollouts, per-step energies, final state, Newton
+    counts.  tol = 1e-7 on both sides as in the BDF2 test below (the lattice of doubles at 1e-9 on a 720 cm chain)."""
+    from redmax_amd import BatchSim, syntheticStates
+    from redmax_amd.scenes import sceneChain
+    sc = sceneChain(72)
+    sc.init()
+    B, K, tol = 2, 6, 1e-7
+    q, qd = syntheticStates(sc.nr, B, first=40)
+    sim = BatchSim(sc, batch=B)
+    sim.opts.tol = tol
+    sim.set_state(q, qd)
+    out = sim.step_bdf1(K, h=sc.h, stats=True, history=True)
+    qg, qdg = sim.get_state()
+    sim.close()
+    oracle_lib.set_newton(tol=tol)
+    try:
+        for b in range(B):
+            o = oracle_lib.Oracle(sc.desc())
+            o.set_state(q[b], qd[b])
+            st, To, Vo = o.step_bdf1(sc.h, K, history=True)
+            qo, qdo = o.get_state()
+            assert st.diverged == 0 and st.not_converged == 0 and out["status"][b] & 15 == 0
+            assert _rel(qg[b], qo) <= 1e-8 and _rel(qdg[b], qdo) <= 1e-6, (b, _rel(qg[b], qo), _rel(qdg[b], qdo))
+            assert np.abs(out["T"][:, b] + out["V"][:, b] - To - Vo).max() <= 1e-8 * (np.abs(To + Vo).max() + 1.0)
+            assert abs(int(out["newton_iters"][b]) - st.newton_iters) <= 2
+    finally:
+        oracle_lib.set_newton()
+
+
 @pytest.mark.parametrize("integ", ["bdf1", "bdf2"])
 def test_free_bodies_rollout_matches_oracle(oracle_lib, integ):
     """20 free-flying bodies (JointFree3D: 121 nodes after lowering, 20 Euler-chart groups), fast spins so that charts switch inside
