@@ -12,13 +12,14 @@
 //                                       when it fits next to the per-node rows (nr <= ~128), else in a global workspace
 //   * dx = -H\g                       : LU with partial pivoting (MATLAB mldivide, driverRedMaxBDF1.m:117; first maximum wins; the pivot
 //                                       column scaled by the reciprocal of the pivot as dgetf2 does), implicit row permutation, pivot
-//                                       search on DPP butterflies.  H in LDS: thread = (row, column group).  H in HBM (nr > ~136):
-//                                       right-looking blocked LU, 32-column panel in LDS, the rank-32 trailing update on the fp64
-//                                       MATRIX CORES (v_mfma_f64_16x16x4_f64: the one contraction of this library that is large
-//                                       enough - up to 224 x 224 x 32 per panel)
+//                                       search on DPP butterflies.  H in LDS below 100 DOFs: unblocked, thread = (row, column group).
+//                                       Above: right-looking blocked LU (H in LDS: 16-column panels in place; H in HBM, nr > ~136:
+//                                       32-column panel copied into LDS), the rank-16 / rank-32 trailing update on the fp64 MATRIX
+//                                       CORES (v_mfma_f64_16x16x4_f64: the one contraction of this library that is large enough -
+//                                       up to 224 x 224 x 32 per panel)
 // Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
-// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 1.8 ms per BDF1 step, a
-// 128-link chain 5.2 ms, a 256-link chain 35 ms (62 in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
+// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 1.6 ms per BDF1 step, a
+// 128-link chain 4.4 ms, a 256-link chain 34 ms (1.9 / 5.4 / 62 in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
 // BDF1, BDF2 (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching, ground contact
 // (ForceGroundCuboid, CT instantiations), rmx_eval_mfd / rmx_compute_values through rmx_eval; not covered: the adjoint, matlab-simple
 // Euler (refused by the C ABI for such models).
@@ -643,6 +644,7 @@ __device__ unsigned long long g_prof[8];
 // forward-substituted (thread = column, U12 kept in LDS), and the trailing matrix is read and written ONCE per panel with the
 // rank-LU_NB update a(r,c) -= sum_j L(r,j) U(j,c) (L(r,:) in registers, U from LDS).  Same pivots, same operations per entry as the
 // unblocked loop up to the order of the subtractions.
+template <bool HL>
 __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     __shared__ int spiv[BT];
@@ -651,10 +653,16 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
     __shared__ int spi[2][BT / 64];
     __shared__ double b[BT];
     __shared__ double xs[BT];
-    constexpr int NB = LU_NB;
+    // H in HBM: a 32-column panel is copied into LDS (dyn[j * nr + r]) and -U12 staged behind it.  H in LDS (HL): the panel is 16 columns
+    // of H IN PLACE, -U12 is staged where the Hessian's column vectors were (cu, cl: dead once H is complete; 16 nr + nr <= 18 n doubles).
+    constexpr int NB = HL ? 16 : LU_NB;
     const int nr = M.nr;
     double* __restrict__ H = w.H;
-    const int oU = NB * nr;            // dyn[j * nr + r]: panel column j, row r;  dyn[oU + j * BT + c]: -U12(j, c-th column of the pass)
+    const int oU = HL ? w.ocu : NB * nr;        // dyn[oU + j * sU + c]: -U12(j, c-th trailing column)
+    const int sU = HL ? nr : BT;
+    const int odummy = HL ? oU + NB * nr : NB * nr;     // where the panel update's accesses past the panel go (one column of nr doubles)
+    auto HR = [&](const size_t i) -> double { if constexpr (HL) return dyn[i]; else return H[i]; };
+    auto HW = [&](const size_t i, const double v) { if constexpr (HL) dyn[i] = v; else H[i] = v; };
     if (ka >= 0) b[ka] = -g;
     sused[t] = 0;
     __syncthreads();
@@ -663,24 +671,27 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
     int mystep = -1;
     for (int kb = 0; kb < nr; kb += NB) {
         const int nb = nr - kb < NB ? nr - kb : NB;
+        const int pb = HL ? kb * nr : 0;            // panel column j, row r: dyn[pb + j * nr + r]
         PROF_T0();
-        if (row) {       // all NB loads in flight (a rolled loop is NB dependent trips to L2 / HBM)
-            double pc[NB];
+        if constexpr (!HL) {
+            if (row) {       // all NB loads in flight (a rolled loop is NB dependent trips to L2 / HBM)
+                double pc[NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-                if (j < nb) pc[j] = H[(size_t)(kb + j) * nr + r];
+                for (int j = 0; j < NB; ++j)
+                    if (j < nb) pc[j] = H[(size_t)(kb + j) * nr + r];
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-                if (j < nb) dyn[j * nr + r] = pc[j];
+                for (int j = 0; j < NB; ++j)
+                    if (j < nb) dyn[j * nr + r] = pc[j];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // The panel, pivot by pivot, in LDS; the multipliers stay in place.  ONE barrier per pivot: the search for pivot j + 1 rides inside
         // step j - its column is updated first, every wavefront reduces its rows' candidates on DPP butterflies while the remaining
         // panel columns are being updated, and the four per-wavefront winners cross in LDS (double-buffered by the parity of j) at the
         // barrier that ends the step.  (Search, two barriers, then update and a third barrier: 4.6 k ticks per pivot for ~600 ticks of
         // work, in-kernel timers.)  Same candidates, same comparisons (|a|, lowest row among equals), same multipliers.
         {
-            double cv = (row && mystep < 0) ? fabs(dyn[r]) : -1.0;
+            double cv = (row && mystep < 0) ? fabs(dyn[pb + r]) : -1.0;
             int ci = r;
             wave_argmax(cv, ci);
             if ((t & 63) == 0) { spv[0][t >> 6] = cv; spi[0][t >> 6] = ci; }
@@ -702,11 +713,11 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
             double l = 0.0, cv = -1.0;
             int ci = r;
             if (elim) {
-                l = dyn[j * nr + r] * recip(dyn[j * nr + pr]);      // dgetf2 scales by the reciprocal of the pivot
-                dyn[j * nr + r] = l;
+                l = dyn[pb + j * nr + r] * recip(dyn[pb + j * nr + pr]);      // dgetf2 scales by the reciprocal of the pivot
+                dyn[pb + j * nr + r] = l;
                 if (j + 1 < nb) {                                  // the look-ahead column and this row's candidate for pivot j + 1
-                    const double a1 = dyn[(j + 1) * nr + r] - l * dyn[(j + 1) * nr + pr];
-                    dyn[(j + 1) * nr + r] = a1;
+                    const double a1 = dyn[pb + (j + 1) * nr + r] - l * dyn[pb + (j + 1) * nr + pr];
+                    dyn[pb + (j + 1) * nr + r] = a1;
                     cv = fabs(a1);
                 }
             }
@@ -720,7 +731,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
                     int cj[8];
                     double pv[8], av[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) cj[u] = (j0 + u < nb ? j0 + u : NB) * nr;
+                    for (int u = 0; u < 8; ++u) cj[u] = j0 + u < nb ? pb + (j0 + u) * nr : odummy;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) pv[u] = dyn[cj[u] + pr];
 #pragma unroll
@@ -732,10 +743,12 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
             }
             __syncthreads();
         }
-        if (row) {       // U (pivot rows) for the back substitution; the multipliers of the other rows are never read from H again
+        if constexpr (!HL) {
+            if (row) {   // U (pivot rows) for the back substitution; the multipliers of the other rows are never read from H again
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-                if (j < nb) H[(size_t)(kb + j) * nr + r] = dyn[j * nr + r];
+                for (int j = 0; j < NB; ++j)
+                    if (j < nb) H[(size_t)(kb + j) * nr + r] = dyn[j * nr + r];
+            }
         }
         PROF_ADD(3);
         // trailing columns (BT >= nr: one pass)
@@ -746,19 +759,19 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
             const int c = c0 + t;
             if (c < nr) {          // thread = column: U12(:, c) = L11^-1 A12(pivot rows, c)
                 double u[NB];
-                double* col = H + (size_t)c * nr;
+                const size_t col = (size_t)c * nr;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     double a = 0.0;
                     if (j < nb) {
                         const int pj = spiv[kb + j];
-                        a = col[pj];
+                        a = HR(col + pj);
 #pragma unroll
-                        for (int i = 0; i < j; ++i) a -= dyn[i * nr + pj] * u[i];
-                        col[pj] = a;
+                        for (int i = 0; i < j; ++i) a -= dyn[pb + i * nr + pj] * u[i];
+                        HW(col + pj, a);
                     }
                     u[j] = a;
-                    dyn[oU + j * BT + t] = -a;
+                    dyn[oU + j * sU + t] = -a;
                 }
             }
             __syncthreads();
@@ -782,7 +795,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
 #pragma unroll
                     for (int kk = 0; kk < NB / 4; ++kk) {
                         const int k = 4 * kk + gg;
-                        lf[kk] = (aon && k < nb) ? dyn[k * nr + arow] : 0.0;
+                        lf[kk] = (aon && k < nb) ? dyn[pb + k * nr + arow] : 0.0;
                     }
                     v4d cn;                   // C of the tile about to be worked on, fetched one tile ahead
                     size_t adn[4];
@@ -793,7 +806,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
                             const int cc = 16 * nbk + 4 * q + gg;
                             okn[q] = cc < ncol && arow < nr;
                             adn[q] = (size_t)(c0 + (cc < ncol ? cc : 0)) * nr + (arow < nr ? arow : 0);
-                            cn[q] = okn[q] ? H[adn[q]] : 0.0;
+                            cn[q] = okn[q] ? HR(adn[q]) : 0.0;
                         }
                     };
                     fetch(0);
@@ -811,14 +824,14 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
 #pragma unroll
                         for (int kk = 0; kk < NB / 4; ++kk) {
                             const int k = 4 * kk + gg;
-                            uf[kk] = (cj < ncol && k < nb) ? dyn[oU + k * BT + cj] : 0.0;
+                            uf[kk] = (cj < ncol && k < nb) ? dyn[oU + k * sU + cj] : 0.0;
                         }
                         if (nbk + 1 < NBK) fetch(nbk + 1);               // in flight underneath the eight MFMAs
 #pragma unroll
                         for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[kk], lf[kk], acc, 0, 0, 0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (ok[q]) H[ad[q]] = acc[q];
+                            if (ok[q]) HW(ad[q], acc[q]);
                     }
                 }
             }
@@ -831,13 +844,13 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
     // the pivot row's owner; the column entries U(r, k) of eight steps are fetched together (each step used to wait for its own trip to
     // L2 / HBM).
     PROF_T0();
-    if (row) xs[r] = recip(H[(size_t)r * nr + spiv[r]]);          // 1 / U(p_k, k), k = r
+    if (row) xs[r] = recip(HR((size_t)r * nr + spiv[r]));         // 1 / U(p_k, k), k = r
     __syncthreads();
     double dxr = 0.0;
     for (int k0 = nr - 1; k0 >= 0; k0 -= 8) {
         double u[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = (row && k0 - i >= 0) ? H[(size_t)(k0 - i) * nr + r] : 0.0;
+        for (int i = 0; i < 8; ++i) u[i] = (row && k0 - i >= 0) ? HR((size_t)(k0 - i) * nr + r) : 0.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = k0 - i;
@@ -855,7 +868,14 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
 
 template <bool HL>
 __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
-    if constexpr (!HL) return big_solve_blocked(M, w, t, ka, g);
+    if constexpr (!HL) return big_solve_blocked<false>(M, w, t, ka, g);
+    // H in LDS: from ~100 DOFs up the blocked form (16-column panels in place, trailing update on the matrix cores) is ahead - the
+    // unblocked update below moves the whole trailing matrix through LDS once per pivot, 1.5 k clocks of LDS bandwidth at 128 DOFs;
+    // below that the per-column cost of a panel (~3 k ticks of serial search / reciprocal / look-ahead) outweighs it (72 DOFs:
+    // 1.57 vs 1.77 ms per step; 128: 4.63 vs 4.40; profiles/r04u_*)
+    if constexpr (HL) {
+        if (M.nr >= 100) return big_solve_blocked<true>(M, w, t, ka, g);       // workgroup-uniform
+    }
     __shared__ int spiv[BT];         // pivot row of step k
     __shared__ double b[BT];         // right-hand side, reduced order
     __shared__ double xs[BT];        // solution, reduced order
