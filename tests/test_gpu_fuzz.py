@@ -133,3 +133,34 @@ def test_random_tree_matches_oracle(oracle_lib, seed):
             assert list(charts[b]) == list(oo.charts())
             assert np.linalg.norm(qg[b] - qo) <= 1e-7 * np.linalg.norm(qo) + 1e-9, (seed, integ, b)
     sim.close()
+
+
+@pytest.mark.parametrize("seed", [100, 103, 105, 107, 110, 111, 200, 201])
+def test_random_tree_compute_values(oracle_lib, seed):
+    """rmx_compute_values on the random trees above (every joint class, joint springs / dampers / limits, ground contact on the
+    seeds with seed % 4 == 3 and on 201, 33..62 nodes from 200 on): the full [M, f, dMdq v, K, D] of computeValues
+    (driverRedMaxBDF1.m:188-243) against the oracle's literal dense path, relative to |M| + |D| + |K|."""
+    from redmax_amd import BatchSim
+    sc = _random_scene(seed, contact=(seed % 4 == 3) or seed == 201, big=seed >= 200)
+    nr = sc.nr
+    rng = np.random.default_rng(seed + 2000)
+    B = 2
+    q = np.tile(sc.getQ()[0], (B, 1)) + rng.uniform(-0.05, 0.05, (B, nr))
+    qd = np.tile(sc.getQ()[1], (B, 1)) + rng.uniform(-0.2, 0.2, (B, nr))
+    v = 1e-2 * rng.standard_normal((B, nr))
+    sim = BatchSim(sc, batch=B)
+    out = sim.compute_values(q, qd, v=v)
+    charts = sim.charts()
+    for b in range(B):
+        o = oracle_lib.Oracle(sc.desc())
+        if len(charts[b]):
+            o.set_charts(list(charts[b]))
+        o.set_state(q[b], qd[b])
+        Mo, fo, dMo, Ko, Do = o.compute_values(deriv=True)
+        scale = np.linalg.norm(Mo) + np.linalg.norm(Do) + np.linalg.norm(Ko)
+        assert np.linalg.norm(out["M"][b] - Mo) <= 1e-10 * scale, (seed, b)
+        assert np.linalg.norm(out["f"][b] - fo) <= 1e-10 * max(np.linalg.norm(fo), 1.0), (seed, b)
+        assert np.linalg.norm(out["D"][b] - Do) <= 1e-10 * scale, (seed, b)
+        assert np.linalg.norm(out["K"][b] - Ko) <= 1e-9 * scale, (seed, b, np.linalg.norm(out["K"][b] - Ko) / scale)
+        assert np.linalg.norm(out["dMv"][b] - np.einsum("rci,c->ri", dMo, v[b])) <= 1e-9 * scale, (seed, b)
+    sim.close()
