@@ -1,6 +1,11 @@
 """Development aid: in-kernel phase timers of the large-tree kernels (rmx_big.hip built with -DRMX_BIG_PROFILE, linked as
 redmax_amd/variants/libredmax_hip_bigprof.so): s_memtime ticks of block 0 in the evaluations, the solve and its parts, per launch.
-    python tools/big_profile.py [links ...]"""
+    python tools/big_profile.py [links ...]
+
+Building the variant (after __graft_entry__.build(), which leaves the other objects in build/):
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iredmax_amd/csrc -DRMX_BIG_PROFILE -c -o build/variants/rmx_big_bigprof.o redmax_amd/csrc/rmx_big.hip
+    hipcc --offload-arch=gfx950 -fPIC -shared -o redmax_amd/variants/libredmax_hip_bigprof.so $(ls build/*.o | grep -v rmx_big.o) build/variants/rmx_big_bigprof.o
+RMX_PROFILE_LIB=<name> picks another redmax_amd/variants/libredmax_hip_<name>.so."""
 import os
 import subprocess
 import sys
