@@ -1624,6 +1624,147 @@ __device__ __forceinline__ void eval_MD(const DevModel& M, const int lane, const
     }
 }
 
+// M and D of a tree of up to 32 nodes on the fp64 matrix cores, for the adjoint's per-step history (k_adjoint_fwd<32>): the same four
+// masked products eval_MD forms column by column with v_readlane broadcasts (24 scalar pairs + ~40 FMAs per column, 2.8 k issue slots
+// per step and 0.2 - 1.1 KB of scratch in the 32-lane forward kernels),
+//     M(a,i) = [a anc i] s_a . r1_i + [a desc i] r1_a . s_i                                   r1 = Ic s
+//     D(a,i) = [a anc i] s_a . yD_i + [a desc i] (r2w_a . sw_i - 2 r1_a . xi_i)               yD = Bc s - 2 Ic xi, r2w = (Bc' s)_w
+// as 2 x 2 tiles of v_mfma_f64_16x16x4_f64 with the operands staged in LDS in [k][node] order (eval_hess's scheme: a row of the
+// staging area serves as A operand - lane (j, g) -> A[row 16 t + j][k 4 kk + g] - and as B operand alike), 27 MFMAs.  The results are
+// stored to the history straight from the MFMA layout (lane (j, g), element r: row 16 mb + 4 r + g, column 16 nb + j), column-major
+// [i * n + a] as the backward sweep reads them; nothing returns to row-per-lane.  Ends with sAcc handed back to the front.
+__device__ __forceinline__ void eval_MD_mfma32_store(const DevModel& M, const int lane, const FrontState& fs, double* __restrict__ sAcc,
+                                                     double* __restrict__ Mk, double* __restrict__ Dk) {
+    constexpr int NP = 32, CS = cstride(NP), ST = HM_OP_STRIDE;
+    constexpr int R_S = 0, R_R1 = 8, R_YD = 16, R_R2 = 24, R_M2 = 32, R_XI = 40, R_MD = 48, R_DD = 49;
+    static_assert(R_DD + 1 <= HM_ROWS, "operand rows");
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int n = M.n;
+    const double mS = fs.S[6];
+    const double* mcS = &fs.S[7];
+    const double* IbS = &fs.S[10];
+    const double* TL = &fs.S[16];
+    const double* hfS = &fs.S[25];
+    double r1[6], ix[6], yD[6], r2w[3], t3[3], b3[3];
+    sym3v(IbS, fs.sw, r1);                    // r1 = Ic s
+    cross3(mcS, fs.sv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1[c] += t3[c];
+    cross3(mcS, fs.sw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r1[3 + c] = mS * fs.sv[c] - t3[c];
+    sym3v(IbS, fs.xiw, ix);                   // ix = Ic xi
+    cross3(mcS, fs.xiv, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ix[c] += t3[c];
+    cross3(mcS, fs.xiw, t3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ix[3 + c] = mS * fs.xiv[c] - t3[c];
+    mat3v(TL, fs.sw, yD);                     // Bc s = [TL sw ; 2 hf x sw]
+    cross3(hfS, fs.sw, b3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        yD[c] -= 2.0 * ix[c];
+        yD[3 + c] = 2.0 * b3[c] - 2.0 * ix[3 + c];
+    }
+    cross3(hfS, fs.sv, b3);                   // r2w = (Bc' s)_w = TL' sw - 2 hf x sv
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r2w[c] = TL[c] * fs.sw[0] + TL[3 + c] * fs.sw[1] + TL[6 + c] * fs.sw[2] - 2.0 * b3[c];
+    const double sr1 = fs.sw[0] * r1[0] + fs.sw[1] * r1[1] + fs.sw[2] * r1[2] + fs.sv[0] * r1[3] + fs.sv[1] * r1[4] + fs.sv[2] * r1[5];
+    const double syD = fs.sw[0] * yD[0] + fs.sw[1] * yD[1] + fs.sw[2] * yD[2] + fs.sv[0] * yD[3] + fs.sv[1] * yD[4] + fs.sv[2] * yD[5];
+    double* sOp = sAcc;
+    if (lane < NP) {      // idle node slots n .. NP-1 carry s = 0, hence all-zero vectors by arithmetic
+        double* o = sOp + lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o[(R_S + c) * ST] = fs.sw[c];
+            o[(R_S + 3 + c) * ST] = fs.sv[c];
+            o[(R_R2 + c) * ST] = r2w[c];
+            o[(R_R2 + 3 + c) * ST] = 0.0;
+            o[(R_XI + c) * ST] = fs.xiw[c];
+            o[(R_XI + 3 + c) * ST] = fs.xiv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            o[(R_R1 + c) * ST] = r1[c];
+            o[(R_YD + c) * ST] = yD[c];
+            o[(R_M2 + c) * ST] = -2.0 * r1[c];
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {         // K = 6 -> 8: two zero rows per operand
+            o[(8 * b + 6) * ST] = 0.0;
+            o[(8 * b + 7) * ST] = 0.0;
+        }
+        o[R_MD * ST] = fs.dof ? sr1 : 1.0;
+        o[R_DD * ST] = fs.dof ? (syD - fs.dd) : 0.0;
+    }
+    RMX_SYNC();
+    const int g = lane >> 4, j = lane & 15;
+    v4d mu[2][2], ml[2][2], du[2][2], dl[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) mu[mb][nb] = ml[mb][nb] = du[mb][nb] = dl[mb][nb] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        double as[2], ar1[2], ar2[2], am2[2], bs[2], br1[2], byd[2], bxi[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int col = 16 * t + j, k = 4 * kk + g;
+            as[t] = sOp[(R_S + k) * ST + col];
+            ar1[t] = sOp[(R_R1 + k) * ST + col];
+            ar2[t] = sOp[(R_R2 + k) * ST + col];
+            am2[t] = sOp[(R_M2 + k) * ST + col];
+            byd[t] = sOp[(R_YD + k) * ST + col];
+            bxi[t] = sOp[(R_XI + k) * ST + col];
+            bs[t] = as[t];
+            br1[t] = ar1[t];
+        }
+        // depth-first numbering: an ancestor has the smaller index - the UP tile (rows 16..31, columns 0..15) and the LO tile (rows
+        // 0..15, columns 16..31) are empty
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                if (nb >= mb) {
+                    mu[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[mb], br1[nb], mu[mb][nb], 0, 0, 0);
+                    du[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[mb], byd[nb], du[mb][nb], 0, 0, 0);
+                }
+                if (nb <= mb) {
+                    ml[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar1[mb], bs[nb], ml[mb][nb], 0, 0, 0);
+                    dl[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar2[mb], bs[nb], dl[mb][nb], 0, 0, 0);
+                    dl[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(am2[mb], bxi[nb], dl[mb][nb], 0, 0, 0);
+                }
+            }
+    }
+    const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;   // relation bit masks of the nodes (as doubles)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int col = 16 * nb + j;
+        const unsigned am = (unsigned)((unsigned long long)__double_as_longlong(cRel[col]) >> g);        // bit a: a is a strict ancestor of col
+        const unsigned dm = (unsigned)((unsigned long long)__double_as_longlong(cRel[CS + col]) >> g);   // ... a strict descendant
+        const double md = sOp[R_MD * ST + col], dd = sOp[R_DD * ST + col];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mb + 4 * r + g, sh = 16 * mb + 4 * r;
+                const double wa = (double)((am >> sh) & 1u), wd = (double)((dm >> sh) & 1u);
+                double mv = 0.0, dv = 0.0;
+                if (nb >= mb) { mv = wa * mu[mb][nb][r]; dv = wa * du[mb][nb][r]; }
+                if (nb <= mb) { mv += wd * ml[mb][nb][r]; dv += wd * dl[mb][nb][r]; }
+                if (row == col) { mv = md; dv = dd; }
+                if (row < n && col < n) {
+                    Mk[(size_t)col * n + row] = mv;
+                    Dk[(size_t)col * n + row] = dv;
+                }
+            }
+    }
+    RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
+    if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+    RMX_SYNC();
+}
+
 // Trees of 33..64 nodes: a 64 x 32 half of H (all rows x the columns i = 2 t + W) on the fp64 matrix cores, from operands staged
 // in LDS ([k][node], stride H64_OP_STRIDE):
 //     H(a,i) = [a strict ancestor of i] RU_a.CU_i + [a strict descendant of i] RL_a.CL_i ,  Hdiag on the diagonal,

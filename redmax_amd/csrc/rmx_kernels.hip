@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
             // Scene.saveHistory keeps H, M, D of the LAST evaluated iterate of the step (driverRedMaxAdjointBDF1.m:100, 127).  Up to 32
             // nodes H rides in registers through the Newton loop (the solve destroys its working copy) and M, D are formed ONCE, after
             // the loop, from the state the last evaluation left behind (fs) - they do not enter the Newton iteration itself; all three
-            // go to HBM once per step.  Larger trees (3 x 64 doubles per lane) form and store them at every iterate, the last store wins.
+            // go to HBM once per step.  Larger trees store H at every iterate (the last store wins) and form M, D once per step as well.
             constexpr bool STORE_ONCE = NP <= 32;
             double Hs[STORE_ONCE ? NP : 1];
             while (true) {
@@ -391,16 +391,12 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
 #pragma unroll
                     for (int i = 0; i < NP; ++i) Hs[i] = Hrow[i];
                 } else if (last_solve) {
-                    double Mrow[NP], Drow[NP];
-                    eval_MD<NP>(M, lane, fs, Mrow, Drow);
+                    // the solve destroys its copy and 64 more doubles per lane do not fit next to it: H of every iterate goes to HBM, the
+                    // last store wins.  M and D do not enter the Newton iteration: they are formed once, after the loop, from fs
                     if (lane < n) {
 #pragma unroll
                         for (int i = 0; i < NP; ++i)
-                            if (i < n) {
-                                Hk[(size_t)i * n + lane] = Hrow[i];
-                                Mk[(size_t)i * n + lane] = Mrow[i];
-                                Dk[(size_t)i * n + lane] = Drow[i];
-                            }
+                            if (i < n) Hk[(size_t)i * n + lane] = Hrow[i];
                     }
                 }
                 if (s == a.task_step && last_solve) {   // J(body rows, joint) = Ad(E_body^-1) s_joint : body-frame twist of the task body per unit qdot
@@ -448,19 +444,26 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
                 if (iter >= o.iterMax) { status |= 2; break; }                // :139-142
                 ++iter;
             }
-            if constexpr (STORE_ONCE) {
-                if (last_solve) {
-                    double Mrow[NP], Drow[NP];
-                    eval_MD<NP>(M, lane, fs, Mrow, Drow);       // fs: the state of the last evaluated iterate
+            if constexpr (NP == 32 && HESS_MFMA) {
+                if (last_solve) {           // M, D on the matrix cores, stored from the MFMA layout (eval_MD_mfma32_store); H from its rows
+                    eval_MD_mfma32_store(M, lane, fs, sAcc, Mk, Dk);
                     if (lane < n) {
 #pragma unroll
                         for (int i = 0; i < NP; ++i)
-                            if (i < n) {
-                                Hk[(size_t)i * n + lane] = Hs[i];
-                                Mk[(size_t)i * n + lane] = Mrow[i];
-                                Dk[(size_t)i * n + lane] = Drow[i];
-                            }
+                            if (i < n) Hk[(size_t)i * n + lane] = Hs[i];
                     }
+                }
+            } else if (last_solve) {
+                double Mrow[NP], Drow[NP];
+                eval_MD<NP>(M, lane, fs, Mrow, Drow);       // fs: the state of the last evaluated iterate
+                if (lane < n) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        if (i < n) {
+                            if constexpr (STORE_ONCE) Hk[(size_t)i * n + lane] = Hs[i];
+                            Mk[(size_t)i * n + lane] = Mrow[i];
+                            Dk[(size_t)i * n + lane] = Drow[i];
+                        }
                 }
             }
             if (INTEG == 2 && s == 1 && sv == 0) {   // :85-87

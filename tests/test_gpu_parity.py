@@ -289,7 +289,7 @@ def test_config1_euler_on_gpu(oracle_lib, sid, Hexp):
     assert _rel(qdg, qdo) <= 1e-8, _rel(qdg, qdo)
 
 
-@pytest.mark.parametrize("n", [2, 5, 16])
+@pytest.mark.parametrize("n", [2, 5, 16, 32, 40])
 def test_adjoint_bdf1_matches_oracle(oracle_lib, n):
     """BASELINE.json configs[3] / SURVEY §8(f)-2: forward + backward adjoint sweep (P and dP/dp) vs the oracle's literal
     restatement of driverRedMaxAdjointBDF1 / TaskBDF1.calcFinal, which itself is pinned by the FD identity
@@ -298,7 +298,7 @@ def test_adjoint_bdf1_matches_oracle(oracle_lib, n):
     from redmax_amd.scenes import sceneAdjointChain
     sc = sceneAdjointChain(n)
     sc.init()
-    B, nsteps = 4, (20 if n < 16 else 10)
+    B, nsteps = 4, (20 if n < 16 else (10 if n == 16 else (6 if n == 32 else 4)))      # 32, 40: the 32- / 64-lane forward kernels
     rng = np.random.default_rng(9)
     p = 0.1 * rng.standard_normal((B, sc.nr))
     p[0] = 0.0
@@ -358,7 +358,7 @@ def test_adjoint_scene100_at_its_own_horizon(oracle_lib):
     assert np.allclose(num, ana, rtol=2e-5, atol=1e-6 * np.abs(ana).max()), (num, ana)
 
 
-@pytest.mark.parametrize("n,nsteps", [(2, 100), (5, 20), (16, 10)])
+@pytest.mark.parametrize("n,nsteps", [(2, 100), (5, 20), (16, 10), (32, 5), (40, 4)])
 def test_adjoint_bdf2_matches_oracle(oracle_lib, n, nsteps):
     """driverRedMaxAdjointBDF2 / TaskBDF2 / TaskBDF2PointPos (scene 101, scenesRedMax.m:437-471, at its own 100-step horizon, and its
     n-link forms): SDIRK2 start step + BDF2 forward, four-block backward sweep - P, dP/dp, the final state and the Newton counts
