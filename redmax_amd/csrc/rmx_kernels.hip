@@ -428,6 +428,25 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
                         dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
                         status |= 16;
                     }
+                } else if constexpr (NP == 64 && LU_SPLIT64) {
+                    // 33..64 nodes: the guarded block-column solve of the step kernels (lu_solve_neg_diag64: H through the front's scratch,
+                    // every update one DPP-fused FMA; a third of the instructions of the pivoted solve); H of this iterate is in the
+                    // history already, so a tripped guard reloads it from there and pivots
+                    (void)hdiag;
+                    bool lu_ok;
+                    dx = lu_solve_neg_diag64(n, lane, sAcc, Hrow, e.g, lu_ok);
+                    if (!lu_ok) {
+                        if (last_solve) {
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) Hrow[i] = (lane < n && i < n) ? Hk[(size_t)i * n + lane] : ((i == lane) ? 1.0 : 0.0);
+                        } else {             // (the SDIRK2a solve leaves nothing in the history: evaluate again)
+                            NodeOut e2;
+                            eval_front<NP, true>(M, sAcc, lane, x, ((x - qA) + xlo) / eta, (x - qB) + xlo, eta, e2, fs);
+                            eval_hess<NP>(M, lane, fs, Hrow, nullptr, sAcc);
+                        }
+                        dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
+                        status |= 16;
+                    }
                 } else {
                     (void)hdiag;
                     dx = lu_solve_neg<NP, true>(n, lane, Hrow, e.g);
