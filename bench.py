@@ -480,7 +480,10 @@ def rank_main(args, make_stepper=None, backend=None):
         backend = backend or ("gloo" if shared else "nccl")
     else:
         device, shared, backend = 0, False, backend or "gloo"
-    dist = sharding.init_process_group(rank, world, backend, device if backend == "nccl" else None) if world > 1 else None
+    # RMX_BENCH_FORCE_DIST=1: form the process group at world size 1 as well - how the RCCL code path (device-tensor all-gather, device
+    # max-reduction, barrier) is exercised on a 1-GPU box (tests/test_gpu_bench_contract.py); nothing else changes
+    force = os.environ.get("RMX_BENCH_FORCE_DIST") == "1"
+    dist = sharding.init_process_group(rank, world, backend, device if backend == "nccl" else None) if (world > 1 or force) else None
     ctx = RankContext(rank, world, torch, dist, on_device=on_gpu and backend == "nccl", device=device, sync_cuda=on_gpu)
 
     wl = args.workload
