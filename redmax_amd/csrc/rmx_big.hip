@@ -630,6 +630,12 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
 // dx = -H\g: LU with partial pivoting on the workspace copy of H (column-major nr x nr), thread = reduced row.  The permutation is
 // implicit (rows are never moved): piv[r] = the step at which row r served as the pivot row, or -1.  First maximum wins (dgetf2).
 // bneg: this node's -g (nodes without a DOF: ignored).  Returns this node's dx.
+// The linear solvers' small arrays: ONE set for the three of them (a kernel holds the guarded diagonal solve and its pivoting fallback;
+// function-local arrays would be allocated once per solver).  Named directly, never through a pointer (see block_sum).
+__shared__ double lu_b[BT];          // right-hand side, reduced order
+__shared__ double lu_xs[BT];         // reciprocals of the pivots
+__shared__ int lu_piv[BT];           // pivot row of step k (pivoting solvers)
+
 #ifdef RMX_BIG_PROFILE
 __device__ unsigned long long g_prof[8];
 #define PROF_T0() const unsigned long long p0_ = __builtin_amdgcn_s_memtime()
@@ -647,12 +653,9 @@ __device__ unsigned long long g_prof[8];
 template <bool HL>
 __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
     typedef double v4d __attribute__((ext_vector_type(4)));
-    __shared__ int spiv[BT];
     __shared__ int sused[BT];          // sused[r] != 0: row r has served as a pivot row (its multipliers are 0 from then on)
     __shared__ double spv[2][BT / 64];  // per-wavefront pivot candidates of the next panel column
     __shared__ int spi[2][BT / 64];
-    __shared__ double b[BT];
-    __shared__ double xs[BT];
     // H in HBM: a 32-column panel is copied into LDS (dyn[j * nr + r]) and -U12 staged behind it.  H in LDS (HL): the panel is 16 columns
     // of H IN PLACE, -U12 is staged where the Hessian's column vectors were (cu, cl: dead once H is complete; 16 nr + nr <= 18 n doubles).
     constexpr int NB = HL ? 16 : LU_NB;
@@ -663,7 +666,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
     const int odummy = HL ? oU + NB * nr : NB * nr;     // where the panel update's accesses past the panel go (one column of nr doubles)
     auto HR = [&](const size_t i) -> double { if constexpr (HL) return dyn[i]; else return H[i]; };
     auto HW = [&](const size_t i, const double v) { if constexpr (HL) dyn[i] = v; else H[i] = v; };
-    if (ka >= 0) b[ka] = -g;
+    if (ka >= 0) lu_b[ka] = -g;
     sused[t] = 0;
     __syncthreads();
     const int r = t;
@@ -704,7 +707,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
 #pragma unroll
             for (int q = 1; q < BT / 64; ++q)
                 if (spv[par][q] > bv || (spv[par][q] == bv && spi[par][q] < pr)) { bv = spv[par][q]; pr = spi[par][q]; }
-            if (t == 0) spiv[kb + j] = pr;
+            if (t == 0) lu_piv[kb + j] = pr;
             if (r == pr) {
                 mystep = kb + j;
                 sused[r] = 1;
@@ -739,7 +742,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
 #pragma unroll
                     for (int u = 0; u < 8; ++u) dyn[cj[u] + r] = av[u] - l * pv[u];
                 }
-                b[r] -= l * b[pr];
+                lu_b[r] -= l * lu_b[pr];
             }
             __syncthreads();
         }
@@ -764,7 +767,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
                 for (int j = 0; j < NB; ++j) {
                     double a = 0.0;
                     if (j < nb) {
-                        const int pj = spiv[kb + j];
+                        const int pj = lu_piv[kb + j];
                         a = HR(col + pj);
 #pragma unroll
                         for (int i = 0; i < j; ++i) a -= dyn[pb + i * nr + pj] * u[i];
@@ -844,7 +847,7 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
     // the pivot row's owner; the column entries U(r, k) of eight steps are fetched together (each step used to wait for its own trip to
     // L2 / HBM).
     PROF_T0();
-    if (row) xs[r] = recip(HR((size_t)r * nr + spiv[r]));         // 1 / U(p_k, k), k = r
+    if (row) lu_xs[r] = recip(HR((size_t)r * nr + lu_piv[r]));         // 1 / U(p_k, k), k = r
     __syncthreads();
     double dxr = 0.0;
     for (int k0 = nr - 1; k0 >= 0; k0 -= 8) {
@@ -855,9 +858,241 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
         for (int i = 0; i < 8; ++i) {
             const int k = k0 - i;
             if (k >= 0) {        // workgroup-uniform
-                const double xk = b[spiv[k]] * xs[k];
+                const double xk = lu_b[lu_piv[k]] * lu_xs[k];
                 if (k == ka) dxr = xk;
-                if (row && mystep < k) b[r] -= u[i] * xk;
+                if (row && mystep < k) lu_b[r] -= u[i] * xk;
+                __syncthreads();
+            }
+        }
+    }
+    PROF_ADD(6);
+    return dxr;
+}
+
+// dx = -H\g WITHOUT the pivot search: right-looking blocked LU on the diagonal under the growth guard of the one-wavefront kernels
+// (rmx_device.h lu_solve_neg_diag: every multiplier of the symmetrically equilibrated matrix below LU_GROWTH_MAX - H = M - eta D -
+// eta^2 K is a modest perturbation of the SPD mass matrix, where that always holds; BigGrowGuard above for the sign).  ok = false: the
+// caller re-assembles H and solves with partial pivoting (big_solve), so mldivide's semantics are kept and paid for only on demand.
+// What the search cost: with a row permutation every pivot is a workgroup-wide argmax plus a barrier, ~3 k ticks of serial latency for
+// ~600 ticks of work, 1.17 M of the 2.4 M ticks of a Newton iteration at 256 DOFs (in-kernel timers, profiles/r04i_big_profile.txt).
+// Without it a panel is THREE barriers:
+//   A  the wavefront that owns rows kb .. kb + NB - 1 (NB | 64: one wavefront) factors the diagonal block in registers - thread = row,
+//      the pivot row broadcast with v_readlane - and eliminates the same columns from the other rows it owns on the same instructions;
+//      the right-hand side rides along.  The other wavefronts have their panel rows and U12 columns in flight from HBM meanwhile.
+//   B  thread = row r >= c0 of the other wavefronts: the same elimination with the rows of U11 broadcast from LDS;
+//      thread = column c >= c0: U12(:, c) = L11^-1 A12(:, c), -U12 staged in LDS for C
+//   C  A22 -= L21 U12 on the fp64 matrix cores, rows and columns >= c0 only (the permuted form had to sweep every row: 1.6 x the
+//      traffic of a launch that is bound by it at 256 DOFs)
+// Same elimination order per entry as big_solve_blocked on a matrix whose pivots are the diagonal.
+// The guard of big_solve_diag.  Unlike the one-wavefront solves it takes NEGATIVE pivots: on long chains H = M - eta D - eta^2 K is
+// indefinite in a good part of the hard Newton iterations (every trip of the positive-pivot guard that tools/big_profile.py printed was a
+// negative pivot, none a multiplier: 41 % of the rollouts of the 256-link bench tripped at least once), and there the fallback costs a
+// re-assembly plus the pivoting solve, three times the guarded one.  What elimination on the diagonal needs for stability is bounded
+// multipliers, not a sign: every multiplier of the symmetrically equilibrated matrix must satisfy l'^2 = |l a| / d_r <= LU_GROWTH_MAX^2
+// (threshold pivoting with tau = 1 / 8 accepts the diagonal), every pivot must be finite and non-zero, every original diagonal entry
+// positive.  Kept on the high words as integers, sign bit cleared (NaN and inf compare high and trip it).
+struct BigGrowGuard {
+    int hi = 0;
+    __device__ __forceinline__ void see(const double prod) {
+        const int h = __double2hiint(prod) & 0x7fffffff;
+        hi = h > hi ? h : hi;
+    }
+    __device__ __forceinline__ bool bad(const double lim) const { return hi > __double2hiint(lim); }
+};
+struct BigPivGuard {
+    int hi = 0;
+    __device__ __forceinline__ void see(const double rinv) {          // 1 / 0 = inf, 1 / NaN = NaN
+        const int h = __double2hiint(rinv) & 0x7fffffff;
+        hi = h > hi ? h : hi;
+    }
+    __device__ __forceinline__ bool ok() const { return hi < 0x7ff00000; }
+};
+
+template <bool HL>
+__device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t, const int ka, const double g, bool& ok) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    constexpr int NB = HL ? 16 : LU_NB;
+    const int nr = M.nr;
+    double* __restrict__ H = w.H;
+    const int oU = HL ? w.ocu : NB * nr;        // dyn[oU + j * sU + c]: -U12(j, c-th trailing column)
+    const int sU = HL ? nr : BT;
+    auto HR = [&](const size_t i) -> double { if constexpr (HL) return dyn[i]; else return H[i]; };
+    auto HW = [&](const size_t i, const double v) { if constexpr (HL) dyn[i] = v; else H[i] = v; };
+    const int r = t;
+    const bool row = r < nr;
+    if (ka >= 0) lu_b[ka] = -g;
+    const double d0 = row ? HR((size_t)r * nr + r) : 1.0;          // the scale of row r in the growth guard
+    BigGrowGuard gg;
+    BigPivGuard pg;
+    __syncthreads();
+    for (int kb = 0; kb < nr; kb += NB) {
+        const int nb = nr - kb < NB ? nr - kb : NB;
+        const int pb = HL ? kb * nr : 0;            // panel column j, row r: dyn[pb + j * nr + r]
+        const int c0 = kb + nb;
+        const int ncol = nr - c0;
+        const bool live = row && r >= kb;
+        const bool below = row && r >= c0;
+        const bool own = (t >> 6) == (kb >> 6);     // this wavefront holds the diagonal block
+        PROF_T0();
+        double a[NB], u[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            a[j] = 0.0;
+            if (live && j < nb) {
+                if constexpr (HL) a[j] = dyn[pb + j * nr + r];
+                else a[j] = H[(size_t)(kb + j) * nr + r];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) u[j] = (below && j < nb) ? HR((size_t)r * nr + kb + j) : 0.0;
+        if (own) {
+            const int lb = kb & 63;
+            const int i = (t & 63) - lb;             // row within the block (the wavefront's other rows: < 0 or >= nb)
+            double bb = live ? lu_b[r] : 0.0, myrinv = 0.0;
+#ifdef RMX_BIG_PROFILE
+            const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {                        // workgroup-uniform
+                    const double piv = readlane_d(a[j], lb + j);
+                    const double rinv = recip(piv);
+                    pg.see(rinv);
+                    const bool el = live && i > j;
+                    const double l = el ? a[j] * rinv : 0.0;
+                    gg.see(a[j] * l);
+#pragma unroll
+                    for (int c = j + 1; c < NB; ++c) a[c] = fma(-l, readlane_d(a[c], lb + j), a[c]);
+                    bb = fma(-l, readlane_d(bb, lb + j), bb);
+                    if (el) a[j] = l;
+                    if (i == j) myrinv = rinv;
+                }
+            }
+#ifdef RMX_BIG_PROFILE
+            if (t == 0 && blockIdx.x == 0) g_prof[7] += __builtin_amdgcn_s_memtime() - pf0;
+#endif
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (j < nb) dyn[pb + j * nr + r] = a[j];
+                if constexpr (!HL) {                 // U11 for the back substitution (the multipliers are never read from H again)
+                    if (i < nb) {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            if (j < nb && i <= j) H[(size_t)(kb + j) * nr + r] = a[j];
+                    }
+                }
+                lu_b[r] = bb;
+                if (i < nb) lu_xs[r] = myrinv;
+            }
+        }
+        __syncthreads();
+        PROF_ADD(3);
+        if (ncol > 0) {          // a full panel (nb == NB) with rows and columns behind it
+            PROF_T0();
+            if (below) {
+                if (!own) {      // row r of L21: the rows of U11 come out of LDS as broadcasts
+                    double bb = lu_b[r];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const double l = a[j] * lu_xs[kb + j];
+                        gg.see(a[j] * l);
+#pragma unroll
+                        for (int c = j + 1; c < NB; ++c) a[c] = fma(-l, dyn[pb + c * nr + kb + j], a[c]);
+                        bb = fma(-l, lu_b[kb + j], bb);
+                        a[j] = l;
+                    }
+                    lu_b[r] = bb;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) dyn[pb + j * nr + r] = a[j];
+                }
+                // column c = r of U12: forward substitution with the unit lower triangle L11, a column of it per step
+                const size_t col = (size_t)r * nr + kb;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+#pragma unroll
+                    for (int j = i + 1; j < NB; ++j) u[j] = fma(-dyn[pb + i * nr + kb + j], u[i], u[j]);
+                    HW(col + i, u[i]);
+                    dyn[oU + i * sU + (t - c0)] = -u[i];
+                }
+            }
+            __syncthreads();
+            PROF_ADD(4);
+            // A22 -= L21 U12 on the matrix cores: the tiling of big_solve_blocked, over the row blocks from c0 on
+            {
+                PROF_T0();
+                const int wave = t >> 6, lane = t & 63, jj = lane & 15, gg4 = lane >> 4;
+                const int MB = (nr + 15) >> 4, NBK = (ncol + 15) >> 4;
+                for (int mb = (c0 >> 4) + wave; mb < MB; mb += BT / 64) {
+                    const int arow = 16 * mb + jj;
+                    const bool aon = arow < nr;
+                    double lf[NB / 4];
+#pragma unroll
+                    for (int kk = 0; kk < NB / 4; ++kk) lf[kk] = aon ? dyn[pb + (4 * kk + gg4) * nr + arow] : 0.0;
+                    v4d cn;                   // C of the tile about to be worked on, fetched one tile ahead
+                    size_t adn[4];
+                    bool okn[4];
+                    auto fetch = [&](const int nbk) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int cc = 16 * nbk + 4 * q + gg4;
+                            okn[q] = cc < ncol && aon;
+                            adn[q] = (size_t)(c0 + (cc < ncol ? cc : 0)) * nr + (aon ? arow : 0);
+                            cn[q] = okn[q] ? HR(adn[q]) : 0.0;
+                        }
+                    };
+                    fetch(0);
+                    for (int nbk = 0; nbk < NBK; ++nbk) {
+                        const int cj = 16 * nbk + jj;                    // this lane's column of the A operand
+                        v4d acc = cn;
+                        size_t ad[4];
+                        bool okq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            ad[q] = adn[q];
+                            okq[q] = okn[q];
+                        }
+                        double uf[NB / 4];
+#pragma unroll
+                        for (int kk = 0; kk < NB / 4; ++kk) uf[kk] = cj < ncol ? dyn[oU + (4 * kk + gg4) * sU + cj] : 0.0;
+                        if (nbk + 1 < NBK) fetch(nbk + 1);               // in flight underneath the MFMAs
+#pragma unroll
+                        for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[kk], lf[kk], acc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (okq[q]) HW(ad[q], acc[q]);
+                    }
+                }
+                __syncthreads();
+                PROF_ADD(5);
+            }
+        }
+    }
+    // the guard, once per solve: l'^2 = |l a| / d_r <= LU_GROWTH_MAX^2 for every multiplier of row r, every pivot finite and non-zero
+    const bool bad = (row && (!(d0 > 0.0) || gg.bad(LU_GROWTH_MAX * LU_GROWTH_MAX * d0))) || !pg.ok();
+    ok = block_any(bad, t) == 0;
+#ifdef RMX_BIG_PROFILE
+    {
+        const double ng = block_sum((row && gg.bad(LU_GROWTH_MAX * LU_GROWTH_MAX * d0)) ? 1.0 : 0.0, t);
+        const double nd = block_sum((row && !(d0 > 0.0)) ? 1.0 : 0.0, t);
+        const double np = block_sum(pg.ok() ? 0.0 : 1.0, t);
+        if (!ok && t == 0 && blockIdx.x < 48) printf("guard tripped, block %d: rows over the growth limit %g, diagonal <= 0: %g, threads that saw a bad pivot %g\n", blockIdx.x, ng, nd, np);
+    }
+#endif
+    // back substitution (x_k formed by every thread from two broadcast reads: one barrier per step, see big_solve_blocked)
+    PROF_T0();
+    double dxr = 0.0;
+    for (int k0 = nr - 1; k0 >= 0; k0 -= 8) {
+        double uu[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) uu[i] = (row && k0 - i > r) ? HR((size_t)(k0 - i) * nr + r) : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 - i;
+            if (k >= 0) {        // workgroup-uniform
+                const double xk = lu_b[k] * lu_xs[k];
+                if (k == ka) dxr = xk;
+                if (row && r < k) lu_b[r] -= uu[i] * xk;
                 __syncthreads();
             }
         }
@@ -876,12 +1111,9 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
     if constexpr (HL) {
         if (M.nr >= 100) return big_solve_blocked<true>(M, w, t, ka, g);       // workgroup-uniform
     }
-    __shared__ int spiv[BT];         // pivot row of step k
-    __shared__ double b[BT];         // right-hand side, reduced order
-    __shared__ double xs[BT];        // solution, reduced order
     const int nr = M.nr;
     double* __restrict__ H = w.H;
-    if (ka >= 0) b[ka] = -g;
+    if (ka >= 0) lu_b[ka] = -g;
     __syncthreads();
     // thread = (reduced row r, column group cg): the BT / nr threads of a row share its trailing columns (c = k+1+cg, step ncg); with
     // one thread per row the update of a row was nr - k dependent global round trips per pivot, which is where the time went
@@ -894,7 +1126,7 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
         const size_t ck = (size_t)k * nr;
         const double cand = (row && cg == 0 && mystep < 0) ? fabs(hget<HL>(H, ck + r)) : -1.0;
         const int pr = block_argmax(cand, r, t);
-        if (t == 0) spiv[k] = pr;
+        if (t == 0) lu_piv[k] = pr;
         if (r == pr) mystep = k;
         if (row && mystep < 0) {
             const double l = hget<HL>(H, ck + r) * recip(hget<HL>(H, ck + pr));      // dgetf2 scales by the reciprocal of the pivot
@@ -925,18 +1157,18 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
                 const size_t cc = (size_t)c * nr;
                 hput<HL>(H, cc + r, hget<HL>(H, cc + r) - l * hget<HL>(H, cc + pr));
             }
-            if (cg == 0) b[r] -= l * b[pr];
+            if (cg == 0) lu_b[r] -= l * lu_b[pr];
         }
         __syncthreads();
     }
     // back substitution on the implicitly permuted upper triangle (one barrier per step: see big_solve_blocked)
-    if (t < nr) xs[t] = recip(hget<HL>(H, (size_t)t * nr + spiv[t]));
+    if (t < nr) lu_xs[t] = recip(hget<HL>(H, (size_t)t * nr + lu_piv[t]));
     __syncthreads();
     double dxr = 0.0;
     for (int k = nr - 1; k >= 0; --k) {
-        const double xk = b[spiv[k]] * xs[k];
+        const double xk = lu_b[lu_piv[k]] * lu_xs[k];
         if (k == ka) dxr = xk;
-        if (row && cg == 0 && mystep < k) b[r] -= hget<HL>(H, (size_t)k * nr + r) * xk;
+        if (row && cg == 0 && mystep < k) lu_b[r] -= hget<HL>(H, (size_t)k * nr + r) * xk;
         __syncthreads();
     }
     return dxr;
@@ -950,14 +1182,29 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
                              int& halvings, int& status, double& xlo) {
     double lo = 0.0;
     BigOut e;
-    int iter = 1, lsfail = 0;
+    int iter = 1, lsfail = 0, pivstreak = 0, pivhold = 0;
     while (true) {
         { PROF_T0(); big_eval<true, HL, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(0); }
         const BigOut e0 = e;
         last = e;
         ++iters;
         double dx;
-        { PROF_T0(); dx = big_solve<HL>(M, w, t, ka, e.g); PROF_ADD(1); }
+        {
+            PROF_T0();
+            bool lu_ok = false;
+            if (o.lu_mode == 0 && pivhold == 0) dx = big_solve_diag<HL>(M, w, t, ka, e.g, lu_ok);
+            if (!lu_ok) {
+                if (o.lu_mode == 0 && pivhold == 0) {        // growth guard tripped: H was destroyed in place - re-assemble, then pivot
+                    status |= 16;
+                    if (++pivstreak >= 2) pivhold = 1;       // a solve that keeps tripping: partial pivoting for the rest of this solve
+                    big_eval<true, HL, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+                }
+                dx = big_solve<HL>(M, w, t, ka, e.g);
+            } else {
+                pivstreak = 0;
+            }
+            PROF_ADD(1);
+        }
         const double dxn2 = block_sum(dx * dx, t);
         if (!(dxn2 == dxn2)) { status |= 4; break; }
         if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }
@@ -1163,8 +1410,8 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
     if (t == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;
 #ifdef RMX_BIG_PROFILE
     if (t == 0 && traj == 0)
-        printf("big profile (ticks, block 0): eval+H %llu solve %llu trial eval %llu | panel %llu U12 %llu trailing %llu backsub %llu | total %llu\n",
-               g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], __builtin_amdgcn_s_memtime() - tick0);
+        printf("big profile (ticks, block 0): eval+H %llu solve %llu trial eval %llu | panel %llu U12 %llu trailing %llu backsub %llu | diagonal blocks of wavefront 0 %llu | total %llu\n",
+               g_prof[0], g_prof[1], g_prof[2], g_prof[3], g_prof[4], g_prof[5], g_prof[6], g_prof[7], __builtin_amdgcn_s_memtime() - tick0);
 #endif
 }
 

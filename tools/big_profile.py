@@ -25,8 +25,8 @@ sim.opts.tol = tol
 sim.set_state(q, qd)
 o = sim.step_bdf1(steps, h=1e-2, stats=True)
 it = o["newton_iters"]
-print("chain %%d B=%%d tol %%g: %%.3f ms per step; Newton iterations per step: rollout 0 %%.2f, mean %%.2f, max %%.2f; halvings rollout 0: %%d; bad %%d" %% (
-    n, B, tol, o["ms"] / steps, it[0] / steps, it.mean() / steps, it.max() / steps, int(o["ls_halvings"][0]), int(((o["status"] & 15) != 0).sum())), flush=True)
+print("chain %%d B=%%d tol %%g: %%.3f ms per step; Newton iterations per step: rollout 0 %%.2f, mean %%.2f, max %%.2f; halvings rollout 0: %%d; bad %%d; pivoted %%d" %% (
+    n, B, tol, o["ms"] / steps, it[0] / steps, it.mean() / steps, it.max() / steps, int(o["ls_halvings"][0]), int(((o["status"] & 15) != 0).sum()), int(((o["status"] & 16) != 0).sum())), flush=True)
 sim.close()
 ''' % (ROOT, ROOT)
 

@@ -18,6 +18,7 @@ for n, tol in ((32, 1e-9), (64, 1e-9), (72, 1e-8), (128, 1e-7), (256, 1e-6)):
         sim.set_state(q, qd)
         sim.step_bdf1(2, h=1e-2)
         o = sim.step_bdf1(20, h=1e-2, stats=True)
-        print("chain %3d  B=%4d tol %g: %.3f ms per step, %.2f Newton iterations per step, %.1f k rollout-steps/s, bad %d" % (
-            n, B, tol, o["ms"] / 20, o["newton_iters"].sum() / (20 * B), B * 20 / o["ms"], int(((o["status"] & 15) != 0).sum())), flush=True)
+        print("chain %3d  B=%4d tol %g: %.3f ms per step, %.2f Newton iterations per step, %.1f k rollout-steps/s, bad %d; slowest rollout %.1f iterations per step, %d rollouts redone with pivoting" % (
+            n, B, tol, o["ms"] / 20, o["newton_iters"].sum() / (20 * B), B * 20 / o["ms"], int(((o["status"] & 15) != 0).sum()),
+            o["newton_iters"].max() / 20, int(((o["status"] & 16) != 0).sum())), flush=True)
         sim.close()
