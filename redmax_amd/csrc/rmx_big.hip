@@ -10,16 +10,21 @@
 //                                       suffix(j) - suffix(end_j)
 //   * the nr x nr Hessian             : thread = row, a loop over the columns (ancestor test j < i < end_j), column-major; in LDS
 //                                       when it fits next to the per-node rows (nr <= ~128), else in a global workspace
-//   * dx = -H\g                       : LU with partial pivoting (MATLAB mldivide, driverRedMaxBDF1.m:117; first maximum wins; the pivot
-//                                       column scaled by the reciprocal of the pivot as dgetf2 does), implicit row permutation, pivot
-//                                       search on DPP butterflies.  H in LDS below 100 DOFs: unblocked, thread = (row, column group).
-//                                       Above: right-looking blocked LU (H in LDS: 16-column panels in place; H in HBM, nr > ~136:
-//                                       32-column panel copied into LDS), the rank-16 / rank-32 trailing update on the fp64 MATRIX
-//                                       CORES (v_mfma_f64_16x16x4_f64: the one contraction of this library that is large enough -
-//                                       up to 224 x 224 x 32 per panel)
+//   * dx = -H\g                       : guarded elimination on the diagonal first (big_solve_diag: right-looking blocked LU without a
+//                                       pivot search - the diagonal block factored in the registers of the wavefront that owns its rows,
+//                                       L21 / U12 by substitution against LDS broadcasts, the rank-16 / rank-32 trailing update on the
+//                                       fp64 MATRIX CORES (v_mfma_f64_16x16x4_f64: the one contraction of this library that is large
+//                                       enough - up to 224 x 224 x 32 per panel), three barriers per panel, one per block in the back
+//                                       substitution; H in LDS: 16-column panels in place, H in HBM (nr > ~136): 32-column panels staged
+//                                       in LDS).  Every multiplier of the equilibrated matrix is checked against LU_GROWTH_MAX; a solve
+//                                       that trips the guard is redone on a re-assembled H with partial pivoting (MATLAB mldivide,
+//                                       driverRedMaxBDF1.m:117; first maximum wins; the pivot column scaled by the reciprocal of the
+//                                       pivot as dgetf2 does; implicit row permutation, pivot search on DPP butterflies; big_solve /
+//                                       big_solve_blocked), rmx_opts.lu_mode = 1 asks for that one always
 // Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
-// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 1.6 ms per BDF1 step, a
-// 128-link chain 4.4 ms, a 256-link chain 34 ms (1.9 / 5.4 / 62 in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
+// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 1.0 ms per BDF1 step, a
+// 128-link chain 2.5 ms, a 256-link chain 13 - 23 ms (its slowest rollouts do not converge at that amplitude; 1.21 M ticks per Newton
+// iteration, 2.4 M with the pivot search; 1.9 / 5.4 / 62 ms in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
 // BDF1, BDF2 (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching, ground contact
 // (ForceGroundCuboid, CT instantiations), rmx_eval_mfd / rmx_compute_values through rmx_eval; not covered: the adjoint, matlab-simple
 // Euler (refused by the C ABI for such models).
@@ -604,25 +609,39 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     // ~1.7 k ticks per column (in-kernel timers, tools/big_profile.py), a fifth of a Newton iteration at 128 DOFs.
     const int nr = M.nr;
     const int ka = act ? M.idx[tj] : -1;
+    // A wavefront holds 64 consecutive rows: a column to the left of all of them can only be an ancestor's (the descendants' product
+    // alone, 12 broadcast reads), one to the right of all of them only a descendant's (6); both products only for the wavefront's own 64
+    // columns.  (Both for every column: 18 reads per column, the LDS pipe the bound of the loop - 25 .. 50 % more than needed.)
     if (ka >= 0) {
         const int ea = M.end[tj];
         double* __restrict__ Hw = w.H;
-#pragma unroll 4
-        for (int i = 0; i < n; ++i) {
+        auto column = [&](const int i, auto wantU, auto wantL) {
             const int ki = s_idx[i], ei = s_end[i];
             double hu = 0.0, hl = 0.0;
+            if constexpr (decltype(wantU)::value) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) hu += sw[c] * dyn[w.ocu + c * LS + i] + sv[c] * dyn[w.ocu + (3 + c) * LS + i];
+                for (int c = 0; c < 3; ++c) hu += sw[c] * dyn[w.ocu + c * LS + i] + sv[c] * dyn[w.ocu + (3 + c) * LS + i];
+            }
+            if constexpr (decltype(wantL)::value) {
 #pragma unroll
-            for (int c = 0; c < 12; ++c) hl += rl[c] * dyn[w.ocl + c * LS + i];
-            if (CT && ncl == 18) {
+                for (int c = 0; c < 12; ++c) hl += rl[c] * dyn[w.ocl + c * LS + i];
+                if (CT && ncl == 18) {
 #pragma unroll
-                for (int c = 12; c < 18; ++c) hl += rl[c] * dyn[w.ocl + c * LS + i];
+                    for (int c = 12; c < 18; ++c) hl += rl[c] * dyn[w.ocl + c * LS + i];
+                }
             }
             const bool anc = t < i && i < ea, desc = i < t && t < ei;
             const double h = (i == t) ? Hdiag : (anc ? hu : (desc ? hl : 0.0));
             if (ki >= 0) hput<HL>(Hw, (size_t)ki * nr + ka, h);
-        }
+        };
+        const int wlo = (t & ~63) < n ? (t & ~63) : n, whi = wlo + 64 < n ? wlo + 64 : n;     // wavefront-uniform
+        int i = 0;
+#pragma unroll 4
+        for (; i < wlo; ++i) column(i, std::false_type{}, std::true_type{});
+#pragma unroll 4
+        for (; i < whi; ++i) column(i, std::true_type{}, std::true_type{});
+#pragma unroll 4
+        for (; i < n; ++i) column(i, std::true_type{}, std::false_type{});
     }
     __syncthreads();
 }
@@ -884,6 +903,11 @@ __device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int
 //   C  A22 -= L21 U12 on the fp64 matrix cores, rows and columns >= c0 only (the permuted form had to sweep every row: 1.6 x the
 //      traffic of a launch that is bound by it at 256 DOFs)
 // Same elimination order per entry as big_solve_blocked on a matrix whose pivots are the diagonal.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // The guard of big_solve_diag.  Unlike the one-wavefront solves it takes NEGATIVE pivots: on long chains H = M - eta D - eta^2 K is
 // indefinite in a good part of the hard Newton iterations (every trip of the positive-pivot guard that tools/big_profile.py printed was a
 // negative pivot, none a multiplier: 41 % of the rollouts of the 256-link bench tripped at least once), and there the fallback costs a
@@ -945,27 +969,83 @@ __device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t,
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) u[j] = (below && j < nb) ? HR((size_t)r * nr + kb + j) : 0.0;
-        if (own) {
+        // NB == 16: the block's rows are one 16-lane DPP row, and the pivot row's broadcast rides on the FMA (v_fmac_f64_dpp row_newbcast,
+        // rmx_device.h fmsub_rowbcast: half the issue slots of two v_readlane plus an FMA).  The wavefront's other rows cannot follow on
+        // those instructions (a DPP row sees its own lanes): they take the LDS route of phase B with the other wavefronts.
+        const bool own16 = NB == 16 && (t >> 4) == (kb >> 4);
+        const bool inA = NB == 16 ? own16 : own;     // this thread's row is eliminated in phase A
+        if constexpr (NB == 16) { if (own) {
+            const int lb = kb & 63;
+            const int i = t & 15;
+            const bool mine = own16 && live;         // (a ragged last block: rows >= nb do not exist)
+            double bb = mine ? lu_b[r] : 0.0, myrinv = 0.0;
+#ifdef RMX_BIG_PROFILE
+            const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
+#endif
+            double rinv = recip(readlane_d(a[0], lb));
+            static_for<16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr bool NOPS = j >= 12;       // the last steps are short: a broadcast may follow the write of its source by < 2 VALU
+                if (j < nb) {                        // workgroup-uniform
+                    pg.see(rinv);
+                    const bool el = mine && i > j;
+                    const double l = el ? a[j] * rinv : 0.0;
+                    gg.see(a[j] * l);
+                    double rnext = 0.0;
+                    if constexpr (j + 1 < 16) {
+                        fmsub_rowbcast<j, NOPS>(a[j + 1], a[j + 1], l);
+                        rnext = recip(readlane_d(a[j + 1], lb + j + 1));
+                    }
+#pragma unroll
+                    for (int c = j + 2; c < 16; ++c) fmsub_rowbcast<j, NOPS>(a[c], a[c], l);
+                    fmsub_rowbcast<j, NOPS>(bb, bb, l);
+                    asm volatile("" : "+v"(rnext));  // formed HERE, among the updates (left alone it sinks into the next step's block)
+                    if (el) a[j] = l;
+                    if (i == j) myrinv = rinv;
+                    rinv = rnext;
+                }
+            });
+#ifdef RMX_BIG_PROFILE
+            if (t == 0 && blockIdx.x == 0) g_prof[7] += __builtin_amdgcn_s_memtime() - pf0;
+#endif
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (j < nb) dyn[pb + j * nr + r] = a[j];
+                lu_b[r] = bb;
+                lu_xs[r] = myrinv;
+            }
+        } }
+        if (NB != 16 && own) {
             const int lb = kb & 63;
             const int i = (t & 63) - lb;             // row within the block (the wavefront's other rows: < 0 or >= nb)
             double bb = live ? lu_b[r] : 0.0, myrinv = 0.0;
 #ifdef RMX_BIG_PROFILE
             const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
 #endif
+            // The reciprocal of pivot j + 1 is started as soon as its column has been updated, underneath the updates of the other
+            // columns (v_rcp_f64 and two Newton steps are ~100 ticks of dependent latency, the serial chain of a block otherwise)
+            double rinv = recip(readlane_d(a[0], lb));
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (j < nb) {                        // workgroup-uniform
-                    const double piv = readlane_d(a[j], lb + j);
-                    const double rinv = recip(piv);
                     pg.see(rinv);
                     const bool el = live && i > j;
                     const double l = el ? a[j] * rinv : 0.0;
                     gg.see(a[j] * l);
+                    double rnext = 0.0;
+                    if (j + 1 < NB) {
+                        const int j1 = j + 1 < NB ? j + 1 : j;
+                        a[j1] = fma(-l, readlane_d(a[j1], lb + j), a[j1]);
+                        rnext = recip(readlane_d(a[j1], lb + j1));
+                    }
 #pragma unroll
-                    for (int c = j + 1; c < NB; ++c) a[c] = fma(-l, readlane_d(a[c], lb + j), a[c]);
+                    for (int c = j + 2; c < NB; ++c) a[c] = fma(-l, readlane_d(a[c], lb + j), a[c]);
                     bb = fma(-l, readlane_d(bb, lb + j), bb);
+                    asm volatile("" : "+v"(rnext));  // formed HERE, among the updates (left alone it sinks into the next step's block)
                     if (el) a[j] = l;
                     if (i == j) myrinv = rinv;
+                    rinv = rnext;
                 }
             }
 #ifdef RMX_BIG_PROFILE
@@ -991,7 +1071,7 @@ __device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t,
         if (ncol > 0) {          // a full panel (nb == NB) with rows and columns behind it
             PROF_T0();
             if (below) {
-                if (!own) {      // row r of L21: the rows of U11 come out of LDS as broadcasts
+                if (!inA) {      // row r of L21: the rows of U11 come out of LDS as broadcasts
                     double bb = lu_b[r];
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
@@ -1029,38 +1109,39 @@ __device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t,
                     double lf[NB / 4];
 #pragma unroll
                     for (int kk = 0; kk < NB / 4; ++kk) lf[kk] = aon ? dyn[pb + (4 * kk + gg4) * nr + arow] : 0.0;
-                    v4d cn;                   // C of the tile about to be worked on, fetched one tile ahead
-                    size_t adn[4];
-                    bool okn[4];
+                    // C two tiles ahead: a tile in flight per wavefront is 2 KB, four wavefronts 8 KB per CU - at the ~1 us of a trip to
+                    // HBM / MALL that is far from what the CU's share of the bandwidth can carry
+                    struct Tile { v4d c; size_t ad[4]; bool ok[4]; };
                     auto fetch = [&](const int nbk) {
+                        Tile T;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int cc = 16 * nbk + 4 * q + gg4;
-                            okn[q] = cc < ncol && aon;
-                            adn[q] = (size_t)(c0 + (cc < ncol ? cc : 0)) * nr + (aon ? arow : 0);
-                            cn[q] = okn[q] ? HR(adn[q]) : 0.0;
+                            T.ok[q] = cc < ncol && aon;
+                            T.ad[q] = (size_t)(c0 + (cc < ncol ? cc : 0)) * nr + (aon ? arow : 0);
+                            T.c[q] = T.ok[q] ? HR(T.ad[q]) : 0.0;
                         }
+                        return T;
                     };
-                    fetch(0);
-                    for (int nbk = 0; nbk < NBK; ++nbk) {
+                    auto work = [&](const int nbk, const Tile& T) {
                         const int cj = 16 * nbk + jj;                    // this lane's column of the A operand
-                        v4d acc = cn;
-                        size_t ad[4];
-                        bool okq[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            ad[q] = adn[q];
-                            okq[q] = okn[q];
-                        }
                         double uf[NB / 4];
 #pragma unroll
                         for (int kk = 0; kk < NB / 4; ++kk) uf[kk] = cj < ncol ? dyn[oU + (4 * kk + gg4) * sU + cj] : 0.0;
-                        if (nbk + 1 < NBK) fetch(nbk + 1);               // in flight underneath the MFMAs
+                        v4d acc = T.c;
 #pragma unroll
                         for (int kk = 0; kk < NB / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(uf[kk], lf[kk], acc, 0, 0, 0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (okq[q]) HW(ad[q], acc[q]);
+                            if (T.ok[q]) HW(T.ad[q], acc[q]);
+                    };
+                    Tile TA = fetch(0), TB = fetch(1);                   // (a tile past the end: all four of its elements masked)
+                    for (int nbk = 0; nbk < NBK; nbk += 2) {
+                        const Tile T0 = TA, T1 = TB;
+                        TA = fetch(nbk + 2);
+                        TB = fetch(nbk + 3);
+                        work(nbk, T0);
+                        if (nbk + 1 < NBK) work(nbk + 1, T1);
                     }
                 }
                 __syncthreads();
@@ -1079,24 +1160,39 @@ __device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t,
         if (!ok && t == 0 && blockIdx.x < 48) printf("guard tripped, block %d: rows over the growth limit %g, diagonal <= 0: %g, threads that saw a bad pivot %g\n", blockIdx.x, ng, nd, np);
     }
 #endif
-    // back substitution (x_k formed by every thread from two broadcast reads: one barrier per step, see big_solve_blocked)
+    // back substitution, ONE barrier per block of NB pivots: the wavefront that owns the block's rows solves the triangle in registers
+    // (x_j broadcast with v_readlane, the other rows it owns updated on the same instructions) and publishes x; the rows of the other
+    // wavefronts take the block's NB terms after the barrier, their entries of U already in flight.  (One barrier per pivot: 113 k ticks
+    // of the 900 k of a solve at 256 DOFs.)
     PROF_T0();
-    double dxr = 0.0;
-    for (int k0 = nr - 1; k0 >= 0; k0 -= 8) {
-        double uu[8];
+    double bb = row ? lu_b[r] : 0.0;
+    for (int kb = ((nr - 1) / NB) * NB; kb >= 0; kb -= NB) {
+        const int nb = nr - kb < NB ? nr - kb : NB;
+        const bool own = (t >> 6) == (kb >> 6);
+        double uu[NB], ri[NB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) uu[i] = (row && k0 - i > r) ? HR((size_t)(k0 - i) * nr + r) : 0.0;
+        for (int j = 0; j < NB; ++j) uu[j] = (row && j < nb && r < kb + j) ? HR((size_t)(kb + j) * nr + r) : 0.0;
+        if (own) {
+            const int lb = kb & 63;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = k0 - i;
-            if (k >= 0) {        // workgroup-uniform
-                const double xk = lu_b[k] * lu_xs[k];
-                if (k == ka) dxr = xk;
-                if (row && r < k) lu_b[r] -= uu[i] * xk;
-                __syncthreads();
+            for (int j = 0; j < NB; ++j) ri[j] = j < nb ? lu_xs[kb + j] : 0.0;
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                if (j < nb) {                        // workgroup-uniform
+                    const double xj = readlane_d(bb, lb + j) * ri[j];
+                    bb = (r == kb + j) ? xj : fma(-uu[j], xj, bb);
+                }
             }
+            if (row && r >= kb && r < kb + nb) lu_b[r] = bb;
+        }
+        __syncthreads();
+        if (!own && row && r < kb) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j < nb) bb = fma(-uu[j], lu_b[kb + j], bb);
         }
     }
+    const double dxr = ka >= 0 ? lu_b[ka] : 0.0;
     PROF_ADD(6);
     return dxr;
 }
