@@ -22,9 +22,9 @@
 //                                       pivot as dgetf2 does; implicit row permutation, pivot search on DPP butterflies; big_solve /
 //                                       big_solve_blocked), rmx_opts.lu_mode = 1 asks for that one always
 // Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
-// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 1.0 ms per BDF1 step, a
-// 128-link chain 2.5 ms, a 256-link chain 13 - 23 ms (its slowest rollouts do not converge at that amplitude; 1.21 M ticks per Newton
-// iteration, 2.4 M with the pivot search; 1.9 / 5.4 / 62 ms in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
+// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 0.88 ms per BDF1 step, a
+// 128-link chain 2.13 ms, a 256-link chain 13 - 20 ms (its slowest rollouts do not converge at that amplitude: 3.8 ms where all do; 1.06 M
+// ticks per Newton iteration, 2.4 M with the pivot search; 1.9 / 5.4 / 62 ms in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
 // BDF1, BDF2 (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching, ground contact
 // (ForceGroundCuboid, CT instantiations), rmx_eval_mfd / rmx_compute_values through rmx_eval; not covered: the adjoint, matlab-simple
 // Euler (refused by the C ABI for such models).
@@ -44,6 +44,23 @@
 namespace {
 
 constexpr int BT = BIG_MAXN;          // threads per workgroup = node slots
+#ifndef RMX_BIG_PHASEB_DPP_HL
+#define RMX_BIG_PHASEB_DPP_HL 1         // phase B of the guarded LU on DPP broadcasts also when H is in LDS (0: LDS broadcasts there; build variants)
+#endif
+// How the Newton loop is laid out for the compiler (build variants; ticks per Newton iteration at 72 / 128 / 256 links, profiles/r05p_*):
+// one call site for the evaluation with H and one per solve, everything inlined 255 / 394 / 1 065 k; the same with the PIVOTING solve
+// out of line (it runs only when the guard trips, and inlined its registers are the hot path's to carry) 229 / 361 / 1 066 k; two call
+// sites for the evaluation (guarded path, fallback) 254 / 392 / 1 064 k.  Left to the inliner's own heuristics the layout flipped with
+// every change of code size (a Newton loop left out of line costs 60 - 70 k ticks per iteration).
+#ifndef RMX_BIG_NEWTON_ONE_SITE
+#define RMX_BIG_NEWTON_ONE_SITE 1
+#endif
+#ifndef RMX_BIG_PIVOT_INLINE
+#define RMX_BIG_PIVOT_INLINE 0
+#endif
+#ifndef RMX_BIG_HESS_MFMA
+#define RMX_BIG_HESS_MFMA 1             // the Hessian's two products on the matrix cores (0: the column loop; build variants)
+#endif
 
 // The per-node workspace lives in LDS (the dynamic array `dyn`, rows of per-node data are [component][n]); only H goes to global memory
 // when it does not fit next to it.  Offsets in doubles; region X is reused: E, V (path products / sums) -> the in-place suffix scan -> H.
@@ -206,7 +223,7 @@ struct BigOut {
 // evalBDF1 / computeValues for the generic implicit residual (see eval_front_e2 / eval_hess in rmx_device.h for the wavefront form and
 // oracle/redmax_tensorfree.c tf_eval for the node-by-node restatement this follows).  Thread t = node t; q, qd, v are this node's.
 template <bool WANT_H, bool HL = false, bool CT = false>
-__device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc, const int t, const double q, const double qd,
+__device__ __forceinline__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc, const int t, const double q, const double qd,
                          const double v, const double eta, BigOut& out) {
     const int n = M.n, NS = M.stride, LS = w.ns;      // NS: stride of the model's constant tables, LS: of the LDS rows
     const bool act = t < n;
@@ -609,6 +626,86 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
     // ~1.7 k ticks per column (in-kernel timers, tools/big_profile.py), a fifth of a Newton iteration at 128 DOFs.
     const int nr = M.nr;
     const int ka = act ? M.idx[tj] : -1;
+    if constexpr (RMX_BIG_HESS_MFMA && HL) {
+    // The two products ARE matrix products - H_upper = S (n x 6) CU (6 x n) above the diagonal, H_lower = RL (n x 12 | 18) CL below - and
+    // run on the fp64 matrix cores, tile by tile (v_mfma_f64_16x16x4_f64, the transposed form of the LU's trailing update: a lane's four
+    // results are four columns of one row, a store touches 16 consecutive rows).  A wavefront takes the four row blocks of its own 64
+    // rows: the row-side operand (this node's s / rl, registers) reaches the lanes that need it through ds_bpermute, no staging; the
+    // column-side operand is the [component][node] rows of cu / cl as they lie in LDS.  Tiles right of the diagonal block need the
+    // ancestors' product only (2 MFMAs), left of it the descendants' (3, or 5 with ground contact), the diagonal block both.
+    // (The column loop it replaces: 6 / 12 / 18 LDS broadcasts and as many FMAs per column and row.  Measured, ticks per Newton iteration:
+    // 72 links 248 -> 238 k, 128 links 389 -> 377 k.  H in HBM keeps the column loop: a thread per row stores 64 consecutive rows of a
+    // column at a time, the tiles 16, and at 256 links what the products gain the stores lose - 1 155 vs 1 178 k.)
+    {
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int lane = t & 63, jj = lane & 15, gg = lane >> 4, wv = t >> 6;
+        const int NBK = (n + 15) >> 4;
+        const int ea_t = act ? M.end[tj] : 0;
+        double* __restrict__ Hw = w.H;
+        auto pick = [&](const double x0, const double x1, const double x2, const double x3) {
+            return gg == 0 ? x0 : (gg == 1 ? x1 : (gg == 2 ? x2 : x3));
+        };
+#pragma unroll 1
+        for (int mbl = 0; mbl < 4; ++mbl) {
+            const int mb = 4 * wv + mbl;
+            if (mb >= NBK) break;                    // wavefront-uniform
+            const int src = 16 * mbl + jj;           // the lane of this wavefront that holds row a
+            const int a = 16 * mb + jj;
+            const int ka_a = __shfl(ka, src, 64), ea_a = __shfl(ea_t, src, 64);
+            const double hd_a = __shfl(Hdiag, src, 64);
+            double su[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                su[c] = __shfl(sw[c], src, 64);
+                su[3 + c] = __shfl(sv[c], src, 64);
+            }
+            const double bU0 = pick(su[0], su[1], su[2], su[3]), bU1 = pick(su[4], su[5], 0.0, 0.0);
+            double bL[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk)
+                bL[kk] = pick(__shfl(rl[4 * kk], src, 64), __shfl(rl[4 * kk + 1], src, 64), __shfl(rl[4 * kk + 2], src, 64), __shfl(rl[4 * kk + 3], src, 64));
+            if (CT && ncl == 18) {
+                bL[3] = pick(__shfl(rl[12], src, 64), __shfl(rl[13], src, 64), __shfl(rl[14], src, 64), __shfl(rl[15], src, 64));
+                bL[4] = pick(__shfl(rl[16], src, 64), __shfl(rl[17], src, 64), 0.0, 0.0);
+            }
+            for (int nbk = 0; nbk < NBK; ++nbk) {
+                const int ia = 16 * nbk + jj;        // this lane's column node in the column-side operand
+                const bool iaon = ia < n;
+                const int ic = iaon ? ia : 0;
+                v4d hu = {0.0, 0.0, 0.0, 0.0}, hl = {0.0, 0.0, 0.0, 0.0};
+                if (nbk >= mb) {                     // wavefront-uniform
+                    const double a0 = iaon ? dyn[w.ocu + gg * LS + ic] : 0.0;
+                    const double a1 = (iaon && gg < 2) ? dyn[w.ocu + (4 + (gg & 1)) * LS + ic] : 0.0;
+                    hu = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bU0, hu, 0, 0, 0);
+                    hu = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bU1, hu, 0, 0, 0);
+                }
+                if (nbk <= mb) {
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const double al = iaon ? dyn[w.ocl + (4 * kk + gg) * LS + ic] : 0.0;
+                        hl = __builtin_amdgcn_mfma_f64_16x16x4f64(al, bL[kk], hl, 0, 0, 0);
+                    }
+                    if (CT && ncl == 18) {
+                        const double a3 = iaon ? dyn[w.ocl + (12 + gg) * LS + ic] : 0.0;
+                        const double a4 = (iaon && gg < 2) ? dyn[w.ocl + (16 + (gg & 1)) * LS + ic] : 0.0;
+                        hl = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, bL[3], hl, 0, 0, 0);
+                        hl = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, bL[4], hl, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * nbk + 4 * q + gg;
+                    if (i < n && a < n) {
+                        const int ki = s_idx[i], ei = s_end[i];
+                        const bool anc = a < i && i < ea_a, desc = i < a && a < ei;
+                        const double h = (i == a) ? hd_a : (anc ? hu[q] : (desc ? hl[q] : 0.0));
+                        if (ki >= 0 && ka_a >= 0) hput<HL>(Hw, (size_t)ki * nr + ka_a, h);
+                    }
+                }
+            }
+        }
+    }
+    } else {
     // A wavefront holds 64 consecutive rows: a column to the left of all of them can only be an ancestor's (the descendants' product
     // alone, 12 broadcast reads), one to the right of all of them only a descendant's (6); both products only for the wavefront's own 64
     // columns.  (Both for every column: 18 reads per column, the LDS pipe the bound of the loop - 25 .. 50 % more than needed.)
@@ -643,6 +740,7 @@ __device__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc
 #pragma unroll 4
         for (; i < n; ++i) column(i, std::true_type{}, std::false_type{});
     }
+    }
     __syncthreads();
 }
 
@@ -670,7 +768,7 @@ __device__ unsigned long long g_prof[8];
 // rank-LU_NB update a(r,c) -= sum_j L(r,j) U(j,c) (L(r,:) in registers, U from LDS).  Same pivots, same operations per entry as the
 // unblocked loop up to the order of the subtractions.
 template <bool HL>
-__device__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
+__device__ __forceinline__ double big_solve_blocked(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     __shared__ int sused[BT];          // sused[r] != 0: row r has served as a pivot row (its multipliers are 0 from then on)
     __shared__ double spv[2][BT / 64];  // per-wavefront pivot candidates of the next panel column
@@ -933,7 +1031,7 @@ struct BigPivGuard {
 };
 
 template <bool HL>
-__device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t, const int ka, const double g, bool& ok) {
+__device__ __forceinline__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t, const int ka, const double g, bool& ok) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     constexpr int NB = HL ? 16 : LU_NB;
     const int nr = M.nr;
@@ -1070,6 +1168,7 @@ __device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t,
         PROF_ADD(3);
         if (ncol > 0) {          // a full panel (nb == NB) with rows and columns behind it
             PROF_T0();
+            if constexpr (HL && !RMX_BIG_PHASEB_DPP_HL) {
             if (below) {
                 if (!inA) {      // row r of L21: the rows of U11 come out of LDS as broadcasts
                     double bb = lu_b[r];
@@ -1095,6 +1194,58 @@ __device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t,
                     HW(col + i, u[i]);
                     dyn[oU + i * sU + (t - c0)] = -u[i];
                 }
+            }
+            } else {
+            // The entries of U11 / L11 are wavefront-uniform, and fetching each one as an LDS broadcast made this phase the LDS pipe's:
+            // ~1 000 reads per thread and 32-column panel, ~8 clocks each with four wavefronts on one pipe.  Instead ROW j of U11 (column
+            // i of L11) is read ONCE into a register - lane 16 r + c holds entry c, the same in all four 16-lane rows - and every
+            // update takes its entry from there on the DPP broadcast that rides on the FMA (fmsub_rowbcast): 16 / 64 reads instead of
+            // 240 / 992.  DPP reads lanes whatever their row does, so the whole wavefront runs the loop (rows that take no part carry the
+            // multiplier 0), under a wavefront-uniform condition.
+            if ((t | 63) >= c0 && (t & ~63) < nr) {
+                const int l15 = t & 15;
+                const bool partL = below && !inA;
+                if (!(NB == 32 && own)) {        // (32-column panels: the owner wavefront eliminated all of its rows in phase A)
+                    double bb = partL ? lu_b[r] : 0.0;
+                    static_for<NB>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const double ulo = dyn[pb + l15 * nr + kb + j];
+                        double uhi = 0.0;
+                        if constexpr (NB == 32) uhi = dyn[pb + (16 + l15) * nr + kb + j];
+                        const double l = partL ? a[j] * lu_xs[kb + j] : 0.0;
+                        gg.see(a[j] * l);
+                        static_for<NB>([&](auto cc) {
+                            constexpr int c = decltype(cc)::value;
+                            if constexpr (c > j && c < 16) fmsub_rowbcast<c>(a[c], ulo, l);
+                            if constexpr (c > j && c >= 16) fmsub_rowbcast<c - 16>(a[c], uhi, l);
+                        });
+                        bb = fma(-l, lu_b[kb + j], bb);
+                        if (partL) a[j] = l;
+                    });
+                    if (partL) {
+                        lu_b[r] = bb;
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) dyn[pb + j * nr + r] = a[j];
+                    }
+                }
+                // column c = r of U12: forward substitution with the unit lower triangle L11, a column of it per step
+                const size_t col = (size_t)r * nr + kb;
+                static_for<NB>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const double llo = dyn[pb + i * nr + kb + l15];
+                    double lhi = 0.0;
+                    if constexpr (NB == 32) lhi = dyn[pb + i * nr + kb + 16 + l15];
+                    static_for<NB>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j > i && j < 16) fmsub_rowbcast<j>(u[j], llo, u[i]);
+                        if constexpr (j > i && j >= 16) fmsub_rowbcast<j - 16>(u[j], lhi, u[i]);
+                    });
+                    if (below) {
+                        HW(col + i, u[i]);
+                        dyn[oU + i * sU + (t - c0)] = -u[i];
+                    }
+                });
+            }
             }
             __syncthreads();
             PROF_ADD(4);
@@ -1197,8 +1348,13 @@ __device__ double big_solve_diag(const DevModel& M, const BigWs& w, const int t,
     return dxr;
 }
 
+#if RMX_BIG_PIVOT_INLINE
+#define BIG_PIVOT_INL __forceinline__
+#else
+#define BIG_PIVOT_INL __noinline__
+#endif
 template <bool HL>
-__device__ double big_solve(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
+__device__ BIG_PIVOT_INL double big_solve(const DevModel& M, const BigWs& w, const int t, const int ka, const double g) {
     if constexpr (!HL) return big_solve_blocked<false>(M, w, t, ka, g);
     // H in LDS: from ~100 DOFs up the blocked form (16-column panels in place, trailing update on the matrix cores) is ahead - the
     // unblocked update below moves the whole trailing matrix through LDS once per pivot, 1.5 k clocks of LDS bandwidth at 128 DOFs;
@@ -1273,13 +1429,42 @@ __device__ double big_solve(const DevModel& M, const BigWs& w, const int t, cons
 // newton (driverRedMaxBDF1.m:94-157) for one implicit solve; see newton_impl (rmx_device.h) for the stall shortcut and the
 // compensated iterate x + lo.  Every decision is workgroup-uniform (norms come out of block_sum identical in all threads).
 template <bool HL, bool CT>
-__device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w, const NodeConsts& nc, const int t,
-                             const int ka, double x, const double qA, const double qB, const double eta, BigOut& last, int& iters,
-                             int& halvings, int& status, double& xlo) {
+__device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpts& o, const BigWs& w, const NodeConsts& nc, const int t,
+                                                 const int ka, double x, const double qA, const double qB, const double eta, BigOut& last,
+                                                 int& iters, int& halvings, int& status, double& xlo) {
     double lo = 0.0;
     BigOut e;
     int iter = 1, lsfail = 0, pivstreak = 0, pivhold = 0;
     while (true) {
+#if RMX_BIG_NEWTON_ONE_SITE
+        // One call site each for the evaluation and the two solves (all three are inlined: a call costs these kernels more than it
+        // saves - arguments by reference live in scratch, the callee saves its registers).  Round 0: H, then elimination on the diagonal;
+        // if its guard trips, round 1: H again (the solve destroyed it in place), then partial pivoting.
+        double dx = 0.0;
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            { PROF_T0(); big_eval<true, HL, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(0); }
+            PROF_T0();
+            if (round == 0 && o.lu_mode == 0 && pivhold == 0) {          // workgroup-uniform
+                bool lu_ok = false;
+                dx = big_solve_diag<HL>(M, w, t, ka, e.g, lu_ok);
+                PROF_ADD(1);
+                if (lu_ok) {
+                    pivstreak = 0;
+                    break;
+                }
+                status |= 16;                                // growth guard tripped
+                if (++pivstreak >= 2) pivhold = 1;           // a solve that keeps tripping: partial pivoting for the rest of this solve
+            } else {
+                dx = big_solve<HL>(M, w, t, ka, e.g);
+                PROF_ADD(1);
+                break;
+            }
+        }
+        const BigOut e0 = e;
+        last = e;
+        ++iters;
+#else
         { PROF_T0(); big_eval<true, HL, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(0); }
         const BigOut e0 = e;
         last = e;
@@ -1301,6 +1486,7 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
             }
             PROF_ADD(1);
         }
+#endif
         const double dxn2 = block_sum(dx * dx, t);
         if (!(dxn2 == dxn2)) { status |= 4; break; }
         if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }
@@ -1341,6 +1527,13 @@ __device__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w
     }
     xlo = lo;
     return x;
+}
+// The BDF2 kernels solve at three places (two SDIRK2 stages, the BDF2 step): one out-of-line copy; the BDF1 kernels inline theirs.
+template <bool HL, bool CT>
+__device__ __noinline__ double big_newton(const DevModel& M, const DevOpts& o, const BigWs& w, const NodeConsts& nc, const int t, const int ka,
+                                          double x, const double qA, const double qB, const double eta, BigOut& last, int& iters, int& halvings,
+                                          int& status, double& xlo) {
+    return big_newton_inl<HL, CT>(M, o, w, nc, t, ka, x, qA, qB, eta, last, iters, halvings, status, xlo);
 }
 
 // Joint.reparam -> JointSpherical.reparam_ for every spherical group (sph_reparam in rmx_device.h, with the group's values read from
@@ -1442,7 +1635,7 @@ __global__ void __launch_bounds__(BT) k_big_step(const DevModel M, const DevOpts
         if (INTEG == 1) {
             const double q0 = q, qd0 = qd;
             const double xg = q0 + h * qd0;
-            const double x = big_newton<HL, CT>(M, o, w, nc, t, id, xg, q0, xg, h, last, iters, halv, status, xlo);
+            const double x = big_newton_inl<HL, CT>(M, o, w, nc, t, id, xg, q0, xg, h, last, iters, halv, status, xlo);
             qd = ((x - q0) + xlo) / h;
             q = x;
         } else if (s == 0 && !started) {

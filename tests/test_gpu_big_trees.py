@@ -336,3 +336,65 @@ def test_ground_contact_on_a_big_tree_rollout(oracle_lib, integ):
     of.set_state(q[0], qd[0])
     (of.step_bdf1 if integ == "bdf1" else of.step_bdf2)(sc.h, nsteps)
     assert _rel(of.get_state()[1], qdo) > 1e-3                 # the floor really was felt
+
+
+@pytest.mark.parametrize("name", ["chain72", "chain128", "tree150", "chain200", "free20"])
+def test_big_tree_lu_modes_agree(name):
+    """The two linear solves of the large-tree kernels - lu_mode 0: blocked elimination on the diagonal under the multiplier guard
+    (big_solve_diag: H in LDS with 16-column panels at 72 / 128 links and 20 free bodies, H in HBM with 32-column panels at 150 / 200 DOFs),
+    lu_mode 1: partial pivoting always (MATLAB mldivide, big_solve / big_solve_blocked) - give the same rollout to rounding, with the
+    same Newton iteration counts."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChain
+    sc = sceneChain(int(name[5:])) if name.startswith("chain") else _scene(name)
+    sc.init()
+    B, K = 4, 6
+    rng = np.random.default_rng(21)
+    qs, qds = sc.getQ()
+    q = np.ascontiguousarray(qs[None, :] + rng.uniform(-0.05, 0.05, (B, sc.nr)))
+    qd = np.ascontiguousarray(qds[None, :] + rng.uniform(-0.1, 0.1, (B, sc.nr)))
+    res = []
+    for mode in (0, 1):
+        sim = BatchSim(sc, batch=B)
+        sim.opts.tol = 1e-7 if name.startswith("chain") else 1e-9
+        sim.opts.lu_mode = mode
+        sim.set_state(q, qd)
+        out = sim.step_bdf1(K, h=sc.h, stats=True)
+        res.append((sim.get_state(), out))
+        sim.close()
+    (s0, o0), (s1, o1) = res
+    assert (o0["status"] & 15 == 0).all() and (o1["status"] & 15 == 0).all()
+    assert (o1["status"] & 16 == 0).all()            # RMX_ST_PIVOTED reports a FALLBACK: never in lu_mode 1
+    for b in range(B):
+        assert _rel(s0[0][b], s1[0][b]) <= 1e-9 and _rel(s0[1][b], s1[1][b]) <= 1e-7, (name, b, _rel(s0[0][b], s1[0][b]))
+    assert np.abs(o0["newton_iters"] - o1["newton_iters"]).max() <= 1, (o0["newton_iters"], o1["newton_iters"])
+
+
+def test_big_tree_guard_falls_back_to_pivoting():
+    """The 256-link chain at U(-0.1, 0.1) (tools/big_tree_bench.py): some of its rollouts whip hard enough for a multiplier of the
+    equilibrated H to pass the guard's bound (profiles/r05d_big_profile_diag_solver.txt: blocks 3, 8, 15, 17, 21 within ten steps).  Those
+    solves are redone with partial pivoting (RMX_ST_PIVOTED) and the rollout goes on as it does with pivoting throughout: every
+    rollout that converges in both modes ends in the same state."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChain, syntheticStates
+    sc = sceneChain(256)
+    sc.init()
+    B, K = 32, 10
+    q, qd = syntheticStates(sc.nr, B)
+    res = []
+    for mode in (0, 1):
+        sim = BatchSim(sc, batch=B)
+        sim.opts.tol = 1e-6
+        sim.opts.lu_mode = mode
+        sim.set_state(q, qd)
+        out = sim.step_bdf1(K, h=1e-2, stats=True)
+        res.append((sim.get_state(), out))
+        sim.close()
+    (s0, o0), (s1, o1) = res
+    assert (o0["status"] & 16 != 0).any(), "no solve tripped the guard: the fallback went untested"
+    assert (o1["status"] & 16 == 0).all()
+    assert np.isfinite(s0[0]).all() and np.isfinite(s0[1]).all()
+    good = ((o0["status"] & 15) == 0) & ((o1["status"] & 15) == 0)
+    assert good.sum() >= B - 4, (o0["status"], o1["status"])
+    for b in np.nonzero(good)[0]:
+        assert _rel(s0[0][b], s1[0][b]) <= 1e-6, (b, _rel(s0[0][b], s1[0][b]), int(o0["status"][b]))
