@@ -100,8 +100,10 @@ typedef struct rmx_opts {
     int iterMaxPerDof;     /* 10     iterMax = iterMaxPerDof * nr                  */
     int iterLsMax;         /* 20     line-search halvings                          */
     int lu_mode;           /* dx = -H\g (driverRedMaxBDF1.m:117, LU with partial pivoting in MATLAB):
-                              0 (default) eliminate on the diagonal under a growth guard (|multiplier| <= 8, i.e. threshold
-                                pivoting with tau = 1/8) and redo the solve with full partial pivoting when the guard trips;
+                              0 (default) eliminate on the diagonal under a growth guard (|multiplier| <= 8 on the symmetrically
+                                equilibrated matrix, i.e. threshold pivoting with tau = 1/8; trees of up to 64 nodes also require
+                                positive pivots, larger trees - blocked LU, rmx_big.hip big_solve_diag - take pivots of either sign)
+                                and redo the solve with full partial pivoting when the guard trips (RMX_ST_PIVOTED);
                               1 always full partial pivoting (the reference behaviour, ~2x slower solve).  The pivot search compares
                                 |H(a,k)| as full doubles, lowest row first among equals: LAPACK's first maximum (idamax in dgetf2),
                                 in every kernel of the library (ABI 108; up to ABI 107 the one-wavefront kernels compared the top 26
