@@ -22,9 +22,9 @@
 //                                       pivot as dgetf2 does; implicit row permutation, pivot search on DPP butterflies; big_solve /
 //                                       big_solve_blocked), rmx_opts.lu_mode = 1 asks for that one always
 // Newton (driverRedMaxBDF1.m:94-157) is the reference's, decision for decision, with the stall shortcut and the compensated iterate
-// of newton_impl (rmx_device.h).  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link chain 0.88 ms per BDF1 step, a
-// 128-link chain 2.13 ms, a 256-link chain 13 - 20 ms (its slowest rollouts do not converge at that amplitude: 3.8 ms where all do; 1.06 M
-// ticks per Newton iteration, 2.4 M with the pivot search; 1.9 / 5.4 / 62 ms in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
+// of newton_impl (rmx_device.h), in the rotated form of newton_rot.  Cost (tools/big_tree_bench.py, 256 rollouts, round 4): a 72-link
+// chain 0.79 ms per BDF1 step, a 128-link chain 2.07 ms, a 256-link chain 13 - 20 ms (its slowest rollouts do not converge at that
+// amplitude: 3.7 ms where all do; 1.02 M ticks per Newton iteration, 2.4 M with the pivot search; 1.9 / 5.4 / 62 ms in round 3); the 64-link chain on the one-wavefront kernels: 0.22 ms.  Covered:
 // BDF1, BDF2 (SDIRK2 start), rmx_eval, rmx_energy, histories, JointSpherical / JointFree3D with Euler-chart switching, ground contact
 // (ForceGroundCuboid, CT instantiations), rmx_eval_mfd / rmx_compute_values through rmx_eval; not covered: the adjoint, matlab-simple
 // Euler (refused by the C ABI for such models).
@@ -54,6 +54,9 @@ constexpr int BT = BIG_MAXN;          // threads per workgroup = node slots
 // every change of code size (a Newton loop left out of line costs 60 - 70 k ticks per iteration).
 #ifndef RMX_BIG_NEWTON_ONE_SITE
 #define RMX_BIG_NEWTON_ONE_SITE 1
+#endif
+#ifndef RMX_BIG_NEWTON_ROT
+#define RMX_BIG_NEWTON_ROT 1             // the rotated Newton loop (0: the reference's order of evaluations; build variants)
 #endif
 #ifndef RMX_BIG_PIVOT_INLINE
 #define RMX_BIG_PIVOT_INLINE 0
@@ -222,9 +225,14 @@ struct BigOut {
 
 // evalBDF1 / computeValues for the generic implicit residual (see eval_front_e2 / eval_hess in rmx_device.h for the wavefront form and
 // oracle/redmax_tensorfree.c tf_eval for the node-by-node restatement this follows).  Thread t = node t; q, qd, v are this node's.
-template <bool WANT_H, bool HL = false, bool CT = false>
+struct BigNoGate {
+    __device__ __forceinline__ bool operator()(double) const { return false; }
+};
+// gate(g), workgroup-uniform, is asked once the residual is complete: true ends the evaluation there, before the Hessian's share of
+// the work (big_newton_inl: a line-search trial that is rejected, or accepted and converged, needs no H).
+template <bool WANT_H, bool HL = false, bool CT = false, class Gate = BigNoGate>
 __device__ __forceinline__ void big_eval(const DevModel& M, const BigWs& w, const NodeConsts& nc, const int t, const double q, const double qd,
-                         const double v, const double eta, BigOut& out) {
+                         const double v, const double eta, BigOut& out, Gate&& gate = Gate()) {
     const int n = M.n, NS = M.stride, LS = w.ns;      // NS: stride of the model's constant tables, LS: of the LDS rows
     const bool act = t < n;
     const int tj = act ? t : 0;
@@ -480,6 +488,7 @@ __device__ __forceinline__ void big_eval(const DevModel& M, const BigWs& w, cons
     const double fr = tau + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) + hitU * (qLimK * (qLimU - q) - qLimD * qd);
     out.g = dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
     if (!WANT_H) return;
+    if (gate(out.g)) return;
     // ---- Hessian vectors of this node (eval_hess in rmx_device.h)
     const double kd = stiff + (hitL + hitU) * qLimK, dd = damp + (hitL + hitU) * qLimD;
     const double* Wt = &S[0];
@@ -1432,6 +1441,103 @@ template <bool HL, bool CT>
 __device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpts& o, const BigWs& w, const NodeConsts& nc, const int t,
                                                  const int ka, double x, const double qA, const double qB, const double eta, BigOut& last,
                                                  int& iters, int& halvings, int& status, double& xlo) {
+#if RMX_BIG_NEWTON_ROT
+    // The ROTATED loop (newton_rot of rmx_device.h): the reference evaluates the residual twice at every point it accepts - as the line
+    // search's trial, then with H at the top of the next iteration.  Here the evaluation at the top of the loop IS the first trial of the
+    // running line search, taken with H: accepted - the usual case - the solve follows at once and a residual-only evaluation (57 of
+    // 361 k ticks per iteration at 128 DOFs) is saved.  The evaluation asks back once its residual is complete (the gate of big_eval):
+    // a trial that is rejected, or accepted and converged, ends there, before the Hessian's share of the work - nothing is wasted; the
+    // halving then goes on with residual-only evaluations and H is evaluated at the point it ends on, as before.  Same points, same tests,
+    // same decisions as the loop below (g of the two instantiations agrees bit for bit, tests/test_gpu_big_trees.py); ONE call site for
+    // the evaluation with H, one for the residual-only one (the layout finding above).
+    double lo = 0.0;
+    BigOut e, e0;
+    int iter = 1, lsfail = 0, pivstreak = 0, pivhold = 0, iterLs = 1;
+    bool inLs = false, repivot = false, stalled = false;
+    double dx = 0.0, alpha = 1.0, g0n2 = 0.0, f0 = 0.0, gn2 = 0.0, x0 = x, lo0 = 0.0;
+    while (true) {
+        bool hvalid = true;
+        big_eval<true, HL, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, [&](const double g) {
+            if (!inLs) return false;
+            gn2 = block_sum(g * g, t);
+            const bool accepted = 0.5 * gn2 < f0;
+            // no H for: a rejected trial with halvings left; a point the Newton loop ends on (converged, or out of iterations)
+            hvalid = accepted ? !(sqrt(gn2) < o.tol || iter >= o.iterMax) : !(iterLs < o.iterLsMax || sqrt(gn2) < o.tol || iter >= o.iterMax);
+            return !hvalid;
+        });
+        last = e;
+        if (inLs) {               // (x, lo) is the first trial point of the line search from (x0, lo0) along dx; gn2 = |g|^2 there
+            inLs = false;
+            if (!(0.5 * gn2 < f0)) {
+                while (true) {
+                    if (iterLs >= o.iterLsMax) break;
+                    alpha *= 0.5;
+                    ++iterLs;
+                    two_sum(x0, fma(alpha, dx, lo0), x, lo);
+                    lo *= o.comp;
+                    if (block_all(x == x0 && lo == lo0, t)) {
+                        stalled = true;
+                        iterLs = o.iterLsMax;
+                        e = e0;
+                        break;
+                    }
+                    big_eval<false, false, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+                    hvalid = false;
+                    gn2 = block_sum(e.g * e.g, t);
+                    if (0.5 * gn2 < f0) break;
+                }
+            }
+            last = e;
+            halvings += iterLs - 1;
+            if (stalled) {
+                if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+                break;
+            }
+            if (sqrt(gn2) < o.tol) break;
+            if (iter >= o.iterMax) { status |= 2; break; }
+            lsfail += (0.5 * gn2 < f0) ? 0 : 1;              // rmx_opts.ls_fail_limit, see newton_impl
+            if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) { status |= 2 | ST_LS_CUT; break; }
+            ++iter;
+            if (!hvalid) continue;                        // H at the accepted point: the evaluation at the top
+        }
+        // e: g and H at (x, lo).  Elimination on the diagonal; if its guard trips, H again (the solve destroyed it in place) and pivoting
+        if (!repivot) ++iters;
+        if (!repivot && o.lu_mode == 0 && pivhold == 0) {     // workgroup-uniform
+            bool lu_ok = false;
+            dx = big_solve_diag<HL>(M, w, t, ka, e.g, lu_ok);
+            if (!lu_ok) {
+                status |= 16;                                // growth guard tripped
+                if (++pivstreak >= 2) pivhold = 1;           // a solve that keeps tripping: partial pivoting for the rest of this solve
+                repivot = true;
+                continue;
+            }
+            pivstreak = 0;
+        } else {
+            dx = big_solve<HL>(M, w, t, ka, e.g);
+            repivot = false;
+        }
+        e0 = e;
+        const double dxn2 = block_sum(dx * dx, t);
+        if (!(dxn2 == dxn2)) { status |= 4; break; }
+        if (sqrt(dxn2) > o.dxMax) { status |= 1; break; }
+        alpha = 1.0;
+        g0n2 = block_sum(e.g * e.g, t);
+        f0 = 0.5 * g0n2;
+        x0 = x;
+        lo0 = lo;
+        iterLs = 1;
+        gn2 = g0n2;
+        two_sum(x0, fma(alpha, dx, lo0), x, lo);
+        lo *= o.comp;
+        if (block_all(x == x0 && lo == lo0, t)) {          // the first trial is the point itself: the stall shortcut of newton_impl
+            last = e;
+            halvings += o.iterLsMax - 1;
+            if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+            break;
+        }
+        inLs = true;
+    }
+#else
     double lo = 0.0;
     BigOut e;
     int iter = 1, lsfail = 0, pivstreak = 0, pivhold = 0;
@@ -1525,6 +1631,7 @@ __device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpt
         if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) { status |= 2 | ST_LS_CUT; break; }
         ++iter;
     }
+#endif
     xlo = lo;
     return x;
 }
