@@ -1457,6 +1457,7 @@ __device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpt
     double dx = 0.0, alpha = 1.0, g0n2 = 0.0, f0 = 0.0, gn2 = 0.0, x0 = x, lo0 = 0.0;
     while (true) {
         bool hvalid = true;
+        PROF_T0();
         big_eval<true, HL, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, [&](const double g) {
             if (!inLs) return false;
             gn2 = block_sum(g * g, t);
@@ -1465,6 +1466,7 @@ __device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpt
             hvalid = accepted ? !(sqrt(gn2) < o.tol || iter >= o.iterMax) : !(iterLs < o.iterLsMax || sqrt(gn2) < o.tol || iter >= o.iterMax);
             return !hvalid;
         });
+        PROF_ADD(0);
         last = e;
         if (inLs) {               // (x, lo) is the first trial point of the line search from (x0, lo0) along dx; gn2 = |g|^2 there
             inLs = false;
@@ -1481,7 +1483,7 @@ __device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpt
                         e = e0;
                         break;
                     }
-                    big_eval<false, false, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e);
+                    { PROF_T0(); big_eval<false, false, CT>(M, w, nc, t, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e); PROF_ADD(2); }
                     hvalid = false;
                     gn2 = block_sum(e.g * e.g, t);
                     if (0.5 * gn2 < f0) break;
@@ -1504,7 +1506,7 @@ __device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpt
         if (!repivot) ++iters;
         if (!repivot && o.lu_mode == 0 && pivhold == 0) {     // workgroup-uniform
             bool lu_ok = false;
-            dx = big_solve_diag<HL>(M, w, t, ka, e.g, lu_ok);
+            { PROF_T0(); dx = big_solve_diag<HL>(M, w, t, ka, e.g, lu_ok); PROF_ADD(1); }
             if (!lu_ok) {
                 status |= 16;                                // growth guard tripped
                 if (++pivstreak >= 2) pivhold = 1;           // a solve that keeps tripping: partial pivoting for the rest of this solve
@@ -1513,7 +1515,7 @@ __device__ __forceinline__ double big_newton_inl(const DevModel& M, const DevOpt
             }
             pivstreak = 0;
         } else {
-            dx = big_solve<HL>(M, w, t, ka, e.g);
+            { PROF_T0(); dx = big_solve<HL>(M, w, t, ka, e.g); PROF_ADD(1); }
             repivot = false;
         }
         e0 = e;
