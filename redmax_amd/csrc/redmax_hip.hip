@@ -622,7 +622,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     hist_free(b);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->park, (void*)b->xch, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -819,6 +819,7 @@ static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
     d.comp = o->compensated ? 1.0 : 0.0;
     if (o->ls_fail_limit < 0) return fail(RMX_E_INVALID, "opts.ls_fail_limit must be >= 0");
     d.lsFailLimit = o->ls_fail_limit;
+    d.parkHalv = 0;
     return RMX_OK;
 }
 
@@ -840,6 +841,27 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     a.ticks = b->ticks;
     rc = pending_error_check(b, "rmx_step");
     if (rc) return rc;
+    // Park and relaunch (rmx_device.h CoopCtx): serial chains of <= 32 nodes with ForceGroundCuboid.  A rollout whose Newton solve keeps
+    // running out its line searches is parked by the launch with the contact terms and finished by groups of COOP_G wavefronts that
+    // evaluate the reference's trial points side by side - same decisions, same results, the launch no longer waits for one wavefront
+    // walking through 20 trials 320 times.  RMX_PARK_HALVINGS=0 switches it off (one wavefront per rollout throughout).
+    o.parkHalv = 0;
+    if (!m->big && m->NP == 32 && m->dm.con && m->dm.is_chain && m->dm.nsph == 0 && m->n_simd >= COOP_G) {
+        const char* e = getenv("RMX_PARK_HALVINGS");       // (read at every call: tests and tools switch it inside one process)
+        o.parkHalv = e ? atoi(e) : 24;
+    }
+    if (o.parkHalv > 0) {
+        if (!b->park) {
+            b->ngroups = std::min(b->B, m->n_simd / COOP_G);     // all groups resident at once: one 512-register wavefront per SIMD
+            HIPCHK(hipMalloc((void**)&b->park, sizeof(int) * (1 + 4 * (size_t)b->B)));
+            HIPCHK(hipMalloc((void**)&b->xch, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups));
+        }
+        HIPCHK(hipMemsetAsync(b->park, 0, sizeof(int), b->stream));
+        HIPCHK(hipMemsetAsync(b->xch, 0, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups, b->stream));
+        a.park = b->park;
+        a.xch = b->xch;
+        a.ngroups = b->ngroups;
+    }
     HIPCHK(hipMemsetAsync(b->ticks, 0, sizeof(unsigned long long) * b->B, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     if (m->big) launch_big_step(m, b, integ, o, a);

@@ -112,6 +112,8 @@ struct DevOpts {
     int lu_mode;      // 0: diagonal pivots under a growth guard, partial pivoting on demand; 1: always partial pivoting
     double comp;      // 1.0: compensated Newton iterate (x + xlo, see newton_impl); 0.0: plain doubles (the reference's lattice)
     int lsFailLimit;  // rmx_opts.ls_fail_limit: > 0 ends a step's Newton loop at its N-th failed line search
+    int parkHalv;     // > 0 (contact kernels of serial chains of <= 32 nodes): a solve whose line searches have spent more than this many
+                      // halvings parks its rollout at the start of the step for the cooperative launch (newton_impl COOP); 0: never
 };
 
 // ----------------------------------------------------------------------------- small helpers
@@ -3292,14 +3294,70 @@ __device__ __forceinline__ void pivot_policy_update(PivotPolicy& piv) {   // aft
 // comes near the ground; the first one that does ends the solve with status bit 64 and the caller redoes it with CT = true.
 constexpr int ST_LEFT_LEAN = 64;
 constexpr int ST_LS_CUT = 128;     // RMX_ST_LS_CUT
+constexpr int ST_PARK = 256;       // internal, like ST_LEFT_LEAN: the solve gave its rollout up to the cooperative launch
+constexpr int ST_COOP_FAULT = 512; // RMX_ST_COOP_FAULT: a member of a cooperative group waited in vain (never seen; the rollout is invalid)
+//
+// The cooperative line search (BASELINE.json configs[4]; DESIGN.md section 4 "park and relaunch").  At a stick / slip kink of the ground
+// contact the reference's backtracking (driverRedMaxBDF2.m newton, the same as driverRedMaxBDF1.m:123-141) runs out its 20 trials - or
+// accepts 2^-13 of the step - on every one of the 320 iterations of a step; its trial points alpha = 1, 1/2, ... are tested IN ORDER
+// but their residuals are independent.  A rollout that meets such a step is parked (DevOpts::parkHalv) and finished by a GROUP of
+// COOP_G wavefronts (one workgroup each, anywhere on the GPU) that all run the SAME Newton iteration redundantly - same code, same
+// inputs, hence bitwise the same x0, dx, f0 in every member, no state to hand over - and differ in one thing only: in a line search
+// member m evaluates trials 2 + 2 m and 3 + 2 m (eval_front_dual: two points per evaluation), i.e. all of trials 2 .. 21 at once.  What
+// the members exchange is the four decision bits of their two points (stalled a / b, f < f0 a / b) in ONE 32-bit word per member and
+// line search, tagged with the group's running count of line searches: a word is complete in itself, so relaxed agent-scope atomics
+// carry it with no fence, and a reader simply polls until the tag is the current one.  Every member then walks the bits in the
+// reference's order and reaches the reference's decision: identical iterates, iteration and halving counts, one evaluation latency
+// per line search instead of ten.
+constexpr int COOP_G = 10;                       // members of a group: trials 2 .. 2 COOP_G + 1 in one evaluation (iterLsMax = 20)
+constexpr int COOP_WORDS = 32;                   // exchange words per group: 2 x COOP_G decision words (even / odd exchanges: a member may
+                                                 // post exchange r + 1 while a slower one still reads r), [2 COOP_G] the group's abort flag
+struct CoopCtx {
+    unsigned* words = nullptr;                   // this group's COOP_WORDS exchange words (global memory)
+    int member = 0;
+    unsigned round = 0;                          // line searches this group has gone through (the tag of the next exchange)
+};
+__device__ __forceinline__ unsigned coop_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coop_store(unsigned* p, const unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Post this member's decision bits for exchange `round` and collect the group's: lane j < COOP_G comes back with member j's word.
+// false: some member did not answer within ~2 s of shader clock (or the group's abort flag was up): the caller gives the rollout up.
+__device__ __forceinline__ bool coop_exchange(CoopCtx& cx, const int lane, const unsigned bits, unsigned& word) {
+    ++cx.round;
+    const unsigned tag = cx.round << 4;
+    unsigned* const slot = cx.words + (cx.round & 1u) * COOP_G;
+    if (lane == 0) coop_store(slot + cx.member, tag | bits);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    bool ok = true;
+    word = tag;
+    while (true) {
+        unsigned w = tag;
+        if (lane < COOP_G) w = coop_load(slot + lane);
+        else if (lane == COOP_G) w = coop_load(cx.words + 2 * COOP_G) ? 0u : tag;    // the abort flag reads as a word that never arrives ...
+        const bool mine = (w & ~15u) == tag;
+        if (__all(mine)) {
+            word = w;
+            break;
+        }
+        const bool aborted = __any(lane == COOP_G && !mine);                          // ... and ends the wait at once
+        if (aborted || __builtin_amdgcn_s_memtime() - t0 > 5000000000ull) {
+            if (lane == 0) coop_store(cx.words + 2 * COOP_G, 1u);
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return ok;
+}
 #ifndef RMX_DUAL_LS
 #define RMX_DUAL_LS 1              // two line-search points per evaluation (eval_front_dual); 0: one (build variants, measurements)
 #endif
-template <int NP, bool PIVOT_ONLY, bool CT = false, bool LEAN = false>
+template <int NP, bool PIVOT_ONLY, bool CT = false, bool LEAN = false, bool COOP = false>
 __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
-                                              int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
+                                              int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo, CoopCtx& cx) {
     (void)sCol;
+    (void)cx;
+    const int halv_in = halvings;
     double Hrow[NP];
     FrontState fs;
     NodeOut e;
@@ -3374,7 +3432,65 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         // points two at a time (eval_front_dual) - same points, same order of decisions
         constexpr bool DUAL_LS = CT && !LEAN && NP == 32 && RMX_DUAL_LS;
         while (true) {
-            if constexpr (DUAL_LS) {
+            if constexpr (DUAL_LS && COOP) {
+                static_assert(!COOP || (CT && !LEAN && NP == 32), "the cooperative line search belongs to the 32-lane kernels with the contact terms");
+                if (iterLs >= 2 && M.is_chain) {
+                    // member m: trial iterLs + 2 m at alpha 4^-m (lanes 0..31) and trial iterLs + 2 m + 1 at half of that (lanes 32..63)
+                    const double x0d = dup_lo(x0), lo0d = dup_lo(lo0), dxd = dup_lo(dx), qAd = dup_lo(qA), qBd = dup_lo(qB);
+                    const bool hiH = lane >= 32;
+                    const double am = ldexp(alpha, -2 * cx.member);           // (alpha is a power of two: exact)
+                    const double al = hiH ? 0.5 * am : am;
+                    double xl, lol;
+                    two_sum(x0d, fma(al, dxd, lo0d), xl, lol);
+                    lol *= o.comp;
+                    const unsigned long long same = __ballot(xl == x0d && lol == lo0d);
+                    const bool stall_a = (unsigned)same == 0xffffffffu, stall_b = (unsigned)(same >> 32) == 0xffffffffu;
+                    unsigned bits = (stall_a ? 1u : 0u) | (stall_b ? 2u : 0u);
+                    if (!stall_a) {       // (a stalled point a: b and every later member's points are stalled too, nobody looks at their f)
+                        const double gd = eval_front_dual<CT>(RMX_CONSTS(sAcc, M.n, NP), Grav3{M.grav[0], M.grav[1], M.grav[2]}, lane, xl,
+                                                              ((xl - qAd) + lol) / eta, (xl - qBd) + lol, eta, dup_lo(fs.tau_add));
+                        double ga2, gb2;
+                        wave_sum_dual(gd * gd, ga2, gb2);
+                        bits |= (0.5 * ga2 < f0 ? 4u : 0u) | (0.5 * gb2 < f0 ? 8u : 0u);
+                    }
+                    unsigned word;
+                    if (!coop_exchange(cx, lane, bits, word)) {
+                        status |= 4 | ST_COOP_FAULT;
+                        xlo = lo0;
+                        return x0;
+                    }
+                    // the reference's walk over the trials, in order (see the two-point path below)
+                    int take = -1;                         // the trial (counted from iterLs) that ends the search
+#pragma unroll 1
+                    for (int m = 0; m < COOP_G && take < 0 && !stalled; ++m) {
+                        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)word, m);
+                        if (w & 1u) { stalled = true; break; }
+                        if ((w & 4u) || iterLs + 2 * m >= o.iterLsMax) { take = 2 * m; break; }
+                        if (w & 2u) { stalled = true; break; }
+                        if ((w & 8u) || iterLs + 2 * m + 1 >= o.iterLsMax) { take = 2 * m + 1; break; }
+                    }
+                    if (stalled) {
+                        iterLs = o.iterLsMax;
+                        e = e0;
+                        x = x0;
+                        lo = lo0;
+                        break;
+                    }
+                    if (take >= 0) {
+                        iterLs += take;
+                        two_sum(x0, fma(ldexp(alpha, -take), dx, lo0), x, lo);       // what the dual layout holds for that point, lane = node
+                        lo *= o.comp;
+                        x = hiH ? x0 : x;
+                        lo = hiH ? lo0 : lo;
+                        eval_front<NP, true, false, CT, LEAN>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, fs);
+                        gn2 = wave_sum(e.g * e.g);
+                        break;
+                    }
+                    alpha = ldexp(alpha, -2 * COOP_G);
+                    iterLs += 2 * COOP_G;
+                    continue;
+                }
+            } else if constexpr (DUAL_LS) {
                 if (iterLs >= 2 && M.is_chain) {
                     // trial iterLs at alpha (lanes 0..31) and trial iterLs + 1 at alpha / 2 (lanes 32..63), node = lane & 31
                     const double x0d = dup_lo(x0), lo0d = dup_lo(lo0), dxd = dup_lo(dx), qAd = dup_lo(qA), qBd = dup_lo(qB);
@@ -3451,6 +3567,13 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
         }
         last = e;
         halvings += iterLs - 1;
+        if constexpr (DUAL_LS && !COOP) {
+            // (see CoopCtx) a solve whose line searches keep running out their trials: hand the rollout over at the start of this step
+            if (o.parkHalv > 0 && halvings - halv_in > o.parkHalv && M.is_chain) {
+                status |= ST_PARK;
+                return x;
+            }
+        }
         if (stalled) {
             // g is g(x0) again.  If it is not below tol the next Newton iteration is this one repeated exactly, and so
             // on until iter >= iterMax ("Newton did not converge", :150-153) with x unchanged: report that now.
@@ -3583,19 +3706,19 @@ __device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o
     return x;
 }
 
-template <int NP, bool CT, bool LEAN>
+template <int NP, bool CT, bool LEAN, bool COOP = false>
 __device__ __forceinline__ double newton_policy(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                                 double x, const double qA, const double qB, const double eta, NodeOut& last,
-                                                int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
+                                                int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo, CoopCtx& cx) {
     constexpr bool ROT = RMX_NEWTON_ROT && !CT && !LEAN;
     if (o.lu_mode != 0 || piv.hold > 0) {     // wave-uniform
         if (piv.hold > 0) --piv.hold;
         if constexpr (ROT) return newton_rot<NP, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
-        else return newton_impl<NP, true, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
+        else return newton_impl<NP, true, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo, cx);
     }
     double r;
     if constexpr (ROT) r = newton_rot<NP, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
-    else r = newton_impl<NP, false, CT, LEAN>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
+    else r = newton_impl<NP, false, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo, cx);
     pivot_policy_update(piv);
     return r;
 }
@@ -3604,18 +3727,18 @@ __device__ __forceinline__ double newton_policy(const DevModel& M, const DevOpts
 // evaluation plus a test that every cuboid of the tree is clear of the ground, under which the contact terms vanish
 // identically.  The first evaluation that fails the test ends the solve: status bit ST_LEFT_LEAN comes back set, nothing else
 // is touched, and the caller parks the trajectory at the start of this step for the launch with the contact terms.
-template <int NP, bool CT = false, bool LEAN = false>
+template <int NP, bool CT = false, bool LEAN = false, bool COOP = false>
 __device__ __forceinline__ double newton_node(const DevModel& M, const DevOpts& o, double* sAcc, double* sCol, const int lane,
                                               double x, const double qA, const double qB, const double eta, NodeOut& last,
-                                              int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo) {
+                                              int& iters, int& halvings, int& status, PivotPolicy& piv, double& xlo, CoopCtx& cx) {
     xlo = 0.0;
     if constexpr (!LEAN) {
-        return newton_policy<NP, CT, false>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo);
+        return newton_policy<NP, CT, false, COOP>(M, o, sAcc, sCol, lane, x, qA, qB, eta, last, iters, halvings, status, piv, xlo, cx);
     } else {
         int it2 = 0, hv2 = 0, st2 = 0;
         PivotPolicy pv2 = piv;
         NodeOut l2;
-        const double r = newton_policy<NP, false, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, l2, it2, hv2, st2, pv2, xlo);
+        const double r = newton_policy<NP, false, true>(M, o, sAcc, sCol, lane, x, qA, qB, eta, l2, it2, hv2, st2, pv2, xlo, cx);
         if (st2 & ST_LEFT_LEAN) {
             status |= ST_LEFT_LEAN;
             return x;

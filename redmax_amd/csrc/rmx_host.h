@@ -32,6 +32,10 @@ struct StepArgs {
     int* histC;       // [nsteps][B][nsph] or null: Euler charts after every step
     int* resume;      // [B] contact-capable kernels: first step the lean launch left to the launch with the contact terms
     unsigned long long* ticks;   // [B] or null: s_memtime ticks each rollout's wavefront spent in the launch(es) of this call (accumulated)
+    // park and relaunch (rmx_device.h CoopCtx; null / 0: off): rollouts the launch with the contact terms gave up at the start of a step
+    int* park;        // [1 + B + 3 B]: [0] their number, [1 .. ] their indices in the order they parked, [1 + B + 3 traj ..] their pivot policy
+    unsigned* xch;    // [ngroups][COOP_WORDS] exchange words of the cooperative groups (zero before the cooperative launch)
+    int ngroups;      // cooperative groups in flight: group g finishes parked rollouts g, g + ngroups, ... one after the other
 };
 
 struct AdjArgs {
@@ -77,6 +81,9 @@ struct rmx_batch {
     int* chart = nullptr;           // [B][nsph] current Euler chart of every spherical joint (JointSpherical.chart), 1..12
     int *it = nullptr, *ls = nullptr, *status = nullptr;
     int* resume = nullptr;          // [B] see StepArgs.resume
+    int* park = nullptr;            // see StepArgs.park / xch (allocated for models whose steps can park: rmx_model::coop)
+    unsigned* xch = nullptr;
+    int ngroups = 0;
     unsigned long long* ticks = nullptr;   // [B] see StepArgs.ticks (rmx_step_ticks)
     double* bigws = nullptr;        // trees of more than 64 nodes: per-rollout workspace of the rmx_big.hip kernels
     size_t bigws_stride = 0;        // doubles per rollout
@@ -113,6 +120,8 @@ struct rmx_batch {
 // 64-lane plain step kernels reading the per-node constants from global memory (rmx_kernels.hip RMX_PART 3) and the staging kernel
 void launch_step_gconst_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_step_fulln_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
+// rmx_kernels.hip RMX_PART 4 (32 lanes): the cooperative launch that finishes the rollouts the launch with the contact terms parked
+void launch_step_coop_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream);
 // rmx_big.hip: trees of 65..BIG_MAXN nodes, one workgroup per rollout
 size_t big_ws_doubles(const rmx_model* m);

@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(64) k_stage_consts(const DevModel M, double* _
 // TAG >= TAG_FULLN: a tree (not necessarily a chain) that fills every node slot: n == NP at compile time, so the per-row bounds of partly
 // filled sizes go (the 64-joint tree of BASELINE.json configs[2]).
 constexpr int TAG_FULLN = 4;
+constexpr int TAG_COOP = 8;      // k_step_bdf1/2<32, true, false, false, TAG_COOP>: the cooperative launch (RMX_PART 4)
 template <int NP, bool FULLCHAIN, int TAG = 0>
 __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
     DevModel M = Min;
@@ -95,7 +96,7 @@ __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
         M.n = NP;
         M.is_chain = 1;
     }
-    if constexpr (TAG >= TAG_FULLN) M.n = NP;
+    if constexpr (TAG >= TAG_FULLN && TAG < TAG_COOP) M.n = NP;
     return M;
 }
 
@@ -104,175 +105,265 @@ __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
 __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
+    constexpr bool COOP = TAG == TAG_COOP;           // the cooperative launch (rmx_device.h CoopCtx): COOP_G workgroups per parked rollout
+    static_assert(!COOP || (CT && !LEAN), "the cooperative launch belongs to the kernels with the contact terms");
+    constexpr bool PARKS = CT && !LEAN && !COOP;     // the launch with the contact terms may park a rollout for the cooperative one
     const DevModel M = model_view<NP, FULLCHAIN, TAG>(Min);
-    const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
-    const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
-    if (s0 >= a.nsteps) return;                    // the lean launch took this trajectory all the way
+    unsigned long long tick0 = __builtin_amdgcn_s_memtime();
+    int traj = blockIdx.x;
+    CoopCtx cx;
+    int pk = 0, npark = 1, pstride = 1;
+    if constexpr (COOP) {
+        pk = blockIdx.x / COOP_G;
+        cx.member = blockIdx.x % COOP_G;
+        cx.words = a.xch + (size_t)pk * COOP_WORDS;
+        npark = a.park[0];
+        pstride = a.ngroups;
+        if (pk >= npark) return;
+        traj = a.park[1 + pk];
+    }
+    const int s0 = (CT && !LEAN && a.resume) ? a.resume[traj] : 0;
+    if (!COOP && s0 >= a.nsteps) return;           // the lean launch took this trajectory all the way
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
-    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int lane = threadIdx.x;
+    int* const chart0 = (CT && M.nsph) ? a.chart : nullptr;
+    if constexpr (CT) con_setup<NP>(M, sCol);
+    const bool writer = !COOP || cx.member == 0;     // (members 1.. of a cooperative group compute, member 0 also stores)
+    for (; pk < npark; pk += pstride) {              // (one pass unless COOP: group g finishes parked rollouts g, g + ngroups, ...)
+    int sfirst = s0;
+    if constexpr (COOP) {
+        traj = a.park[1 + pk];
+        sfirst = a.resume[traj];
+        tick0 = __builtin_amdgcn_s_memtime();
+    }
     const int id = (lane < M.n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     double q = id >= 0 ? a.q[off] : 0.0;
     double qd = id >= 0 ? a.qd[off] : 0.0;
     int iters = 0, halv = 0, status = 0;
     PivotPolicy piv;
-    int* const chart = (CT && M.nsph) ? a.chart + (size_t)traj * M.nsph : nullptr;
+    if constexpr (COOP) {
+        const int* pp = a.park + 1 + a.B + 3 * traj;
+        piv.hold = pp[0]; piv.len = pp[1]; piv.streak = pp[2];
+    }
+    int* const chart = chart0 ? chart0 + (size_t)traj * M.nsph : nullptr;
     if constexpr (CT) {
-        con_setup<NP>(M, sCol);
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
     }
     int stop = a.nsteps;
-    for (int s = s0; s < a.nsteps; ++s) {
+    for (int s = sfirst; s < a.nsteps; ++s) {
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
         NodeOut last;
         double xlo;
-        const double x = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo);
+        const int it_in = iters, hv_in = halv, st_in = status;
+        const PivotPolicy piv_in = piv;
+        const double x = newton_node<NP, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo, cx);
         if (LEAN && (status & ST_LEFT_LEAN)) {
             status &= ~ST_LEFT_LEAN;
             stop = s;
             break;
         }
+        if (PARKS && (status & ST_PARK)) {         // this step goes to the cooperative launch, from its start: nothing of it is kept
+            iters = it_in; halv = hv_in; status = st_in; piv = piv_in;
+            stop = s;
+            break;
+        }
+        if (COOP && (status & ST_COOP_FAULT)) break;
         qd = ((x - q0) + xlo) / o.h;               // (:72), with the low-order part of the iterate the residual was evaluated at
         q = x;
         if constexpr (CT) {                        // jroot.reparam() (:78)
             double np0 = 0.0, np1 = 0.0;
             if (M.nsph && sph_reparam<NP, false>(M, sCol, lane, chart, q, qd, np0, np1)) status |= 32;
         }
-        if (a.histT) {                             // Scene.saveHistory (Scene.m:134-161)
+        if (a.histT && writer) {                   // Scene.saveHistory (Scene.m:134-161)
             const double T = wave_sum(last.eT), V = wave_sum(last.eV);
             if (lane == 0) {
                 a.histT[(size_t)s * a.B + traj] = T;
                 a.histV[(size_t)s * a.B + traj] = V;
             }
         }
-        if (a.histQ && id >= 0) {
+        if (a.histQ && id >= 0 && writer) {
             a.histQ[(size_t)s * a.B * M.nr + off] = q;
             a.histQd[(size_t)s * a.B * M.nr + off] = qd;
         }
         if constexpr (CT) {
-            if (a.histC && lane < M.nsph) a.histC[((size_t)s * a.B + traj) * M.nsph + lane] = chart[lane];
+            if (a.histC && lane < M.nsph && writer) a.histC[((size_t)s * a.B + traj) * M.nsph + lane] = chart[lane];
         }
     }
-    if (id >= 0) {
+    if (id >= 0 && writer) {
         a.q[off] = q;
         a.qd[off] = qd;
     }
     if (LEAN && lane == 0) a.resume[traj] = stop;
-    if (lane == 0 && a.it) {
+    if constexpr (PARKS) {
+        if (a.park && lane == 0) {
+            a.resume[traj] = stop;
+            if (stop < a.nsteps) {
+                a.park[1 + atomicAdd(a.park, 1)] = traj;
+                int* pp = a.park + 1 + a.B + 3 * traj;
+                pp[0] = piv.hold; pp[1] = piv.len; pp[2] = piv.streak;
+            }
+        }
+    }
+    if (lane == 0 && a.it && writer) {
         a.it[traj] += iters;
         a.ls[traj] += halv;
         a.status[traj] |= status;
     }
-    if (lane == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
+    if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
+    }
 }
 
 // simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.  CT / LEAN: see k_step_bdf1.
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
 __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
+    constexpr bool COOP = TAG == TAG_COOP;           // see k_step_bdf1
+    static_assert(!COOP || (CT && !LEAN), "the cooperative launch belongs to the kernels with the contact terms");
+    constexpr bool PARKS = CT && !LEAN && !COOP;
     const DevModel M = model_view<NP, FULLCHAIN, TAG>(Min);
-    const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
-    const int s0 = (CT && !LEAN && a.resume) ? a.resume[blockIdx.x] : 0;
-    if (s0 >= a.nsteps) return;
+    unsigned long long tick0 = __builtin_amdgcn_s_memtime();
+    int traj = blockIdx.x;
+    CoopCtx cx;
+    int pk = 0, npark = 1, pstride = 1;
+    if constexpr (COOP) {
+        pk = blockIdx.x / COOP_G;
+        cx.member = blockIdx.x % COOP_G;
+        cx.words = a.xch + (size_t)pk * COOP_WORDS;
+        npark = a.park[0];
+        pstride = a.ngroups;
+        if (pk >= npark) return;
+        traj = a.park[1 + pk];
+    }
+    const int s0 = (CT && !LEAN && a.resume) ? a.resume[traj] : 0;
+    if (!COOP && s0 >= a.nsteps) return;
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
-    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int lane = threadIdx.x;
+    int* const chart0 = (CT && M.nsph) ? a.chart : nullptr;
+    if constexpr (CT) con_setup<NP>(M, sCol);
+    const bool writer = !COOP || cx.member == 0;
+    const double h = o.h;
+    for (; pk < npark; pk += pstride) {              // (one pass unless COOP)
+    int sfirst = s0;
+    if constexpr (COOP) {
+        traj = a.park[1 + pk];
+        sfirst = a.resume[traj];
+        tick0 = __builtin_amdgcn_s_memtime();
+    }
     const int id = (lane < M.n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
     double q = id >= 0 ? a.q[off] : 0.0;
     double qd = id >= 0 ? a.qd[off] : 0.0;
     double qp = id >= 0 ? a.qp[off] : 0.0;       // step k-1 (Joint.q1 / qdot1 in the reference)
     double qdp = id >= 0 ? a.qdp[off] : 0.0;
-    const bool started = (*a.started) != 0 || s0 > 0;    // resumed behind the lean launch: its steps are this call's history
-    const double h = o.h;
+    const bool started = (*a.started) != 0 || sfirst > 0;    // resumed behind the lean launch: its steps are this call's history
     int iters = 0, halv = 0, status = 0;
     PivotPolicy piv;
-    int* const chart = (CT && M.nsph) ? a.chart + (size_t)traj * M.nsph : nullptr;
+    if constexpr (COOP) {
+        const int* pp = a.park + 1 + a.B + 3 * traj;
+        piv.hold = pp[0]; piv.len = pp[1]; piv.streak = pp[2];
+    }
+    int* const chart = chart0 ? chart0 + (size_t)traj * M.nsph : nullptr;
     if constexpr (CT) {
-        con_setup<NP>(M, sCol);
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
     }
     int stop = a.nsteps;
-    for (int s = s0; s < a.nsteps; ++s) {
+    for (int s = sfirst; s < a.nsteps; ++s) {
         NodeOut last;
         double xlo;       // low-order part of the converged iterate: below the rounding of the multistep velocity formulas, not used
+        const int it_in = iters, hv_in = halv, st_in = status;
+        const PivotPolicy piv_in = piv;
+        bool left = false;                         // the step was given up to the next launch (lean -> contact terms -> cooperative)
         if (s == 0 && !started) {
             const double al = (2.0 - sqrt(2.0)) / 2.0;    // (:74)
             const double q0 = q, qd0 = qd;
             // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
             const double xa0 = q0 + al * h * qd0;
-            const double qa = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv, xlo);
-            if (LEAN && (status & ST_LEFT_LEAN)) {
-                status &= ~ST_LEFT_LEAN;
-                stop = s;
-                break;
+            const double qa = newton_node<NP, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, xa0, q0, q0 + (al * h) * qd0, al * h, last, iters, halv, status, piv, xlo, cx);
+            left = (LEAN && (status & ST_LEFT_LEAN)) || (PARKS && (status & ST_PARK)) || (COOP && (status & ST_COOP_FAULT));
+            if (!left) {
+                const double qda = (qa - q0) / (al * h);
+                // SDIRK2b (evalSDIRK2b :228-260)
+                const double x10 = qa + (1.0 - al) * h * qda;
+                const double qA = q0 + (1.0 - al) * h * qda;
+                const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
+                const double q1 = newton_node<NP, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv, xlo, cx);
+                left = (LEAN && (status & ST_LEFT_LEAN)) || (PARKS && (status & ST_PARK)) || (COOP && (status & ST_COOP_FAULT));
+                if (!left) {
+                    qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
+                    q = q1;
+                    qp = q0;
+                    qdp = qd0;
+                }
             }
-            const double qda = (qa - q0) / (al * h);
-            // SDIRK2b (evalSDIRK2b :228-260)
-            const double x10 = qa + (1.0 - al) * h * qda;
-            const double qA = q0 + (1.0 - al) * h * qda;
-            const double qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-            const double q1 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x10, qA, qB, al * h, last, iters, halv, status, piv, xlo);
-            if (LEAN && (status & ST_LEFT_LEAN)) {
-                status &= ~ST_LEFT_LEAN;
-                stop = s;
-                break;
-            }
-            qd = (q1 - q0 - (1.0 - al) * h * qda) / (al * h);
-            q = q1;
-            qp = q0;
-            qdp = qd0;
         } else {
             // BDF2 (evalBDF2 :263-293): eta = 2h/3
             const double q0 = qp, qd0 = qdp, q1 = q, qd1 = qd;
             const double x0 = q1 + h * qd1;
             const double qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
             const double qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-            const double q2 = newton_node<NP, CT, LEAN>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv, xlo);
-            if (LEAN && (status & ST_LEFT_LEAN)) {
-                status &= ~ST_LEFT_LEAN;
-                stop = s;
-                break;
+            const double q2 = newton_node<NP, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, x0, qA, qB, (2.0 / 3.0) * h, last, iters, halv, status, piv, xlo, cx);
+            left = (LEAN && (status & ST_LEFT_LEAN)) || (PARKS && (status & ST_PARK)) || (COOP && (status & ST_COOP_FAULT));
+            if (!left) {
+                qp = q1;
+                qdp = qd1;
+                qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
+                q = q2;
+                // the Newton residual was evaluated with qdot = (q2-qA)/eta, identical up to rounding
             }
-            qp = q1;
-            qdp = qd1;
-            qd = (3.0 / (2.0 * h)) * (q2 - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
-            q = q2;
-            // the Newton residual was evaluated with qdot = (q2-qA)/eta, identical up to rounding
+        }
+        if (left) {
+            if (COOP) break;                       // (ST_COOP_FAULT stays in the status)
+            // nothing of this step is kept: the next launch takes it from its start (a solve of the start step that went through included)
+            iters = it_in; halv = hv_in; status = st_in; piv = piv_in;
+            stop = s;
+            break;
         }
         if constexpr (CT) {                        // jroot.reparam() (:112): q, qdot and the previous step's q1, qdot1
             if (M.nsph && sph_reparam<NP, true>(M, sCol, lane, chart, q, qd, qp, qdp)) status |= 32;
         }
-        if (a.histT) {
+        if (a.histT && writer) {
             const double T = wave_sum(last.eT), V = wave_sum(last.eV);
             if (lane == 0) {
                 a.histT[(size_t)s * a.B + traj] = T;
                 a.histV[(size_t)s * a.B + traj] = V;
             }
         }
-        if (a.histQ && id >= 0) {
+        if (a.histQ && id >= 0 && writer) {
             a.histQ[(size_t)s * a.B * M.nr + off] = q;
             a.histQd[(size_t)s * a.B * M.nr + off] = qd;
         }
         if constexpr (CT) {
-            if (a.histC && lane < M.nsph) a.histC[((size_t)s * a.B + traj) * M.nsph + lane] = chart[lane];
+            if (a.histC && lane < M.nsph && writer) a.histC[((size_t)s * a.B + traj) * M.nsph + lane] = chart[lane];
         }
     }
-    if (id >= 0) {
+    if (id >= 0 && writer) {
         a.q[off] = q;
         a.qd[off] = qd;
         a.qp[off] = qp;
         a.qdp[off] = qdp;
     }
     if (LEAN && lane == 0) a.resume[traj] = stop;
-    if (lane == 0 && a.it) {
+    if constexpr (PARKS) {
+        if (a.park && lane == 0) {
+            a.resume[traj] = stop;
+            if (stop < a.nsteps) {
+                a.park[1 + atomicAdd(a.park, 1)] = traj;
+                int* pp = a.park + 1 + a.B + 3 * traj;
+                pp[0] = piv.hold; pp[1] = piv.len; pp[2] = piv.streak;
+            }
+        }
+    }
+    if (lane == 0 && a.it && writer) {
         a.it[traj] += iters;
         a.ls[traj] += halv;
         a.status[traj] |= status;
     }
-    if (lane == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
+    if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
+    }
 }
 
 // euler (matlab-simple/testRedMax.m:67-109), BASELINE.json configs[0]: linearly-implicit Euler,
@@ -785,6 +876,17 @@ void RMX_CAT(launch_step_gconst_, RMX_NP)(const rmx_model* m, const rmx_batch* b
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, 3>), grid, block, bytes, b->stream, m->dm, o, a);
 }
 
+#elif RMX_PART == 4      // the cooperative launch of the 32-lane kernels with the contact terms (rmx_device.h CoopCtx)
+#if RMX_NP != 32
+#error "RMX_PART 4 is compiled for RMX_NP = 32"
+#endif
+
+void launch_step_coop_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(a.ngroups * COOP_G), block(64);     // group g = workgroups COOP_G g .. COOP_G g + COOP_G - 1, all of them resident at once
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<32, true, false, false, TAG_COOP>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<32, true, false, false, TAG_COOP>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+}
+
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
 
 void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
@@ -821,6 +923,10 @@ void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     // ... and the rest of its steps with the contact terms
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+#if RMX_NP == 32
+    // ... and what that launch parked (a Newton solve that keeps running out its line searches) in cooperative groups
+    if (a.park && o.parkHalv > 0) launch_step_coop_32(m, b, integ, o, a);
+#endif
 }
 void RMX_CAT(launch_energy_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);
