@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 108
+#define RMX_VERSION 109
 
 enum {
     RMX_OK = 0,
@@ -219,7 +219,12 @@ int rmx_eval_mfd(rmx_batch* b, const double* q, const double* qdot, double* M, d
  * The world-frame kernels never form K, D or the tensor on their own: H(eta; v) = M + dMdq v - eta D - eta^2 K is what
  * they evaluate, exactly, for any eta and v.  This hook takes the pieces apart on the host from a few such evaluations at the SAME
  * (q, qdot) (qA = q - eta qdot): v = 0 at eta = 1 (and 2, 1/2 for trees of more than 64 nodes, where M and D have no kernel of their
- * own) gives M, D, K; one more with the caller's v gives dMv = H(1; v) - H(1; 0).  Same conventions as rmx_eval_mfd for Euler
+ * own) gives M, D, K; one more with the caller's v gives dMv = H(1; v) - H(1; 0).
+ * Accuracy: up to 64 nodes M and D come from their own kernel and K = (M - D) - H(1; 0) carries an absolute error of order eps |M|.  Larger
+ * trees: an evaluation of H(eta) carries roundoff of order eps (|M| + eta |D| + eta^2 |K|), so each piece is taken from a triple H(e),
+ * H(2 e), H(e / 2) at its own power-of-two e - K at e_K ~ sqrt(|M| / |K|), D at min(|M| / |D|, e_K), M at the smallest of these and 1 - which
+ * leaves every piece with an error of order eps times ITS OWN norm (plus the cross terms eps |D| sqrt(|K| / |M|) in K and
+ * eps sqrt(|M| |K|) in D); 3 to 9 evaluations (ABI 109; ABI 108 took all three at e = 1: eps |M| absolute in D and K).  Same conventions as rmx_eval_mfd for Euler
  * charts and ForceGroundCuboid.  Does not change state. */
 int rmx_compute_values(rmx_batch* b, const double* q, const double* qdot, const double* v,
                        double* M, double* f, double* D, double* K, double* dMv, double* dMdq);
@@ -299,9 +304,6 @@ int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hist_T, double* h
  * host arrays [batch]. */
 int rmx_energy(rmx_batch* b, double* T, double* V);
 
-/* Timing hook for benchmarks: milliseconds spent in the kernels of the last rmx_step_* call, measured
- * with hipEvents on the batch's own stream. */
-double rmx_last_step_ms(const rmx_batch* b);
 /* The HIP stream the batch's kernels are enqueued on (as void*), for callers that order other work
  * (e.g. a torch.distributed gather) after it. */
 void* rmx_batch_stream(const rmx_batch* b);
@@ -360,14 +362,7 @@ int rmx_group_energy(rmx_group* g, double* T, double* V);                      /
  * end_ms = when its launch began / ended relative to the start of the FIRST shard on the same device (HIP events of one device
  * share a clock; 0 / kernel_ms for that first shard).  Shards run concurrently when start_ms of one lies before end_ms of another. */
 int rmx_group_timing(rmx_group* g, double* wall_ms, double* kernel_ms, double* start_ms, double* end_ms);
-/* Profiling hook: mean shader-clock cycles per wavefront of {residual evaluation, residual+Hessian evaluation,
- * LU solve, the two norm reductions} of one Newton iteration at the current state (reps repetitions per trajectory)
- * in cycles16[0..3]; cycles16[4..15] split the residual+Hessian evaluation into its 12 stages (rmx_device.h RMX_STAMP). */
-int rmx_profile_phases(rmx_batch* b, int reps, double h, double* cycles16);
-/* Per-rollout share of the last rmx_step_bdf1 / bdf2 / history / bdf1_async launch: ticks[batch] = shader-clock ticks (s_memtime) each
- * rollout's wavefront spent inside the kernel(s) of that call.  All rollouts of a batch run concurrently (one wavefront each) and the
- * launch ends with the slowest: the distribution (median, 99th percentile, maximum) says how much of the launch time is its tail. */
-int rmx_step_ticks(rmx_batch* b, unsigned long long* ticks);
+/* Per-trajectory counters kept on the device across *_async calls (see "Asynchronous stepping" above). */
 int rmx_stats_reset(rmx_batch* b);
 int rmx_stats_read(rmx_batch* b, rmx_stats* stats);
 

@@ -57,6 +57,7 @@
 
 #include "mex.h"
 #include "redmax_hip.h"
+#include "redmax_hip_profile.h"   /* 'timing' / 'ticks': measurement hooks, not part of the host-facing ABI */
 
 typedef struct {
     uint64_t magic;
@@ -506,6 +507,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     }
     char cmd[24];      /* the command table: tests/test_mex_gateway.py checks that matlab/+redmax/HipSim.m uses these and only these */
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) die("first argument must be a command string");
+    /* include/redmax_hip.h "Asynchronous stepping": between a 'step_async' and its 'sync' only 'sync', 'timing', 'info' and 'destroy'
+     * may name the handle ('step' / 'step_async' refuse with their own text).  Everything below reads or writes the state, the
+     * scratch buffers or the counters of a launch in flight, and would clear its pending mark without taking the event time. */
+    static const char* const needs_idle[] = {"set", "get", "euler", "eval", "values", "energy", "getcharts", "setcharts", "ticks",
+                                             "adjoint", NULL};
+    for (int i = 0; needs_idle[i]; ++i)
+        if (!strcmp(cmd, needs_idle[i]) && get_handle(nrhs, prhs)->pending)
+            mexErrMsgIdAndTxt("redmax:hip", "'%s' while a 'step_async' of this handle is in flight: 'sync' first", cmd);
     if (!strcmp(cmd, "version")) {
         plhs[0] = mxCreateDoubleScalar((double)rmx_version());
     } else if (!strcmp(cmd, "devices")) {

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libredmax_hip.so")
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
-# every symbol include/redmax_hip.h declares (tests/test_abi_symbols.py checks the .so exports them all)
+# every symbol include/redmax_hip.h and include/redmax_hip_profile.h (the measurement hooks) declare (tests/test_abi_symbols.py checks the .so exports them all)
 SYMBOLS = (
     "rmx_last_error", "rmx_version", "rmx_device_count", "rmx_opts_default",
     "rmx_model_create", "rmx_model_destroy", "rmx_model_nr", "rmx_model_nm", "rmx_model_idxR",

@@ -17,6 +17,7 @@ class BatchSim:
     def __init__(self, scene_or_desc, batch=1, device=0):
         d = scene_or_desc.desc() if hasattr(scene_or_desc, "desc") else scene_or_desc
         self._L = _abi.lib()
+        self._async = None                                 # (nsteps, record) of a step_history_async whose record has not been replaced
         self._desc, self._keep = _abi.make_desc(d)
         self._model = C.c_void_p()
         self._batch = C.c_void_p()
@@ -142,6 +143,7 @@ class BatchSim:
     def _step(self, fn, nsteps, h, stats, history):
         if h is not None:
             self.opts.h = float(h)
+        self._async = None                                 # any step call replaces the record of an earlier step_history_async
         st = None
         out = {}
         if stats:
@@ -231,11 +233,13 @@ class BatchSim:
     def step_bdf1_async(self, nsteps, h=None):
         if h is not None:
             self.opts.h = float(h)
+        self._async = None
         _abi.check(self._L.rmx_step_bdf1_async(self._batch, C.byref(self.opts), int(nsteps)), "rmx_step_bdf1_async")
 
     def step_bdf2_async(self, nsteps, h=None):
         if h is not None:
             self.opts.h = float(h)
+        self._async = None
         _abi.check(self._L.rmx_step_bdf2_async(self._batch, C.byref(self.opts), int(nsteps)), "rmx_step_bdf2_async")
 
     def step_history_async(self, nsteps, integrator=1, record=_abi.REC_ENERGY | _abi.REC_STATE, h=None):
@@ -247,6 +251,9 @@ class BatchSim:
         _abi.check(self._L.rmx_step_history_async(self._batch, C.byref(self.opts), int(nsteps), int(integrator), int(record)), "rmx_step_history_async")
 
     def history_read(self):
+        if self._async is None:
+            raise _abi.RedMaxHipError("history_read: no step_history_async record is outstanding on this batch "
+                                      "(the last step call was synchronous, unrecorded, or has replaced it)")
         nsteps, record = self._async
         out = {}
         hist = _abi.History()
@@ -372,7 +379,10 @@ class GroupSim:
         _abi.check(self._L.rmx_group_step_async(self._g, C.byref(self.opts), int(nsteps), int(integrator), int(record)), "rmx_group_step_async")
 
     def sync(self):
+        if self._async is None:
+            raise _abi.RedMaxHipError("GroupSim.sync: no step_async launch is outstanding on this group")
         nsteps, record = self._async
+        self._async = None
         out, st, hist = self._outputs(nsteps, record)
         _abi.check(self._L.rmx_group_sync(self._g, C.byref(st), C.byref(hist)), "rmx_group_sync")
         out.update(self.timing())

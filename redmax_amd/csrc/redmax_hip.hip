@@ -774,13 +774,43 @@ extern "C" int rmx_compute_values(rmx_batch* b, const double* q, const double* q
             if (int rc = rmx_eval_mfd(b, q, qdot, M, ft.data(), D)) return rc;
             if (K) for (size_t i = 0; i < nn; ++i) K[i] = (M[i] - D[i]) - H1[i];
         } else {
-            std::vector<double> H2(nn), Hh(nn);
-            if (int rc = eval_at(2.0, nullptr, H2)) return rc;   // M - 2 D - 4 K
-            if (int rc = eval_at(0.5, nullptr, Hh)) return rc;   // M - D / 2 - K / 4
+            // No M / D kernel at this size: the pieces are taken apart from H(e), H(2 e), H(e / 2):
+            //   3 H(e) - H(2 e) - 2 H(e / 2) = 3/2 e^2 K ;  H(e) - H(2 e) = e D + 3 e^2 K ;  M = H(e) + e D + e^2 K.
+            // H(e) carries roundoff of order eps (|M| + e |D| + e^2 |K|), so a piece comes out with good RELATIVE accuracy only from a
+            // triple whose e makes it as large as the others: a first triple at e = 1 gives the scales, then K is taken at
+            // e_K ~ sqrt(|M| / |K|), D at e_D ~ min(|M| / |D|, e_K) and M at min(1, e_K, e_D) (powers of two: the scalings are exact; a triple
+            // whose e is 1 again is not repeated).  At e = 1 alone D and K would carry an ABSOLUTE error of ~10 eps |M| per entry.
+            struct Triple { double e = 0.0; std::vector<double> H, H2, Hh; };
+            auto run = [&](Triple& t, const double e, const std::vector<double>* have) -> int {
+                t.e = e;
+                if (have) t.H = *have;
+                else { t.H.resize(nn); if (int rc = eval_at(e, nullptr, t.H)) return rc; }
+                t.H2.resize(nn);
+                t.Hh.resize(nn);
+                if (int rc = eval_at(2.0 * e, nullptr, t.H2)) return rc;
+                return eval_at(0.5 * e, nullptr, t.Hh);
+            };
+            auto k_of = [](const Triple& t, size_t i) { return (3.0 * t.H[i] - t.H2[i] - 2.0 * t.Hh[i]) * (2.0 / 3.0) / (t.e * t.e); };
+            auto d_of = [](const Triple& t, size_t i, double k) { return ((t.H[i] - t.H2[i]) - 3.0 * t.e * t.e * k) / t.e; };
+            Triple t1, tK, tD;
+            if (int rc = run(t1, 1.0, &H1)) return rc;
+            double nM = 0.0, nD = 0.0, nK = 0.0;
             for (size_t i = 0; i < nn; ++i) {
-                const double k = (3.0 * H1[i] - H2[i] - 2.0 * Hh[i]) * (2.0 / 3.0);
-                const double d = (H1[i] - H2[i]) - 3.0 * k;
-                M[i] = H1[i] + d + k;
+                const double k = k_of(t1, i), d = d_of(t1, i, k), mm = H1[i] + d + k;
+                nM += mm * mm; nD += d * d; nK += k * k;
+            }
+            auto pow2 = [](double x) { return std::ldexp(1.0, (int)std::lround(std::log2(std::min(std::max(x, 0x1p-20), 0x1p20)))); };
+            const double eK = nK > 0.0 ? pow2(std::sqrt(std::sqrt(nM / nK))) : 1.0;      // (nM, nD, nK are squared norms)
+            const double eD = nD > 0.0 ? std::min(pow2(std::sqrt(nM / nD)), eK) : 1.0;      // (beyond e_K the e |K| term of the roundoff grows)
+            const double eM = std::min(1.0, std::min(eK, eD));
+            const Triple* pK = &t1;
+            if (eK != 1.0) { if (int rc = run(tK, eK, nullptr)) return rc; pK = &tK; }
+            const Triple* pD = eD == 1.0 ? &t1 : (eD == eK ? pK : &tD);
+            if (pD == &tD) { if (int rc = run(tD, eD, nullptr)) return rc; }
+            const std::vector<double>* HM = eM == 1.0 ? &H1 : (eM == eK ? &pK->H : &pD->H);      // (eM is 1, eK or eD)
+            for (size_t i = 0; i < nn; ++i) {
+                const double k = k_of(*pK, i), d = d_of(*pD, i, k);
+                M[i] = (*HM)[i] + eM * d + eM * eM * k;
                 D[i] = d;
                 if (K) K[i] = k;
             }
@@ -876,26 +906,46 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
 }
 
 // ---- the per-step record of a step call (Scene.saveHistory, Scene.m:134-161), in device buffers that live on the batch
-static void hist_free(rmx_batch* b) {
-    for (void* p : {(void*)b->hist.T, (void*)b->hist.V, (void*)b->hist.Q, (void*)b->hist.Qd, (void*)b->hist.C})
+static void hist_release(rmx_batch* b) { b->hist = rmx_batch::Hist{}; }      // forget the record, keep the buffers
+static void hist_free(rmx_batch* b) {                                          // batch teardown
+    for (void* p : {(void*)b->hpool.T, (void*)b->hpool.V, (void*)b->hpool.Q, (void*)b->hpool.Qd, (void*)b->hpool.C})
         if (p) (void)hipFree(p);
-    b->hist = rmx_batch::Hist{};
+    b->hpool = rmx_batch::HistPool{};
+    hist_release(b);
+}
+template <class T>
+static hipError_t pool_grow(rmx_batch* b, T*& p, size_t& cap, size_t need, T** second = nullptr) {
+    if (need <= cap) return hipSuccess;
+    // growing frees the old buffer: whatever this batch still has in flight may be writing it
+    hipError_t e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) return e;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    if (second && *second) { (void)hipFree(*second); *second = nullptr; }
+    cap = 0;
+    e = hipMalloc((void**)&p, need * sizeof(T));
+    if (e == hipSuccess && second) e = hipMalloc((void**)second, need * sizeof(T));
+    if (e == hipSuccess) cap = need;
+    return e;
 }
 static int hist_alloc(rmx_batch* b, int nsteps, int record) {
-    hist_free(b);
+    hist_release(b);
     const rmx_model* m = b->m;
     const size_t nh = (size_t)nsteps * b->B, nq = nh * m->nr, nc = nh * (size_t)m->dm.nsph;
     hipError_t e = hipSuccess;
     if ((record & RMX_REC_ENERGY) && nh) {
-        e = hipMalloc((void**)&b->hist.T, nh * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void**)&b->hist.V, nh * sizeof(double));
+        e = pool_grow(b, b->hpool.T, b->hpool.capH, nh, &b->hpool.V);
+        if (e == hipSuccess) { b->hist.T = b->hpool.T; b->hist.V = b->hpool.V; }
     }
     if (e == hipSuccess && (record & RMX_REC_STATE) && nq) {
-        e = hipMalloc((void**)&b->hist.Q, nq * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void**)&b->hist.Qd, nq * sizeof(double));
+        e = pool_grow(b, b->hpool.Q, b->hpool.capQ, nq, &b->hpool.Qd);
+        if (e == hipSuccess) { b->hist.Q = b->hpool.Q; b->hist.Qd = b->hpool.Qd; }
     }
     // models with spherical joints run the extended (CT) step kernels, which record the chart after every step
-    if (e == hipSuccess && (record & RMX_REC_CHARTS) && nc) e = hipMalloc((void**)&b->hist.C, nc * sizeof(int));
+    if (e == hipSuccess && (record & RMX_REC_CHARTS) && nc) {
+        e = pool_grow<int>(b, b->hpool.C, b->hpool.capC, nc);
+        if (e == hipSuccess) b->hist.C = b->hpool.C;
+    }
     if (e != hipSuccess) {
         hist_free(b);
         (void)hipGetLastError();      // the failed allocation must not be taken for a failed launch later on
@@ -955,6 +1005,10 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
     rmx_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
     if (nsteps == 0 || m->nr == 0) return RMX_OK;
+    if (b->async_pending && (b->hist.T || b->hist.Q || b->hist.C))
+        // a recorded *_async launch is still in flight and its record has not been read: a synchronous call would replace it
+        // (include/redmax_hip.h "Asynchronous stepping": only *_async / rmx_sync / rmx_stats_reset until rmx_sync)
+        return fail(RMX_E_INVALID, "a recorded asynchronous step is pending on this batch: rmx_sync / rmx_history_read first");
     int rc = hist_alloc(b, nsteps, (hT ? RMX_REC_ENERGY : 0) | (hQ ? RMX_REC_STATE : 0) | (hC ? RMX_REC_CHARTS : 0));
     if (rc) return rc;
     const bool ws = st != nullptr;
@@ -977,7 +1031,7 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
             }
         }
     }
-    hist_free(b);                               // a synchronous call has delivered its record: nothing to keep
+    hist_release(b);                            // a synchronous call has delivered its record: nothing to keep (the buffers stay)
     if (rc) return rc;
     if (e != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_step: ") + hipGetErrorString(e));
     return RMX_OK;

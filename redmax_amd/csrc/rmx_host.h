@@ -7,7 +7,7 @@
 #include <string>
 #include <vector>
 
-#include "redmax_hip.h"
+#include "redmax_hip_profile.h"   /* redmax_hip.h + the measurement hooks */
 #include "rmx_device.h"
 
 using namespace rmx;
@@ -98,7 +98,14 @@ struct rmx_batch {
         double *Q = nullptr, *Qd = nullptr;     // [nsteps][B][nr]
         int* C = nullptr;                       // [nsteps][B][nsph]
         int nsteps = 0;
-    } hist;
+    } hist;                                     // the record of the last step call: null = that part was not recorded
+    // The device buffers behind `hist` live on the batch and only grow: no hipFree (device-synchronising) sits between the launches
+    // of shards that share a device, and a step call never pulls a buffer from under a launch still in flight.
+    struct HistPool {
+        double *T = nullptr, *V = nullptr, *Q = nullptr, *Qd = nullptr;
+        int* C = nullptr;
+        size_t capH = 0, capQ = 0, capC = 0;    // elements
+    } hpool;
 };
 
 // launchers defined by rmx_kernels.hip for one RMX_NP each

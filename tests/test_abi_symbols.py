@@ -7,10 +7,26 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "redmax_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rmx_[A-Za-z0-9_]+)\s*\(", src)))
+HEADERS = ("redmax_hip.h", "redmax_hip_profile.h")      # the host-facing ABI; the measurement hooks bench.py / tools / 'ticks' bind
+
+
+def _declared(headers=HEADERS):
+    out = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(rmx_[A-Za-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_measurement_hooks_are_not_in_the_host_facing_header():
+    """Profiling / timing entries live in include/redmax_hip_profile.h: what a MEX or ctypes host binds to simulate has none of them."""
+    host = _declared(("redmax_hip.h",))
+    prof = _declared(("redmax_hip_profile.h",))
+    assert prof == ["rmx_last_step_ms", "rmx_profile_phases", "rmx_step_ticks"]
+    assert not set(host) & set(prof)
+    txt = open(os.path.join(ROOT, "include", "redmax_hip.h")).read()
+    assert "s_memtime" not in txt and "RMX_STAMP" not in txt
 
 
 def test_header_and_binding_agree():
@@ -25,7 +41,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_abi.LIB_PATH)
     for name in _declared():
         assert hasattr(L, name), name
-    assert _abi.lib().rmx_version() == 108
+    assert _abi.lib().rmx_version() == 109
 
 
 def test_no_device_fails_loudly():

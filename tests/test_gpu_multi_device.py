@@ -43,6 +43,48 @@ def test_group_on_two_streams_equals_one_batch_and_overlaps():
     # shorter than the two kernels back to back
     assert out["start_ms"][1] < out["end_ms"][0], out
     assert out["wall_ms"] < out["kernel_ms"].sum(), out
+    # ... and on a SECOND recorded step as well: the per-step record lives in buffers that stay on the batch (no hipFree, which
+    # synchronises the device, between the two shards' launches; round-4 advice)
+    out2 = g.step(K, integrator=1, h=sc.h, record=3)
+    assert out2["start_ms"][1] < out2["end_ms"][0], out2
+    assert out2["wall_ms"] < out2["kernel_ms"].sum(), out2
+    g.close()
+
+
+def test_async_bookkeeping_fails_loudly():
+    """history_read / GroupSim.sync with nothing outstanding, and a synchronous step over a recorded launch still in flight."""
+    from redmax_amd import BatchSim, GroupSim, sceneChain, syntheticStates
+    from redmax_amd._abi import RedMaxHipError
+    sc = sceneChain(8)
+    sc.init()
+    q, qd = syntheticStates(sc.nr, 4)
+    sim = BatchSim(sc, batch=4)
+    sim.set_state(q, qd)
+    with pytest.raises(RedMaxHipError, match="no step_history_async"):
+        sim.history_read()
+    sim.step_history_async(3, integrator=1, h=sc.h)
+    with pytest.raises(RedMaxHipError, match="pending"):
+        sim.step_bdf1(1, h=sc.h, history=True)               # would replace the record of the launch in flight
+    sim.step_history_async(3, integrator=1, h=sc.h)          # (the refused call has dropped the python-side shape: record again)
+    sim.sync()
+    rec = sim.history_read()
+    assert rec["q"].shape == (3, 4, sc.nr)
+    sim.step_bdf1_async(2, h=sc.h)                           # an unrecorded launch replaces the record ...
+    sim.sync()
+    with pytest.raises(RedMaxHipError, match="no step_history_async"):
+        sim.history_read()                                   # ... so there is nothing to read (no stale shapes, no empty arrays)
+    # half a history pair is refused BEFORE the state advances
+    q1, _ = sim.get_state()
+    import ctypes as C
+    from redmax_amd import _abi
+    T = np.empty((1, 4))
+    rc = sim._L.rmx_step_bdf1(sim._batch, C.byref(sim.opts), 1, None, _abi.dptr(T), None)
+    assert rc == -1
+    assert np.array_equal(sim.get_state()[0], q1)
+    sim.close()
+    g = GroupSim(sc, 4, devices=(0, 0))
+    with pytest.raises(RedMaxHipError, match="no step_async"):
+        g.sync()
     g.close()
 
 

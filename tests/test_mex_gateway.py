@@ -145,7 +145,7 @@ def flatten(scene):
 
 
 def test_gateway_builds_warning_free_and_answers_version(gw):
-    assert gw.call(1, "version") == 108
+    assert gw.call(1, "version") == 109
 
 
 def test_gateway_reports_errors_the_matlab_way(gw):
@@ -302,6 +302,13 @@ def test_two_shards_through_the_gateway_async_and_sync(gw):
             gw.call(0, "step_async", h, 1.0, 1e-2, float(K), {}, 3.0)
             with pytest.raises(MexError, match="in flight"):
                 gw.call(1, "step", h, 1.0, 1e-2, 1.0)
+            # every command that touches the state, the scratch buffers or the counters waits for 'sync' too (round-4 advice);
+            # 'info' and 'timing' stay available
+            for cmd in (("get",), ("set", q.T, qd.T), ("energy",), ("ticks",), ("eval", q.T, q.T, q.T, 1e-2), ("values", q.T, qd.T)):
+                with pytest.raises(MexError, match="in flight"):
+                    gw.call(1, cmd[0], h, *cmd[1:])
+            gw.call(1, "info", h)
+            gw.call(1, "timing", h)
             T, V, st, Q, Qd = gw.call(5, "sync", h)
         else:
             T, V, st, Q, Qd = gw.call(5, "step", h, 1.0, 1e-2, float(K))
