@@ -22,7 +22,8 @@ Objects on the JSON line besides the driver's contract:
   value_at_survey_init     the same launch from SURVEY 8(d)'s wide initial-state ranges, 100 steps
   value_at_max_valid_init  the same launch at the largest initial-state amplitude the reference algorithm survives (measured: 0.1856)
   value_at_tol_1e-8        the tolerance rounds 1 and 2 ran the headline at
-  strong_scaling           1024 rollouts in total over the N ranks
+  strong_scaling           1024 rollouts in total over the N ranks; its figure is also the top-level `value_strong` (N > 1)
+  kernel_ms_per_rank       (N > 1) HIP-event kernel time of every rank's timed launch, weak and strong plan, in rank order
   cpu_baseline             the literal CPU restatement of the reference (oracle) on the host cores, bounded sample
   cpu_baseline_tensor_free the tensor-free CPU implementation (the algorithm the GPU executes), same sample protocol
   newton_count_agreement   per-rollout Newton iteration counts, GPU vs oracle, on the in-run sample
@@ -285,6 +286,16 @@ class RankContext:
         dev = self.torch.device("cuda", self.device) if (self.on_device and self.dist is not None) else None
         return sharding.max_over_ranks(x, dev) if self.dist is not None else float(x)
 
+    def per_rank(self, x):
+        """x of every rank, in rank order (what makes a multi-GPU line readable at a glance: which rank was the slow one)."""
+        if self.dist is None:
+            return [float(x)]
+        dev = self.torch.device("cuda", self.device) if self.on_device else "cpu"
+        mine = self.torch.tensor([float(x)], dtype=self.torch.float64, device=dev)
+        allx = self.torch.empty(self.world, dtype=self.torch.float64, device=dev)
+        self.dist.all_gather_into_tensor(allx, mine)
+        return [float(v) for v in allx.cpu().tolist()]
+
     def sum_int(self, x):
         if self.dist is None:
             return int(x)
@@ -333,7 +344,7 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
     s = st.stats()
     qf, qdf = st.get_state()
     out = {
-        "elapsed": elapsed, "kernel_ms": ctx.max(kernel_ms),
+        "elapsed": elapsed, "kernel_ms": ctx.max(kernel_ms), "kernel_ms_per_rank": [round(v, 4) for v in ctx.per_rank(kernel_ms)],
         "iters": ctx.sum_int(s["newton_iters"].sum()), "halvings": ctx.sum_int(s["ls_halvings"].sum()),
         "bad": ctx.sum_int(((s["status"] & 15) != 0).sum()), "pivoted": ctx.sum_int(((s["status"] & 16) != 0).sum()),
         "finite": bool(np.isfinite(qf).all() and np.isfinite(qdf).all()), "rollouts": shard.global_batch,
@@ -616,6 +627,9 @@ def rank_main(args, make_stepper=None, backend=None):
             out["note"] = ("METRIC-CONFORMANT FIGURE AT N > 1: strong_scaling.value (BASELINE.json's metric is a 1024-rollout batch: 1024 rollouts "
                            "in TOTAL over the %d ranks).  `value` is the weak-scaling figure the bench contract asks for: %d rollouts per GPU, a "
                            "%d-rollout job" % (world, B, m["rollouts"]))
+            # the metric-conformant figure beside `value`, at the top level (round-4 review): BASELINE.json's 1024-rollout batch in total
+            out["value_strong"] = round(strong["rollouts"] * K / strong["elapsed"], 1)
+            out["kernel_ms_per_rank"] = {"weak": m["kernel_ms_per_rank"], "strong": strong["kernel_ms_per_rank"]}
             out["strong_scaling"] = {
                 "global_batch": strong["rollouts"], "batch_per_gpu": strong["rollouts"] / world,
                 "value": round(strong["rollouts"] * K / strong["elapsed"], 1), "unit": "rollout-steps/s",

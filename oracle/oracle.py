@@ -96,6 +96,8 @@ def lib():
         L.otf_batch_step_bdf1.restype = C.c_long
         L.orc_set_newton.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
         L.orc_set_ls_fail_limit.argtypes = [C.c_int]
+        L.orc_set_trace.argtypes = [_dp, C.c_int]
+        L.orc_trace_count.restype = C.c_int
         L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_set_ground_contact_body.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
         L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
@@ -405,6 +407,25 @@ class Oracle:
 def set_newton(tol=1e-9, dxMax=1e3, iterMaxPerDof=10, iterLsMax=20):
     """Newton constants for every subsequent step call (defaults = driverRedMaxBDF1.m:95-98)."""
     lib().orc_set_newton(float(tol), float(dxMax), int(iterMaxPerDof), int(iterLsMax))
+
+
+class newton_trace:
+    """with newton_trace() as t: o.step_bdf1(h, 1) -> t.rows = [[|g| at the start of the iteration, |g| after its line search, trials], ...]
+    of every Newton iteration run inside the block (diagnostic of the oracle's newton(); single-threaded calls only)."""
+
+    def __init__(self, cap=4096):
+        self._buf = np.zeros((cap, 3))
+        self.rows = None
+
+    def __enter__(self):
+        lib().orc_set_trace(_p(self._buf), self._buf.shape[0])
+        return self
+
+    def __exit__(self, *exc):
+        n = lib().orc_trace_count()
+        lib().orc_set_trace(None, 0)
+        self.rows = self._buf[:n].copy()
+        return False
 
 
 def set_ls_fail_limit(n=0):

@@ -930,6 +930,14 @@ void orc_set_newton(double tol, double dxMax, int iterMaxPerDof, int iterLsMax) 
 static int g_lsFailLimit = 0;
 void orc_set_ls_fail_limit(int n) { g_lsFailLimit = n > 0 ? n : 0; }
 
+/* Diagnostic, changes nothing newton() computes: per Newton iteration three doubles {|g| the iteration starts from, |g| its line
+ * search ends with, trials the line search took} into a caller's buffer (single-threaded use only: Oracle.step_bdf1, not the OpenMP
+ * batch).  tests/test_gpu_reference_tol.py logs them at the steps where the GPU's iteration count differs. */
+static double* g_trace = NULL;
+static int g_trace_cap = 0, g_trace_n = 0;
+void orc_set_trace(double* buf, int cap_iters) { g_trace = buf; g_trace_cap = buf ? cap_iters : 0; g_trace_n = 0; }
+int orc_trace_count(void) { return g_trace_n; }
+
 /* newton (driverRedMaxBDF1.m:94-157): x updated in place */
 static void newton(orc_scene* s, double* x, const double* qA, const double* qB, double eta, orc_stats* st) {
     const int nr = s->nr;
@@ -960,6 +968,12 @@ static void newton(orc_scene* s, double* x, const double* qA, const double* qB, 
             iterLs++;
         }
         if (st) st->ls_halvings += iterLs - 1;
+        if (g_trace && g_trace_n < g_trace_cap) {
+            g_trace[3 * g_trace_n] = sqrt(2.0 * f0);
+            g_trace[3 * g_trace_n + 1] = vnorm(nr, g);
+            g_trace[3 * g_trace_n + 2] = (double)iterLs;
+            g_trace_n++;
+        }
         if (vnorm(nr, g) < tol) break;
         if (iter >= iterMax) { if (st) { st->not_converged++; if (vnorm(nr, g) > st->worst_exit_g) st->worst_exit_g = vnorm(nr, g); } break; }
         lsfail += decreased ? 0 : 1;

@@ -108,6 +108,9 @@ typedef struct orc_stats {
 
 /* Newton constants used by every orc_step_* call (process-global).  Defaults = the reference's hard-coded
  * values tol=1e-9, dxMax=1e3, iterMax=10*nr, iterLsMax=20 (driverRedMaxBDF1.m:95-98). */
+/* diagnostic (single-threaded): newton() logs {|g| at the start of an iteration, |g| after its line search, trials} per iteration */
+void orc_set_trace(double* buf, int cap_iters);
+int orc_trace_count(void);
 void orc_set_newton(double tol, double dxMax, int iterMaxPerDof, int iterLsMax);
 /* rmx_opts.ls_fail_limit restated (NOT reference behaviour; 0 = off = the reference) */
 void orc_set_ls_fail_limit(int n);

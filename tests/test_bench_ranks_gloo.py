@@ -3,6 +3,8 @@ gather, max-over-ranks timing, JSON assembly) driven at world_size 2 on CPU: tor
 oracle-backed stepper standing in for the HIP one (same methods as bench.GpuStepper; there is no GPU here).  Covers the weak
 line, the strong-scaling line with UNEVEN shards (3 rollouts over 2 ranks: the padded gather), and the side measurements."""
 import json
+
+import pytest
 import os
 import socket
 import sys
@@ -101,6 +103,9 @@ def test_bench_rank_code_world_size_2(tmp_path):
     assert d["repeat"]["launches"] == 2
     s = d["strong_scaling"]
     assert s["global_batch"] == 3 and s["value"] > 0                                   # 2 + 1 rollouts: uneven shards
+    assert d["value_strong"] == s["value"]                                             # the metric-conformant figure, top level
+    k = d["kernel_ms_per_rank"]
+    assert len(k["weak"]) == 2 and len(k["strong"]) == 2 and min(k["weak"] + k["strong"]) > 0
     assert d["config"]["newton_tol"] == 1e-9 == d["config"]["reference_newton_tol"]      # the headline runs the reference's constant
     r = d["value_plain_iterate"]
     assert r["newton_tol"] == 1e-9 and r["steps"] == 4 and r["value"] > 0 and r["all_finite"]

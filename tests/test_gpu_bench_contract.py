@@ -74,6 +74,7 @@ def test_two_ranks_on_one_gpu_self_launch():
     assert d["scaling"] == "weak" and d["value"] > 0 and d["config"]["all_finite"]
     s = d["strong_scaling"]
     assert s["global_batch"] == 256 and s["batch_per_gpu"] == 128 and s["value"] > 0
+    assert d["value_strong"] == s["value"] and len(d["kernel_ms_per_rank"]["weak"]) == 2 and min(d["kernel_ms_per_rank"]["strong"]) > 0
 
 
 @pytest.mark.parametrize("wl", ["tree64", "ground"])
@@ -126,3 +127,72 @@ def test_rccl_code_path_at_world_size_one():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert "RCCL" in d["config"]["parallelism"] and d["config"]["gathered_rows"] == 1024 and d["config"]["all_finite"]
     assert d["value"] > 0 and d["n_gpus"] == 1
+
+
+_RCCL_TWO_RANKS = r'''
+import datetime, json, os, sys, traceback
+sys.path.insert(0, sys.argv[1])
+rank, port, out = int(sys.argv[2]), sys.argv[3], sys.argv[4]
+import torch
+import torch.distributed as dist
+from redmax_amd import sharding
+res = {"rank": rank, "stage": "init", "error": None}
+try:
+    torch.cuda.set_device(0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "1"
+    # exactly bench.py's rank_main call for a rank that owns a GPU: backend nccl (= RCCL), device_id given -> eager communicator
+    import functools
+    orig = dist.init_process_group
+    dist.init_process_group = functools.partial(orig, timeout=datetime.timedelta(seconds=60))
+    d = sharding.init_process_group(rank, 2, "nccl", device=0)
+    res["stage"] = "collective"
+    plan = sharding.plan(rank, 2, 4, "weak")
+    q = torch.full((4, 3), float(rank), dtype=torch.float64, device="cuda:0")
+    qa, _ = sharding.gather_states(q, q.clone(), plan)
+    torch.cuda.synchronize()
+    res["stage"] = "done"
+    res["rows"] = int(qa.shape[0])
+except BaseException as e:      # noqa: BLE001 - the text of the failure is the test's subject
+    res["error"] = "%s: %s" % (type(e).__name__, e)
+    res["trace"] = traceback.format_exc()[-1500:]
+json.dump(res, open(out, "w"))
+os._exit(0)
+'''
+
+
+def test_rccl_group_of_two_ranks_on_one_gpu_is_refused_as_expected(tmp_path):
+    """The N = 2 RCCL path as far as a 1-GPU box allows (round-4 review): two processes build bench.py's own process group -
+    sharding.init_process_group(rank, 2, "nccl", device) with device_id, then the gather of sharding.gather_states on device
+    tensors - with BOTH ranks on device 0.  RCCL must refuse exactly that ("Duplicate GPU detected"): every line up to the
+    communicator has then run with world size 2 (rendezvous, device_id, eager init), and a typo on that path shows up here as some
+    OTHER error instead of surviving until the driver's 8-GPU run.  (bench.py itself detects shared devices and takes gloo.)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    script = tmp_path / "two_ranks.py"
+    script.write_text(_RCCL_TWO_RANKS)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), port, str(tmp_path / ("r%d.json" % r))], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            logs.append("TIMEOUT " + p.communicate()[0])
+    res = [json.load(open(tmp_path / ("r%d.json" % r))) if (tmp_path / ("r%d.json" % r)).exists() else None for r in range(2)]
+    text = " ".join(logs) + " ".join((r or {}).get("error") or "" for r in res)
+    print(res, logs[0][-800:], logs[1][-800:])
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    json.dump({"results": res, "logs": [lg[-3000:] for lg in logs]}, open(os.path.join(out_dir, "rccl_two_ranks_one_gpu.json"), "w"), indent=1)
+    assert all(r is not None for r in res), "a rank died without reporting"
+    assert any(r["error"] for r in res), "RCCL accepted two ranks on one GPU?"
+    assert "uplicate GPU" in text or "invalid usage" in text, text[-1500:]
+    for r in res:                         # nothing failed BEFORE the communicator: no NameError / TypeError / AttributeError on the path
+        assert not (r["error"] or "").startswith(("NameError", "TypeError", "AttributeError", "ImportError", "KeyError")), r

@@ -116,15 +116,24 @@ def test_random_tree_matches_oracle(oracle_lib, seed):
         o.set_state(q1[b], qd0[b])
         To, Vo = o.energy()
         assert abs(T[b] - To) <= 1e-10 * max(abs(To), 1) and abs(V[b] - Vo) <= 1e-10 * max(abs(Vo), 1)
+    # the oracle's four rollouts (2 integrators x B) side by side on host threads (ctypes releases the GIL; every Oracle object owns its
+    # scene): a state on which the reference's Newton creeps for its 10 nr iterations costs the test one such rollout, not four in a row
+    def _oracle_rollout(integ, b):
+        oo = oracle_lib.Oracle(sc.desc())
+        oo.set_state(q0[b], qd0[b])
+        st = (oo.step_bdf1 if integ == "bdf1" else oo.step_bdf2)(h, 6)
+        return oo, st
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2 * B) as ex:
+        fut = {(integ, b): ex.submit(_oracle_rollout, integ, b) for integ in ("bdf1", "bdf2") for b in range(B)}
+        orc = {k: f.result() for k, f in fut.items()}
     for integ in ("bdf1", "bdf2"):
         sim.set_state(q0, qd0)
         out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(6, h=h, stats=True)
         qg, qdg = sim.get_state()
         charts = sim.charts()
         for b in range(B):
-            oo = oracle_lib.Oracle(sc.desc())
-            oo.set_state(q0[b], qd0[b])
-            st = (oo.step_bdf1 if integ == "bdf1" else oo.step_bdf2)(h, 6)
+            oo, st = orc[(integ, b)]
             qo, qdo = oo.get_state()
             if st.diverged or st.not_converged:
                 assert out["status"][b] & 3                 # the reference algorithm fails on this state: so must we

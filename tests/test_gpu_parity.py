@@ -85,9 +85,15 @@ def test_single_step_matches_oracle(oracle_lib, name):
         qo, qdo = o.get_state()
         assert _close(qg[b], qo, 1e-11, 1e-10), (name, b, _rel(qg[b], qo))
         assert _close(qdg[b], qdo, 1e-9, 1e-8), (name, b, _rel(qdg[b], qdo))
-        if name != "chain32":       # chain32: tol sits at the fp64 noise floor of g, counts are roundoff-dependent
+        if name != "chain32":
             assert out["newton_iters"][b] == st.newton_iters, (name, b)
             assert out["ls_halvings"][b] == st.ls_halvings
+        else:
+            # chain32: |M| ulp(q) ~ tol, the literal oracle ends its steps wandering over the lattice of doubles; the
+            # compensated iterate never needs MORE iterations.  The per-step agreement at 1e-9 and 1e-8 is asserted on 64 rollouts x
+            # 20 steps in test_gpu_reference_tol.py::test_chain32_newton_counts_vs_literal_oracle_at_reference_tol
+            assert out["newton_iters"][b] <= st.newton_iters, (name, b, out["newton_iters"][b], st.newton_iters)
+            assert out["ls_halvings"][b] <= st.ls_halvings
     assert not (out["status"] & 5).any()
 
 

@@ -57,7 +57,13 @@ def test_chain32_soak_slice_with_newton_counts(oracle_lib):
     assert abs(int(it_g.sum()) - int(it_o.sum())) <= 0.002 * it_o.sum()
 
 
-@pytest.mark.parametrize("seed", list(range(300, 330)) + list(range(600, 606)))
+# seeds whose oracle rollouts take 38 - 80 s each on the GPU box (GPUTEST r04 / r5a durations): run with RMX_FULL_TESTS=1 only
+# (round-4 review: the GPU suite under 600 s of the driver's 1200 s step limit)
+_SLOW_SEEDS = (307, 319, 323, 605)
+
+
+@pytest.mark.parametrize("seed", [s for s in list(range(300, 330)) + list(range(600, 606))
+                                  if s not in _SLOW_SEEDS or os.environ.get("RMX_FULL_TESTS") == "1"])
 def test_random_tree_matches_oracle_extended(oracle_lib, seed, monkeypatch):
     import test_gpu_fuzz as tf
     if seed >= 600:       # the suite's convention for the 33..62-node trees

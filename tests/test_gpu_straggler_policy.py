@@ -53,7 +53,9 @@ def test_ls_fail_limit_cuts_the_stragglers_and_nothing_else(oracle_lib):
     assert sb["newton_iters"][cut].sum() < 0.5 * sa["newton_iters"][cut].sum()
     print("ls_fail_limit=2: %d of %d rollouts cut; slowest wavefront %.3g -> %.3g ticks, total Newton iterations %d -> %d"
           % (cut.sum(), B, ta.max(), tb.max(), sa["newton_iters"].sum(), sb["newton_iters"].sum()))
-    assert tb.max() < ta.max() / 3.0
+    # (3 x before round 5; the default launch itself now parks its creeping rollouts for the cooperative line search, 42 -> 16 M ticks
+    # measured on the slowest wavefront)
+    assert tb.max() < ta.max() / 2.0
     # the oracle with the same option, on two of the rollouts that were cut
     oracle_lib.set_newton(tol=1e-9)
     oracle_lib.set_ls_fail_limit(2)
