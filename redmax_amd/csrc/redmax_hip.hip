@@ -622,7 +622,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     hist_free(b);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->park, (void*)b->xch, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->park, (void*)b->xch, (void*)b->xrec, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -876,7 +876,8 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     // evaluate the reference's trial points side by side - same decisions, same results, the launch no longer waits for one wavefront
     // walking through 20 trials 320 times.  RMX_PARK_HALVINGS=0 switches it off (one wavefront per rollout throughout).
     o.parkHalv = 0;
-    if (!m->big && m->NP == 32 && m->dm.con && m->dm.is_chain && m->dm.nsph == 0 && m->n_simd >= COOP_G) {
+    m->pair32 = !m->big && m->NP == 32 && m->dm.con && m->dm.is_chain && m->dm.nsph == 0;
+    if (m->pair32 && m->n_simd >= COOP_G && b->B >= 1) {
         const char* e = getenv("RMX_PARK_HALVINGS");       // (read at every call: tests and tools switch it inside one process)
         o.parkHalv = e ? atoi(e) : 24;
     }
@@ -885,11 +886,14 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
             b->ngroups = std::min(b->B, m->n_simd / COOP_G);     // all groups resident at once: one 512-register wavefront per SIMD
             HIPCHK(hipMalloc((void**)&b->park, sizeof(int) * (1 + 4 * (size_t)b->B)));
             HIPCHK(hipMalloc((void**)&b->xch, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups));
+            HIPCHK(hipMalloc((void**)&b->xrec, sizeof(unsigned long long) * 2 * COOP_REC * (size_t)b->ngroups));
         }
         HIPCHK(hipMemsetAsync(b->park, 0, sizeof(int), b->stream));
         HIPCHK(hipMemsetAsync(b->xch, 0, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups, b->stream));
+        HIPCHK(hipMemsetAsync(b->xrec, 0, sizeof(unsigned long long) * 2 * COOP_REC * (size_t)b->ngroups, b->stream));
         a.park = b->park;
         a.xch = b->xch;
+        a.xrec = b->xrec;
         a.ngroups = b->ngroups;
     }
     HIPCHK(hipMemsetAsync(b->ticks, 0, sizeof(unsigned long long) * b->B, b->stream));
@@ -902,6 +906,24 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     HIPCHK(hipMemsetAsync(b->started, integ == INTEG_BDF2 ? 1 : 0, sizeof(int), b->stream));   // BDF2: any non-zero value
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, b->stream));
+#ifdef RMX_COOP_PROFILE
+    if (a.xch && getenv("RMX_COOP_DUMP")) {      // measurement build only: the groups' exchange words after the launch, as text
+        std::vector<unsigned> w((size_t)COOP_WORDS * b->ngroups);
+        std::vector<int> pk(1 + (size_t)b->B);
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(hipMemcpy(w.data(), b->xch, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pk.data(), b->park, pk.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(getenv("RMX_COOP_DUMP"), "w")) {
+            fprintf(f, "parked %d groups %d\n", pk[0], b->ngroups);
+            for (int g = 0; g < b->ngroups && g < pk[0]; ++g) {
+                fprintf(f, "group %d rollout %d wait_kticks", g, pk[1 + g]);
+                for (int k = 0; k < COOP_G; ++k) fprintf(f, " %u", w[(size_t)g * COOP_WORDS + 22 + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+#endif
     return RMX_OK;
 }
 

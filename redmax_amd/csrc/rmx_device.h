@@ -543,7 +543,7 @@ __device__ __forceinline__ GroundC ground_of(const DevModel& M, const double* __
 template <int MODE>
 __device__ __forceinline__ bool contact_body(const GroundC& G, const bool con, const double sd[3], const double R[9],
                                              const double p[3], const double phw[3], const double phv[3], double (&F)[6],
-                                             double (&KD)[36], double& V) {
+                                             double (&KD)[36], double& V, bool* lane_pen = nullptr) {
     const double n[3] = {G.n[0], G.n[1], G.n[2]};
     const double kn = G.kn, kt = G.kt, mu = G.mu, kdc = G.kdc;
     if (MODE == 0) {
@@ -570,6 +570,7 @@ __device__ __forceinline__ bool contact_body(const GroundC& G, const bool con, c
         const double d = n[0] * (x[0] - G.gx[0]) + n[1] * (x[1] - G.gx[1]) + n[2] * (x[2] - G.gx[2]);
         if (con && !(d > 0.0)) rem |= 1u << ic;
     }
+    if (lane_pen) *lane_pen = rem != 0u;      // this lane's body has a corner in the ground (eval_front_pair: which of two iterates)
     bool touched = false;
 #pragma unroll 1     // unrolled, the scheduler interleaves the corners and their temporaries spill
     while (__any(rem != 0u)) {
@@ -3312,10 +3313,17 @@ constexpr int ST_COOP_FAULT = 512; // RMX_ST_COOP_FAULT: a member of a cooperati
 constexpr int COOP_G = 10;                       // members of a group: trials 2 .. 2 COOP_G + 1 in one evaluation (iterLsMax = 20)
 constexpr int COOP_WORDS = 32;                   // exchange words per group: 2 x COOP_G decision words (even / odd exchanges: a member may
                                                  // post exchange r + 1 while a slower one still reads r), [2 COOP_G] the group's abort flag
+constexpr int COOP_REC = 40;                     // doubles per group the winner of a line search publishes (rmx_ct32.h CoopPub)
 struct CoopCtx {
     unsigned* words = nullptr;                   // this group's COOP_WORDS exchange words (global memory)
     int member = 0;
     unsigned round = 0;                          // line searches this group has gone through (the tag of the next exchange)
+#ifdef RMX_COOP_PROFILE                          // measurement build (tools/coop_profile.py): shader-clock ticks spent inside coop_exchange
+    unsigned long long waited = 0;
+#endif
+#ifdef RMX_TICK_PHASE                            // measurement build (rmx_ct32.h RMX_PH_BEGIN): ticks of one phase of newton_pair
+    unsigned long long phase = 0;
+#endif
 };
 __device__ __forceinline__ unsigned coop_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coop_store(unsigned* p, const unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -3346,6 +3354,9 @@ __device__ __forceinline__ bool coop_exchange(CoopCtx& cx, const int lane, const
         }
         __builtin_amdgcn_s_sleep(8);
     }
+#ifdef RMX_COOP_PROFILE
+    cx.waited += __builtin_amdgcn_s_memtime() - t0;
+#endif
     return ok;
 }
 #ifndef RMX_DUAL_LS

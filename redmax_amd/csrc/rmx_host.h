@@ -36,6 +36,7 @@ struct StepArgs {
     int* park;        // [1 + B + 3 B]: [0] their number, [1 .. ] their indices in the order they parked, [1 + B + 3 traj ..] their pivot policy
     unsigned* xch;    // [ngroups][COOP_WORDS] exchange words of the cooperative groups (zero before the cooperative launch)
     int ngroups;      // cooperative groups in flight: group g finishes parked rollouts g, g + ngroups, ... one after the other
+    unsigned long long* xrec;   // [ngroups][2 COOP_REC] what the winner of a line search publishes to its group (rmx_ct32.h CoopPub; zero before the launch)
 };
 
 struct AdjArgs {
@@ -67,6 +68,7 @@ struct rmx_model {
     void* dgconst = nullptr;        // 64-lane plain models: the staged per-node constants in global memory (DevModel::gconst)
     int gconst_min_batch = 0;       // batches of at least this many rollouts run the global-constants kernels (0: never)
     bool big = false;               // more than 64 nodes: the one-workgroup-per-tree kernels of rmx_big.hip
+    bool pair32 = false;            // serial chain of <= 32 nodes with ForceGroundCuboid, no Euler-chart joints: the kernels around newton_pair
     std::vector<struct rmx_batch*> batches;   // live batches of this model (rmx_model_set_ground_contact drains their streams only)
 };
 
@@ -83,6 +85,7 @@ struct rmx_batch {
     int* resume = nullptr;          // [B] see StepArgs.resume
     int* park = nullptr;            // see StepArgs.park / xch (allocated for models whose steps can park: rmx_model::coop)
     unsigned* xch = nullptr;
+    unsigned long long* xrec = nullptr;
     int ngroups = 0;
     unsigned long long* ticks = nullptr;   // [B] see StepArgs.ticks (rmx_step_ticks)
     double* bigws = nullptr;        // trees of more than 64 nodes: per-rollout workspace of the rmx_big.hip kernels
@@ -127,8 +130,9 @@ struct rmx_batch {
 // 64-lane plain step kernels reading the per-node constants from global memory (rmx_kernels.hip RMX_PART 3) and the staging kernel
 void launch_step_gconst_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_step_fulln_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
-// rmx_kernels.hip RMX_PART 4 (32 lanes): the cooperative launch that finishes the rollouts the launch with the contact terms parked
-void launch_step_coop_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
+// rmx_kernels.hip RMX_PART 4 (32 lanes): serial chains with ground contact - the launch with the contact terms around newton_pair
+// (rmx_ct32.h) and the cooperative launch that finishes the rollouts it parked
+void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream);
 // rmx_big.hip: trees of 65..BIG_MAXN nodes, one workgroup per rollout
 size_t big_ws_doubles(const rmx_model* m);

@@ -876,15 +876,179 @@ void RMX_CAT(launch_step_gconst_, RMX_NP)(const rmx_model* m, const rmx_batch* b
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, 3>), grid, block, bytes, b->stream, m->dm, o, a);
 }
 
-#elif RMX_PART == 4      // the cooperative launch of the 32-lane kernels with the contact terms (rmx_device.h CoopCtx)
+#elif RMX_PART == 4      // serial chains of <= 32 nodes with ForceGroundCuboid: the step kernels around newton_pair (rmx_ct32.h)
 #if RMX_NP != 32
 #error "RMX_PART 4 is compiled for RMX_NP = 32"
 #endif
+#include "rmx_ct32.h"
 
-void launch_step_coop_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
-    const dim3 grid(a.ngroups * COOP_G), block(64);     // group g = workgroups COOP_G g .. COOP_G g + COOP_G - 1, all of them resident at once
-    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<32, true, false, false, TAG_COOP>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
-    else RMX_LAUNCH((k_step_bdf2<32, true, false, false, TAG_COOP>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+// simLoop of driverRedMaxBDF1.m:57-91 / driverRedMaxBDF2.m:57-125 (integ, wave-uniform) for one rollout of a chain of <= 32 nodes with
+// ground contact, from the step the lean launch (k_step_bdf1/2<32, true, true>: free flight) left it at.  ONE call site of the Newton
+// solve for every stage of every integrator: the SDIRK2 start step is two passes of the stage loop, everything else one.
+// COOP = false: one wavefront per rollout; a solve whose line searches keep running out their trials parks the rollout at the start
+// of that step (DevOpts::parkHalv).  COOP = true: groups of COOP_G workgroups, group g finishes the parked rollouts g, g + ngroups, ...
+template <bool COOP>
+__global__ void __launch_bounds__(64) k_step_pair(const DevModel M, const DevOpts o, const StepArgs a, const int integ) {
+    constexpr int NP = 32;
+    unsigned long long tick0 = __builtin_amdgcn_s_memtime();
+    int traj = blockIdx.x;
+    CoopCtx cx;
+    CoopPub pb;
+    int pk = 0, npark = 1, pstride = 1;
+    if constexpr (COOP) {
+        pk = blockIdx.x / COOP_G;
+        cx.member = blockIdx.x % COOP_G;
+        cx.words = a.xch + (size_t)pk * COOP_WORDS;
+        pb.rec = a.xrec + (size_t)pk * 2 * COOP_REC;
+        npark = a.park[0];
+        pstride = a.ngroups;
+        if (pk >= npark) return;
+        traj = a.park[1 + pk];
+    }
+    const int s0 = a.resume ? a.resume[traj] : 0;
+    if (!COOP && s0 >= a.nsteps) return;           // the lean launch took this trajectory all the way
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x;
+    con_setup<NP>(M, sCol);
+    const bool writer = !COOP || cx.member == 0;     // (members 1.. of a cooperative group compute, member 0 also stores)
+    const double h = o.h;
+    const bool bdf2 = integ == INTEG_BDF2;
+    for (; pk < npark; pk += pstride) {              // (one pass unless COOP)
+        int sfirst = s0;
+        if constexpr (COOP) {
+            traj = a.park[1 + pk];
+            sfirst = a.resume[traj];
+            tick0 = __builtin_amdgcn_s_memtime();
+        }
+        const int id = (lane < M.n) ? M.idx[lane] : -1;
+        const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+        double q = id >= 0 ? a.q[off] : 0.0;
+        double qd = id >= 0 ? a.qd[off] : 0.0;
+        double qp = (bdf2 && id >= 0) ? a.qp[off] : 0.0;       // step k-1 (Joint.q1 / qdot1 in the reference)
+        double qdp = (bdf2 && id >= 0) ? a.qdp[off] : 0.0;
+        const bool started = (*a.started) != 0 || sfirst > 0;    // resumed behind the lean launch: its steps are this call's history
+        int iters = 0, halv = 0, status = 0;
+        PivotPolicy piv;
+        if constexpr (COOP) {
+            const int* pp = a.park + 1 + a.B + 3 * traj;
+            piv.hold = pp[0]; piv.len = pp[1]; piv.streak = pp[2];
+        }
+        int stop = a.nsteps;
+        for (int s = sfirst; s < a.nsteps; ++s) {
+            NodeOut last;
+            last.g = last.eT = last.eV = 0.0;
+            double xlo = 0.0;
+            const int it_in = iters, hv_in = halv, st_in = status;
+            const PivotPolicy piv_in = piv;
+            const bool start2 = bdf2 && s == 0 && !started;       // SDIRK2 start step (driverRedMaxBDF2.m:64-88): two solves
+            const double al = (2.0 - sqrt(2.0)) / 2.0;            // (:74)
+            const double q0 = (bdf2 && !start2) ? qp : q, qd0 = (bdf2 && !start2) ? qdp : qd, q1 = q, qd1 = qd;
+            double qa = 0.0, qda = 0.0, xsol = 0.0;
+            bool left = false;
+            for (int stage = 0; stage < (start2 ? 2 : 1) && !left; ++stage) {
+                double xi, qA, qB, eta;
+                if (!bdf2) {                       // BDF1 (evalBDF1 :160-187): eta = h, qA = q0, qB = q0 + h qdot0 = the initial guess (:70)
+                    xi = q0 + h * qd0; qA = q0; qB = xi; eta = h;
+                } else if (!start2) {              // BDF2 (evalBDF2 :263-293): eta = 2h/3
+                    xi = q1 + h * qd1;
+                    qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
+                    qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
+                    eta = (2.0 / 3.0) * h;
+                } else if (stage == 0) {           // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
+                    xi = q0 + al * h * qd0; qA = q0; qB = q0 + (al * h) * qd0; eta = al * h;
+                } else {                           // SDIRK2b (evalSDIRK2b :228-260)
+                    xi = qa + (1.0 - al) * h * qda;
+                    qA = q0 + (1.0 - al) * h * qda;
+                    qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
+                    eta = al * h;
+                }
+                // the pivot policy of newton_policy (rmx_device.h): a hold after three tripped solves in a row
+                const bool pivot_all = o.lu_mode != 0 || piv.hold > 0;
+                if (piv.hold > 0) --piv.hold;
+                xsol = newton_pair<COOP>(M, o, sAcc, lane, xi, qA, qB, eta, last, iters, halv, status, piv, pivot_all, xlo, cx, pb);
+                if (!pivot_all) pivot_policy_update(piv);
+                left = (!COOP && (status & ST_PARK)) || (COOP && (status & ST_COOP_FAULT));
+                if (start2 && stage == 0 && !left) {
+                    qa = xsol;
+                    qda = (qa - q0) / (al * h);
+                }
+            }
+            if (left) {
+                if (COOP) break;                   // (ST_COOP_FAULT stays in the status)
+                // nothing of this step is kept: the cooperative launch takes it from its start (a solve of the start step that went through included)
+                iters = it_in; halv = hv_in; status = st_in & ~ST_PARK; piv = piv_in;
+                stop = s;
+                break;
+            }
+            if (!bdf2) {
+                qd = ((xsol - q0) + xlo) / h;      // (:72), with the low-order part of the iterate the residual was evaluated at
+                q = xsol;
+            } else if (start2) {
+                qd = (xsol - q0 - (1.0 - al) * h * qda) / (al * h);
+                q = xsol;
+                qp = q0;
+                qdp = qd0;
+            } else {
+                qp = q1;
+                qdp = qd1;
+                qd = (3.0 / (2.0 * h)) * (xsol - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
+                q = xsol;
+            }
+            if (a.histT && writer) {               // Scene.saveHistory (Scene.m:134-161)
+                const double T = wave_sum(last.eT), V = wave_sum(last.eV);
+                if (lane == 0) {
+                    a.histT[(size_t)s * a.B + traj] = T;
+                    a.histV[(size_t)s * a.B + traj] = V;
+                }
+            }
+            if (a.histQ && id >= 0 && writer) {
+                a.histQ[(size_t)s * a.B * M.nr + off] = q;
+                a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+            }
+        }
+        if (id >= 0 && writer) {
+            a.q[off] = q;
+            a.qd[off] = qd;
+            if (bdf2) {
+                a.qp[off] = qp;
+                a.qdp[off] = qdp;
+            }
+        }
+        if constexpr (!COOP) {
+            if (lane == 0) {
+                a.resume[traj] = stop;
+                if (a.park && stop < a.nsteps) {
+                    a.park[1 + atomicAdd(a.park, 1)] = traj;
+                    int* pp = a.park + 1 + a.B + 3 * traj;
+                    pp[0] = piv.hold; pp[1] = piv.len; pp[2] = piv.streak;
+                }
+            }
+        }
+        if (lane == 0 && a.it && writer) {
+            a.it[traj] += iters;
+            a.ls[traj] += halv;
+            a.status[traj] |= status;
+        }
+#ifdef RMX_TICK_PHASE
+        if (lane == 0 && a.ticks && writer) a.ticks[traj] += cx.phase;
+        cx.phase = 0;
+#else
+        if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
+#endif
+#ifdef RMX_COOP_PROFILE
+        if constexpr (COOP) {      // words 22 .. 31: ticks / 1024 member m spent waiting for its group (exchange + collect), last rollout of the group
+            if (lane == 0) cx.words[22 + cx.member] = (unsigned)(cx.waited >> 10);
+        }
+#endif
+    }
+}
+
+// the launch with the contact terms of a chain of <= 32 nodes (behind the lean launch of launch_step_ct_32), then the cooperative one
+void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    RMX_LAUNCH((k_step_pair<false>), dim3(b->B), dim3(64), m->smem_bytes, b->stream, m->dm, o, a, integ);
+    // group g = workgroups COOP_G g .. COOP_G g + COOP_G - 1, all of them resident at once
+    if (a.park && o.parkHalv > 0) RMX_LAUNCH((k_step_pair<true>), dim3(a.ngroups * COOP_G), dim3(64), m->smem_bytes, b->stream, m->dm, o, a, integ);
 }
 
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
@@ -920,13 +1084,14 @@ void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     if (!m->dm.con) return;
+#if RMX_NP == 32
+    // serial chains (no Euler-chart joints): the kernels around newton_pair (RMX_PART 4, rmx_ct32.h) take the rest of the steps with the
+    // contact terms, and what they park (a Newton solve that keeps running out its line searches) in cooperative groups
+    if (m->pair32) return launch_step_pair_32(m, b, integ, o, a);
+#endif
     // ... and the rest of its steps with the contact terms
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
-#if RMX_NP == 32
-    // ... and what that launch parked (a Newton solve that keeps running out its line searches) in cooperative groups
-    if (a.park && o.parkHalv > 0) launch_step_coop_32(m, b, integ, o, a);
-#endif
 }
 void RMX_CAT(launch_energy_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, double* dT, double* dV) {
     const dim3 grid(b->B), block(64);

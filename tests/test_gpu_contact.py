@@ -429,3 +429,41 @@ def test_compute_values_full_output_with_ground_contact(oracle_lib, name):
         touched += _rel(o_free.compute_values(deriv=True)[3], Ko) > 1e-6
     assert touched >= 1                                   # the contact stiffness really was in K
     sim.close()
+
+
+def test_config5_flagged_rollouts_replay_on_the_oracle(oracle_lib):
+    """BASELINE.json configs[4] (32-link chain over the frictional ground, BDF2, h = 5e-4, 100 steps): the rollouts whose Newton creeps
+    through its 320 iterations on one step (status MAXITER; the default launch parks them and finishes them in cooperative groups of
+    wavefronts, rmx_ct32.h) against the literal oracle: the SAME Newton iteration counts, the SAME line-search halving counts, the same
+    'did not converge' verdict, q to 1e-7.  (tests/config5_check.py was the manual form of this.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from redmax_amd import BatchSim, sceneChainGround, syntheticStates
+    B, K = 256, 100
+    sc = sceneChainGround(32)
+    sc.init()
+    q, qd = syntheticStates(sc.nr, B, sq=5e-4, sv=0.1)
+    q[0], qd[0] = sc.getQ()
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q, qd)
+    out = sim.step_bdf2(K, h=sc.h, stats=True)
+    qg, _ = sim.get_state()
+    sim.close()
+    it, ls, st = out["newton_iters"], out["ls_halvings"], out["status"]
+    assert (st & 512).max() == 0                      # no cooperative group gave up
+    flagged = np.nonzero(st & 2)[0]
+    assert len(flagged) >= 4, len(flagged)            # the workload does have such rollouts (12 of the first 256 when written)
+    pick = list(flagged[:5]) + [1, 2]
+
+    def replay(b):
+        o = oracle_lib.Oracle(sc.desc())
+        o.set_state(q[b], qd[b])
+        s = o.step_bdf2(sc.h, K)
+        return s, o.get_state()[0]
+    with ThreadPoolExecutor(max_workers=len(pick)) as ex:
+        res = list(ex.map(replay, pick))
+    for b, (s, qo) in zip(pick, res):
+        print("rollout %3d: iterations gpu %d oracle %d, halvings gpu %d oracle %d, oracle not converged %d" % (
+            b, it[b], s.newton_iters, ls[b], s.ls_halvings, s.not_converged))
+        assert it[b] == s.newton_iters and ls[b] == s.ls_halvings, b
+        assert bool(st[b] & 2) == (s.not_converged > 0) and s.diverged == 0
+        assert np.linalg.norm(qg[b] - qo) <= 1e-7 * np.linalg.norm(qo), b
