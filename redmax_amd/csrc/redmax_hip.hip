@@ -622,7 +622,7 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     hist_free(b);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
-                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->park, (void*)b->xch, (void*)b->xrec, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
+                    (void*)b->started, (void*)b->it, (void*)b->ls, (void*)b->status, (void*)b->resume, (void*)b->park, (void*)b->xch, (void*)b->xrec, b->gargs, (void*)b->chart, (void*)b->ticks, (void*)b->bigws, b->adjws})
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -884,17 +884,26 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     if (o.parkHalv > 0) {
         if (!b->park) {
             b->ngroups = std::min(b->B, m->n_simd / COOP_G);     // all groups resident at once: one 512-register wavefront per SIMD
-            HIPCHK(hipMalloc((void**)&b->park, sizeof(int) * (1 + 4 * (size_t)b->B)));
+            HIPCHK(hipMalloc((void**)&b->park, sizeof(int) * (2 + 4 * (size_t)b->B)));
             HIPCHK(hipMalloc((void**)&b->xch, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups));
             HIPCHK(hipMalloc((void**)&b->xrec, sizeof(unsigned long long) * 2 * COOP_REC * (size_t)b->ngroups));
         }
-        HIPCHK(hipMemsetAsync(b->park, 0, sizeof(int), b->stream));
+        HIPCHK(hipMemsetAsync(b->park, 0, sizeof(int) * (2 + 4 * (size_t)b->B), b->stream));
         HIPCHK(hipMemsetAsync(b->xch, 0, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups, b->stream));
         HIPCHK(hipMemsetAsync(b->xrec, 0, sizeof(unsigned long long) * 2 * COOP_REC * (size_t)b->ngroups, b->stream));
         a.park = b->park;
         a.xch = b->xch;
         a.xrec = b->xrec;
         a.ngroups = b->ngroups;
+    }
+    if (m->pair32) {
+        // RMX_GROUND_FUSED: 2 (default) free flight and the steps with the contact terms of a rollout in ONE launch (a rollout that
+        // leaves free flight early is not held back by the last one to do so), the cooperative groups in a second; 1 the groups in
+        // the same launch as well (measured slower: DESIGN.md section 6); 0 three launches (lean, contact terms, groups)
+        const char* f = getenv("RMX_GROUND_FUSED");
+        a.fused = f ? atoi(f) : 2;
+        if (a.fused == 1 && o.parkHalv <= 0) a.fused = 2;
+        if (a.fused && !b->gargs) HIPCHK(hipMalloc(&b->gargs, RMX_GARGS_BYTES));
     }
     HIPCHK(hipMemsetAsync(b->ticks, 0, sizeof(unsigned long long) * b->B, b->stream));
     HIPCHK(hipEventRecord(b->ev0, b->stream));

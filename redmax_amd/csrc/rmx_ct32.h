@@ -38,8 +38,9 @@ namespace rmx {
 
 // suffix sums of NS numbers per node along two chains of 32 nodes side by side (lanes 0..31, 32..63): row_shl scans inside the
 // 16-lane rows, then rows 0 and 2 add the complete total of lane 16 / 48
-template <int NS>
-__device__ __forceinline__ void chain_suffix_sum_pair(const int lane, double (&S)[NACC]) {
+template <int NS, int NA>
+__device__ __forceinline__ void chain_suffix_sum_pair(const int lane, double (&S)[NA]) {
+    static_assert(NS <= NA, "scan wider than the array");
 #pragma unroll
     for (int c = 0; c < NS; ++c) S[c] += dpp_shl0<1>(S[c]);
 #pragma unroll
@@ -49,9 +50,9 @@ __device__ __forceinline__ void chain_suffix_sum_pair(const int lane, double (&S
 #pragma unroll
     for (int c = 0; c < NS; ++c) S[c] += dpp_shl0<8>(S[c]);
     const double w0 = ((lane >> 4) == 0) ? 1.0 : 0.0, w2 = ((lane >> 4) == 2) ? 1.0 : 0.0;
-    constexpr int BATCH = 7;           // broadcasts ahead of their FMAs (readlane -> use hazard), in batches the SGPR file holds
-    static_assert(NS % BATCH == 0 || NS == 6, "batching");
-    constexpr int NB = NS == 6 ? 6 : BATCH;
+    // broadcasts ahead of their FMAs (readlane -> use hazard), in batches the SGPR file holds
+    constexpr int NB = NS % 7 == 0 ? 7 : 6;
+    static_assert(NS % NB == 0, "batching");
 #pragma unroll
     for (int c0 = 0; c0 < NS; c0 += NB) {
         double t0[NB], t2[NB];
@@ -267,7 +268,7 @@ __device__ __forceinline__ void eval_front_pair(const int n, const double* __res
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) S[25 + c] = hf[c];
-    chain_suffix_sum_pair<NACC>(lane, S);
+    chain_suffix_sum_pair<NACC, NACC>(lane, S);
     const double fr = (tau + fs.tau_add) + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
                       hitU * (qLimK * (qLimU - q) - qLimD * qd);
     out.g = dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
@@ -575,9 +576,17 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
         if (!redo) ++iters;
         if (need_solve) {
             double Hrow[NP];
+#if defined(RMX_TICK_PHASE) && RMX_TICK_PHASE >= 20      // 20 + k: stamp k of the Hessian stage (12: stiffness block, 13: damping block,
+            {                                                // 9: the node's vectors, 10: column vectors, 11: products, staging and H)
+                unsigned long long st[16] = {0};
+                eval_hess<NP, true, true, false>(M, lane, fs, Hrow, st, sAcc, e.g);
+                cx.phase += st[RMX_TICK_PHASE - 20];
+            }
+#else
             RMX_PH_BEGIN(2)
             eval_hess<NP, false, true, false>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
             RMX_PH_END(2)
+#endif
             bool lu_ok = true;
             RMX_PH_BEGIN(3)
             if (pivot_all || redo) {

@@ -1941,6 +1941,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                     cxr3[r] = e2 * a3;
                 }
             }
+            RMX_STAMP(12)
             {   // damping block, symmetric: 21 numbers, one pass
                 double Dx[36];
                 contact_body<2>(G, con, sd, fs.Rw, fs.pw, phw, phv, Fc, Dx, eVc);
@@ -1958,6 +1959,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                     cxr2[r] = a2;
                 }
             }
+            RMX_STAMP(13)
         }
     }
     const double (&bw)[3] = fs.bw;

@@ -13,6 +13,7 @@
 using namespace rmx;
 
 enum { INTEG_BDF1 = 1, INTEG_BDF2 = 2 };
+constexpr size_t RMX_GARGS_BYTES = 1024;
 
 struct StepArgs {
     int B, nsteps;
@@ -33,9 +34,11 @@ struct StepArgs {
     int* resume;      // [B] contact-capable kernels: first step the lean launch left to the launch with the contact terms
     unsigned long long* ticks;   // [B] or null: s_memtime ticks each rollout's wavefront spent in the launch(es) of this call (accumulated)
     // park and relaunch (rmx_device.h CoopCtx; null / 0: off): rollouts the launch with the contact terms gave up at the start of a step
-    int* park;        // [1 + B + 3 B]: [0] their number, [1 .. ] their indices in the order they parked, [1 + B + 3 traj ..] their pivot policy
+    int* park;        // [1 + B + 3 B + 1]: [0] their number, [1 .. ] their indices + 1 in the order they parked (0: no entry yet),
+                      // [1 + B + 3 traj ..] their pivot policy, [1 + 4 B] rollout workgroups that have finished (k_ground32)
     unsigned* xch;    // [ngroups][COOP_WORDS] exchange words of the cooperative groups (zero before the cooperative launch)
     int ngroups;      // cooperative groups in flight: group g finishes parked rollouts g, g + ngroups, ... one after the other
+    int fused;        // the whole call in one launch (rmx_kernels.hip k_ground32): rollouts and cooperative groups side by side
     unsigned long long* xrec;   // [ngroups][2 COOP_REC] what the winner of a line search publishes to its group (rmx_ct32.h CoopPub; zero before the launch)
 };
 
@@ -86,6 +89,7 @@ struct rmx_batch {
     int* park = nullptr;            // see StepArgs.park / xch (allocated for models whose steps can park: rmx_model::coop)
     unsigned* xch = nullptr;
     unsigned long long* xrec = nullptr;
+    void* gargs = nullptr;          // RMX_GARGS_BYTES: the arguments of the fused ground launch (rmx_kernels.hip GroundArgs)
     int ngroups = 0;
     unsigned long long* ticks = nullptr;   // [B] see StepArgs.ticks (rmx_step_ticks)
     double* bigws = nullptr;        // trees of more than 64 nodes: per-rollout workspace of the rmx_big.hip kernels
@@ -132,7 +136,7 @@ void launch_step_gconst_64(const rmx_model* m, const rmx_batch* b, int integ, co
 void launch_step_fulln_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 // rmx_kernels.hip RMX_PART 4 (32 lanes): serial chains with ground contact - the launch with the contact terms around newton_pair
 // (rmx_ct32.h) and the cooperative launch that finishes the rollouts it parked
-void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
+void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a, bool fused);
 void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream);
 // rmx_big.hip: trees of 65..BIG_MAXN nodes, one workgroup per rollout
 size_t big_ws_doubles(const rmx_model* m);

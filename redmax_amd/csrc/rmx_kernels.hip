@@ -883,10 +883,149 @@ void RMX_CAT(launch_step_gconst_, RMX_NP)(const rmx_model* m, const rmx_batch* b
 #include "rmx_ct32.h"
 
 // simLoop of driverRedMaxBDF1.m:57-91 / driverRedMaxBDF2.m:57-125 (integ, wave-uniform) for one rollout of a chain of <= 32 nodes with
-// ground contact, from the step the lean launch (k_step_bdf1/2<32, true, true>: free flight) left it at.  ONE call site of the Newton
-// solve for every stage of every integrator: the SDIRK2 start step is two passes of the stage loop, everything else one.
-// COOP = false: one wavefront per rollout; a solve whose line searches keep running out their trials parks the rollout at the start
-// of that step (DevOpts::parkHalv).  COOP = true: groups of COOP_G workgroups, group g finishes the parked rollouts g, g + ngroups, ...
+// ground contact, steps sfirst .. nsteps - 1.  ONE call site of newton_pair for every stage of every integrator: the SDIRK2 start step
+// is two passes of the stage loop, everything else one.
+// Returns the step at which the rollout was handed on (nsteps: it is complete).  One Newton flavour per instantiation:
+// RUN_LEAN: free flight - the lean solve (newton_node<32, true, true>: the plain evaluation plus the test that every cuboid is clear of
+//   the ground, under which the contact terms vanish identically); the rollout is handed on at the start of the first STEP in which an
+//   evaluation fails that test (what the lean launch of launch_step_ct_32 does).
+// RUN_PAIR: newton_pair, one wavefront; a solve whose line searches keep running out their trials hands the rollout on, at the start
+//   of that step, to a cooperative group (DevOpts::parkHalv).
+// RUN_COOP: this wavefront is a member of the group that finishes a parked rollout.
+enum { RUN_LEAN = 0, RUN_PAIR = 1, RUN_COOP = 2 };
+template <int MODE>
+__device__ __forceinline__ int run_rollout(const DevModel& M, const DevOpts& o, const StepArgs& a, const int integ, double* sAcc, double* sCol,
+                                           const int lane, const int traj, const int sfirst, CoopCtx& cx, const CoopPub& pb,
+                                           const unsigned long long tick0) {
+    constexpr int NP = 32;
+    constexpr bool COOP = MODE == RUN_COOP;
+    const bool writer = !COOP || cx.member == 0;     // (members 1.. of a cooperative group compute, member 0 also stores)
+    const double h = o.h;
+    const bool bdf2 = integ == INTEG_BDF2;
+    const int id = (lane < M.n) ? M.idx[lane] : -1;
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    double qp = (bdf2 && id >= 0) ? a.qp[off] : 0.0;       // step k-1 (Joint.q1 / qdot1 in the reference)
+    double qdp = (bdf2 && id >= 0) ? a.qdp[off] : 0.0;
+    const bool started = (*a.started) != 0 || sfirst > 0;    // resumed behind earlier steps of this call: they are its history
+    int iters = 0, halv = 0, status = 0;
+    PivotPolicy piv;
+    if constexpr (COOP) {
+        const int* pp = a.park + 1 + a.B + 3 * traj;
+        piv.hold = pp[0]; piv.len = pp[1]; piv.streak = pp[2];
+    }
+    int stop = a.nsteps;
+    for (int s = sfirst; s < a.nsteps; ++s) {
+        NodeOut last;
+        last.g = last.eT = last.eV = 0.0;
+        double xlo = 0.0;
+        const int it_in = iters, hv_in = halv, st_in = status;
+        const PivotPolicy piv_in = piv;
+        const bool start2 = bdf2 && s == 0 && !started;       // SDIRK2 start step (driverRedMaxBDF2.m:64-88): two solves
+        const double al = (2.0 - sqrt(2.0)) / 2.0;            // (:74)
+        const double q0 = (bdf2 && !start2) ? qp : q, qd0 = (bdf2 && !start2) ? qdp : qd, q1 = q, qd1 = qd;
+        double qa = 0.0, qda = 0.0, xsol = 0.0;
+        bool left = false;
+        for (int stage = 0; stage < (start2 ? 2 : 1) && !left; ++stage) {
+            double xi, qA, qB, eta;
+            if (!bdf2) {                       // BDF1 (evalBDF1 :160-187): eta = h, qA = q0, qB = q0 + h qdot0 = the initial guess (:70)
+                xi = q0 + h * qd0; qA = q0; qB = xi; eta = h;
+            } else if (!start2) {              // BDF2 (evalBDF2 :263-293): eta = 2h/3
+                xi = q1 + h * qd1;
+                qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
+                qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
+                eta = (2.0 / 3.0) * h;
+            } else if (stage == 0) {           // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
+                xi = q0 + al * h * qd0; qA = q0; qB = q0 + (al * h) * qd0; eta = al * h;
+            } else {                           // SDIRK2b (evalSDIRK2b :228-260)
+                xi = qa + (1.0 - al) * h * qda;
+                qA = q0 + (1.0 - al) * h * qda;
+                qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
+                eta = al * h;
+            }
+            if constexpr (MODE == RUN_LEAN) {
+                xsol = newton_node<NP, true, true, false>(M, o, sAcc, sCol, lane, xi, qA, qB, eta, last, iters, halv, status, piv, xlo, cx);
+                left = (status & ST_LEFT_LEAN) != 0;   // a cuboid comes near the ground: nothing of this step is kept
+            } else {
+                // the pivot policy of newton_policy (rmx_device.h): a hold after three tripped solves in a row
+                const bool pivot_all = o.lu_mode != 0 || piv.hold > 0;
+                if (piv.hold > 0) --piv.hold;
+                xsol = newton_pair<COOP>(M, o, sAcc, lane, xi, qA, qB, eta, last, iters, halv, status, piv, pivot_all, xlo, cx, pb);
+                if (!pivot_all) pivot_policy_update(piv);
+                left = (MODE == RUN_PAIR && (status & ST_PARK)) || (COOP && (status & ST_COOP_FAULT));
+            }
+            if (start2 && stage == 0 && !left) {
+                qa = xsol;
+                qda = (qa - q0) / (al * h);
+            }
+        }
+        if (left) {
+            if (COOP) break;                   // (ST_COOP_FAULT stays in the status)
+            // nothing of this step is kept: whoever takes the rollout on starts the step again (a solve of the start step that went through included)
+            iters = it_in; halv = hv_in; status = st_in & ~(ST_PARK | ST_LEFT_LEAN); piv = piv_in;
+            stop = s;
+            break;
+        }
+        if (!bdf2) {
+            qd = ((xsol - q0) + xlo) / h;      // (:72), with the low-order part of the iterate the residual was evaluated at
+            q = xsol;
+        } else if (start2) {
+            qd = (xsol - q0 - (1.0 - al) * h * qda) / (al * h);
+            q = xsol;
+            qp = q0;
+            qdp = qd0;
+        } else {
+            qp = q1;
+            qdp = qd1;
+            qd = (3.0 / (2.0 * h)) * (xsol - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
+            q = xsol;
+        }
+        if (a.histT && writer) {               // Scene.saveHistory (Scene.m:134-161)
+            const double T = wave_sum(last.eT), V = wave_sum(last.eV);
+            if (lane == 0) {
+                a.histT[(size_t)s * a.B + traj] = T;
+                a.histV[(size_t)s * a.B + traj] = V;
+            }
+        }
+        if (a.histQ && id >= 0 && writer) {
+            a.histQ[(size_t)s * a.B * M.nr + off] = q;
+            a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+        }
+    }
+    if (id >= 0 && writer) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+        if (bdf2) {
+            a.qp[off] = qp;
+            a.qdp[off] = qdp;
+        }
+    }
+    if constexpr (!COOP) {
+        if (lane == 0) {
+            a.resume[traj] = stop;
+            if (MODE == RUN_PAIR && a.park && stop < a.nsteps) {
+                int* pp = a.park + 1 + a.B + 3 * traj;
+                pp[0] = piv.hold; pp[1] = piv.len; pp[2] = piv.streak;
+            }
+        }
+    }
+    if (lane == 0 && a.it && writer) {
+        a.it[traj] += iters;
+        a.ls[traj] += halv;
+        a.status[traj] |= status;
+    }
+#ifdef RMX_TICK_PHASE
+    if (lane == 0 && a.ticks && writer) a.ticks[traj] += cx.phase;
+    cx.phase = 0;
+#else
+    if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
+#endif
+    return stop;
+}
+
+// Three launches (RMX_GROUND_FUSED=0, and whenever the cooperative groups are switched off): the lean launch of launch_step_ct_32, then
+// COOP = false for every rollout from its a.resume, then COOP = true: group g finishes the parked rollouts g, g + ngroups, ...
 template <bool COOP>
 __global__ void __launch_bounds__(64) k_step_pair(const DevModel M, const DevOpts o, const StepArgs a, const int integ) {
     constexpr int NP = 32;
@@ -903,7 +1042,7 @@ __global__ void __launch_bounds__(64) k_step_pair(const DevModel M, const DevOpt
         npark = a.park[0];
         pstride = a.ngroups;
         if (pk >= npark) return;
-        traj = a.park[1 + pk];
+        traj = a.park[1 + pk] - 1;
     }
     const int s0 = a.resume ? a.resume[traj] : 0;
     if (!COOP && s0 >= a.nsteps) return;           // the lean launch took this trajectory all the way
@@ -911,141 +1050,144 @@ __global__ void __launch_bounds__(64) k_step_pair(const DevModel M, const DevOpt
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x;
     con_setup<NP>(M, sCol);
-    const bool writer = !COOP || cx.member == 0;     // (members 1.. of a cooperative group compute, member 0 also stores)
-    const double h = o.h;
-    const bool bdf2 = integ == INTEG_BDF2;
     for (; pk < npark; pk += pstride) {              // (one pass unless COOP)
         int sfirst = s0;
         if constexpr (COOP) {
-            traj = a.park[1 + pk];
+            traj = a.park[1 + pk] - 1;
             sfirst = a.resume[traj];
             tick0 = __builtin_amdgcn_s_memtime();
         }
-        const int id = (lane < M.n) ? M.idx[lane] : -1;
-        const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
-        double q = id >= 0 ? a.q[off] : 0.0;
-        double qd = id >= 0 ? a.qd[off] : 0.0;
-        double qp = (bdf2 && id >= 0) ? a.qp[off] : 0.0;       // step k-1 (Joint.q1 / qdot1 in the reference)
-        double qdp = (bdf2 && id >= 0) ? a.qdp[off] : 0.0;
-        const bool started = (*a.started) != 0 || sfirst > 0;    // resumed behind the lean launch: its steps are this call's history
-        int iters = 0, halv = 0, status = 0;
-        PivotPolicy piv;
-        if constexpr (COOP) {
-            const int* pp = a.park + 1 + a.B + 3 * traj;
-            piv.hold = pp[0]; piv.len = pp[1]; piv.streak = pp[2];
-        }
-        int stop = a.nsteps;
-        for (int s = sfirst; s < a.nsteps; ++s) {
-            NodeOut last;
-            last.g = last.eT = last.eV = 0.0;
-            double xlo = 0.0;
-            const int it_in = iters, hv_in = halv, st_in = status;
-            const PivotPolicy piv_in = piv;
-            const bool start2 = bdf2 && s == 0 && !started;       // SDIRK2 start step (driverRedMaxBDF2.m:64-88): two solves
-            const double al = (2.0 - sqrt(2.0)) / 2.0;            // (:74)
-            const double q0 = (bdf2 && !start2) ? qp : q, qd0 = (bdf2 && !start2) ? qdp : qd, q1 = q, qd1 = qd;
-            double qa = 0.0, qda = 0.0, xsol = 0.0;
-            bool left = false;
-            for (int stage = 0; stage < (start2 ? 2 : 1) && !left; ++stage) {
-                double xi, qA, qB, eta;
-                if (!bdf2) {                       // BDF1 (evalBDF1 :160-187): eta = h, qA = q0, qB = q0 + h qdot0 = the initial guess (:70)
-                    xi = q0 + h * qd0; qA = q0; qB = xi; eta = h;
-                } else if (!start2) {              // BDF2 (evalBDF2 :263-293): eta = 2h/3
-                    xi = q1 + h * qd1;
-                    qA = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0;
-                    qB = (4.0 / 3.0) * q1 - (1.0 / 3.0) * q0 + (8.0 / 9.0) * h * qd1 - (2.0 / 9.0) * h * qd0;
-                    eta = (2.0 / 3.0) * h;
-                } else if (stage == 0) {           // SDIRK2a (evalSDIRK2a :194-225): eta = a h, qA = q0, qB = q0 + a h qdot0
-                    xi = q0 + al * h * qd0; qA = q0; qB = q0 + (al * h) * qd0; eta = al * h;
-                } else {                           // SDIRK2b (evalSDIRK2b :228-260)
-                    xi = qa + (1.0 - al) * h * qda;
-                    qA = q0 + (1.0 - al) * h * qda;
-                    qB = q0 + (2.0 * al - 1.0) * h * qd0 + 2.0 * (1.0 - al) * h * qda;
-                    eta = al * h;
-                }
-                // the pivot policy of newton_policy (rmx_device.h): a hold after three tripped solves in a row
-                const bool pivot_all = o.lu_mode != 0 || piv.hold > 0;
-                if (piv.hold > 0) --piv.hold;
-                xsol = newton_pair<COOP>(M, o, sAcc, lane, xi, qA, qB, eta, last, iters, halv, status, piv, pivot_all, xlo, cx, pb);
-                if (!pivot_all) pivot_policy_update(piv);
-                left = (!COOP && (status & ST_PARK)) || (COOP && (status & ST_COOP_FAULT));
-                if (start2 && stage == 0 && !left) {
-                    qa = xsol;
-                    qda = (qa - q0) / (al * h);
-                }
-            }
-            if (left) {
-                if (COOP) break;                   // (ST_COOP_FAULT stays in the status)
-                // nothing of this step is kept: the cooperative launch takes it from its start (a solve of the start step that went through included)
-                iters = it_in; halv = hv_in; status = st_in & ~ST_PARK; piv = piv_in;
-                stop = s;
-                break;
-            }
-            if (!bdf2) {
-                qd = ((xsol - q0) + xlo) / h;      // (:72), with the low-order part of the iterate the residual was evaluated at
-                q = xsol;
-            } else if (start2) {
-                qd = (xsol - q0 - (1.0 - al) * h * qda) / (al * h);
-                q = xsol;
-                qp = q0;
-                qdp = qd0;
-            } else {
-                qp = q1;
-                qdp = qd1;
-                qd = (3.0 / (2.0 * h)) * (xsol - (4.0 / 3.0) * q1 + (1.0 / 3.0) * q0);
-                q = xsol;
-            }
-            if (a.histT && writer) {               // Scene.saveHistory (Scene.m:134-161)
-                const double T = wave_sum(last.eT), V = wave_sum(last.eV);
-                if (lane == 0) {
-                    a.histT[(size_t)s * a.B + traj] = T;
-                    a.histV[(size_t)s * a.B + traj] = V;
-                }
-            }
-            if (a.histQ && id >= 0 && writer) {
-                a.histQ[(size_t)s * a.B * M.nr + off] = q;
-                a.histQd[(size_t)s * a.B * M.nr + off] = qd;
-            }
-        }
-        if (id >= 0 && writer) {
-            a.q[off] = q;
-            a.qd[off] = qd;
-            if (bdf2) {
-                a.qp[off] = qp;
-                a.qdp[off] = qdp;
-            }
-        }
+        const int stop = run_rollout<COOP ? RUN_COOP : RUN_PAIR>(M, o, a, integ, sAcc, sCol, lane, traj, sfirst, cx, pb, tick0);
         if constexpr (!COOP) {
-            if (lane == 0) {
-                a.resume[traj] = stop;
-                if (a.park && stop < a.nsteps) {
-                    a.park[1 + atomicAdd(a.park, 1)] = traj;
-                    int* pp = a.park + 1 + a.B + 3 * traj;
-                    pp[0] = piv.hold; pp[1] = piv.len; pp[2] = piv.streak;
-                }
-            }
+            if (lane == 0 && a.park && stop < a.nsteps) a.park[1 + atomicAdd(a.park, 1)] = traj + 1;
         }
-        if (lane == 0 && a.it && writer) {
-            a.it[traj] += iters;
-            a.ls[traj] += halv;
-            a.status[traj] |= status;
-        }
-#ifdef RMX_TICK_PHASE
-        if (lane == 0 && a.ticks && writer) a.ticks[traj] += cx.phase;
-        cx.phase = 0;
-#else
-        if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
-#endif
-#ifdef RMX_COOP_PROFILE
-        if constexpr (COOP) {      // words 22 .. 31: ticks / 1024 member m spent waiting for its group (exchange + collect), last rollout of the group
-            if (lane == 0) cx.words[22 + cx.member] = (unsigned)(cx.waited >> 10);
-        }
-#endif
     }
 }
 
-// the launch with the contact terms of a chain of <= 32 nodes (behind the lean launch of launch_step_ct_32), then the cooperative one
-void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+// ONE launch for the whole call: workgroups 0 .. B - 1 are the rollouts (lean solve, then newton_pair from the step that comes near the
+// ground, until the end or until a solve parks the rollout), workgroups B .. are the members of the cooperative groups - workgroups are
+// dispatched in index order (per XCD), so they take the SIMDs that finished rollouts leave - and pick the parked rollouts up as they
+// appear: group g the g-th, (g + ngroups)-th ... entry of the list.  No launch boundary anywhere: a rollout that leaves free flight
+// early is not held back by the last one to do so, and a parked rollout does not wait for the last unparked one.
+// The list: a.park[1 + e] = rollout + 1 (zero before the launch), published with release semantics after the rollout's state;
+// a.park[1 + 4 B] counts the rollout workgroups that have finished (the groups leave when all have and the list is exhausted).
+// The three roles are OUT-OF-LINE functions: inlined into one kernel their three Newton loops share one register allocation (688 bytes
+// of scratch, 860 spilled SGPRs, every loop slower than in a kernel of its own).  They take the launch's arguments as a pointer
+// into global memory (scalar loads, as kernel arguments are) and name the LDS array themselves: a generic pointer into LDS handed
+// to an out-of-line function loses its address space.
+struct GroundArgs {
+    DevModel M;
+    DevOpts o;
+    StepArgs a;
+    int integ;
+};
+__device__ __forceinline__ void role_smem(const DevModel& M, double*& sAcc, double*& sCol) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    sAcc = smem;
+    sCol = smem + acc_doubles(M.n, 32);
+}
+// (the arguments are copied into locals once: read through the pointer, every field would be loaded again behind every store and
+// every scheduling pin of the Newton loop - the compiler cannot know that nothing writes them)
+__device__ __attribute__((noinline)) int role_lean(const GroundArgs* __restrict__ g, const int traj) {
+    const DevModel M = g->M;
+    const DevOpts o = g->o;
+    const StepArgs a = g->a;
+    const int integ = g->integ;
+    double *sAcc, *sCol;
+    role_smem(M, sAcc, sCol);
+    CoopCtx cx;
+    CoopPub pb;
+    return run_rollout<RUN_LEAN>(M, o, a, integ, sAcc, sCol, threadIdx.x, traj, 0, cx, pb, __builtin_amdgcn_s_memtime());
+}
+__device__ __attribute__((noinline)) int role_pair(const GroundArgs* __restrict__ g, const int traj, const int sfirst) {
+    const DevModel M = g->M;
+    const DevOpts o = g->o;
+    const StepArgs a = g->a;
+    const int integ = g->integ;
+    double *sAcc, *sCol;
+    role_smem(M, sAcc, sCol);
+    CoopCtx cx;
+    CoopPub pb;
+    return run_rollout<RUN_PAIR>(M, o, a, integ, sAcc, sCol, threadIdx.x, traj, sfirst, cx, pb, __builtin_amdgcn_s_memtime());
+}
+__device__ __attribute__((noinline)) void role_coop(const GroundArgs* __restrict__ g, const int grp, const int member) {
+    const DevModel M = g->M;
+    const DevOpts o = g->o;
+    const StepArgs a = g->a;
+    const int integ = g->integ;
+    double *sAcc, *sCol;
+    role_smem(M, sAcc, sCol);
+    const int lane = threadIdx.x;
+    CoopCtx cx;
+    CoopPub pb;
+    cx.member = member;
+    cx.words = a.xch + (size_t)grp * COOP_WORDS;
+    pb.rec = a.xrec + (size_t)grp * 2 * COOP_REC;
+    int* const done = a.park + 1 + 4 * a.B;
+    for (int e = grp; e < a.B; e += a.ngroups) {
+        int v = 0;
+        while (true) {
+            if (lane == 0) v = __hip_atomic_load(a.park + 1 + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v != 0) break;
+            int d = 0, cnt = 0;
+            if (lane == 0) {
+                d = __hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                cnt = __hip_atomic_load(a.park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            d = __builtin_amdgcn_readfirstlane(d);
+            cnt = __builtin_amdgcn_readfirstlane(cnt);
+            if (d >= a.B && cnt <= e) return;            // every rollout has finished or parked, and this entry does not exist
+            __builtin_amdgcn_s_sleep(32);
+        }
+        __threadfence();                                 // acquire
+        const int traj = v - 1;
+        const int sfirst = __hip_atomic_load(a.resume + traj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run_rollout<RUN_COOP>(M, o, a, integ, sAcc, sCol, lane, traj, sfirst, cx, pb, __builtin_amdgcn_s_memtime());
+    }
+}
+__global__ void __launch_bounds__(64) k_ground32(const GroundArgs* __restrict__ g) {
+    constexpr int NP = 32;
+    {
+        double *sAcc, *sCol;
+        smem_setup<NP>(g->M, sAcc, sCol);
+        con_setup<NP>(g->M, sCol);
+    }
+    const int B = g->a.B, nsteps = g->a.nsteps;
+    if ((int)blockIdx.x >= B) {
+        role_coop(g, ((int)blockIdx.x - B) / COOP_G, ((int)blockIdx.x - B) % COOP_G);
+        return;
+    }
+    const int traj = blockIdx.x;
+    int stop = role_lean(g, traj);
+    if (stop < nsteps) stop = role_pair(g, traj, stop);
+    int* const park = g->a.park;
+    if (!park) return;                                   // (no cooperative groups in this call: nothing parks, nobody waits)
+    __threadfence();                                     // release: this rollout's state, counters and pivot policy before its list entry
+    if (threadIdx.x == 0) {
+        if (stop < nsteps) {
+            const int e = atomicAdd(park, 1);
+            __hip_atomic_store(park + 1 + e, traj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_fetch_add(park + 1 + 4 * B, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// the steps with the contact terms of a chain of <= 32 nodes: fused (one launch for everything) or behind the lean launch of launch_step_ct_32
+void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a, bool fused) {
+    if (fused) {
+        // a.fused 1: rollouts and cooperative groups in one launch; 2: the rollouts (free flight + contact terms) in one launch, the groups in a second
+        const int inline_groups = a.fused == 1 ? a.ngroups : 0;
+        GroundArgs ga;
+        ga.M = m->dm; ga.o = o; ga.a = a; ga.integ = integ;
+        ga.a.ngroups = inline_groups;
+        static_assert(sizeof(GroundArgs) <= RMX_GARGS_BYTES, "rmx_batch::gargs");
+        (void)hipMemcpyAsync(b->gargs, &ga, sizeof ga, hipMemcpyHostToDevice, b->stream);      // (pageable source: staged before the call returns)
+        RMX_LAUNCH(k_ground32, dim3(b->B + inline_groups * COOP_G), dim3(64), m->smem_bytes, b->stream, (const GroundArgs*)b->gargs);
+        if (a.fused != 1 && a.park && o.parkHalv > 0)
+            RMX_LAUNCH((k_step_pair<true>), dim3(a.ngroups * COOP_G), dim3(64), m->smem_bytes, b->stream, m->dm, o, a, integ);
+        return;
+    }
     RMX_LAUNCH((k_step_pair<false>), dim3(b->B), dim3(64), m->smem_bytes, b->stream, m->dm, o, a, integ);
     // group g = workgroups COOP_G g .. COOP_G g + COOP_G - 1, all of them resident at once
     if (a.park && o.parkHalv > 0) RMX_LAUNCH((k_step_pair<true>), dim3(a.ngroups * COOP_G), dim3(64), m->smem_bytes, b->stream, m->dm, o, a, integ);
@@ -1080,6 +1222,10 @@ void RMX_CAT(launch_mfd_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, dou
 }
 void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+#if RMX_NP == 32
+    // serial chains with ForceGroundCuboid (no Euler-chart joints): free flight, contact and the cooperative groups in ONE launch
+    if (m->pair32 && m->dm.con && a.fused) return launch_step_pair_32(m, b, integ, o, a, true);
+#endif
     // every trajectory as far as it stays clear of the ground (all the way in scenes without ForceGroundCuboid) ...
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, true, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
@@ -1087,7 +1233,7 @@ void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
 #if RMX_NP == 32
     // serial chains (no Euler-chart joints): the kernels around newton_pair (RMX_PART 4, rmx_ct32.h) take the rest of the steps with the
     // contact terms, and what they park (a Newton solve that keeps running out its line searches) in cooperative groups
-    if (m->pair32) return launch_step_pair_32(m, b, integ, o, a);
+    if (m->pair32) return launch_step_pair_32(m, b, integ, o, a, false);
 #endif
     // ... and the rest of its steps with the contact terms
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);

@@ -17,8 +17,9 @@ sc = sceneChainGround(32); sc.init(); B = 1024
 q, qd = syntheticStates(sc.nr, B, sq=5e-4, sv=0.1); q[0], qd[0] = sc.getQ()
 sim = BatchSim(sc, batch=B)
 res = []
-for park in ("0", "24"):
+for park, fused in (("0", "2"), ("24", "0"), ("24", "2")):
     os.environ["RMX_PARK_HALVINGS"] = park
+    os.environ["RMX_GROUND_FUSED"] = fused
     ms = []
     for r in range(2):
         sim.set_state(q, qd)
@@ -26,10 +27,10 @@ for park in ("0", "24"):
     tk = sim.step_ticks().astype(float)
     qf, _ = sim.get_state()
     i = int(np.argmax(o["newton_iters"]))
-    res.append("park %%2s: %%.2f ms, iters %%d halv %%d bad %%d | ticks/2.4e3: max %%.0f us, p50 %%.0f us, rollout %%d (most iterations: %%d) %%.0f us, sum over parked-like (top 48) %%.0f us" %% (
-        park, min(ms), o["newton_iters"].sum(), o["ls_halvings"].sum(), ((o["status"] & 15) != 0).sum(), tk.max() / 2.4e3, np.median(tk) / 2.4e3, i, o["newton_iters"][i], tk[i] / 2.4e3,
+    res.append("park %%2s fused %%s: %%.2f ms, iters %%d halv %%d bad %%d | ticks/2.4e3: max %%.0f us, p50 %%.0f us, rollout %%d (most iterations: %%d) %%.0f us, sum over parked-like (top 48) %%.0f us" %% (
+        park, fused, min(ms), o["newton_iters"].sum(), o["ls_halvings"].sum(), ((o["status"] & 15) != 0).sum(), tk.max() / 2.4e3, np.median(tk) / 2.4e3, i, o["newton_iters"][i], tk[i] / 2.4e3,
         np.sort(tk)[-48:].mean() / 2.4e3))
-    np.save(sys.argv[2] + park + ".npy", qf)
+    np.save(sys.argv[2] + park + fused + ".npy", qf)
 print("\n".join(res))
 ''' % ROOT
 
@@ -45,10 +46,10 @@ def main():
         if p.returncode != 0:
             print("%-12s FAILED: %s" % (name, p.stderr.strip()[-300:]))
             continue
-        q0, q24 = np.load(out + "0.npy"), np.load(out + "24.npy")
+        q0, q24, q24f = np.load(out + "02.npy"), np.load(out + "240.npy"), np.load(out + "242.npy")
         if ref is None:
             ref = q0
-        print("== %-12s park == no-park: %s, == in-tree: %s" % (name, np.array_equal(q0, q24), np.array_equal(q0, ref)))
+        print("== %-12s park == no-park: %s, fused == no-park: %s, == in-tree: %s" % (name, np.array_equal(q0, q24), np.array_equal(q0, q24f), np.array_equal(q0, ref)))
         print(p.stdout.strip(), flush=True)
 
 
