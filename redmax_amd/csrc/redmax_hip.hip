@@ -895,6 +895,8 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
         a.xch = b->xch;
         a.xrec = b->xrec;
         a.ngroups = b->ngroups;
+        const char* cm = getenv("RMX_COOP_MAP");
+        a.coop_map = cm ? atoi(cm) : 0;
     }
     if (m->pair32) {
         // RMX_GROUND_FUSED: 2 (default) free flight and the steps with the contact terms of a rollout in ONE launch (a rollout that

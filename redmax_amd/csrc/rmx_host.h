@@ -38,6 +38,7 @@ struct StepArgs {
                       // [1 + B + 3 traj ..] their pivot policy, [1 + 4 B] rollout workgroups that have finished (k_ground32)
     unsigned* xch;    // [ngroups][COOP_WORDS] exchange words of the cooperative groups (zero before the cooperative launch)
     int ngroups;      // cooperative groups in flight: group g finishes parked rollouts g, g + ngroups, ... one after the other
+    int coop_map;     // measurement aid (RMX_COOP_MAP): 1 = member-major mapping of the cooperative launch's workgroups onto (group, member)
     int fused;        // the whole call in one launch (rmx_kernels.hip k_ground32): rollouts and cooperative groups side by side
     unsigned long long* xrec;   // [ngroups][2 COOP_REC] what the winner of a line search publishes to its group (rmx_ct32.h CoopPub; zero before the launch)
 };

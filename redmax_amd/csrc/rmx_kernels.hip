@@ -1035,8 +1035,13 @@ __global__ void __launch_bounds__(64) k_step_pair(const DevModel M, const DevOpt
     CoopPub pb;
     int pk = 0, npark = 1, pstride = 1;
     if constexpr (COOP) {
+#ifdef RMX_COOP_MAP_AID      // measurement builds: RMX_COOP_MAP=1 scatters the members of a group over the launch (member-major mapping)
+        pk = a.coop_map ? blockIdx.x % a.ngroups : blockIdx.x / COOP_G;
+        cx.member = a.coop_map ? blockIdx.x / a.ngroups : blockIdx.x % COOP_G;
+#else
         pk = blockIdx.x / COOP_G;
         cx.member = blockIdx.x % COOP_G;
+#endif
         cx.words = a.xch + (size_t)pk * COOP_WORDS;
         pb.rec = a.xrec + (size_t)pk * 2 * COOP_REC;
         npark = a.park[0];

@@ -37,7 +37,7 @@ F64 = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_IN
 
 # kernels of the timed step call, per workload: name fragments as rocprofv3 prints them (demangled)
 KERNELS = {
-    "chain": ("k_step_bdf1<32",), "tree64": ("k_step_bdf1<64",), "tree64x": ("k_step_bdf1<64",), "ground": ("k_step_bdf2<32",),
+    "chain": ("k_step_bdf1<32",), "tree64": ("k_step_bdf1<64",), "tree64x": ("k_step_bdf1<64",), "ground": ("k_ground32", "k_step_pair<"),
     "adjoint": ("k_adjoint_fwd<16", "k_adjoint_bwd<16"), "chain128": ("k_big_step",),
 }
 
