@@ -899,11 +899,12 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
         a.coop_map = cm ? atoi(cm) : 0;
     }
     if (m->pair32) {
-        // RMX_GROUND_FUSED: 2 (default) free flight and the steps with the contact terms of a rollout in ONE launch (a rollout that
-        // leaves free flight early is not held back by the last one to do so), the cooperative groups in a second; 1 the groups in
-        // the same launch as well (measured slower: DESIGN.md section 6); 0 three launches (lean, contact terms, groups)
+        // RMX_GROUND_FUSED: 1 (default) ONE launch for the whole call - the rollouts (free flight, then the steps with the contact terms)
+        // and, behind them in dispatch order, the cooperative groups that pick the parked rollouts up as they appear: no launch
+        // boundary holds a rollout back (rmx_kernels.hip k_ground32); 2 the groups in a second launch; 0 three launches (lean, contact
+        // terms, groups); 3 measurement aid (the groups as a second launch of k_ground32)
         const char* f = getenv("RMX_GROUND_FUSED");
-        a.fused = f ? atoi(f) : 2;
+        a.fused = f ? atoi(f) : 1;
         if (a.fused == 1 && o.parkHalv <= 0) a.fused = 2;
         if (a.fused && !b->gargs) HIPCHK(hipMalloc(&b->gargs, RMX_GARGS_BYTES));
     }

@@ -359,7 +359,7 @@ __device__ __forceinline__ bool coop_collect(const CoopPub& pb, const CoopCtx& c
             if (lane == 0) coop_store(cx.words + 2 * COOP_G, 1u);
             return false;
         }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(RMX_COOP_SLEEP_C);
     }
     const double v = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
     dx = lane < 32 ? v : 0.0;

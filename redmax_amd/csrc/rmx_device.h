@@ -3316,6 +3316,12 @@ constexpr int COOP_G = 10;                       // members of a group: trials 2
 constexpr int COOP_WORDS = 32;                   // exchange words per group: 2 x COOP_G decision words (even / odd exchanges: a member may
                                                  // post exchange r + 1 while a slower one still reads r), [2 COOP_G] the group's abort flag
 constexpr int COOP_REC = 40;                     // doubles per group the winner of a line search publishes (rmx_ct32.h CoopPub)
+#ifndef RMX_COOP_SLEEP_X
+#define RMX_COOP_SLEEP_X 8          // poll interval of the decision-word exchange, in 64-clock units (build variants)
+#endif
+#ifndef RMX_COOP_SLEEP_C
+#define RMX_COOP_SLEEP_C 4          // poll interval of the wait for the winner's record
+#endif
 struct CoopCtx {
     unsigned* words = nullptr;                   // this group's COOP_WORDS exchange words (global memory)
     int member = 0;
@@ -3354,7 +3360,7 @@ __device__ __forceinline__ bool coop_exchange(CoopCtx& cx, const int lane, const
             ok = false;
             break;
         }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(RMX_COOP_SLEEP_X);
     }
 #ifdef RMX_COOP_PROFILE
     cx.waited += __builtin_amdgcn_s_memtime() - t0;

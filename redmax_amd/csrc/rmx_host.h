@@ -13,7 +13,7 @@
 using namespace rmx;
 
 enum { INTEG_BDF1 = 1, INTEG_BDF2 = 2 };
-constexpr size_t RMX_GARGS_BYTES = 1024;
+constexpr size_t RMX_GARGS_BYTES = 2048;
 
 struct StepArgs {
     int B, nsteps;

@@ -1085,6 +1085,7 @@ struct GroundArgs {
     DevOpts o;
     StepArgs a;
     int integ;
+    int coop_only;      // measurement aid (RMX_GROUND_FUSED=3): every workgroup of this launch is a member of a cooperative group
 };
 __device__ __forceinline__ void role_smem(const DevModel& M, double*& sAcc, double*& sCol) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1115,7 +1116,7 @@ __device__ __attribute__((noinline)) int role_pair(const GroundArgs* __restrict_
     CoopPub pb;
     return run_rollout<RUN_PAIR>(M, o, a, integ, sAcc, sCol, threadIdx.x, traj, sfirst, cx, pb, __builtin_amdgcn_s_memtime());
 }
-__device__ __attribute__((noinline)) void role_coop(const GroundArgs* __restrict__ g, const int grp, const int member) {
+__device__ __forceinline__ void role_coop(const GroundArgs* __restrict__ g, const int grp, const int member) {
     const DevModel M = g->M;
     const DevOpts o = g->o;
     const StepArgs a = g->a;
@@ -1132,18 +1133,23 @@ __device__ __attribute__((noinline)) void role_coop(const GroundArgs* __restrict
     for (int e = grp; e < a.B; e += a.ngroups) {
         int v = 0;
         while (true) {
-            if (lane == 0) v = __hip_atomic_load(a.park + 1 + e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            // (relaxed polls: an agent-scope ACQUIRE invalidates this XCD's L2 under every wavefront that lives in it, hundreds of
+            // times per microsecond with ~500 idle members polling; the one fence below, after the entry has been seen, is what orders
+            // the reads of the rollout's state)
+            if (lane == 0) v = __hip_atomic_load(a.park + 1 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v = __builtin_amdgcn_readfirstlane(v);
             if (v != 0) break;
             int d = 0, cnt = 0;
             if (lane == 0) {
-                d = __hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 cnt = __hip_atomic_load(a.park, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             d = __builtin_amdgcn_readfirstlane(d);
             cnt = __builtin_amdgcn_readfirstlane(cnt);
-            if (d >= a.B && cnt <= e) return;            // every rollout has finished or parked, and this entry does not exist
-            __builtin_amdgcn_s_sleep(32);
+            // every rollout has finished or parked (its list entry is written BEFORE it is counted, both by the same lane with release
+            // semantics), and the count of entries, read after the count of finished rollouts, does not reach this one
+            if (d >= a.B && cnt <= e) return;
+            __builtin_amdgcn_s_sleep(127);
         }
         __threadfence();                                 // acquire
         const int traj = v - 1;
@@ -1158,7 +1164,7 @@ __global__ void __launch_bounds__(64) k_ground32(const GroundArgs* __restrict__ 
         smem_setup<NP>(g->M, sAcc, sCol);
         con_setup<NP>(g->M, sCol);
     }
-    const int B = g->a.B, nsteps = g->a.nsteps;
+    const int B = g->coop_only ? 0 : g->a.B, nsteps = g->a.nsteps;
     if ((int)blockIdx.x >= B) {
         role_coop(g, ((int)blockIdx.x - B) / COOP_G, ((int)blockIdx.x - B) % COOP_G);
         return;
@@ -1186,9 +1192,18 @@ void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, cons
         GroundArgs ga;
         ga.M = m->dm; ga.o = o; ga.a = a; ga.integ = integ;
         ga.a.ngroups = inline_groups;
-        static_assert(sizeof(GroundArgs) <= RMX_GARGS_BYTES, "rmx_batch::gargs");
+        ga.coop_only = 0;
+        static_assert(2 * sizeof(GroundArgs) <= RMX_GARGS_BYTES, "rmx_batch::gargs");
         (void)hipMemcpyAsync(b->gargs, &ga, sizeof ga, hipMemcpyHostToDevice, b->stream);      // (pageable source: staged before the call returns)
         RMX_LAUNCH(k_ground32, dim3(b->B + inline_groups * COOP_G), dim3(64), m->smem_bytes, b->stream, (const GroundArgs*)b->gargs);
+        if (a.fused == 3 && a.park && o.parkHalv > 0) {      // measurement aid: the groups as a second launch of the SAME kernel (its out-of-line role)
+            ga.a.ngroups = a.ngroups;
+            ga.coop_only = 1;
+            GroundArgs* g2 = (GroundArgs*)b->gargs + 1;
+            (void)hipMemcpyAsync(g2, &ga, sizeof ga, hipMemcpyHostToDevice, b->stream);
+            RMX_LAUNCH(k_ground32, dim3(a.ngroups * COOP_G), dim3(64), m->smem_bytes, b->stream, (const GroundArgs*)g2);
+            return;
+        }
         if (a.fused != 1 && a.park && o.parkHalv > 0)
             RMX_LAUNCH((k_step_pair<true>), dim3(a.ngroups * COOP_G), dim3(64), m->smem_bytes, b->stream, m->dm, o, a, integ);
         return;

@@ -17,7 +17,7 @@ sc = sceneChainGround(32); sc.init(); B = 1024
 q, qd = syntheticStates(sc.nr, B, sq=5e-4, sv=0.1); q[0], qd[0] = sc.getQ()
 sim = BatchSim(sc, batch=B)
 res = []
-for park, fused in (("0", "2"), ("24", "0"), ("24", "2")):
+for park, fused in (("0", "2"), ("24", "1"), ("24", "2")):
     os.environ["RMX_PARK_HALVINGS"] = park
     os.environ["RMX_GROUND_FUSED"] = fused
     ms = []
@@ -46,7 +46,7 @@ def main():
         if p.returncode != 0:
             print("%-12s FAILED: %s" % (name, p.stderr.strip()[-300:]))
             continue
-        q0, q24, q24f = np.load(out + "02.npy"), np.load(out + "240.npy"), np.load(out + "242.npy")
+        q0, q24, q24f = np.load(out + "02.npy"), np.load(out + "241.npy"), np.load(out + "242.npy")
         if ref is None:
             ref = q0
         print("== %-12s park == no-park: %s, fused == no-park: %s, == in-tree: %s" % (name, np.array_equal(q0, q24), np.array_equal(q0, q24f), np.array_equal(q0, ref)))
