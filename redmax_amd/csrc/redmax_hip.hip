@@ -918,24 +918,6 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     HIPCHK(hipMemsetAsync(b->started, integ == INTEG_BDF2 ? 1 : 0, sizeof(int), b->stream));   // BDF2: any non-zero value
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, b->stream));
-#ifdef RMX_COOP_PROFILE
-    if (a.xch && getenv("RMX_COOP_DUMP")) {      // measurement build only: the groups' exchange words after the launch, as text
-        std::vector<unsigned> w((size_t)COOP_WORDS * b->ngroups);
-        std::vector<int> pk(1 + (size_t)b->B);
-        HIPCHK(hipStreamSynchronize(b->stream));
-        HIPCHK(hipMemcpy(w.data(), b->xch, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(pk.data(), b->park, pk.size() * sizeof(int), hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(getenv("RMX_COOP_DUMP"), "w")) {
-            fprintf(f, "parked %d groups %d\n", pk[0], b->ngroups);
-            for (int g = 0; g < b->ngroups && g < pk[0]; ++g) {
-                fprintf(f, "group %d rollout %d wait_kticks", g, pk[1 + g]);
-                for (int k = 0; k < COOP_G; ++k) fprintf(f, " %u", w[(size_t)g * COOP_WORDS + 22 + k]);
-                fprintf(f, "\n");
-            }
-            fclose(f);
-        }
-    }
-#endif
     return RMX_OK;
 }
 

@@ -322,7 +322,7 @@ __device__ __forceinline__ void hess_rows_from_staging(const int n, const int la
 }
 
 // ---- the cooperative group's second channel: what the winner of a line search publishes (see the header of this file)
-constexpr int COOP_CODE_DX = 1, COOP_CODE_END = 2, COOP_CODE_REDO = 3;
+constexpr int COOP_CODE_DX = 1, COOP_CODE_END = 2, COOP_CODE_REDO = 3, COOP_CODE_STALL = 4, COOP_CODE_WIDE = 5;      // (+ 16 x accepted trial + 4096 x status bits)
 // No fence anywhere: an agent-scope release / acquire on this part writes back and invalidates an L2 (one per XCD) that the scratch
 // traffic of every wavefront of the XCD lives in - measured, a fenced hand-over cost 60 us per line search.  Instead every 64-bit word of
 // the record is complete in itself, like the decision words: the round it belongs to in its upper half, 32 bits of payload in its lower
@@ -370,6 +370,31 @@ __device__ __forceinline__ bool coop_collect(const CoopPub& pb, const CoopCtx& c
     return true;
 }
 
+// Flow control of the narrow rounds (newton_pair): there the decision words are not exchanged, so nothing keeps member 0 from
+// publishing record s + 1 over a record s that a late member - one that has only just picked the rollout up - has not read yet.
+// Every member therefore notes the last record it has handled in its own word (cx.words[COOP_ACK + m], relaxed), and member 0 looks
+// at the nine words before it overwrites the record: all of them at s - 1 or beyond.  (In a wide round the exchange of the decision
+// words itself is that guarantee: nobody posts its word before it has read the previous record.)
+constexpr int COOP_ACK = 22;                     // cx.words[22 .. 31]
+__device__ __forceinline__ void coop_ack(const CoopCtx& cx, const int lane, const unsigned seq) {
+    if (lane == 0) coop_store(cx.words + COOP_ACK + cx.member, seq);
+}
+__device__ __forceinline__ bool coop_wait_acks(const CoopCtx& cx, const int lane, const unsigned seq) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (true) {
+        unsigned w = seq;
+        if (lane < COOP_G && lane != cx.member) w = coop_load(cx.words + COOP_ACK + lane);
+        if (__all((int)(w - seq) >= 0)) return true;
+        unsigned ab = 0u;
+        if (lane == 0) ab = coop_load(cx.words + 2 * COOP_G);
+        if (__any(ab != 0u) || __builtin_amdgcn_s_memtime() - t0 > 5000000000ull) {
+            if (lane == 0) coop_store(cx.words + 2 * COOP_G, 1u);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
 // newton (driverRedMaxBDF1.m:94-157) for a serial chain of <= 32 nodes with the contact terms: decisions as newton_impl, see the
 // header of this file.  pivot_all (wave-uniform): every solve with partial pivoting (lu_mode 1 / the pivot policy's hold).
 template <bool COOP>
@@ -401,7 +426,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
             lol = dup_lo(lo);
         } else {
             const double x0d = dup_lo(x0), lo0d = dup_lo(lo0), dxd = dup_lo(dx);
-            const double am = COOP ? ldexp(alpha, -2 * cx.member) : alpha;      // (alpha is a power of two: exact)
+            const double am = (COOP && cx.wide) ? ldexp(alpha, -2 * cx.member) : alpha;      // (alpha is a power of two: exact)
             const double al = hiH ? 0.5 * am : am;
             two_sum(x0d, fma(al, dxd, lo0d), xl, lol);       // x + lo = x0 + (lo0 + alpha dx)
             lol *= o.comp;
@@ -413,35 +438,77 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
         }
         bool ta = false, tb = false;
         double ga2 = 0.0, gb2 = 0.0;
-        if (!(mode == 1 && stall_a)) {                     // (a stalled: so are b and every later trial; nobody looks at their f)
+        // COOP, narrow round (the last line search of this rollout ended within its first two trials - every ordinary Newton iteration
+        // does): member 0 alone evaluates trials 1 and 2 and the group waits for its record; the decision words are not exchanged at all
+        const bool narrow = COOP && mode == 1 && !cx.wide;
+        if (!(mode == 1 && stall_a) && !(narrow && cx.member != 0)) {      // (a stalled: so are b and every later trial; nobody looks at their f)
             RMX_PH_BEGIN(1)
             eval_front_pair<true>(M.n, cK, grav, lane, xl, ((xl - qAd) + lol) / eta, (xl - qBd) + lol, eta, e, fs, ta, tb);
             wave_sum_dual(e.g * e.g, ga2, gb2);
             RMX_PH_END(1)
         }
         bool need_solve = true;                            // this member runs the Hessian stage and the solve at the accepted point
+        int take_pub = 0;                                  // (COOP) the accepted trial, as the winner's record names it
         if (mode == 1) {
             int take = -1;                                 // the trial, counted from iterLs, that ends the search
             bool stalled = false;
+            // (COOP) a record collected in the narrow round, used further down in place of the wait for the winner
+            bool have_rec = false;
+            double rT = 0.0, rV = 0.0, rdx = 0.0, rgn2 = 0.0;
+            int rcode = 0;
             if constexpr (COOP) {
-                unsigned bits = (stall_a ? 1u : 0u) | (stall_b ? 2u : 0u);
-                if (!stall_a) bits |= (0.5 * ga2 < f0 ? 4u : 0u) | (0.5 * gb2 < f0 ? 8u : 0u);
-                unsigned word;
-                RMX_PH_BEGIN(4)
-                const bool xok = coop_exchange(cx, lane, bits, word);
-                RMX_PH_END(4)
-                if (!xok) {
-                    status |= 4 | ST_COOP_FAULT;
-                    xlo = lo0;
-                    return x0;
-                }
+                if (narrow) {
+                    if (cx.member == 0) {
+                        if (stall_a) stalled = true;
+                        else if (0.5 * ga2 < f0 || iterLs >= o.iterLsMax) take = 0;
+                        else if (stall_b) stalled = true;
+                        else if (0.5 * gb2 < f0 || iterLs + 1 >= o.iterLsMax) take = 1;
+                        if (stalled || take < 0) {         // nothing to hand over but the verdict: "stalled" / "the rest of the trials, everybody"
+                            ++cx.rseq;
+                            if (!coop_wait_acks(cx, lane, cx.rseq - 1)) {
+                                status |= 4 | ST_COOP_FAULT;
+                                xlo = lo0;
+                                return x0;
+                            }
+                            coop_publish(pb, cx.rseq, lane, 0.0, stalled ? COOP_CODE_STALL : COOP_CODE_WIDE, 0.0, 0.0, 0.0);
+                            coop_ack(cx, lane, cx.rseq);
+                        }
+                    } else {
+                        ++cx.rseq;
+                        RMX_PH_BEGIN(5)
+                        const bool cok = coop_collect(pb, cx, cx.rseq, lane, rgn2, rcode, rT, rV, rdx);
+                        RMX_PH_END(5)
+                        if (!cok) {
+                            status |= 4 | ST_COOP_FAULT;
+                            xlo = lo0;
+                            return x0;
+                        }
+                        have_rec = true;
+                        coop_ack(cx, lane, cx.rseq);
+                        const int what = rcode & 15;
+                        if (what == COOP_CODE_STALL) stalled = true;
+                        else if (what != COOP_CODE_WIDE) take = (rcode >> 4) & 31;
+                    }
+                } else {
+                    unsigned bits = (stall_a ? 1u : 0u) | (stall_b ? 2u : 0u);
+                    if (!stall_a) bits |= (0.5 * ga2 < f0 ? 4u : 0u) | (0.5 * gb2 < f0 ? 8u : 0u);
+                    unsigned word;
+                    RMX_PH_BEGIN(4)
+                    const bool xok = coop_exchange(cx, lane, bits, word);
+                    RMX_PH_END(4)
+                    if (!xok) {
+                        status |= 4 | ST_COOP_FAULT;
+                        xlo = lo0;
+                        return x0;
+                    }
 #pragma unroll 1
-                for (int m = 0; m < COOP_G; ++m) {         // the reference's walk over the trials, in order
-                    const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)word, m);
-                    if (w & 1u) { stalled = true; break; }
-                    if ((w & 4u) || iterLs + 2 * m >= o.iterLsMax) { take = 2 * m; break; }
-                    if (w & 2u) { stalled = true; break; }
-                    if ((w & 8u) || iterLs + 2 * m + 1 >= o.iterLsMax) { take = 2 * m + 1; break; }
+                    for (int m = 0; m < COOP_G; ++m) {     // the reference's walk over the trials, in order
+                        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)word, m);
+                        if (w & 1u) { stalled = true; break; }
+                        if ((w & 4u) || iterLs + 2 * m >= o.iterLsMax) { take = 2 * m; break; }
+                        if (w & 2u) { stalled = true; break; }
+                        if ((w & 8u) || iterLs + 2 * m + 1 >= o.iterLsMax) { take = 2 * m + 1; break; }
+                    }
                 }
             } else {
                 if (stall_a) stalled = true;
@@ -461,20 +528,23 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                 if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
                 break;
             }
-            constexpr int PER = COOP ? 2 * COOP_G : 2;
+            const int PER = (COOP && !narrow) ? 2 * COOP_G : 2;
             if (take < 0) {                                // none of this round's trials ends the search
                 alpha = ldexp(alpha, -PER);
                 iterLs += PER;
+                if constexpr (COOP) cx.wide = true;        // the rest of this search, and the next ones, with the whole group
                 continue;
             }
             iterLs += take;
             halvings += iterLs - 1;
+            take_pub = take;
             bool mine = true;                              // the accepted trial was evaluated by this wavefront
             if constexpr (COOP) {
                 // every member: the accepted iterate from what all of them hold bit for bit
                 two_sum(x0, fma(ldexp(alpha, -take), dx, lo0), x, lo);
                 lo *= o.comp;
-                mine = (take >> 1) == cx.member;
+                mine = narrow ? cx.member == 0 : (take >> 1) == cx.member;
+                cx.wide = iterLs > 2;                      // the next search starts with member 0 alone again once one ends within two trials
             } else {
                 const double xs = (take & 1) ? take_hi(xl) : xl, ls = (take & 1) ? take_hi(lol) : lol;
                 x = hiH ? x0 : xs;
@@ -510,26 +580,41 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                     if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) end_bits = 2 | ST_LS_CUT;
                 }
                 if constexpr (COOP) {
-                    if (end_bits >= 0) coop_publish(pb, cx.round, lane, gn2, COOP_CODE_END | (end_bits << 8), readlane_d(last.eT, 0), readlane_d(last.eV, 0), 0.0);
+                    if (end_bits >= 0) {
+                        ++cx.rseq;
+                        if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1)) {
+                            status |= 4 | ST_COOP_FAULT;
+                            xlo = lo0;
+                            return x0;
+                        }
+                        coop_publish(pb, cx.rseq, lane, gn2, COOP_CODE_END | (take << 4) | (end_bits << 12), readlane_d(last.eT, 0), readlane_d(last.eV, 0), 0.0);
+                        coop_ack(cx, lane, cx.rseq);
+                    }
                 }
             } else {
                 // (COOP only) wait for the winner: the end of the solve, the next direction, or "re-evaluate and pivot"
-                double T, V, dxn;
-                int code;
-                RMX_PH_BEGIN(5)
-                const bool cok = coop_collect(pb, cx, cx.round, lane, gn2, code, T, V, dxn);
-                RMX_PH_END(5)
-                if (!cok) {
-                    status |= 4 | ST_COOP_FAULT;
-                    xlo = lo0;
-                    return x0;
+                double T = rT, V = rV, dxn = rdx;
+                int code = rcode;
+                if (have_rec) {
+                    gn2 = rgn2;
+                } else {
+                    ++cx.rseq;
+                    RMX_PH_BEGIN(5)
+                    const bool cok = coop_collect(pb, cx, cx.rseq, lane, gn2, code, T, V, dxn);
+                    RMX_PH_END(5)
+                    if (!cok) {
+                        status |= 4 | ST_COOP_FAULT;
+                        xlo = lo0;
+                        return x0;
+                    }
+                    coop_ack(cx, lane, cx.rseq);
                 }
                 last.g = 0.0;
                 last.eT = lane == 0 ? T : 0.0;
                 last.eV = lane == 0 ? V : 0.0;
-                const int what = code & 255;
+                const int what = code & 15;
                 if (what == COOP_CODE_END) {
-                    end_bits = code >> 8;
+                    end_bits = code >> 12;
                 } else {
                     lsfail += (0.5 * gn2 < f0) ? 0 : 1;
                     if (what == COOP_CODE_REDO) {          // the guarded solve tripped at the winner: everybody re-evaluates x and pivots
@@ -600,7 +685,16 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                 ++piv.streak;
                 status |= 16;
                 if constexpr (COOP) {
-                    if (mode == 1) coop_publish(pb, cx.round, lane, gn2, COOP_CODE_REDO, eT0, eV0, 0.0);
+                    if (mode == 1) {
+                        ++cx.rseq;
+                        if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1)) {
+                            status |= 4 | ST_COOP_FAULT;
+                            xlo = lo0;
+                            return x0;
+                        }
+                        coop_publish(pb, cx.rseq, lane, gn2, COOP_CODE_REDO | (take_pub << 4), eT0, eV0, 0.0);
+                        coop_ack(cx, lane, cx.rseq);
+                    }
                 }
                 mode = 0;
                 redo = true;
@@ -610,7 +704,16 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                 // the winner of the line search that led here hands the direction to the group (a first / redone evaluation was run
                 // by every member: nothing to hand over)
                 RMX_PH_BEGIN(6)
-                if (mode == 1) coop_publish(pb, cx.round, lane, gn2, COOP_CODE_DX, eT0, eV0, dx);
+                if (mode == 1) {
+                    ++cx.rseq;
+                    if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1)) {
+                        status |= 4 | ST_COOP_FAULT;
+                        xlo = lo0;
+                        return x0;
+                    }
+                    coop_publish(pb, cx.rseq, lane, gn2, COOP_CODE_DX | (take_pub << 4), eT0, eV0, dx);
+                    coop_ack(cx, lane, cx.rseq);
+                }
                 RMX_PH_END(6)
             }
         }

@@ -3325,7 +3325,9 @@ constexpr int COOP_REC = 40;                     // doubles per group the winner
 struct CoopCtx {
     unsigned* words = nullptr;                   // this group's COOP_WORDS exchange words (global memory)
     int member = 0;
-    unsigned round = 0;                          // line searches this group has gone through (the tag of the next exchange)
+    unsigned round = 0;                          // decision-word exchanges this group has gone through (the tag of the next one)
+    unsigned rseq = 0;                           // records the group has passed on (rmx_ct32.h CoopPub: the tag of the next one)
+    bool wide = false;                           // the line search in progress / the next one takes the whole group (rmx_ct32.h newton_pair)
 #ifdef RMX_COOP_PROFILE                          // measurement build (tools/coop_profile.py): shader-clock ticks spent inside coop_exchange
     unsigned long long waited = 0;
 #endif
