@@ -374,16 +374,23 @@ __device__ __forceinline__ bool coop_collect(const CoopPub& pb, const CoopCtx& c
 // publishing record s + 1 over a record s that a late member - one that has only just picked the rollout up - has not read yet.
 // Every member therefore notes the last record it has handled in its own word (cx.words[COOP_ACK + m], relaxed), and member 0 looks
 // at the nine words before it overwrites the record: all of them at s - 1 or beyond.  (In a wide round the exchange of the decision
-// words itself is that guarantee: nobody posts its word before it has read the previous record.)
+// words itself is that guarantee: nobody posts its word before it has read the previous record, and the gather waits for every word.)
 constexpr int COOP_ACK = 22;                     // cx.words[22 .. 31]
 __device__ __forceinline__ void coop_ack(const CoopCtx& cx, const int lane, const unsigned seq) {
     if (lane == 0) coop_store(cx.words + COOP_ACK + cx.member, seq);
 }
-__device__ __forceinline__ bool coop_wait_acks(const CoopCtx& cx, const int lane, const unsigned seq) {
+// first: this lane's acknowledgement word as read a while ago (coop_ack_peek, issued before the solve so that the round trip of the
+// load hides behind it); only if that reading does not settle it is the word polled
+__device__ __forceinline__ unsigned coop_ack_peek(const CoopCtx& cx, const int lane) {
+    return (lane < COOP_G && lane != cx.member) ? coop_load(cx.words + COOP_ACK + lane) : 0xffffffffu;
+}
+__device__ __forceinline__ bool coop_wait_acks(const CoopCtx& cx, const int lane, const unsigned seq, const unsigned first) {
+    const bool idle = !(lane < COOP_G && lane != cx.member);
+    if (__all(idle || (int)(first - seq) >= 0)) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     while (true) {
         unsigned w = seq;
-        if (lane < COOP_G && lane != cx.member) w = coop_load(cx.words + COOP_ACK + lane);
+        if (!idle) w = coop_load(cx.words + COOP_ACK + lane);
         if (__all((int)(w - seq) >= 0)) return true;
         unsigned ab = 0u;
         if (lane == 0) ab = coop_load(cx.words + 2 * COOP_G);
@@ -415,18 +422,29 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
     double lo = 0.0, dx = 0.0, alpha = 1.0, f0 = 0.0, g0n2 = 0.0, x0 = x, lo0 = 0.0, gn2 = 0.0;
     int iter = 1, lsfail = 0, iterLs = 1;
     int mode = 0;                  // 0: evaluate x for the Hessian stage (first evaluation of the solve / before a pivoting re-solve);
-                                   // 1: the next two (COOP: 2 COOP_G) trials of the line search
+                                   // 1: the next two (COOP, wide round: 2 COOP_G) trials of the line search
     bool redo = false;             // mode 0 is the re-evaluation before the pivoting solve of the same iteration
     last.g = last.eT = last.eV = 0.0;
+#define RMX_COOP_GIVE_UP()              \
+    {                                   \
+        status |= 4 | ST_COOP_FAULT;    \
+        xlo = lo0;                      \
+        return x0;                      \
+    }
     while (true) {
+        // ---- A. the points of this evaluation
         double xl, lol;
         bool stall_a = false, stall_b = false;
+        // COOP, narrow round (the last line search of this rollout ended within its first two trials - every ordinary Newton iteration
+        // does): member 0 alone evaluates trials 1 and 2 and the group waits for its record; the decision words are not exchanged at all
+        const bool narrow = COOP && mode == 1 && !cx.wide;
+        const bool wide = COOP && mode == 1 && cx.wide;
         if (mode == 0) {
             xl = dup_lo(x);
             lol = dup_lo(lo);
         } else {
             const double x0d = dup_lo(x0), lo0d = dup_lo(lo0), dxd = dup_lo(dx);
-            const double am = (COOP && cx.wide) ? ldexp(alpha, -2 * cx.member) : alpha;      // (alpha is a power of two: exact)
+            const double am = wide ? ldexp(alpha, -2 * cx.member) : alpha;      // (alpha is a power of two: exact)
             const double al = hiH ? 0.5 * am : am;
             two_sum(x0d, fma(al, dxd, lo0d), xl, lol);       // x + lo = x0 + (lo0 + alpha dx)
             lol *= o.comp;
@@ -436,22 +454,72 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
             stall_a = (unsigned)same == 0xffffffffu;
             stall_b = (unsigned)(same >> 32) == 0xffffffffu;
         }
+        // ---- B. the evaluation
         bool ta = false, tb = false;
         double ga2 = 0.0, gb2 = 0.0;
-        // COOP, narrow round (the last line search of this rollout ended within its first two trials - every ordinary Newton iteration
-        // does): member 0 alone evaluates trials 1 and 2 and the group waits for its record; the decision words are not exchanged at all
-        const bool narrow = COOP && mode == 1 && !cx.wide;
-        if (!(mode == 1 && stall_a) && !(narrow && cx.member != 0)) {      // (a stalled: so are b and every later trial; nobody looks at their f)
+        const bool evaluates = !(mode == 1 && stall_a) && !(narrow && cx.member != 0);      // (a stalled: so are b and every later trial)
+        if (evaluates) {
             RMX_PH_BEGIN(1)
             eval_front_pair<true>(M.n, cK, grav, lane, xl, ((xl - qAd) + lol) / eta, (xl - qBd) + lol, eta, e, fs, ta, tb);
             wave_sum_dual(e.g * e.g, ga2, gb2);
             RMX_PH_END(1)
         }
-        bool need_solve = true;                            // this member runs the Hessian stage and the solve at the accepted point
+        // (COOP) the group's acknowledgement words, read NOW for the publish that may follow the Hessian stage and the solve
+        unsigned ackw = 0u;
+        if constexpr (COOP) {
+            if (narrow) ackw = coop_ack_peek(cx, lane);
+        }
+        // ---- C. what can be decided before the Hessian stage, and whether the stage runs NOW, on which half's state
+        //   mode 0: always (half a).
+        //   a line search decided by this wavefront alone (not COOP; COOP narrow round, member 0): once the trial that ends the search
+        //   is known and the solve does not end there.
+        //   COOP wide round: SPECULATIVELY, between posting this member's decision word and collecting the group's - on the first of
+        //   its two trials that could end the search.  If the walk over the group's words then names this member the winner, that is
+        //   the accepted trial and the stage is already done; if not, the work is dropped (the member would have idled instead).
+        int take = -1;                 // the trial, counted from iterLs, that ends the search
+        bool stalled = false;
+        bool conv = false, maxit = false, cut = false, park = false;     // the checks that follow a line search, for the accepted trial
+        bool hess_now = mode == 0;
+        int hess_half = 0;
+        const bool local = mode == 1 && (!COOP || (narrow && cx.member == 0));
+        if (local) {
+            if (stall_a) stalled = true;
+            else if (0.5 * ga2 < f0 || iterLs >= o.iterLsMax) take = 0;
+            else if (stall_b) stalled = true;
+            else if (0.5 * gb2 < f0 || iterLs + 1 >= o.iterLsMax) take = 1;
+            if (take >= 0) {
+                const double g2 = take ? gb2 : ga2;
+                conv = sqrt(g2) < o.tol;
+                maxit = iter >= o.iterMax;
+                cut = o.lsFailLimit > 0 && lsfail + ((0.5 * g2 < f0) ? 0 : 1) >= o.lsFailLimit;
+                park = !COOP && o.parkHalv > 0 && halvings + (iterLs + take - 1) - halv_in > o.parkHalv;
+                hess_now = !(conv || maxit || cut || park);
+                hess_half = take;
+            }
+        } else if (wide) {
+            unsigned bits = (stall_a ? 1u : 0u) | (stall_b ? 2u : 0u);
+            if (!stall_a) bits |= (0.5 * ga2 < f0 ? 4u : 0u) | (0.5 * gb2 < f0 ? 8u : 0u);
+            coop_post(cx, lane, bits);
+            const int ta_ix = iterLs + 2 * cx.member;                     // this member's trials, as line-search counts
+            const bool cand_a = !stall_a && ((bits & 4u) || ta_ix >= o.iterLsMax);
+            const bool cand_b = !stall_a && !stall_b && ((bits & 8u) || ta_ix + 1 >= o.iterLsMax);
+            hess_now = cand_a || cand_b;
+            hess_half = cand_a ? 0 : 1;
+        }
+        bool hdone = false;
+        if (hess_now) {
+            if (hess_half) front_take_hi(fs, e);
+            fs.touched = hess_half ? tb : ta;
+            double Hdummy[NP];
+            RMX_PH_BEGIN(2)
+            eval_hess<NP, false, true, false>(M, lane, fs, Hdummy, nullptr, sAcc, e.g);
+            RMX_PH_END(2)
+            hdone = true;
+        }
+        // ---- D. the line search's decision and what follows it
+        bool need_solve = true;                            // this member runs the solve at the accepted point
         int take_pub = 0;                                  // (COOP) the accepted trial, as the winner's record names it
         if (mode == 1) {
-            int take = -1;                                 // the trial, counted from iterLs, that ends the search
-            bool stalled = false;
             // (COOP) a record collected in the narrow round, used further down in place of the wait for the winner
             bool have_rec = false;
             double rT = 0.0, rV = 0.0, rdx = 0.0, rgn2 = 0.0;
@@ -459,17 +527,9 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
             if constexpr (COOP) {
                 if (narrow) {
                     if (cx.member == 0) {
-                        if (stall_a) stalled = true;
-                        else if (0.5 * ga2 < f0 || iterLs >= o.iterLsMax) take = 0;
-                        else if (stall_b) stalled = true;
-                        else if (0.5 * gb2 < f0 || iterLs + 1 >= o.iterLsMax) take = 1;
                         if (stalled || take < 0) {         // nothing to hand over but the verdict: "stalled" / "the rest of the trials, everybody"
                             ++cx.rseq;
-                            if (!coop_wait_acks(cx, lane, cx.rseq - 1)) {
-                                status |= 4 | ST_COOP_FAULT;
-                                xlo = lo0;
-                                return x0;
-                            }
+                            if (!coop_wait_acks(cx, lane, cx.rseq - 1, ackw)) RMX_COOP_GIVE_UP()
                             coop_publish(pb, cx.rseq, lane, 0.0, stalled ? COOP_CODE_STALL : COOP_CODE_WIDE, 0.0, 0.0, 0.0);
                             coop_ack(cx, lane, cx.rseq);
                         }
@@ -478,11 +538,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                         RMX_PH_BEGIN(5)
                         const bool cok = coop_collect(pb, cx, cx.rseq, lane, rgn2, rcode, rT, rV, rdx);
                         RMX_PH_END(5)
-                        if (!cok) {
-                            status |= 4 | ST_COOP_FAULT;
-                            xlo = lo0;
-                            return x0;
-                        }
+                        if (!cok) RMX_COOP_GIVE_UP()
                         have_rec = true;
                         coop_ack(cx, lane, cx.rseq);
                         const int what = rcode & 15;
@@ -490,17 +546,12 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                         else if (what != COOP_CODE_WIDE) take = (rcode >> 4) & 31;
                     }
                 } else {
-                    unsigned bits = (stall_a ? 1u : 0u) | (stall_b ? 2u : 0u);
-                    if (!stall_a) bits |= (0.5 * ga2 < f0 ? 4u : 0u) | (0.5 * gb2 < f0 ? 8u : 0u);
                     unsigned word;
                     RMX_PH_BEGIN(4)
-                    const bool xok = coop_exchange(cx, lane, bits, word);
+                    const bool xok = coop_gather(cx, lane, word, iterLs, o.iterLsMax, true);       // (every word: the exchange stays a barrier of the group;
+                    // returning at the word that ends the search, with acknowledgements before every publish instead, measured no faster)
                     RMX_PH_END(4)
-                    if (!xok) {
-                        status |= 4 | ST_COOP_FAULT;
-                        xlo = lo0;
-                        return x0;
-                    }
+                    if (!xok) RMX_COOP_GIVE_UP()
 #pragma unroll 1
                     for (int m = 0; m < COOP_G; ++m) {     // the reference's walk over the trials, in order
                         const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)word, m);
@@ -510,11 +561,16 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                         if ((w & 8u) || iterLs + 2 * m + 1 >= o.iterLsMax) { take = 2 * m + 1; break; }
                     }
                 }
-            } else {
-                if (stall_a) stalled = true;
-                else if (0.5 * ga2 < f0 || iterLs >= o.iterLsMax) take = 0;
-                else if (stall_b) stalled = true;
-                else if (0.5 * gb2 < f0 || iterLs + 1 >= o.iterLsMax) take = 1;
+            }
+            bool mine = true;                              // the accepted trial was evaluated by this wavefront
+            if constexpr (COOP) mine = take >= 0 && (narrow ? cx.member == 0 : (take >> 1) == cx.member);
+            if (hdone && !(mine && !stalled)) {
+                // a Hessian stage run ahead for a trial that did not end the search: the staging area goes back to the state the next
+                // stage expects (row n of the accumulation scratch zero; see eval_hess)
+                hdone = false;
+                RMX_SYNC();
+                if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+                RMX_SYNC();
             }
             if (stalled) {
                 // g is g(x0) again.  If it is not below tol the next Newton iteration is this one repeated exactly, and so on until
@@ -528,7 +584,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                 if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
                 break;
             }
-            const int PER = (COOP && !narrow) ? 2 * COOP_G : 2;
+            const int PER = wide ? 2 * COOP_G : 2;
             if (take < 0) {                                // none of this round's trials ends the search
                 alpha = ldexp(alpha, -PER);
                 iterLs += PER;
@@ -538,12 +594,10 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
             iterLs += take;
             halvings += iterLs - 1;
             take_pub = take;
-            bool mine = true;                              // the accepted trial was evaluated by this wavefront
             if constexpr (COOP) {
                 // every member: the accepted iterate from what all of them hold bit for bit
                 two_sum(x0, fma(ldexp(alpha, -take), dx, lo0), x, lo);
                 lo *= o.comp;
-                mine = narrow ? cx.member == 0 : (take >> 1) == cx.member;
                 cx.wide = iterLs > 2;                      // the next search starts with member 0 alone again once one ends within two trials
             } else {
                 const double xs = (take & 1) ? take_hi(xl) : xl, ls = (take & 1) ? take_hi(lol) : lol;
@@ -552,7 +606,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
             }
             int end_bits = -1;                             // >= 0: the solve ends here, with these status bits
             if (mine) {
-                if (take & 1) front_take_hi(fs, e);
+                if (!hdone && (take & 1)) front_take_hi(fs, e);      // (hdone: the state is already where the stage worked on it)
                 gn2 = (take & 1) ? gb2 : ga2;
                 fs.touched = (take & 1) ? tb : ta;
                 last.g = e.g;
@@ -563,30 +617,30 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                     last.eV = wave_sum(last.eV);
                     last.eT = lane == 0 ? last.eT : 0.0;
                     last.eV = lane == 0 ? last.eV : 0.0;
-                } else {
-                    // a solve whose line searches keep running out their trials: hand the rollout over, at the start of this step, to
-                    // the cooperative launch (see CoopCtx)
-                    if (o.parkHalv > 0 && halvings - halv_in > o.parkHalv) {
-                        status |= ST_PARK;
-                        xlo = lo;
-                        return x;
-                    }
+                }
+                if (!local) {                              // (a wide round's winner: the checks the deciding wavefront makes in C)
+                    conv = sqrt(gn2) < o.tol;
+                    maxit = iter >= o.iterMax;
+                    cut = o.lsFailLimit > 0 && lsfail + ((0.5 * gn2 < f0) ? 0 : 1) >= o.lsFailLimit;
+                }
+                // a solve whose line searches keep running out their trials: hand the rollout over, at the start of this step, to
+                // a cooperative group (see CoopCtx)
+                if (park) {
+                    status |= ST_PARK;
+                    xlo = lo;
+                    return x;
                 }
                 // the checks that follow a line search (:142-153; rmx_opts.ls_fail_limit: see newton_impl)
-                if (sqrt(gn2) < o.tol) end_bits = 0;
-                else if (iter >= o.iterMax) end_bits = 2;          // "Newton did not converge"
+                if (conv) end_bits = 0;
+                else if (maxit) end_bits = 2;              // "Newton did not converge"
                 else {
                     lsfail += (0.5 * gn2 < f0) ? 0 : 1;
-                    if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) end_bits = 2 | ST_LS_CUT;
+                    if (cut) end_bits = 2 | ST_LS_CUT;
                 }
                 if constexpr (COOP) {
                     if (end_bits >= 0) {
                         ++cx.rseq;
-                        if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1)) {
-                            status |= 4 | ST_COOP_FAULT;
-                            xlo = lo0;
-                            return x0;
-                        }
+                        if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1, ackw)) RMX_COOP_GIVE_UP()
                         coop_publish(pb, cx.rseq, lane, gn2, COOP_CODE_END | (take << 4) | (end_bits << 12), readlane_d(last.eT, 0), readlane_d(last.eV, 0), 0.0);
                         coop_ack(cx, lane, cx.rseq);
                     }
@@ -602,11 +656,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                     RMX_PH_BEGIN(5)
                     const bool cok = coop_collect(pb, cx, cx.rseq, lane, gn2, code, T, V, dxn);
                     RMX_PH_END(5)
-                    if (!cok) {
-                        status |= 4 | ST_COOP_FAULT;
-                        xlo = lo0;
-                        return x0;
-                    }
+                    if (!cok) RMX_COOP_GIVE_UP()
                     coop_ack(cx, lane, cx.rseq);
                 }
                 last.g = 0.0;
@@ -634,19 +684,23 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
             }
             if (end_bits >= 0) {
                 status |= end_bits;
+                if (hdone) {                               // (a stage run ahead at a point the solve ends at: see above)
+                    RMX_SYNC();
+                    if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+                    RMX_SYNC();
+                }
                 break;
             }
             ++iter;
         } else {
             gn2 = ga2;
-            fs.touched = ta;
             if (!redo) {
                 last.g = e.g;
                 last.eT = hiH ? 0.0 : e.eT;
                 last.eV = hiH ? 0.0 : e.eV;
             }
         }
-        // ---- Hessian stage and dx = -H\g at the accepted point (its state in lanes 0..31)
+        // ---- E. dx = -H\g at the accepted point (the Hessian stage has left H and -g in the staging area)
         if constexpr (COOP) {
             eT0 = readlane_d(wave_sum(last.eT), 0);
             eV0 = readlane_d(wave_sum(last.eV), 0);
@@ -660,21 +714,12 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
         }
         if (!redo) ++iters;
         if (need_solve) {
-            double Hrow[NP];
-#if defined(RMX_TICK_PHASE) && RMX_TICK_PHASE >= 20      // 20 + k: stamp k of the Hessian stage (12: stiffness block, 13: damping block,
-            {                                                // 9: the node's vectors, 10: column vectors, 11: products, staging and H)
-                unsigned long long st[16] = {0};
-                eval_hess<NP, true, true, false>(M, lane, fs, Hrow, st, sAcc, e.g);
-                cx.phase += st[RMX_TICK_PHASE - 20];
-            }
-#else
-            RMX_PH_BEGIN(2)
-            eval_hess<NP, false, true, false>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
-            RMX_PH_END(2)
-#endif
+            // (by construction the stage has run: mode 0 always, a locally decided search when the solve goes on, a wide round's winner
+            // on its candidate trial)
             bool lu_ok = true;
             RMX_PH_BEGIN(3)
             if (pivot_all || redo) {
+                double Hrow[NP];
                 hess_rows_from_staging(M.n, lane, sAcc, Hrow);
                 dx = lu_solve_neg<NP>(M.n, lane, Hrow, hiH ? 0.0 : e.g);
             } else {
@@ -687,11 +732,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                 if constexpr (COOP) {
                     if (mode == 1) {
                         ++cx.rseq;
-                        if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1)) {
-                            status |= 4 | ST_COOP_FAULT;
-                            xlo = lo0;
-                            return x0;
-                        }
+                        if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1, ackw)) RMX_COOP_GIVE_UP()
                         coop_publish(pb, cx.rseq, lane, gn2, COOP_CODE_REDO | (take_pub << 4), eT0, eV0, 0.0);
                         coop_ack(cx, lane, cx.rseq);
                     }
@@ -706,11 +747,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
                 RMX_PH_BEGIN(6)
                 if (mode == 1) {
                     ++cx.rseq;
-                    if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1)) {
-                        status |= 4 | ST_COOP_FAULT;
-                        xlo = lo0;
-                        return x0;
-                    }
+                    if (narrow && !coop_wait_acks(cx, lane, cx.rseq - 1, ackw)) RMX_COOP_GIVE_UP()
                     coop_publish(pb, cx.rseq, lane, gn2, COOP_CODE_DX | (take_pub << 4), eT0, eV0, dx);
                     coop_ack(cx, lane, cx.rseq);
                 }
@@ -736,6 +773,7 @@ __device__ __forceinline__ double newton_pair(const DevModel& M, const DevOpts& 
         iterLs = 1;
         mode = 1;
     }
+#undef RMX_COOP_GIVE_UP
     xlo = lo;
     return x;
 }

@@ -3328,9 +3328,6 @@ struct CoopCtx {
     unsigned round = 0;                          // decision-word exchanges this group has gone through (the tag of the next one)
     unsigned rseq = 0;                           // records the group has passed on (rmx_ct32.h CoopPub: the tag of the next one)
     bool wide = false;                           // the line search in progress / the next one takes the whole group (rmx_ct32.h newton_pair)
-#ifdef RMX_COOP_PROFILE                          // measurement build (tools/coop_profile.py): shader-clock ticks spent inside coop_exchange
-    unsigned long long waited = 0;
-#endif
 #ifdef RMX_TICK_PHASE                            // measurement build (rmx_ct32.h RMX_PH_BEGIN): ticks of one phase of newton_pair
     unsigned long long phase = 0;
 #endif
@@ -3339,11 +3336,20 @@ __device__ __forceinline__ unsigned coop_load(const unsigned* p) { return __hip_
 __device__ __forceinline__ void coop_store(unsigned* p, const unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Post this member's decision bits for exchange `round` and collect the group's: lane j < COOP_G comes back with member j's word.
 // false: some member did not answer within ~2 s of shader clock (or the group's abort flag was up): the caller gives the rollout up.
-__device__ __forceinline__ bool coop_exchange(CoopCtx& cx, const int lane, const unsigned bits, unsigned& word) {
+// (the exchange in two halves: a member may work between posting its word and collecting the group's - rmx_ct32.h newton_pair runs
+// the Hessian stage of its own candidate trial there)
+__device__ __forceinline__ void coop_post(CoopCtx& cx, const int lane, const unsigned bits) {
     ++cx.round;
+    unsigned* const slot = cx.words + (cx.round & 1u) * COOP_G;
+    if (lane == 0) coop_store(slot + cx.member, (cx.round << 4) | bits);
+}
+// iterLs / iterLsMax: the walk over the trials stops at the first member whose word ends the search - a stalled trial, an accepted one, or
+// the one that is the last the reference allows - so the gather returns as soon as the words of the members up to and including that
+// one are in (words of later members come back as "not arrived": the walk never reads them).
+__device__ __forceinline__ bool coop_gather(CoopCtx& cx, const int lane, unsigned& word, const int iterLs, const int iterLsMax,
+                                            const bool all = false) {
     const unsigned tag = cx.round << 4;
     unsigned* const slot = cx.words + (cx.round & 1u) * COOP_G;
-    if (lane == 0) coop_store(slot + cx.member, tag | bits);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     bool ok = true;
     word = tag;
@@ -3352,8 +3358,12 @@ __device__ __forceinline__ bool coop_exchange(CoopCtx& cx, const int lane, const
         if (lane < COOP_G) w = coop_load(slot + lane);
         else if (lane == COOP_G) w = coop_load(cx.words + 2 * COOP_G) ? 0u : tag;    // the abort flag reads as a word that never arrives ...
         const bool mine = (w & ~15u) == tag;
-        if (__all(mine)) {
-            word = w;
+        const bool ends = !all && lane < COOP_G && mine && ((w & 15u) != 0u || iterLs + 2 * lane + 1 >= iterLsMax);
+        const unsigned long long arrived = __ballot(mine), ending = __ballot(ends);
+        // every member up to the first one whose word ends the search has answered (lanes >= COOP_G always count as answered)
+        const unsigned long long upto = ending ? ((ending & (0ull - ending)) << 1) - 1ull : ~0ull;
+        if ((arrived & upto) == upto) {
+            word = mine ? w : tag;
             break;
         }
         const bool aborted = __any(lane == COOP_G && !mine);                          // ... and ends the wait at once
@@ -3364,10 +3374,11 @@ __device__ __forceinline__ bool coop_exchange(CoopCtx& cx, const int lane, const
         }
         __builtin_amdgcn_s_sleep(RMX_COOP_SLEEP_X);
     }
-#ifdef RMX_COOP_PROFILE
-    cx.waited += __builtin_amdgcn_s_memtime() - t0;
-#endif
     return ok;
+}
+__device__ __forceinline__ bool coop_exchange(CoopCtx& cx, const int lane, const unsigned bits, unsigned& word) {
+    coop_post(cx, lane, bits);
+    return coop_gather(cx, lane, word, 0, 0, true);      // (every word: this form is a plain all-to-all exchange)
 }
 #ifndef RMX_DUAL_LS
 #define RMX_DUAL_LS 1              // two line-search points per evaluation (eval_front_dual); 0: one (build variants, measurements)
