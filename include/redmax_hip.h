@@ -175,7 +175,7 @@ int rmx_model_set_ground_contact(rmx_model* m, const rmx_ground_contact* gc);
  * chart changed), so q/qdot returned by rmx_get_state are coordinates in the charts rmx_get_charts reports.  rmx_set_state
  * puts every joint back to CHART_XYZ; rmx_set_charts (after it) declares other charts for the given coordinates.
  * charts: host [batch][nsph], spherical joints in listing order.  rmx_step_euler / rmx_adjoint_bdf1 refuse such models.  A scene may
- * hold at most 21 JointSpherical / JointFree3D joints (rmx_model_create refuses more), whatever its node count. */
+ * hold as many JointSpherical / JointFree3D joints as its node limit allows (256 nodes: 85; ABI 109 - 21 up to ABI 108). */
 int rmx_model_nsph(const rmx_model* m);
 int rmx_get_charts(rmx_batch* b, int* charts);
 int rmx_set_charts(rmx_batch* b, const int* charts);

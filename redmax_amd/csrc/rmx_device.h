@@ -50,7 +50,7 @@ constexpr int MAXROUNDS = 6;      // log2(MAXN)
 constexpr int NCON = 14;          // rows of DevModel::con
 constexpr int NGROUND = 10;       // of which per-body ground frame and constants (GroundC)
 constexpr int NCONST = 68;        // per-node constants staged in LDS: K(36) sb(6) I4(4) prm(8) type(1) rel(2) anc(6) end(1) contact(1) sides(3)
-constexpr int MAXSPH = 21;        // spherical joints per tree (three nodes each)
+constexpr int MAXSPH = 85;        // spherical joints per tree (three nodes each): BIG_MAXN / 3; the one-wavefront kernels (<= 64 nodes) see at most 21
 constexpr int SPH_ROWS = 42;      // per-node constants that depend on a spherical node's axis: K(36) + sb(6), the first LDS rows
 // doubles of the accumulation scratch at the start of a wavefront's LDS: (n+1) rows of the subtree scan, or the Hessian's
 // column vectors [NP][NCOLX], whichever is larger; the per-node constants follow it

@@ -231,6 +231,41 @@ def test_free_bodies_rollout_matches_oracle(oracle_lib, integ, nbodies):
     assert int(out["newton_iters"][0]) == st.newton_iters
 
 
+def test_more_than_21_euler_chart_joints(oracle_lib):
+    """JointSpherical.m has no cap on the number of spherical joints of a scene; up to ABI 108 the library refused more than 21 (the size of
+    the one-wavefront kernels' chart tables) although trees of 256 nodes are accepted.  26 free-flying bodies (157 nodes, 26 Euler-chart
+    groups): g, H against the literal oracle, and a BDF1 rollout with fast spins - charts, final state, Newton counts."""
+    from redmax_amd import BatchSim
+    sc = _free_bodies(26)
+    sc.h = 2e-2
+    for j in sc.joints[1:]:
+        j.qdot[3:] *= 2.0
+    sc.init()
+    qs, qds = sc.getQ()
+    h = sc.h
+    rng = np.random.default_rng(2)
+    q1 = qs + h * qds + 1e-3 * rng.standard_normal(sc.nr)
+    sim = BatchSim(sc, batch=1)
+    assert sim.nsph == 26
+    g, H = sim.eval_bdf1(q1[None, :], qs[None, :], qds[None, :], h)
+    o = oracle_lib.Oracle(sc.desc())
+    go, Ho = o.eval_bdf1(q1, qs, qds, h)
+    assert _rel(g[0], go) <= 1e-10 and _rel(H[0], Ho) <= 1e-10
+    K = 5
+    sim.set_state(qs[None, :], qds[None, :])
+    out = sim.step_bdf1(K, h=h, stats=True)
+    qg, qdg = sim.get_state()
+    charts = sim.charts()
+    sim.close()
+    o.set_state(qs, qds)
+    st = o.step_bdf1(h, K)
+    qo, qdo = o.get_state()
+    assert st.diverged == 0 and st.not_converged == 0 and (out["status"] & 15 == 0).all()
+    assert np.array_equal(charts[0], o.charts())
+    assert _rel(qg[0], qo) <= 1e-8 and _rel(qdg[0], qdo) <= 1e-6
+    assert int(out["newton_iters"][0]) == st.newton_iters
+
+
 def test_big_tree_refusals():
     """What the one-workgroup kernels do not cover is refused loudly, not silently dropped."""
     from redmax_amd import BatchSim
