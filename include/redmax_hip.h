@@ -151,7 +151,12 @@ int rmx_model_idxR(const rmx_model* m, int* idx);
  * (static/dynamic branch per corner, :112-150), energy 0.5 kn d^2 (:176).  Replaces, for one ground frame per scene,
  *     f = redmax.ForceGroundCuboid(body); f.setTransform(E); f.setStiffness(kn,kt); f.setDamping(kd); f.setFriction(mu);
  * (scenesRedMax.m:303-309).  Arrays follow the scene listing like rmx_model_desc.  Call before stepping; BDF1/BDF2/eval/energy
- * honour it, rmx_step_euler and rmx_adjoint_bdf1 refuse such a model.  All flags zero removes the contact. */
+ * honour it, rmx_step_euler and rmx_adjoint_bdf1 refuse such a model.  All flags zero removes the contact.
+ * The reference keeps its force objects in a list (Force.m:26-56) and a body may carry several (a floor and a wall).  This struct
+ * holds ONE object per listing entry: a host lists every further force of a body as an extra entry of rmx_model_desc - a
+ * RMX_JOINT_FIXED child of the body's joint, E0_pj = identity, E0_ji and sides those of the body, I_i = 0 - flagged here with its own
+ * frame and constants.  Same corners, same twist: the same wrench, K and D through the same Jacobian rows; no DOF is added
+ * (redmax_amd.Scene.desc() and matlab/+redmax/flattenScene.m do this; tests/test_oracle_fd.py, tests/test_gpu_contact.py). */
 typedef struct rmx_ground_contact {
     const int* flags;        /* [n] 1: this body carries a ForceGroundCuboid                       */
     const double* sides;     /* [n][3] cuboid side lengths (BodyCuboid.sides)  ForceGroundCuboid.m:71-75 */

@@ -122,9 +122,24 @@ for i = 1 : numel(scene.forces)
 				error('redmax:hip','flattenScene: ForceGroundCuboid on a body that is not in the scene');
 			end
 			if desc.contact(hit)
-				% a floor and a wall on one cuboid: the device tables hold one force object per body; overwriting the first
-				% silently would drop its contact (redmax_amd/redmax.py Scene.desc raises for the same case)
-				error('redmax:hip','flattenScene: one ForceGroundCuboid per body (body %d carries two)',hit);
+				% A second (third ...) ForceGroundCuboid on this cuboid - a floor and a wall; the reference's forces are a list
+				% (Force.m:26-56) and nothing ties a body to one.  The library takes ONE force object per listing entry, so the force
+				% is listed as a fixed, massless child of the body's joint with the body's own transform and sides: the same corners
+				% moving with the same twist, hence the same wrench, K and D pulled through the same Jacobian rows.  No DOF is added
+				% (redmax_amd/redmax.py Scene.desc does the same; tests/test_oracle_fd.py shows the two forms agree to roundoff).
+				m = desc.njoints + 1;
+				desc.njoints = m;
+				desc.parent(m) = hit - 1; % 0-based: the joint of that body
+				desc.type(m) = 0;         % RMX_JOINT_FIXED
+				desc.axis(:,m) = [0;0;1];
+				desc.E0_pj(:,:,m) = eye(4);
+				desc.E0_ji(:,:,m) = f.cuboid.E0_ji;
+				desc.I_i(:,m) = zeros(6,1);
+				desc.qRest(m) = 0; desc.tau(m) = 0; desc.stiffness(m) = 0; desc.damping(m) = 0;
+				desc.qLimL(m) = -inf; desc.qLimU(m) = inf; desc.qLimK(m) = 0; desc.qLimD(m) = 0;
+				desc.plane(:,m) = [1;0;0;0;1;0];
+				desc.contact(m) = 0;
+				hit = m;
 			end
 			desc.contact(hit) = 1;
 			desc.sides(:,hit) = f.cuboid.sides(:);

@@ -100,6 +100,8 @@ def lib():
         L.orc_trace_count.restype = C.c_int
         L.orc_set_ground_contact.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_set_ground_contact_body.argtypes = [C.c_void_p, _ip, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
+        L.orc_add_ground_contact.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_add_ground_contact.restype = C.c_int
         L.orc_adjoint_bdf1.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(TaskPointPos), _dp, _dp, C.POINTER(Stats)]
         L.orc_adjoint_bdf1.restype = C.c_double
         L.orc_adjoint_bdf2.argtypes = L.orc_adjoint_bdf1.argtypes
@@ -166,6 +168,8 @@ def lower_composite(d):
     typ = np.asarray(d["type"])
     n = int(d["njoints"])
     if not np.any(typ > 2):
+        if d.get("extra_forces"):                    # (listing entry = node)
+            d = dict(d, extra_forces=[dict(f, node=int(f["body"])) for f in d["extra_forces"]])
         return d
     ndof = [0 if t == 0 else 1 if t <= 2 else len(_composite_subjoints(t, np.zeros(6))) for t in typ]
     base = [0] * n
@@ -223,6 +227,8 @@ def lower_composite(d):
         if d.get("ground_body") is not None:      # one frame / set of constants per ForceGroundCuboid object, listing order -> node order
             gb = d["ground_body"]
             low["ground_body"] = {k: np.ascontiguousarray(np.asarray(gb[k], dtype=np.float64)[out["gL"]]) for k in ("E", "kn", "kt", "mu", "kd")}
+        if d.get("extra_forces"):                    # further force objects: the body of listing entry L is carried by node last[L]
+            low["extra_forces"] = [dict(f, node=int(last[int(f["body"])])) for f in d["extra_forces"]]
     return low
 
 
@@ -262,6 +268,11 @@ class Oracle:
                 self._ck = [np.ascontiguousarray(gb[k], dtype=np.float64) for k in ("kn", "kt", "mu", "kd")]
                 self._L.orc_set_ground_contact_body(self._h, self._cflags.ctypes.data_as(_ip), _p(self._csides), _p(self._cEb), 1,
                                                     _p(self._ck[0]), _p(self._ck[1]), _p(self._ck[2]), _p(self._ck[3]), 1)
+            # the reference keeps its force objects in a list (Force.m:26-56): any number of ForceGroundCuboid per body
+            for f in desc_dict.get("extra_forces") or ():
+                E = np.ascontiguousarray(np.asarray(f["E"], dtype=np.float64).reshape(4, 4).T.reshape(16))
+                if self._L.orc_add_ground_contact(self._h, int(f["node"]), _p(E), float(f["kn"]), float(f["kt"]), float(f["mu"]), float(f["kd"])) != 0:
+                    raise ValueError("extra force on a body that carries no ForceGroundCuboid")
 
     def __del__(self):
         try:

@@ -176,6 +176,9 @@ struct orc_scene {
     int* contact;                        /* [n] flag */
     double* sides;                       /* [n][3]   */
     struct ogf { m4 E; double kn, kt, mu, kd; } *gf;      /* [n] the ground frame and constants of each body's ForceGroundCuboid */
+    /* further ForceGroundCuboid objects on bodies that already carry one: the reference keeps its forces in a linked list
+     * (Force.m:26-56, Scene.m:87-89) and nothing limits a body to one (a floor and a wall) */
+    int nxf; int* xf_body; struct ogf* xf;
     /* JointSpherical groups (three consecutive revolute nodes each) and their Euler charts */
     int nsph; int* sph_first; int* sph_chart; int* sph_chart1;
 };
@@ -395,7 +398,7 @@ void orc_destroy(orc_scene* s) {
     free(s->nd); free(s->qInit); free(s->qdotInit);
     free(s->J); free(s->Jdot); free(s->dJdq); free(s->dJdotdq);
     free(s->Mm); free(s->Km); free(s->Dm); free(s->fm); free(s->fr); free(s->Kr); free(s->Dr);
-    free(s->contact); free(s->sides); free(s->gf);
+    free(s->contact); free(s->sides); free(s->gf); free(s->xf_body); free(s->xf);
     free(s->sph_first); free(s->sph_chart); free(s->sph_chart1);
     free(s);
 }
@@ -555,11 +558,12 @@ static void compute_ground_contact(orc_scene* s, int deriv) {
     if (!s->contact) return;
     double eb[3][3][3];
     for (int c = 0; c < 3; c++) { double e[3] = { 0, 0, 0 }; e[c] = 1.0; se3_brac3(eb[c], e); }
-    for (int ib = 0; ib < s->n; ib++) {
-        if (!s->contact[ib]) continue;
+    for (int fi = 0; fi < s->n + s->nxf; fi++) {       /* Force.computeValues walks the list of force objects (Force.m:26-56) */
+        const int ib = fi < s->n ? fi : s->xf_body[fi - s->n];
+        if (fi < s->n && !s->contact[ib]) continue;
         onode* j = &s->nd[ib];
         /* every force object holds its own E, kn, kt, mu, kd (ForceGroundCuboid.m:6-13, 56-57) */
-        const struct ogf* gf = &s->gf[ib];
+        const struct ogf* gf = fi < s->n ? &s->gf[ib] : &s->xf[fi - s->n];
         const double kn = gf->kn, kt = gf->kt, mu = gf->mu, kd = gf->kd;
         double xg[3], ng[3], N[3][3], T[3][3];
         for (int a = 0; a < 3; a++) { xg[a] = gf->E[a][3]; ng[a] = gf->E[a][2]; }
@@ -674,8 +678,10 @@ static void compute_ground_contact(orc_scene* s, int deriv) {
 static double ground_contact_energy(const orc_scene* s) {
     if (!s->contact) return 0.0;
     double v = 0;
-    for (int ib = 0; ib < s->n; ib++) {
-        if (!s->contact[ib]) continue;
+    for (int fi = 0; fi < s->n + s->nxf; fi++) {
+        const int ib = fi < s->n ? fi : s->xf_body[fi - s->n];
+        if (fi < s->n && !s->contact[ib]) continue;
+        const struct ogf* gf = fi < s->n ? &s->gf[ib] : &s->xf[fi - s->n];
         const onode* j = &s->nd[ib];
         for (int ic = 0; ic < 8; ic++) {
             double xli[3] = { ((ic & 4) ? 0.5 : -0.5) * s->sides[3 * ib], ((ic & 2) ? 0.5 : -0.5) * s->sides[3 * ib + 1],
@@ -683,10 +689,10 @@ static double ground_contact_energy(const orc_scene* s) {
             double d = 0;
             for (int a = 0; a < 3; a++) {
                 double xw = j->E_wi[a][0] * xli[0] + j->E_wi[a][1] * xli[1] + j->E_wi[a][2] * xli[2] + j->E_wi[a][3];
-                d += s->gf[ib].E[a][2] * (xw - s->gf[ib].E[a][3]);
+                d += gf->E[a][2] * (xw - gf->E[a][3]);
             }
             if (d > 0) continue;
-            v += 0.5 * s->gf[ib].kn * (d * d);
+            v += 0.5 * gf->kn * (d * d);
         }
     }
     return v;
@@ -701,6 +707,7 @@ void orc_set_ground_contact(orc_scene* s, const int* flags, const double* sides,
 void orc_set_ground_contact_body(orc_scene* s, const int* flags, const double* sides, const double* E16, int E_per_body,
                                  const double* kn, const double* kt, const double* mu, const double* kd, int k_per_body) {
     free(s->contact); free(s->sides); free(s->gf);
+    free(s->xf_body); free(s->xf); s->xf_body = NULL; s->xf = NULL; s->nxf = 0;
     s->contact = (int*)malloc(sizeof(int) * (size_t)s->n);
     s->sides = (double*)malloc(sizeof(double) * 3 * (size_t)s->n);
     s->gf = (struct ogf*)calloc((size_t)s->n, sizeof(struct ogf));
@@ -712,6 +719,20 @@ void orc_set_ground_contact_body(orc_scene* s, const int* flags, const double* s
         s->gf[i].kn = kn[k]; s->gf[i].kt = kt[k]; s->gf[i].mu = mu[k]; s->gf[i].kd = kd[k];
     }
     orc_reset(s);
+}
+
+/* One more ForceGroundCuboid object on a body that orc_set_ground_contact[_body] has flagged (its sides are taken from there): the
+ * reference appends force objects to a list (scenesRedMax.m:303-309 `scene.forces{end+1} = ...`), any number per body. */
+int orc_add_ground_contact(orc_scene* s, int body, const double* E16, double kn, double kt, double mu, double kd) {
+    if (!s->contact || body < 0 || body >= s->n || !s->contact[body]) return -1;
+    s->xf_body = (int*)realloc(s->xf_body, sizeof(int) * (size_t)(s->nxf + 1));
+    s->xf = (struct ogf*)realloc(s->xf, sizeof(struct ogf) * (size_t)(s->nxf + 1));
+    s->xf_body[s->nxf] = body;
+    cm16_to_m4(s->xf[s->nxf].E, E16);
+    s->xf[s->nxf].kn = kn; s->xf[s->nxf].kt = kt; s->xf[s->nxf].mu = mu; s->xf[s->nxf].kd = kd;
+    s->nxf++;
+    orc_reset(s);
+    return 0;
 }
 
 /* Joint.computeForce (Joint.m:437-487).  Kr, Dr are diagonal for 1-DOF joints. */

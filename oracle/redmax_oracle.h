@@ -79,6 +79,8 @@ void orc_set_ground_contact(orc_scene* s, const int* flags, const double* sides,
  * E16 [n][16] if E_per_body else [16]; kn..kd [n] if k_per_body else [1] */
 void orc_set_ground_contact_body(orc_scene* s, const int* flags, const double* sides, const double* E16, int E_per_body,
                                  const double* kn, const double* kt, const double* mu, const double* kd, int k_per_body);
+/* a further ForceGroundCuboid on an already flagged body (the reference's force list has no one-per-body rule); -1: body not flagged */
+int orc_add_ground_contact(orc_scene* s, int body, const double* E16, double kn, double kt, double mu, double kd);
 
 /* Joint.computeJacobian at the current state; any pointer may be NULL.
  * J,Jdot: nm x nr column-major; dJdq,dJdotdq: nm x nr x nr (MATLAB layout). */

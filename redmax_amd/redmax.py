@@ -317,8 +317,6 @@ class Scene:
                 raise NotImplementedError("only ForceNull and ForceGroundCuboid are in scope (SURVEY.md §2 row 10)")
             if not isinstance(f.cuboid, BodyCuboid) or f.cuboid not in self.bodies:
                 raise ValueError("ForceGroundCuboid needs a BodyCuboid of this scene")
-        if len({id(f.cuboid) for f in self.forces}) != len(self.forces):
-            raise NotImplementedError("one ForceGroundCuboid per body (several grounds under one body are outside the HIP path)")
         nr = 0
         nm = 0
         for j in reversed(joints):                   # leaf-to-root numbering
@@ -395,21 +393,64 @@ class Scene:
             "qRestR": np.concatenate([np.zeros(0)] + [getattr(j, "qRestAll", np.array(j.q[:j.ndof], dtype=np.float64)) for j in reversed(joints)]),
         }
         if self.forces:
+            # The reference keeps its force objects in a list (Force.m:26-56, Scene.m:87-89): a body may carry several
+            # ForceGroundCuboid (a floor and a wall).  The C ABI takes ONE per listing entry (rmx_ground_contact: flags[n], E_body[n] ...),
+            # so the second, third ... force of a body is listed as a fixed, massless child of that body's joint with the body's own
+            # transform and sides: the same corners moving with the same twist, hence the same wrench, K and D blocks pulled through the
+            # same Jacobian rows - as the multi-DOF joints are chains with massless links.  No DOF is added: q, qdot, idxR are unchanged.
+            first = {}
+            for f in self.forces:
+                first.setdefault(id(f.cuboid), f)
+            extra = [f for f in self.forces if first[id(f.cuboid)] is not f]
+            body_joint = {id(j.body): i for i, j in enumerate(joints)}
+            lit = None
+            if extra:
+                lit = dict(d)                    # the literal listing (what the oracle restates: forces appended to the body's own list)
+                for key in ("parent", "type"):
+                    d[key] = np.concatenate([d[key], np.array([body_joint[id(f.cuboid)] if key == "parent" else 0 for f in extra], dtype=np.int32)])
+                d["axis"] = np.concatenate([d["axis"], np.tile(np.array([[0.0, 0.0, 1.0]]), (len(extra), 1))])
+                d["E0_pj"] = np.concatenate([d["E0_pj"], np.tile(self._cm(np.eye(4))[None, :], (len(extra), 1))])
+                d["E0_ji"] = np.concatenate([d["E0_ji"], np.stack([self._cm(f.cuboid.E0_ji) for f in extra])])
+                d["I_i"] = np.concatenate([d["I_i"], np.zeros((len(extra), 6))])
+                d["plane"] = np.concatenate([d["plane"], np.zeros((len(extra), 6))])
+                for key in ("q", "qdot", "qRest", "tau", "stiffness", "damping", "qLimK", "qLimD"):
+                    d[key] = np.concatenate([d[key], np.zeros(len(extra))])
+                d["qLimL"] = np.concatenate([d["qLimL"], np.full(len(extra), -np.inf)])
+                d["qLimU"] = np.concatenate([d["qLimU"], np.full(len(extra), np.inf)])
+                d["njoints"] = n + len(extra)
             f0 = self.forces[0]
-            touched = {id(f.cuboid) for f in self.forces}
-            d["contact"] = np.array([1 if id(j.body) in touched else 0 for j in joints], dtype=np.int32)
-            d["sides"] = np.ascontiguousarray(np.stack([getattr(j.body, "sides", np.zeros(3)) for j in joints]), dtype=np.float64)
+            flag = [1 if id(j.body) in first else 0 for j in joints]
+            sides = [getattr(j.body, "sides", np.zeros(3)) for j in joints]
+            fb = [first.get(id(j.body), f0) for j in joints]
+            d["contact"] = np.array(flag + [1] * len(extra), dtype=np.int32)
+            d["sides"] = np.ascontiguousarray(np.stack(sides + [f.cuboid.sides for f in extra]), dtype=np.float64)
             d["ground"] = {"E": f0.E.copy(), "kn": f0.kn, "kt": f0.kt, "mu": f0.mu, "kd": f0.kd}
             # every ForceGroundCuboid object holds its own E, kn, kt, mu, kd (ForceGroundCuboid.m:6-13): per body when they differ
+
+            def per_entry(fs):
+                return {"E": np.stack([np.asarray(f.E, dtype=np.float64) for f in fs]),
+                        "kn": np.array([f.kn for f in fs], dtype=np.float64), "kt": np.array([f.kt for f in fs], dtype=np.float64),
+                        "mu": np.array([f.mu for f in fs], dtype=np.float64), "kd": np.array([f.kd for f in fs], dtype=np.float64)}
             same = all(np.array_equal(f.E, f0.E) and (f.kn, f.kt, f.mu, f.kd) == (f0.kn, f0.kt, f0.mu, f0.kd) for f in self.forces)
             if not same:
-                of = {id(f.cuboid): f for f in self.forces}
-                fb = [of.get(id(j.body), f0) for j in joints]
-                d["ground_body"] = {"E": np.stack([np.asarray(f.E, dtype=np.float64) for f in fb]),
-                                    "kn": np.array([f.kn for f in fb], dtype=np.float64), "kt": np.array([f.kt for f in fb], dtype=np.float64),
-                                    "mu": np.array([f.mu for f in fb], dtype=np.float64), "kd": np.array([f.kd for f in fb], dtype=np.float64)}
+                d["ground_body"] = per_entry(fb + extra)
+            if lit is not None:
+                lit["contact"] = np.array(flag, dtype=np.int32)
+                lit["sides"] = np.ascontiguousarray(np.stack(sides), dtype=np.float64)
+                lit["ground"] = d["ground"]
+                if not same:
+                    lit["ground_body"] = per_entry(fb)
+                lit["extra_forces"] = [{"body": body_joint[id(f.cuboid)], "E": np.asarray(f.E, dtype=np.float64), "kn": f.kn, "kt": f.kt,
+                                        "mu": f.mu, "kd": f.kd} for f in extra]
+                self._desc_literal = lit
         self._desc = d
         return d
+
+    def desc_literal(self):
+        """The scene as the reference holds it - every force object in its body's own list (Force.m:26-56) - for a checker that
+        restates the reference literally (tests: the oracle).  Equal to desc() unless a body carries several ForceGroundCuboid."""
+        d = self.desc()
+        return getattr(self, "_desc_literal", None) or d
 
     # -- Scene.reset, Scene.m:122-131 (energies come from the device, see driver.py) --
     def reset(self):

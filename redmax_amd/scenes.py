@@ -305,6 +305,26 @@ def sceneChainGround(n=32, ground_z=-2.0, q0=0.0):
     return scene
 
 
+def sceneChainFloorAndWall(n=6, ground_z=-1.0, wall_x=None):
+    """Every body of the chain carries TWO ForceGroundCuboid objects - the floor of sceneChainGround and a wall, a plane whose normal is
+    the world x axis, softer and with less friction - which the reference allows: its forces are a list (Force.m:26-56, scenesRedMax.m:303
+    `scene.forces{end+1} = ...`), nothing ties a body to one.  wall_x: where the wall stands (default: under the chain's first link, so
+    that the root-side bodies start inside it)."""
+    scene = sceneChainGround(n, ground_z=ground_z)
+    scene.name = "%d-link chain over a floor and against a wall" % n
+    if wall_x is None:
+        wall_x = 4.0
+    wall = np.array([[0.0, 0.0, 1.0, wall_x], [0.0, 1.0, 0.0, 0.0], [-1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])      # Z axis of the frame = +x
+    for b in list(scene.bodies):
+        f = ForceGroundCuboid(b)
+        f.setTransform(wall)
+        f.setStiffness(4e4, 5e1)
+        f.setDamping(2e1)
+        f.setFriction(0.2)
+        scene.forces.append(f)
+    return scene
+
+
 def sceneChainTwoGrounds(n=8, ground_z=-1.0):
     """sceneChainGround with TWO kinds of ForceGroundCuboid objects, which the reference allows (every object holds its own E, kn, kt,
     mu, kd: ForceGroundCuboid.m:6-13): even bodies over the z-up floor at ground_z with scene 11's constants, odd bodies over a plane

@@ -477,3 +477,52 @@ def test_config5_flagged_rollouts_replay_on_the_oracle(oracle_lib):
         # rollout 11 when written; the rollouts that converge throughout to 1e-7)
         assert np.linalg.norm(qg[b] - qo) <= (1e-6 if st[b] & 2 else 1e-7) * np.linalg.norm(qo), b
     assert same_counts >= (len(pick) + 1) // 2, same_counts
+
+
+def test_floor_and_wall_on_every_body(oracle_lib):
+    """Several ForceGroundCuboid objects on one body (Force.m:26-56: the reference's forces are a list; refused up to round 4).  A 6-link
+    chain whose every body carries a floor and a wall: the host mirror lists each second force as a fixed, massless child of the body's
+    joint (one force per listing entry is what the C ABI takes), the ORACLE adds both objects to the same body literally
+    (Scene.desc_literal()).  g, H at states inside both planes, energies, BDF1 and BDF2 rollouts."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneChainFloorAndWall
+    sc = sceneChainFloorAndWall(6, ground_z=-1.0)
+    sc.init()
+    lit = sc.desc_literal()
+    assert sc.desc()["njoints"] == 12 and lit["njoints"] == 6
+    B, nr, h = 3, sc.nr, sc.h
+    rng = np.random.default_rng(12)
+    q0 = rng.uniform(0.05, 0.35, (B, nr))
+    qd0 = rng.uniform(-3, 3, (B, nr))
+    q1 = q0 + h * qd0 + 1e-4 * rng.standard_normal((B, nr))
+    sim = BatchSim(sc, batch=B)
+    assert sim.nr == nr
+    g, H = sim.eval_residual(q1, q0, q0 + h * qd0, h)
+    sim.set_state(q0, qd0)
+    T, V = sim.energy()
+    o_floor = oracle_lib.Oracle(dict(lit, extra_forces=None))
+    for b in range(B):
+        o = oracle_lib.Oracle(lit)
+        go, Ho = o.eval_residual(q1[b], q0[b], q0[b] + h * qd0[b], h)
+        assert _rel(g[b], go) <= 1e-10 and _rel(H[b], Ho) <= 1e-10, b
+        o.set_state(q0[b], qd0[b])
+        To, Vo = o.energy()
+        assert abs(T[b] - To) <= 1e-10 * max(abs(To), 1) and abs(V[b] - Vo) <= 1e-10 * max(abs(Vo), 1)
+        o_floor.set_state(q0[b], qd0[b])
+        assert Vo > o_floor.energy()[1] > 0             # the wall is in play, and so is the floor
+    for integ in ("bdf1", "bdf2"):
+        sim.set_state(q0, qd0)
+        out = (sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2)(40, h=h, stats=True)
+        qg, _ = sim.get_state()
+        for b in range(B):
+            o = oracle_lib.Oracle(lit)
+            o.set_state(q0[b], qd0[b])
+            st = (o.step_bdf1 if integ == "bdf1" else o.step_bdf2)(h, 40)
+            qo, _ = o.get_state()
+            if st.diverged or st.not_converged:
+                assert out["status"][b] & 3
+                continue
+            assert out["status"][b] & 7 == 0, (integ, b)
+            assert out["newton_iters"][b] == st.newton_iters, (integ, b, out["newton_iters"][b], st.newton_iters)
+            assert _rel(qg[b], qo) <= 1e-7, (integ, b, _rel(qg[b], qo))
+    sim.close()

@@ -158,8 +158,7 @@ def test_gateway_reports_errors_the_matlab_way(gw):
 
 
 def test_create_without_a_device_fails_loudly(gw):
-    import torch
-    if torch.cuda.is_available():
+    if gw.call(1, "devices") > 0:          # (what the library itself sees: torch may not see a device the HIP runtime does)
         pytest.skip("a HIP device is present")
     from redmax_amd.scenes import scenesRedMax
     sc = scenesRedMax(0)
@@ -207,13 +206,25 @@ def test_command_table_matches_the_matlab_callers():
     assert {"step_async", "sync", "timing"} <= hipsim          # the multi-device / asynchronous commands (ABI 107)
 
 
-def test_flattenScene_refuses_two_force_objects_on_one_body():
-    """a floor and a wall on one cuboid must raise in the MATLAB path as it does in redmax.py (the device tables
-    hold one ForceGroundCuboid per body) - the .m file cannot be executed here, so the guard is checked to sit before the writes."""
+def test_flattenScene_lists_further_force_objects_as_fixed_massless_children():
+    """A floor and a wall on one cuboid (the reference's forces are a list, Force.m:26-56): up to round 4 flattenScene.m raised, as
+    redmax.py did; now both list the second force as a fixed, massless child of the body's joint (one force object per listing entry
+    is what the library takes).  The .m file cannot be executed here: the block is checked to be there, to add a JointFixed entry
+    with zero inertia and the body's own transform, and to sit BEFORE the writes of the force's own fields."""
     m = open(os.path.join(ROOT, "matlab", "+redmax", "flattenScene.m")).read()
     guard = m.index("if desc.contact(hit)")
-    assert "error('redmax:hip','flattenScene: one ForceGroundCuboid per body" in m[guard:guard + 400]
-    assert guard < m.index("desc.contact(hit) = 1;")
+    block = m[guard:m.index("desc.contact(hit) = 1;")]
+    assert "error(" not in block
+    for line in ("desc.njoints = m;", "desc.parent(m) = hit - 1;", "desc.type(m) = 0;", "desc.E0_ji(:,:,m) = f.cuboid.E0_ji;",
+                 "desc.I_i(:,m) = zeros(6,1);", "hit = m;"):
+        assert line in block, line
+    # the Python mirror does the same, and names the literal listing for checkers
+    from redmax_amd.scenes import sceneChainFloorAndWall
+    sc = sceneChainFloorAndWall(3)
+    sc.init()
+    d = sc.desc()
+    assert d["njoints"] == 6 and list(d["type"][3:]) == [0, 0, 0] and list(d["parent"][3:]) == [0, 1, 2] and not d["I_i"][3:].any()
+    assert sc.desc_literal()["njoints"] == 3 and len(sc.desc_literal()["extra_forces"]) == 3
 
 
 @pytest.mark.gpu

@@ -142,3 +142,42 @@ def test_per_body_ground_frames_equal_the_shared_frame_when_they_are_the_same(or
         o = oracle_lib.Oracle(dd)
         out.append(o.eval_bdf1(q + sc.h * qd, q, qd, sc.h))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_several_ground_forces_on_one_body(oracle_lib):
+    """The reference keeps its force objects in a list (Force.m:26-56): a body may carry a floor AND a wall.  The oracle restates that
+    literally (orc_add_ground_contact: both objects' fm, Km, Dm into the same body rows); the product's host mirror lists the second
+    force as a fixed, massless child of the body's joint (Scene.desc(), what the C ABI takes: one force per listing entry).  Here, on the
+    CPU: (i) the two descriptions give the same g, H, energies on the oracle (the lowering is exact), (ii) the literal H is the
+    derivative of the literal g (central differences) at a state where floor and wall are both penetrated."""
+    from redmax_amd.scenes import sceneChainFloorAndWall
+    sc = sceneChainFloorAndWall(4, ground_z=-1.0)
+    sc.init()
+    d, lit = sc.desc(), sc.desc_literal()
+    assert d["njoints"] == 8 and lit["njoints"] == 4 and len(lit["extra_forces"]) == 4
+    o_lit, o_low = oracle_lib.Oracle(lit), oracle_lib.Oracle(d)
+    assert o_lit.nr == o_low.nr == 4
+    rng = np.random.default_rng(3)
+    h = sc.h
+    q = rng.uniform(0.1, 0.4, 4)
+    qd = rng.uniform(-3, 3, 4)
+    q1 = q + h * qd
+    for o in (o_lit, o_low):
+        o.set_state(q, qd)
+    Vl, Vw = o_lit.energy()[1], o_low.energy()[1]
+    o_floor = oracle_lib.Oracle(dict(lit, extra_forces=None))
+    o_floor.set_state(q, qd)
+    assert Vl > o_floor.energy()[1] > 0                 # both the floor and the wall are in play
+    assert abs(Vl - Vw) <= 1e-12 * abs(Vl)
+    g, H = o_lit.eval_bdf1(q1, q, qd, h)
+    g2, H2 = o_low.eval_bdf1(q1, q, qd, h)
+    assert _err(g2, g) < 1e-12 and _err(H2, H) < 1e-12
+    H_ = np.zeros_like(H)
+    for i in range(4):
+        gp = []
+        for sgn in (+1, -1):
+            x = q1.copy()
+            x[i] += sgn * 1e-7
+            gp.append(o_lit.eval_bdf1(x, q, qd, h, want_H=False))
+        H_[:, i] = (gp[0] - gp[1]) / 2e-7
+    assert _err(H_, H) < 1e-6
