@@ -435,7 +435,7 @@ def test_config5_flagged_rollouts_replay_on_the_oracle(oracle_lib):
     """BASELINE.json configs[4] (32-link chain over the frictional ground, BDF2, h = 5e-4, 100 steps): the rollouts whose Newton creeps
     through its 320 iterations on one step (status MAXITER; the default launch parks them and finishes them in cooperative groups of
     wavefronts, rmx_ct32.h) against the literal oracle: the Newton iteration and line-search halving counts (equal on most, within 1 % on all), the same
-    'did not converge' verdict, q to 1e-6 (1e-7 on the rollouts that converge on every step).  (tests/config5_check.py was the manual form of this.)"""
+    'did not converge' verdict, q to 1e-6 (1e-7 on the rollouts that converge on every step).  (the manual script tests/config5_check.py of rounds 2-4, collected.)"""
     from concurrent.futures import ThreadPoolExecutor
     from redmax_amd import BatchSim, sceneChainGround, syntheticStates
     B, K = 256, 100
@@ -526,3 +526,32 @@ def test_floor_and_wall_on_every_body(oracle_lib):
             assert out["newton_iters"][b] == st.newton_iters, (integ, b, out["newton_iters"][b], st.newton_iters)
             assert _rel(qg[b], qo) <= 1e-7, (integ, b, _rel(qg[b], qo))
     sim.close()
+
+
+def test_one_launch_cooperative_path_at_odd_sizes(monkeypatch):
+    """The default launch of a chain with ground contact is ONE kernel in which the rollouts and, dispatched behind them, the cooperative
+    groups run side by side (rmx_kernels.hip k_ground32).  Sizes it must survive: more rollouts than SIMDs (1500 on 1024), a handful (37:
+    fewer rollouts than a group has members to spare), and two shards of 600 on ONE device - two such launches competing for the SIMDs.
+    Every case against one wavefront per rollout: states bit for bit, no group gave up (status 512)."""
+    from redmax_amd import BatchSim, GroupSim, sceneChainGround, syntheticStates
+    sc = sceneChainGround(32)
+    sc.init()
+
+    def run(B, park, group=False):
+        monkeypatch.setenv("RMX_PARK_HALVINGS", park)
+        q, qd = syntheticStates(sc.nr, B, sq=5e-4, sv=0.1)
+        q[0], qd[0] = sc.getQ()
+        sim = GroupSim(sc, B, devices=(0, 0)) if group else BatchSim(sc, batch=B)
+        sim.set_state(q, qd)
+        out = sim.step(100, integrator=2, h=sc.h) if group else sim.step_bdf2(100, h=sc.h, stats=True)
+        qf, qdf = sim.get_state()
+        sim.close()
+        return qf, qdf, out
+    for B in (1500, 37):
+        ref = run(B, "0")
+        got = run(B, "24")
+        assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]), B
+        assert np.array_equal(ref[2]["newton_iters"], got[2]["newton_iters"]) and (got[2]["status"] & 512).max() == 0, B
+    ref = run(1200, "24")
+    got = run(1200, "24", group=True)
+    assert np.array_equal(ref[0], got[0]) and (got[2]["status"] & 512).max() == 0
