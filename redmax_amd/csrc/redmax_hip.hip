@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,7 @@ static int fail(int code, const std::string& msg) {
 
 extern "C" const char* rmx_last_error(void) { return g_err.c_str(); }
 static void hist_free(rmx_batch* b);
+static hipError_t set_started(rmx_batch* b, int v);
 
 // An error already pending in this thread's HIP state when an entry point is about to launch.  If this batch still has an
 // asynchronous launch of its own that nobody waited for (rmx_step_bdf1_async without rmx_sync), the error is reported as that
@@ -641,7 +643,7 @@ static int copy_state(rmx_batch* b, const double* q, const double* qd, hipMemcpy
     if (set) {
         if (q) HIPCHK(hipMemcpyAsync(b->q, q, nb, kind, b->stream));
         if (qd) HIPCHK(hipMemcpyAsync(b->qd, qd, nb, kind, b->stream));
-        HIPCHK(hipMemsetAsync(b->started, 0, sizeof(int), b->stream));   // a new state restarts BDF2 with SDIRK2
+        HIPCHK(set_started(b, 0));   // a new state restarts BDF2 with SDIRK2
         if (b->chart && q) {   // the new coordinates are read in CHART_XYZ (rmx_set_charts afterwards says otherwise)
             const std::vector<int> c7((size_t)b->B * b->m->dm.nsph, 7);
             HIPCHK(hipMemcpyAsync(b->chart, c7.data(), c7.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
@@ -915,7 +917,7 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     // BDF2 keeps (q, qdot) of step k-1 in qp/qdp.  BDF1 steps do not maintain them (and, with JointSpherical, may leave q in
     // another Euler chart than qp), so a BDF1 call invalidates the multistep history: the next rmx_step_bdf2 restarts with
     // SDIRK2, as a fresh driverRedMaxBDF2 run from that state would (driverRedMaxBDF2.m:64-88).
-    HIPCHK(hipMemsetAsync(b->started, integ == INTEG_BDF2 ? 1 : 0, sizeof(int), b->stream));   // BDF2: any non-zero value
+    HIPCHK(set_started(b, integ == INTEG_BDF2 ? 1 : 0));   // BDF2: any non-zero value
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     return RMX_OK;
@@ -1007,6 +1009,14 @@ static hipError_t stats_copy_out(rmx_batch* b, const rmx_stats* st) {
     if (e == hipSuccess && st->status) e = hipMemcpyAsync(st->status, b->status, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
     return e;
 }
+// the device flag that tells BDF2 whether (q, qdot) of step k-1 are in place: written only when its value changes (one fill dispatch
+// less on the stream of every step call: ~5 us of a 0.8 ms launch at the driver's --steps 20)
+static hipError_t set_started(rmx_batch* b, const int v) {
+    if (b->started_host == v) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(b->started, v, sizeof(int), b->stream);
+    b->started_host = e == hipSuccess ? v : -1;
+    return e;
+}
 static void take_event_time(rmx_batch* b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
@@ -1091,7 +1101,7 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
     DISPATCH_NP(m->NP, launch_euler, m, b, h, a);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b->started, 0, sizeof(int), b->stream);
+    if (e == hipSuccess) e = set_started(b, 0);
     if (e == hipSuccess && hT) {
         e = hipMemcpyAsync(hT, dT, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(hV, dV, nh * sizeof(double), hipMemcpyDeviceToHost, b->stream);
@@ -1174,7 +1184,7 @@ static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rm
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
         // after a BDF2 rollout (q, qdot) of step k-1 are in place: rmx_step_bdf2 may continue it; a BDF1 rollout invalidates them
-        if (e == hipSuccess) e = hipMemsetAsync(b->started, integ == INTEG_BDF2 ? 1 : 0, sizeof(int), b->stream);
+        if (e == hipSuccess) e = set_started(b, integ == INTEG_BDF2 ? 1 : 0);
         if (e == hipSuccess) e = hipMemcpyAsync(P, a.P, sizes[4], hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(dPdp, a.dPdp, sizes[5], hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess && stats) {
@@ -1270,7 +1280,15 @@ extern "C" int rmx_step_ticks(rmx_batch* b, unsigned long long* ticks) {
 extern "C" int rmx_sync(rmx_batch* b) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     HIPCHK(hipSetDevice(b->m->device));
-    const hipError_t es = hipStreamSynchronize(b->stream);
+    // a short launch is waited for by polling (hipStreamSynchronize's wake-up costs ~10 us of a 0.8 ms launch); after 2 ms the host
+    // thread blocks as before
+    hipError_t es = hipErrorNotReady;
+    for (const auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2);) {
+        es = hipStreamQuery(b->stream);
+        if (es != hipErrorNotReady) break;
+    }
+    if (es == hipErrorNotReady) es = hipStreamSynchronize(b->stream);
+    else (void)hipGetLastError();      // (hipStreamQuery leaves hipErrorNotReady as the thread's last error while it polls)
     b->async_pending = false;
     if (es != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_sync: the asynchronous launch failed: ") + hipGetErrorString(es));
     take_event_time(b);

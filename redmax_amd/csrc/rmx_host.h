@@ -87,6 +87,7 @@ struct rmx_batch {
     int* chart = nullptr;           // [B][nsph] current Euler chart of every spherical joint (JointSpherical.chart), 1..12
     int *it = nullptr, *ls = nullptr, *status = nullptr;
     int* resume = nullptr;          // [B] see StepArgs.resume
+    int started_host = -1;          // what the device flag `started` holds (-1: not known): a step call rewrites it only when it changes
     int* park = nullptr;            // see StepArgs.park / xch (allocated for models whose steps can park: rmx_model::coop)
     unsigned* xch = nullptr;
     unsigned long long* xrec = nullptr;
