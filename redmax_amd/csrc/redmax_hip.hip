@@ -400,6 +400,9 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
         m->dm.gconst = (const double*)m->dgconst;
         const char* thr = getenv("RMX_GCONST_MIN");
         m->gconst_min_batch = thr ? atoi(thr) : (m->n_simd > 0 ? m->n_simd / 2 + 1 : 513);
+        // ... and batches of at most one rollout per two SIMDs the two-wave kernels (rmx_kernels.hip RMX_PART 5)
+        const char* w2 = getenv("RMX_W2_MAX");
+        m->w2_max_batch = w2 ? atoi(w2) : (m->n_simd > 0 ? m->n_simd / 2 : 512);
     }
     *out = m;
     return RMX_OK;

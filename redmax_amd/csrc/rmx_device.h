@@ -25,6 +25,22 @@
 #ifndef RMX_SYNC
 #define RMX_SYNC() __syncthreads()
 #endif
+// RMX_W2 (a translation unit compiled with it, rmx_kernels.hip RMX_PART 5): workgroups of TWO wavefronts per 64-node tree.  Wave 0 is
+// the rollout; wave 1 joins it for the Hessian tiles (its column half) and for the block-column elimination (its share of the later
+// column blocks of every phase) and waits at a workgroup barrier otherwise.  RMX_SYNC() is wave-local ordering in that unit (the
+// front, the pivoting fallback and everything else belong to wave 0 alone); RMX_WG_BAR() is the barrier both waves meet at.
+#ifndef RMX_W2
+#define RMX_W2 0
+#endif
+#define RMX_WG_BAR() __syncthreads()
+#if RMX_W2
+// __syncthreads() without the s_barrier: LDS traffic of ONE wavefront is ordered by the wait alone
+__device__ __forceinline__ void rmx_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#endif
 // RMX_GLOBAL_CONSTS (a translation unit compiled with it, rmx_kernels.hip RMX_PART 3): the per-node constants are NOT staged in LDS
 // but read from a table in global memory (DevModel::gconst, same [row][node] layout, L2-resident and shared by the whole batch).
 // A 64-lane tree needs 33.8 KB of scratch (H for the block-column solve) plus 34.8 KB of constants per wavefront: two wavefronts
@@ -1854,6 +1870,23 @@ __device__ __forceinline__ void hess64_tiles(const int lane, const double* __res
             }
 }
 
+// RMX_W2: the command word of a two-wave workgroup (1: a Hessian stage and a guarded solve follow, 0: the rollout is over)
+__device__ __forceinline__ volatile int* w2_cmd() {
+    __shared__ int cmd[2];
+    return cmd;
+}
+// ... and one wave's column half of H (hess64_tiles<NP, W>) into the row-major matrix
+template <int W>
+__device__ __forceinline__ void w2_store_half(double* __restrict__ sAcc, const int lane, const double (&hv)[4][2][4]) {
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sAcc[(16 * mb + 4 * r + g) * H64_STRIDE + 32 * nb + 2 * j + W] = hv[mb][nb][r];
+}
+
 // Hessian row of this node: Hrow[i] = H(row of this node, column of node i); rows/columns of idle node slots are the identity.
 // Returns H(lane,lane).  ZERO_IDLE = false (n <= 32 MFMA path only): lanes 32..63 are left with mirrored rows instead of zeros.
 // Column I (and on) of H for trees of up to 16 nodes, see eval_hess: H(a, i) = [i strict descendant of a] s_a . cu_i +
@@ -2312,8 +2345,20 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             for (int c = 6; c < 18; ++c) o[(H64_R_CL + c - 6) * ST] = cv[c];
             o[H64_R_HD * ST] = Hdiag;
         }
-        RMX_SYNC();
         const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;
+        if constexpr (RMX_W2 && !ZERO_IDLE) {
+            // two waves (w2_helper is the other one): this wave takes the even columns, the helper the odd ones
+            if (lane == 0) *w2_cmd() = 1;
+            RMX_WG_BAR();
+            double h0[4][2][4];
+            hess64_tiles<NP, 0>(lane, sOp, cRel, h0);
+            RMX_WG_BAR();           // both waves are done with the operands: the same LDS now takes H
+            w2_store_half<0>(sAcc, lane, h0);
+            sAcc[lane * H64_STRIDE + 64] = -g_stage;
+            RMX_WG_BAR();
+            return Hdiag;
+        }
+        RMX_SYNC();
         double h0[4][2][4], h1[4][2][4];
         hess64_tiles<NP, 0>(lane, sOp, cRel, h0);
         __builtin_amdgcn_sched_barrier(0);      // one half's accumulators at a time
@@ -3051,8 +3096,9 @@ template <int P>
 __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&b)[4], GrowGuard (&gm)[4], double (&rown)[4],
                                            PivGuard& pg, const int jv) {
     typedef double v2d __attribute__((ext_vector_type(2)));
-    constexpr int CW = 4;                      // columns of a later block per DPP row
+    constexpr int CW = RMX_W2 ? 2 : 4;         // columns of a later block per DPP row (RMX_W2: the 8 DPP rows of two waves)
     const int r4 = lane >> 4, j = lane & 15;
+    const int r8 = RMX_W2 ? 4 * (int)(threadIdx.x >> 6) + r4 : r4;
     double S[4][16];
 #pragma unroll
     for (int s = P; s < 4; ++s) {
@@ -3071,7 +3117,7 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
     for (int B = P + 1; B < 4; ++B) {
         __builtin_amdgcn_sched_barrier(0);      // one block in registers at a time (hoisted loads of all blocks spill)
         double X[4][CW];
-        const int col = 16 * B + CW * r4;
+        const int col = 16 * B + CW * r8;
 #pragma unroll
         for (int s = P; s < 4; ++s) {
             const v2d* rd = reinterpret_cast<const v2d*>(sH + (16 * s + j) * H64_STRIDE + col);
@@ -3090,9 +3136,10 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
             for (int c = 0; c < CW / 2; ++c) w[c] = v2d{X[s][2 * c], X[s][2 * c + 1]};
         }
     }
-    RMX_SYNC();                                // the next phase reads what all the DPP rows have written
+    if constexpr (RMX_W2) RMX_WG_BAR();
+    else RMX_SYNC();                           // the next phase reads what all the DPP rows have written
     // the finished rows of this phase: their part of U, for the back substitution
-    if (lane < 16) {
+    if (RMX_W2 ? threadIdx.x < 16 : lane < 16) {
         v2d* w = reinterpret_cast<v2d*>(sH + (16 * P + j) * H64_STRIDE + 16 * P);
 #pragma unroll
         for (int c = 0; c < 8; ++c) w[c] = v2d{S[P][2 * c], S[P][2 * c + 1]};
@@ -3139,7 +3186,8 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     lu64_phase<1>(sH, lane, b, gm, rown, pg, jv);
     lu64_phase<2>(sH, lane, b, gm, rown, pg, jv);
     lu64_phase<3>(sH, lane, b, gm, rown, pg, jv);
-    RMX_SYNC();                 // (the finished rows of phase 3)
+    if constexpr (RMX_W2) RMX_WG_BAR();
+    else RMX_SYNC();            // (the finished rows of phase 3)
     // back substitution, block column by block column from the right
     double x[4];
 #pragma unroll
@@ -3175,11 +3223,31 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     for (int s = 0; s < 4; ++s) bad = bad || gm[s].bad(lim[s]);
     ok = !__any(bad) && pg.ok();
     const double dx = r4 == 0 ? x[0] : (r4 == 1 ? x[1] : (r4 == 2 ? x[2] : x[3]));
-    RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
+    if constexpr (RMX_W2) {
+        RMX_WG_BAR();           // both waves have read their last of H
+        if (threadIdx.x >= 64) return dx;
+    } else RMX_SYNC();          // sAcc goes back to the front, whose subtree scan relies on a zero row n
     if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
     RMX_SYNC();
     return dx;
 }
+
+#if RMX_W2
+// One copy of the solve for both waves of a workgroup (out of line: the two run it in step, on the same instruction-cache lines).
+struct W2Lu {
+    double dx;
+    int ok;
+};
+#ifndef RMX_W2_LU_INLINE
+__attribute__((noinline))
+#endif
+__device__ W2Lu w2_lu_call() {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    bool ok;
+    const double dx = lu_solve_neg_diag64_staged(64, (int)(threadIdx.x & 63u), smem, ok);
+    return W2Lu{dx, ok ? 1 : 0};
+}
+#endif
 
 // the row-per-lane form of the interface (callers whose Hessian stage leaves H in registers)
 __device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lane, double* sAcc, const double (&Hrow)[64], const double g,
@@ -3694,8 +3762,14 @@ __device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o
             bool lu_ok;
             if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
             else if constexpr (NP == 64 && LU_SPLIT64) {
+#if RMX_W2
+                const W2Lu r = w2_lu_call();
+                dx = r.dx;
+                lu_ok = r.ok != 0;
+#else
                 if constexpr (HESS_MFMA64) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
                 else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
+#endif
             }
             else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
             if (lu_ok) {

@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(64) k_stage_consts(const DevModel M, double* _
 // filled sizes go (the 64-joint tree of BASELINE.json configs[2]).
 constexpr int TAG_FULLN = 4;
 constexpr int TAG_COOP = 8;      // k_step_bdf1/2<32, true, false, false, TAG_COOP>: the cooperative launch (RMX_PART 4)
+constexpr int TAG_W2 = 16;       // k_step_bdf1/2<64, false, false, false, TAG_W2>: two wavefronts per 64-node tree (RMX_PART 5, RMX_W2)
 template <int NP, bool FULLCHAIN, int TAG = 0>
 __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
     DevModel M = Min;
@@ -96,14 +97,41 @@ __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
         M.n = NP;
         M.is_chain = 1;
     }
-    if constexpr (TAG >= TAG_FULLN && TAG < TAG_COOP) M.n = NP;
+    if constexpr ((TAG >= TAG_FULLN && TAG < TAG_COOP) || TAG == TAG_W2) M.n = NP;
     return M;
+}
+
+// RMX_W2: wave 1 of a two-wave workgroup.  It serves wave 0's guarded Newton iterations - the odd columns of the Hessian tiles, its
+// share of the block-column elimination - and sleeps at the workgroup barrier in between (eval_hess and lu_solve_neg_diag64_staged
+// hold wave 0's side of the same barriers).
+template <int NP>
+__device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict__ sAcc, const int lane) {
+    if constexpr (NP == 64 && RMX_W2) {
+        constexpr int CS = cstride(NP);
+        const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;
+        for (;;) {
+            RMX_WG_BAR();
+            if (*w2_cmd() == 0) break;
+            double h1[4][2][4];
+            hess64_tiles<NP, 1>(lane, sAcc, cRel, h1);
+            RMX_WG_BAR();
+            w2_store_half<1>(sAcc, lane, h1);
+            RMX_WG_BAR();
+#if RMX_W2
+            (void)w2_lu_call();
+#endif
+        }
+    }
+}
+__device__ __forceinline__ void w2_release(const int lane) {
+    if (lane == 0) *w2_cmd() = 0;
+    RMX_WG_BAR();
 }
 
 // TAG: keeps the kernel names of a translation unit compiled with other macros (RMX_GLOBAL_CONSTS) distinct (0, 3); TAG_FULLN, TAG_FULLN + 1:
 // the n == NP instantiations of the two
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
-__global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
+__global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     constexpr bool COOP = TAG == TAG_COOP;           // the cooperative launch (rmx_device.h CoopCtx): COOP_G workgroups per parked rollout
     static_assert(!COOP || (CT && !LEAN), "the cooperative launch belongs to the kernels with the contact terms");
@@ -127,6 +155,12 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevO
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x;
+    if constexpr (TAG == TAG_W2) {
+        if (threadIdx.x >= 64) {
+            w2_helper<NP>(M, sAcc, lane - 64);
+            return;
+        }
+    }
     int* const chart0 = (CT && M.nsph) ? a.chart : nullptr;
     if constexpr (CT) con_setup<NP>(M, sCol);
     const bool writer = !COOP || cx.member == 0;     // (members 1.. of a cooperative group compute, member 0 also stores)
@@ -214,11 +248,12 @@ __global__ void __launch_bounds__(64) k_step_bdf1(const DevModel Min, const DevO
     }
     if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
     }
+    if constexpr (TAG == TAG_W2) w2_release(lane);
 }
 
 // simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.  CT / LEAN: see k_step_bdf1.
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
-__global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
+__global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     constexpr bool COOP = TAG == TAG_COOP;           // see k_step_bdf1
     static_assert(!COOP || (CT && !LEAN), "the cooperative launch belongs to the kernels with the contact terms");
@@ -242,6 +277,12 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevO
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x;
+    if constexpr (TAG == TAG_W2) {
+        if (threadIdx.x >= 64) {
+            w2_helper<NP>(M, sAcc, lane - 64);
+            return;
+        }
+    }
     int* const chart0 = (CT && M.nsph) ? a.chart : nullptr;
     if constexpr (CT) con_setup<NP>(M, sCol);
     const bool writer = !COOP || cx.member == 0;
@@ -364,6 +405,7 @@ __global__ void __launch_bounds__(64) k_step_bdf2(const DevModel Min, const DevO
     }
     if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
     }
+    if constexpr (TAG == TAG_W2) w2_release(lane);
 }
 
 // euler (matlab-simple/testRedMax.m:67-109), BASELINE.json configs[0]: linearly-implicit Euler,
@@ -1213,6 +1255,17 @@ void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, cons
     if (a.park && o.parkHalv > 0) RMX_LAUNCH((k_step_pair<true>), dim3(a.ngroups * COOP_G), dim3(64), m->smem_bytes, b->stream, m->dm, o, a, integ);
 }
 
+#elif RMX_PART == 5      // 64-node trees, two wavefronts per rollout (RMX_W2): batches of up to one rollout per two SIMDs
+#if RMX_NP != 64 || !RMX_W2
+#error "RMX_PART 5 is compiled for RMX_NP = 64 with -DRMX_W2=1 and a wave-local RMX_SYNC()"
+#endif
+
+void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(128);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+}
+
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
 
 void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
@@ -1285,6 +1338,8 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     // instead of 68.6 KB: four wavefronts per CU instead of two).  Up to two per CU the LDS-resident constants are faster (-7 %).
     if (m->dm.gconst && m->gconst_min_batch > 0 && b->B >= m->gconst_min_batch) return launch_step_gconst_64(m, b, integ, o, a);
 #if !defined(RMX_NO_FULLCHAIN)
+    // a full tree in a batch of at most one rollout per two SIMDs: a second wavefront per rollout for the Hessian and the solve
+    if (m->dm.n == RMX_NP && m->w2_max_batch > 0 && b->B <= m->w2_max_batch) return launch_step_w2_64(m, b, integ, o, a);
     if (m->dm.n == RMX_NP) return launch_step_fulln_64(m, b, integ, o, a);
 #endif
 #endif

@@ -198,6 +198,47 @@ def test_tree64_global_constants_kernels(oracle_lib, monkeypatch):
         assert _rel(qb[b], qo) <= 1e-8 and int(ob["newton_iters"][b]) == st.newton_iters
 
 
+def test_tree64_two_wave_kernels(monkeypatch):
+    """Batches of at most one rollout per two SIMDs give a full 64-node tree TWO wavefronts (rmx_kernels.hip RMX_PART 5): the second
+    one takes the odd columns of the Hessian tiles and its share of the later column blocks in every phase of the block-column
+    elimination.  Every matrix entry sees the same operations on the same values in the same order as in the one-wave kernels:
+    bit-identical states, iteration counts and status words (RMX_W2_MAX moves the threshold, read at model creation) - BDF1 and BDF2,
+    the guarded solve, pivoting throughout (lu_mode 1: wave 0 alone, the helper released at the end), history on, and states wild
+    enough for line searches and failed steps."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneTree
+    sc = sceneTree(64)
+    sc.init()
+    B, K = 12, 12
+    q, qd = _tree_states(sc, B)
+    rng = np.random.default_rng(7)
+    wild_q = q + rng.uniform(-1.5, 1.5, q.shape)
+    wild_qd = rng.uniform(-40.0, 40.0, qd.shape)
+    for integ in ("bdf1", "bdf2"):
+        for lu_mode, (qq, qqd), tol in ((0, (q, qd), 1e-9), (1, (q, qd), 1e-9), (0, (wild_q, wild_qd), 1e-6)):
+            res = []
+            for w2 in ("0", "100000"):       # never / always
+                monkeypatch.setenv("RMX_W2_MAX", w2)
+                sim = BatchSim(sc, batch=B)
+                sim.opts.lu_mode = lu_mode
+                sim.opts.tol = tol
+                sim.set_state(qq, qqd)
+                step = sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2
+                step(2, h=1e-2)                                          # (BDF2: the second call runs on history)
+                out = step(K, h=1e-2, stats=True, history=True)
+                res.append((sim.get_state(), out))
+                sim.close()
+            ((qa, qda), oa), ((qb, qdb), ob) = res
+            assert np.array_equal(qa, qb, equal_nan=True) and np.array_equal(qda, qdb, equal_nan=True), (integ, lu_mode, tol)
+            for k in ("newton_iters", "ls_halvings", "status", "T", "V"):
+                assert np.array_equal(oa[k], ob[k], equal_nan=True), (integ, lu_mode, tol, k)
+            if tol == 1e-9:
+                assert (oa["status"] & 15 == 0).all()
+            else:
+                assert oa["ls_halvings"].sum() > 0 or (oa["status"] & 15).any(), "no line search ran: the wild states are too tame"
+    monkeypatch.delenv("RMX_W2_MAX")
+
+
 def test_max_valid_amplitude_sample(oracle_lib):
     """The headline workload at the LARGEST initial-state amplitude the reference algorithm survives (q, qdot ~ U(-0.1856, 0.1856):
     found by tools/max_valid_amplitude.py on the literal oracle, profiles/r04_max_valid_amplitude.json): 1024 rollouts x 100 BDF1

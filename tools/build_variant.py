@@ -35,7 +35,8 @@ def main():
     vdir = os.path.join(ROOT, "build", "variants")
     os.makedirs(vdir, exist_ok=True)
     obj = os.path.join(vdir, "%s.o" % a.name)
-    tu = ["-DRMX_NP=%d" % a.np, "-DRMX_PART=%d" % a.part, ge.HIP_KERNEL_SRC]
+    part_flags = {3: ["-DRMX_GLOBAL_CONSTS"], 5: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()"]}.get(a.part, [])
+    tu = ["-DRMX_NP=%d" % a.np, "-DRMX_PART=%d" % a.part] + part_flags + [ge.HIP_KERNEL_SRC]
     procs = [subprocess.Popen([hipcc] + flags + ilp + extra + ["-c", "-o", obj] + tu)]
     if a.asm:
         os.makedirs(os.path.join(ROOT, "build", "isa"), exist_ok=True)
@@ -49,7 +50,8 @@ def main():
             if part == 2 and n < 16:
                 continue
             objs.append(obj if (n == a.np and part == a.part) else os.path.join(ge.OBJ_DIR, "rmx_kernels_np%d_p%d.o" % (n, part)))
-    objs.append(os.path.join(ge.OBJ_DIR, "rmx_kernels_np64_p3.o"))
+    for n, part in ((64, 3), (32, 4), (64, 5)):      # the one-size parts
+        objs.append(obj if (n == a.np and part == a.part) else os.path.join(ge.OBJ_DIR, "rmx_kernels_np%d_p%d.o" % (n, part)))
     out = os.path.join(ROOT, "redmax_amd", "variants", "libredmax_hip_%s.so" % a.name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs)
     print(out)
