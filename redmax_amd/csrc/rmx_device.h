@@ -3241,10 +3241,10 @@ struct W2Lu {
 #ifndef RMX_W2_LU_INLINE
 __attribute__((noinline))
 #endif
-__device__ W2Lu w2_lu_call() {
+__device__ W2Lu w2_lu_call(const int n) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     bool ok;
-    const double dx = lu_solve_neg_diag64_staged(64, (int)(threadIdx.x & 63u), smem, ok);
+    const double dx = lu_solve_neg_diag64_staged(n, (int)(threadIdx.x & 63u), smem, ok);
     return W2Lu{dx, ok ? 1 : 0};
 }
 #endif
@@ -3763,7 +3763,7 @@ __device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o
             if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
             else if constexpr (NP == 64 && LU_SPLIT64) {
 #if RMX_W2
-                const W2Lu r = w2_lu_call();
+                const W2Lu r = w2_lu_call(M.n);
                 dx = r.dx;
                 lu_ok = r.ok != 0;
 #else

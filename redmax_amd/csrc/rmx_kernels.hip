@@ -89,7 +89,9 @@ __global__ void __launch_bounds__(64) k_stage_consts(const DevModel M, double* _
 // filled sizes go (the 64-joint tree of BASELINE.json configs[2]).
 constexpr int TAG_FULLN = 4;
 constexpr int TAG_COOP = 8;      // k_step_bdf1/2<32, true, false, false, TAG_COOP>: the cooperative launch (RMX_PART 4)
-constexpr int TAG_W2 = 16;       // k_step_bdf1/2<64, false, false, false, TAG_W2>: two wavefronts per 64-node tree (RMX_PART 5, RMX_W2)
+constexpr int TAG_W2 = 16;       // k_step_bdf1/2<64, false, false, false, TAG_W2>: two wavefronts per 64-node tree (RMX_PART 5, RMX_W2);
+                                 // TAG_W2 + 1: the same for trees of 33..63 nodes (n at run time)
+constexpr bool tag_w2(const int tag) { return tag == TAG_W2 || tag == TAG_W2 + 1; }
 template <int NP, bool FULLCHAIN, int TAG = 0>
 __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
     DevModel M = Min;
@@ -118,7 +120,7 @@ __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict_
             w2_store_half<1>(sAcc, lane, h1);
             RMX_WG_BAR();
 #if RMX_W2
-            (void)w2_lu_call();
+            (void)w2_lu_call(M.n);
 #endif
         }
     }
@@ -131,7 +133,7 @@ __device__ __forceinline__ void w2_release(const int lane) {
 // TAG: keeps the kernel names of a translation unit compiled with other macros (RMX_GLOBAL_CONSTS) distinct (0, 3); TAG_FULLN, TAG_FULLN + 1:
 // the n == NP instantiations of the two
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
-__global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
+__global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     constexpr bool COOP = TAG == TAG_COOP;           // the cooperative launch (rmx_device.h CoopCtx): COOP_G workgroups per parked rollout
     static_assert(!COOP || (CT && !LEAN), "the cooperative launch belongs to the kernels with the contact terms");
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf1(const De
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x;
-    if constexpr (TAG == TAG_W2) {
+    if constexpr (tag_w2(TAG)) {
         if (threadIdx.x >= 64) {
             w2_helper<NP>(M, sAcc, lane - 64);
             return;
@@ -248,12 +250,12 @@ __global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf1(const De
     }
     if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
     }
-    if constexpr (TAG == TAG_W2) w2_release(lane);
+    if constexpr (tag_w2(TAG)) w2_release(lane);
 }
 
 // simLoop (driverRedMaxBDF2.m:57-125): SDIRK2 start step (two Newton solves), then BDF2.  CT / LEAN: see k_step_bdf1.
 template <int NP, bool CT, bool LEAN = false, bool FULLCHAIN = false, int TAG = 0>
-__global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
+__global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf2(const DevModel Min, const DevOpts o, const StepArgs a) {
     static_assert(!LEAN || CT, "the lean launch belongs to the contact-capable kernels");
     constexpr bool COOP = TAG == TAG_COOP;           // see k_step_bdf1
     static_assert(!COOP || (CT && !LEAN), "the cooperative launch belongs to the kernels with the contact terms");
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf2(const De
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     const int lane = threadIdx.x;
-    if constexpr (TAG == TAG_W2) {
+    if constexpr (tag_w2(TAG)) {
         if (threadIdx.x >= 64) {
             w2_helper<NP>(M, sAcc, lane - 64);
             return;
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(TAG == TAG_W2 ? 128 : 64) k_step_bdf2(const De
     }
     if (lane == 0 && a.ticks && writer) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;      // this rollout's share of the launch (rmx_step_ticks)
     }
-    if constexpr (TAG == TAG_W2) w2_release(lane);
+    if constexpr (tag_w2(TAG)) w2_release(lane);
 }
 
 // euler (matlab-simple/testRedMax.m:67-109), BASELINE.json configs[0]: linearly-implicit Euler,
@@ -607,7 +609,11 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
                 }
             } else if (last_solve) {
                 double Mrow[NP], Drow[NP];
+#ifdef RMX_ADJ_SKIP_MD      // measurement aid: what the forward kernel costs without forming M, D (they are stored as zeros)
+                for (int i = 0; i < NP; ++i) Mrow[i] = Drow[i] = 0.0;
+#else
                 eval_MD<NP>(M, lane, fs, Mrow, Drow);       // fs: the state of the last evaluated iterate
+#endif
                 if (lane < n) {
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
@@ -1262,8 +1268,13 @@ void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, cons
 
 void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(128);
-    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
-    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    if (m->dm.n == RMX_NP) {          // every node slot in use: the n == NP instantiation
+        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        return;
+    }
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2 + 1>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2 + 1>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
 
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
@@ -1337,9 +1348,9 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     // More than two rollouts per CU: the kernels that read the per-node constants from global memory (33.8 KB of LDS per wavefront
     // instead of 68.6 KB: four wavefronts per CU instead of two).  Up to two per CU the LDS-resident constants are faster (-7 %).
     if (m->dm.gconst && m->gconst_min_batch > 0 && b->B >= m->gconst_min_batch) return launch_step_gconst_64(m, b, integ, o, a);
+    // a batch of at most one rollout per two SIMDs: a second wavefront per rollout for the Hessian and the solve
+    if (m->w2_max_batch > 0 && b->B <= m->w2_max_batch) return launch_step_w2_64(m, b, integ, o, a);
 #if !defined(RMX_NO_FULLCHAIN)
-    // a full tree in a batch of at most one rollout per two SIMDs: a second wavefront per rollout for the Hessian and the solve
-    if (m->dm.n == RMX_NP && m->w2_max_batch > 0 && b->B <= m->w2_max_batch) return launch_step_w2_64(m, b, integ, o, a);
     if (m->dm.n == RMX_NP) return launch_step_fulln_64(m, b, integ, o, a);
 #endif
 #endif
