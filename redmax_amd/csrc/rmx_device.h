@@ -33,6 +33,9 @@
 #define RMX_W2 0
 #endif
 #define RMX_WG_BAR() __syncthreads()
+#ifndef RMX_W2_FULL_HELPER
+#define RMX_W2_FULL_HELPER 0      // 1: the helper wave stays in the solve to its end (back substitution included, result dropped)
+#endif
 #if RMX_W2
 // __syncthreads() without the s_barrier: LDS traffic of ONE wavefront is ordered by the wait alone
 __device__ __forceinline__ void rmx_wave_sync() {
@@ -3136,7 +3139,7 @@ __device__ __forceinline__ void lu64_phase(double* sH, const int lane, double (&
             for (int c = 0; c < CW / 2; ++c) w[c] = v2d{X[s][2 * c], X[s][2 * c + 1]};
         }
     }
-    if constexpr (RMX_W2) RMX_WG_BAR();
+    if constexpr (RMX_W2 && (P < 3 || RMX_W2_FULL_HELPER)) RMX_WG_BAR();      // (phase 3 has no later block: wave 0 alone)
     else RMX_SYNC();                           // the next phase reads what all the DPP rows have written
     // the finished rows of this phase: their part of U, for the back substitution
     if (RMX_W2 ? threadIdx.x < 16 : lane < 16) {
@@ -3185,8 +3188,14 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     lu64_phase<0>(sH, lane, b, gm, rown, pg, jv);
     lu64_phase<1>(sH, lane, b, gm, rown, pg, jv);
     lu64_phase<2>(sH, lane, b, gm, rown, pg, jv);
+    if constexpr (RMX_W2 && !RMX_W2_FULL_HELPER) {     // the helper wave has applied its share of the last later block: the rest is wave 0's
+        if (threadIdx.x >= 64) {
+            ok = true;
+            return 0.0;
+        }
+    }
     lu64_phase<3>(sH, lane, b, gm, rown, pg, jv);
-    if constexpr (RMX_W2) RMX_WG_BAR();
+    if constexpr (RMX_W2 && RMX_W2_FULL_HELPER) RMX_WG_BAR();
     else RMX_SYNC();            // (the finished rows of phase 3)
     // back substitution, block column by block column from the right
     double x[4];
@@ -3223,28 +3232,30 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     for (int s = 0; s < 4; ++s) bad = bad || gm[s].bad(lim[s]);
     ok = !__any(bad) && pg.ok();
     const double dx = r4 == 0 ? x[0] : (r4 == 1 ? x[1] : (r4 == 2 ? x[2] : x[3]));
-    if constexpr (RMX_W2) {
-        RMX_WG_BAR();           // both waves have read their last of H
-        if (threadIdx.x >= 64) return dx;
-    } else RMX_SYNC();          // sAcc goes back to the front, whose subtree scan relies on a zero row n
+    if constexpr (RMX_W2) {     // (the caller hands the scratch back to the front: w2_lu_call is one function for every n)
+        if constexpr (RMX_W2_FULL_HELPER) RMX_WG_BAR();           // both waves have read their last of H
+        return dx;
+    }
+    RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
     if (lane < ACC_STRIDE) sAcc[n * ACC_STRIDE + lane] = 0.0;
     RMX_SYNC();
     return dx;
 }
 
 #if RMX_W2
-// One copy of the solve for both waves of a workgroup (out of line: the two run it in step, on the same instruction-cache lines).
+// The solve as both waves of a workgroup call it (wave 0 from the Newton loop, wave 1 from w2_helper).
 struct W2Lu {
     double dx;
     int ok;
 };
-#ifndef RMX_W2_LU_INLINE
-__attribute__((noinline))
+#ifdef RMX_W2_LU_SHARED      // measurement aid: ONE out-of-line copy of the solve for both waves (416 B of callee-saved registers in scratch: 5 % slower)
+__attribute__((noinline)) __device__ W2Lu w2_lu_call() {
+#else
+__device__ __forceinline__ W2Lu w2_lu_call() {
 #endif
-__device__ W2Lu w2_lu_call(const int n) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     bool ok;
-    const double dx = lu_solve_neg_diag64_staged(n, (int)(threadIdx.x & 63u), smem, ok);
+    const double dx = lu_solve_neg_diag64_staged(64, (int)(threadIdx.x & 63u), smem, ok);
     return W2Lu{dx, ok ? 1 : 0};
 }
 #endif
@@ -3763,9 +3774,12 @@ __device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o
             if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
             else if constexpr (NP == 64 && LU_SPLIT64) {
 #if RMX_W2
-                const W2Lu r = w2_lu_call(M.n);
+                const W2Lu r = w2_lu_call();
                 dx = r.dx;
                 lu_ok = r.ok != 0;
+                RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+                if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+                RMX_SYNC();
 #else
                 if constexpr (HESS_MFMA64) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
                 else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);

@@ -120,7 +120,7 @@ __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict_
             w2_store_half<1>(sAcc, lane, h1);
             RMX_WG_BAR();
 #if RMX_W2
-            (void)w2_lu_call(M.n);
+            (void)w2_lu_call();
 #endif
         }
     }

@@ -17,7 +17,7 @@ wl, R = sys.argv[2], int(sys.argv[3])
 if wl == "chain":
     sc = sceneChain(32); sc.init(); B = 1024; q, qd = syntheticStates(32, B)
 else:
-    sc = sceneTree(64); sc.init(); B = 512; q, qd = syntheticStates(sc.nr, B); q = q * 0.5 + sc.getQ()[0]
+    sc = sceneTree(64); sc.init(); B = int(os.environ.get("RMX_VB_BATCH", "512")); q, qd = syntheticStates(sc.nr, B); q = q * 0.5 + sc.getQ()[0]
 sim = BatchSim(sc, batch=B)
 ms = []
 for r in range(R):

@@ -6,6 +6,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from redmax_amd import _abi  # noqa: E402
+if os.environ.get("RMX_W2_LIB"):          # a variant library (tools/build_variant.py) instead of the in-tree one
+    _abi.LIB_PATH = os.environ["RMX_W2_LIB"]
 from redmax_amd import BatchSim, sceneTree  # noqa: E402
 
 
@@ -35,7 +38,7 @@ def run(B, w2, integ="bdf1", tol=1e-9):
 
 def main():
     batches = [int(a) for a in sys.argv[1:]] or [64, 256, 512]
-    for integ in ("bdf1", "bdf2"):
+    for integ in os.environ.get("RMX_W2_INTEG", "bdf1 bdf2").split():
         for B in batches:
             t1, q1, qd1, it1, st1 = run(B, False, integ)
             t2, q2, qd2, it2, st2 = run(B, True, integ)
