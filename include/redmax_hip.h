@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 109
+#define RMX_VERSION 110
 
 enum {
     RMX_OK = 0,
@@ -299,6 +299,15 @@ int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_t
  * BDF2 history in place (rmx_step_bdf2 may continue it). */
 int rmx_adjoint_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
                      double* P, double* dPdp, rmx_stats* stats);
+
+/* The same two calls with DEVICE pointers for p, P and dPdp (ABI 110): an optimiser that lives on the device - or a caller that
+ * evaluates many parameter batches - pays no host round trip for them (three small copies and their synchronisation were a sixth
+ * of the 20-step configs[3] call).  d_p: [batch][nr], d_P: [batch], d_dPdp: [batch][nr], none of them retained; stats (host
+ * arrays, may be NULL) as above.  The call returns when the kernels have finished. */
+int rmx_adjoint_bdf1_device(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* d_p,
+                            double* d_P, double* d_dPdp, rmx_stats* stats);
+int rmx_adjoint_bdf2_device(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* d_p,
+                            double* d_P, double* d_dPdp, rmx_stats* stats);
 
 /* euler() of matlab-simple/testRedMax.m:67-109 (BASELINE.json configs[0]): nsteps linearly-implicit Euler steps,
  *   Mr = J'MmJ ; (Mr + h Dr - h^2 Kr) qdot1 = Mr qdot0 + h (J'(fm - Mm Jdot qdot0) + fr) ; q1 = q0 + h qdot1.

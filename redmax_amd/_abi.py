@@ -23,7 +23,7 @@ SYMBOLS = (
     "rmx_model_set_ground_contact", "rmx_model_nsph", "rmx_get_charts", "rmx_set_charts",
     "rmx_batch_create", "rmx_batch_destroy", "rmx_batch_size",
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
-    "rmx_eval", "rmx_eval_mfd", "rmx_compute_values", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_history", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_adjoint_bdf2", "rmx_energy",
+    "rmx_eval", "rmx_eval_mfd", "rmx_compute_values", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_history", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_adjoint_bdf2", "rmx_adjoint_bdf1_device", "rmx_adjoint_bdf2_device", "rmx_energy",
     "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_step_bdf2_async", "rmx_step_history_async", "rmx_sync",
     "rmx_history_read", "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases", "rmx_step_ticks",
     "rmx_group_create", "rmx_group_destroy", "rmx_group_batch_size", "rmx_group_nshards", "rmx_group_shard", "rmx_group_shard_batch",
@@ -116,6 +116,8 @@ def lib():
     L.rmx_step_euler.argtypes = [vp, C.c_double, C.c_int, _dp, _dp]
     L.rmx_adjoint_bdf1.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(TaskPointPos), _dp, _dp, _dp, C.POINTER(Stats)]
     L.rmx_adjoint_bdf2.argtypes = L.rmx_adjoint_bdf1.argtypes
+    L.rmx_adjoint_bdf1_device.argtypes = [vp, C.POINTER(Opts), C.c_int, C.POINTER(TaskPointPos), vp, vp, vp, C.POINTER(Stats)]
+    L.rmx_adjoint_bdf2_device.argtypes = L.rmx_adjoint_bdf1_device.argtypes
     L.rmx_step_ticks.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.rmx_energy.argtypes = [vp, _dp, _dp]
     L.rmx_last_step_ms.argtypes = [vp]

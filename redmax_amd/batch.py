@@ -224,6 +224,34 @@ class BatchSim:
         info["ms"] = self._L.rmx_last_step_ms(self._batch)
         return P, dPdp, info
 
+    def adjoint_bdf1_device(self, nsteps, h, task, p_ptr, P_ptr, dPdp_ptr, stats=False, _fn="rmx_adjoint_bdf1_device"):
+        """adjoint_bdf1 with DEVICE pointers (integers, e.g. torch.Tensor.data_ptr()) for p [B][nr], P [B] and dPdp [B][nr]: nothing
+        crosses the host boundary but the optional counters.  Returns info."""
+        tk = _abi.TaskPointPos()
+        tk.body = int(task["body"])
+        for i in range(3):
+            tk.xlocal[i] = float(task["xlocal"][i])
+            tk.xtarget[i] = float(task["xtarget"][i])
+        tk.step = int(task["step"]) if "step" in task else int(round(float(task["t"]) / float(h)))
+        tk.pscale, tk.wreg, tk.wpos = float(task["pscale"]), float(task["wreg"]), float(task["wpos"])
+        opts = _abi.Opts()
+        C.memmove(C.byref(opts), C.byref(self.opts), C.sizeof(opts))
+        opts.h = float(h)
+        opts.iterMaxPerDof = 5                      # driverRedMaxAdjointBDF1.m:108
+        info = {}
+        st = None
+        if stats:
+            info["newton_iters"] = np.zeros(self.B, dtype=np.int32)
+            info["status"] = np.zeros(self.B, dtype=np.int32)
+            st = _abi.Stats(_abi.iptr(info["newton_iters"]), None, _abi.iptr(info["status"]))
+        _abi.check(getattr(self._L, _fn)(self._batch, C.byref(opts), int(nsteps), C.byref(tk), C.c_void_p(p_ptr), C.c_void_p(P_ptr),
+                                         C.c_void_p(dPdp_ptr), C.byref(st) if st is not None else None), _fn)
+        info["ms"] = self._L.rmx_last_step_ms(self._batch)
+        return info
+
+    def adjoint_bdf2_device(self, nsteps, h, task, p_ptr, P_ptr, dPdp_ptr, stats=False):
+        return self.adjoint_bdf1_device(nsteps, h, task, p_ptr, P_ptr, dPdp_ptr, stats=stats, _fn="rmx_adjoint_bdf2_device")
+
     def step_ticks(self):
         """Shader-clock ticks each rollout's wavefront spent in the kernel(s) of the last step call (rmx_step_ticks): [B] uint64."""
         t = np.zeros(self.B, dtype=np.uint64)

@@ -1122,7 +1122,7 @@ extern "C" int rmx_step_euler(rmx_batch* b, double h, int nsteps, double* hT, do
 
 
 static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p, double* P,
-                        double* dPdp, rmx_stats* stats, const int integ) {
+                        double* dPdp, rmx_stats* stats, const int integ, const bool on_device = false) {
     if (!b || !task || !p || !P || !dPdp) return fail(RMX_E_INVALID, "null argument");
     rmx_model* m = b->m;
     if (nsteps < 1) return fail(RMX_E_INVALID, "nsteps < 1");
@@ -1178,18 +1178,21 @@ static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rm
             for (int i = 0; i < 6; ++i) bufs[i] = (char*)b->adjws + offs[i];
     }
     if (e == hipSuccess) e = hipMemsetAsync(bufs[3], 0, sizes[3], b->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(b->tmpA, p, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess && !on_device) e = hipMemcpyAsync(b->tmpA, p, nv * sizeof(double), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
         a.Hs = (double*)bufs[0]; a.Ms = (double*)bufs[1]; a.Ds = (double*)bufs[2];
         a.dPdq = (double*)bufs[3]; a.P = (double*)bufs[4]; a.dPdp = (double*)bufs[5];
+        if (on_device) {          // the caller's device arrays directly: nothing staged, nothing copied back
+            a.p = p; a.P = P; a.dPdp = dPdp;
+        }
         e = hipEventRecord(b->ev0, b->stream);
             DISPATCH_NP(m->NP, launch_adjoint, m, b, integ, o, a);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(b->ev1, b->stream);
         // after a BDF2 rollout (q, qdot) of step k-1 are in place: rmx_step_bdf2 may continue it; a BDF1 rollout invalidates them
         if (e == hipSuccess) e = set_started(b, integ == INTEG_BDF2 ? 1 : 0);
-        if (e == hipSuccess) e = hipMemcpyAsync(P, a.P, sizes[4], hipMemcpyDeviceToHost, b->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(dPdp, a.dPdp, sizes[5], hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess && !on_device) e = hipMemcpyAsync(P, a.P, sizes[4], hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess && !on_device) e = hipMemcpyAsync(dPdp, a.dPdp, sizes[5], hipMemcpyDeviceToHost, b->stream);
         if (e == hipSuccess && stats) {
             if (stats->newton_iters) e = hipMemcpyAsync(stats->newton_iters, b->it, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
             if (e == hipSuccess && stats->status) e = hipMemcpyAsync(stats->status, b->status, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
@@ -1212,6 +1215,15 @@ extern "C" int rmx_adjoint_bdf1(rmx_batch* b, const rmx_opts* opts, int nsteps, 
 extern "C" int rmx_adjoint_bdf2(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* p,
                                 double* P, double* dPdp, rmx_stats* stats) {
     return adjoint_impl(b, opts, nsteps, task, p, P, dPdp, stats, INTEG_BDF2);
+}
+
+extern "C" int rmx_adjoint_bdf1_device(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* d_p,
+                                       double* d_P, double* d_dPdp, rmx_stats* stats) {
+    return adjoint_impl(b, opts, nsteps, task, d_p, d_P, d_dPdp, stats, INTEG_BDF1, true);
+}
+extern "C" int rmx_adjoint_bdf2_device(rmx_batch* b, const rmx_opts* opts, int nsteps, const rmx_task_pointpos* task, const double* d_p,
+                                       double* d_P, double* d_dPdp, rmx_stats* stats) {
+    return adjoint_impl(b, opts, nsteps, task, d_p, d_P, d_dPdp, stats, INTEG_BDF2, true);
 }
 
 // simLoop of one batch enqueued on its stream, nothing waited for (include/redmax_hip.h "Asynchronous stepping")

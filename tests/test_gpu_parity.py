@@ -325,6 +325,61 @@ def test_adjoint_bdf1_matches_oracle(oracle_lib, n):
         assert info["newton_iters"][b] == st.newton_iters
 
 
+class _DevArray:
+    """A device array through the HIP runtime the library itself is linked against (torch brings its own copy of the runtime: once
+    the library has initialised the system one in this process, torch's no longer finds the GPU)."""
+    _hip = None
+
+    def __init__(self, host):
+        import ctypes as C
+        if _DevArray._hip is None:
+            _DevArray._hip = C.CDLL("libamdhip64.so")
+        self.C, self.host = C, np.ascontiguousarray(host, dtype=np.float64)
+        self.ptr = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(self.host.nbytes)) == 0
+        assert self._hip.hipMemcpy(self.ptr, self.host.ctypes.data_as(C.c_void_p), C.c_size_t(self.host.nbytes), 1) == 0    # hipMemcpyHostToDevice
+
+    def get(self):
+        out = np.empty_like(self.host)
+        assert self._hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.ptr, self.C.c_size_t(out.nbytes), 2) == 0      # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        self._hip.hipFree(self.ptr)
+
+
+@pytest.mark.parametrize("integ", [1, 2])
+def test_adjoint_with_device_arrays_equals_the_host_call(integ):
+    """rmx_adjoint_bdf1_device / rmx_adjoint_bdf2_device (ABI 110): p, P, dPdp as device arrays - the same kernels on the same values,
+    so P, dPdp, the final state and the counters equal the host-array call bit for bit; the caller's p is not touched."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneAdjointChain
+    sc = sceneAdjointChain(16)
+    sc.init()
+    B, nsteps = 8, 10
+    p = 0.1 * np.random.default_rng(11).standard_normal((B, sc.nr))
+    task = dict(sc.task, t=nsteps * sc.h)
+    q0, qd0 = sc.getQ()
+    sim = BatchSim(sc, batch=B)
+    sim.set_state(q0[None, :], qd0[None, :])
+    P, dPdp, info = (sim.adjoint_bdf1 if integ == 1 else sim.adjoint_bdf2)(nsteps, sc.h, task, p, stats=True)
+    qa, qda = sim.get_state()
+    p_d, P_d, dP_d = _DevArray(p), _DevArray(np.full(B, np.nan)), _DevArray(np.full((B, sc.nr), np.nan))
+    sim.set_state(q0[None, :], qd0[None, :])
+    fn = sim.adjoint_bdf1_device if integ == 1 else sim.adjoint_bdf2_device
+    info_d = fn(nsteps, sc.h, task, p_d.ptr.value, P_d.ptr.value, dP_d.ptr.value, stats=True)
+    qb, qdb = sim.get_state()
+    assert np.array_equal(P_d.get(), P) and np.array_equal(dP_d.get(), dPdp)
+    assert np.array_equal(qa, qb) and np.array_equal(qda, qdb)
+    assert np.array_equal(info["newton_iters"], info_d["newton_iters"]) and np.array_equal(info["status"], info_d["status"])
+    assert np.array_equal(p_d.get(), p)
+    with pytest.raises(Exception):
+        fn(nsteps, sc.h, task, 0, P_d.ptr.value, dP_d.ptr.value)
+    for d in (p_d, P_d, dP_d):
+        d.free()
+    sim.close()
+
+
 def test_adjoint_scene100_at_its_own_horizon(oracle_lib):
     """The reference's own adjoint scene (scene 100, scenesRedMax.m:402-436: 2 links, tEnd = 1, h = 1e-2) for its full 100 steps:
     forward + backward sweep against the oracle (P, dP/dp, final state, Newton counts), and the reference's testGrad identity
