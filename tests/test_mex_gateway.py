@@ -145,7 +145,7 @@ def flatten(scene):
 
 
 def test_gateway_builds_warning_free_and_answers_version(gw):
-    assert gw.call(1, "version") == 109
+    assert gw.call(1, "version") == 110
 
 
 def test_gateway_reports_errors_the_matlab_way(gw):
