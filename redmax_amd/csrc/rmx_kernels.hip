@@ -1268,6 +1268,11 @@ void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, cons
 
 void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(128);
+    if (m->dm.is_chain && m->dm.n == RMX_NP) {      // a serial chain that fills every node slot: FULLCHAIN (no tree paths in the front)
+        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, true, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        return;
+    }
     if (m->dm.n == RMX_NP) {          // every node slot in use: the n == NP instantiation
         if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
         else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
@@ -1341,6 +1346,10 @@ void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool 
 void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
     if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_step_ct_, RMX_NP)(m, b, integ, o, a);
+#if RMX_NP == 64
+    // 33..64 nodes in a batch of at most one rollout per two SIMDs: a second wavefront per rollout for the Hessian and the solve
+    if (m->w2_max_batch > 0 && b->B <= m->w2_max_batch) return launch_step_w2_64(m, b, integ, o, a);
+#endif
 #if RMX_NP >= 16 && !defined(RMX_NO_FULLCHAIN)      // (the macro: development aid, tools/build_variant.py)
     if (m->dm.is_chain && m->dm.n == RMX_NP) return RMX_CAT(launch_step_fullchain_, RMX_NP)(m, b, integ, o, a);
 #endif
@@ -1348,8 +1357,6 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     // More than two rollouts per CU: the kernels that read the per-node constants from global memory (33.8 KB of LDS per wavefront
     // instead of 68.6 KB: four wavefronts per CU instead of two).  Up to two per CU the LDS-resident constants are faster (-7 %).
     if (m->dm.gconst && m->gconst_min_batch > 0 && b->B >= m->gconst_min_batch) return launch_step_gconst_64(m, b, integ, o, a);
-    // a batch of at most one rollout per two SIMDs: a second wavefront per rollout for the Hessian and the solve
-    if (m->w2_max_batch > 0 && b->B <= m->w2_max_batch) return launch_step_w2_64(m, b, integ, o, a);
 #if !defined(RMX_NO_FULLCHAIN)
     if (m->dm.n == RMX_NP) return launch_step_fulln_64(m, b, integ, o, a);
 #endif

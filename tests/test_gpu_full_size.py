@@ -198,17 +198,18 @@ def test_tree64_global_constants_kernels(oracle_lib, monkeypatch):
         assert _rel(qb[b], qo) <= 1e-8 and int(ob["newton_iters"][b]) == st.newton_iters
 
 
-@pytest.mark.parametrize("nodes", [64, 41])
+@pytest.mark.parametrize("nodes", [64, 41, -64])
 def test_tree64_two_wave_kernels(monkeypatch, nodes):
     """Batches of at most one rollout per two SIMDs give a full 64-node tree TWO wavefronts (rmx_kernels.hip RMX_PART 5): the second
     one takes the odd columns of the Hessian tiles and its share of the later column blocks in every phase of the block-column
     elimination.  Every matrix entry sees the same operations on the same values in the same order as in the one-wave kernels:
     bit-identical states, iteration counts and status words (RMX_W2_MAX moves the threshold, read at model creation) - BDF1 and BDF2,
     the guarded solve, pivoting throughout (lu_mode 1: wave 0 alone, the helper released at the end), history on, and states wild
-    enough for line searches and failed steps.  41 nodes: the instantiation for partly filled trees (n at run time)."""
+    enough for line searches and failed steps.  41 nodes: the instantiation for partly filled trees (n at run time); -64: the
+    64-link serial chain (FULLCHAIN front)."""
     from redmax_amd import BatchSim
-    from redmax_amd.scenes import sceneTree
-    sc = sceneTree(nodes)
+    from redmax_amd.scenes import sceneChain, sceneTree
+    sc = sceneTree(nodes) if nodes > 0 else sceneChain(-nodes)       # (-64: the 64-link serial chain, the FULLCHAIN instantiation)
     sc.init()
     B, K = 12, 12
     q, qd = _tree_states(sc, B)
