@@ -903,6 +903,10 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
         const char* cm = getenv("RMX_COOP_MAP");
         a.coop_map = cm ? atoi(cm) : 0;
     }
+    {
+        const char* ra = getenv("RMX_W2_RUNAHEAD");
+        a.w2_noahead = (ra && atoi(ra) == 0) ? 1 : 0;
+    }
     if (m->pair32) {
         // RMX_GROUND_FUSED: 1 (default) ONE launch for the whole call - the rollouts (free flight, then the steps with the contact terms)
         // and, behind them in dispatch order, the cooperative groups that pick the parked rollouts up as they appear: no launch

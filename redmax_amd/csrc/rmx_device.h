@@ -37,6 +37,11 @@
 #define RMX_W2_FULL_HELPER 0      // 1: the helper wave stays in the solve to its end (back substitution included, result dropped)
 #endif
 #if RMX_W2
+// (the base of the dynamic LDS: RMX_CONSTS of that translation unit must not depend on which scratch an evaluation works on)
+__device__ __forceinline__ double* rmx_smem_base() {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    return smem;
+}
 // __syncthreads() without the s_barrier: LDS traffic of ONE wavefront is ordered by the wait alone
 __device__ __forceinline__ void rmx_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -826,7 +831,8 @@ __device__ __forceinline__ void lds_subtree_sum(const DevModel& M, double* __res
 // FULL: accumulate the Hessian's subtree sums as well (28 numbers per body instead of 6).
 // e2 is the coefficient of f in g = M v - e2 f: eta^2 for the implicit integrators; the linearly-implicit Euler step of
 // matlab-simple uses e2 = -h with v = qdot0 so that g = M qdot0 + h f is its right-hand side.
-template <int NP, bool FULL, bool TIMED = false, bool CT = false, bool NEARCHK = false>
+// AS: the row stride of the accumulation scratch (ACC_STRIDE; a residual-only evaluation on a scratch of its own may take a smaller odd one)
+template <int NP, bool FULL, bool TIMED = false, bool CT = false, bool NEARCHK = false, int AS = ACC_STRIDE>
 __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restrict__ sAcc, const int lane, const double xq,
                                               const double xqd, const double xv, const double eta, const double e2, NodeOut& out,
                                               FrontState& fs, unsigned long long* stamps = nullptr) {
@@ -1115,7 +1121,7 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
         // general tree: transpose through LDS (stride 29: conflict-free), one lane per component scans the nodes in
         // depth-first order in registers; subtree(j) = suffix(j) - suffix(end_j), row n of sAcc is kept zero
         if (act) {
-            double* A = sAcc + lane * ACC_STRIDE;
+            double* A = sAcc + lane * AS;
 #pragma unroll
             for (int c = 0; c < NS; ++c) A[c] = S[c];
         }
@@ -1133,10 +1139,10 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             const bool full = n == NP;             // wave-uniform: every node slot in use, no per-row bounds needed
             if (full) {
 #pragma unroll
-                for (int t = 0; t < HALF; ++t) a[t] = sAcc[(base + t) * ACC_STRIDE + comp];   // lanes >= NS read finite junk, never stored
+                for (int t = 0; t < HALF; ++t) a[t] = sAcc[(base + t) * AS + comp];   // lanes >= NS read finite junk, never stored
             } else {
 #pragma unroll
-                for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * ACC_STRIDE + comp] : 0.0;
+                for (int t = 0; t < HALF; ++t) a[t] = (on && base + t < n) ? sAcc[(base + t) * AS + comp] : 0.0;
             }
             double acc = 0.0;
 #pragma unroll
@@ -1152,17 +1158,17 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             if (on) {
                 if (full) {
 #pragma unroll
-                    for (int t = 0; t < HALF; ++t) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+                    for (int t = 0; t < HALF; ++t) sAcc[(base + t) * AS + comp] = a[t];
                 } else {
 #pragma unroll
                     for (int t = 0; t < HALF; ++t)
-                        if (base + t < n) sAcc[(base + t) * ACC_STRIDE + comp] = a[t];
+                        if (base + t < n) sAcc[(base + t) * AS + comp] = a[t];
                 }
             }
         } else if (lane < NS) {
             double a[NP];
 #pragma unroll
-            for (int jn = 0; jn < NP; ++jn) a[jn] = (jn < n) ? sAcc[jn * ACC_STRIDE + lane] : 0.0;
+            for (int jn = 0; jn < NP; ++jn) a[jn] = (jn < n) ? sAcc[jn * AS + lane] : 0.0;
             double acc = 0.0;
 #pragma unroll
             for (int jn = NP - 1; jn >= 0; --jn) {
@@ -1171,17 +1177,17 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             }
 #pragma unroll
             for (int jn = 0; jn < NP; ++jn)
-                if (jn < n) sAcc[jn * ACC_STRIDE + lane] = a[jn];
+                if (jn < n) sAcc[jn * AS + lane] = a[jn];
         }
         RMX_STAMP(6)
         RMX_SYNC();
         {
-            const double* A = sAcc + jj * ACC_STRIDE;
+            const double* A = sAcc + jj * AS;
 #pragma unroll
             for (int c = 0; c < NS; ++c) S[c] = A[c];
             if (!M.is_chain) {
                 const int en = (int)cEnd[jc];
-                const double* E = sAcc + en * ACC_STRIDE;
+                const double* E = sAcc + en * AS;
 #pragma unroll
                 for (int c = 0; c < NS; ++c) S[c] -= E[c];
             }
@@ -1873,7 +1879,14 @@ __device__ __forceinline__ void hess64_tiles(const int lane, const double* __res
             }
 }
 
-// RMX_W2: the command word of a two-wave workgroup (1: a Hessian stage and a guarded solve follow, 0: the rollout is over)
+// RMX_W2: the helper wave's own area of the workgroup's LDS, behind the per-node constants: an accumulation scratch for residual-only
+// evaluations (row stride 7: the six sums of a node), the arguments of one evaluation (x, qdot, v per lane, eta) and its results
+constexpr int W2_HELP_AS = 7;
+constexpr int W2_HELP_ARGS = (MAXN + 1) * W2_HELP_AS + 1;
+constexpr int W2_HELP_RES = W2_HELP_ARGS + 3 * 64 + 2;         // |g|^2, T, V
+constexpr int W2_HELP_DOUBLES = W2_HELP_RES + 4;
+// RMX_W2: the command word of a two-wave workgroup (1: a Hessian stage and a guarded solve follow, 2: one residual-only evaluation,
+// 0: the rollout is over)
 __device__ __forceinline__ volatile int* w2_cmd() {
     __shared__ int cmd[2];
     return cmd;

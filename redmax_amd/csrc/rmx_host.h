@@ -41,6 +41,7 @@ struct StepArgs {
     int coop_map;     // measurement aid (RMX_COOP_MAP): 1 = member-major mapping of the cooperative launch's workgroups onto (group, member)
     int fused;        // the whole call in one launch (rmx_kernels.hip k_ground32): rollouts and cooperative groups side by side
     unsigned long long* xrec;   // [ngroups][2 COOP_REC] what the winner of a line search publishes to its group (rmx_ct32.h CoopPub; zero before the launch)
+    int w2_noahead;   // two-wave tree kernels (rmx_kernels.hip w2_steps_bdf1): 1 = no evaluation is run ahead (RMX_W2_RUNAHEAD=0; tests)
 };
 
 struct AdjArgs {

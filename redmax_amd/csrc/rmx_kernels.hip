@@ -103,6 +103,10 @@ __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
     return M;
 }
 
+template <int NP>
+__device__ __forceinline__ double* w2_help_area(const DevModel& M, double* sAcc) {      // (W2_HELP_*: behind the per-node constants)
+    return const_cast<double*>(static_cast<const double*>(RMX_CONSTS(sAcc, M.n, NP))) + (NCONST + NGROUND) * cstride(NP);
+}
 // RMX_W2: wave 1 of a two-wave workgroup.  It serves wave 0's guarded Newton iterations - the odd columns of the Hessian tiles, its
 // share of the block-column elimination - and sleeps at the workgroup barrier in between (eval_hess and lu_solve_neg_diag64_staged
 // hold wave 0's side of the same barriers).
@@ -111,9 +115,27 @@ __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict_
     if constexpr (NP == 64 && RMX_W2) {
         constexpr int CS = cstride(NP);
         const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;
+        double* const hp = w2_help_area<NP>(M, sAcc);
+        if (lane < W2_HELP_AS) hp[M.n * W2_HELP_AS + lane] = 0.0;                    // (row n of an accumulation scratch stays zero)
         for (;;) {
             RMX_WG_BAR();
-            if (*w2_cmd() == 0) break;
+            const int cmd = *w2_cmd();
+            if (cmd == 0) break;
+            if (cmd == 2) {       // an evaluation that may end wave 0's solve: residual and energies only, on this wave's scratch
+                const double x = hp[W2_HELP_ARGS + lane], xqd = hp[W2_HELP_ARGS + 64 + lane], xv = hp[W2_HELP_ARGS + 128 + lane];
+                const double eta = hp[W2_HELP_ARGS + 192];
+                NodeOut e;
+                FrontState f2;
+                eval_front_e2<NP, false, false, false, false, W2_HELP_AS>(M, hp, lane, x, xqd, xv, eta, eta * eta, e, f2);
+                const double gn2 = wave_sum_np<NP>(e.g * e.g), T = wave_sum(e.eT), V = wave_sum(e.eV);
+                if (lane == 0) {
+                    hp[W2_HELP_RES] = gn2;
+                    hp[W2_HELP_RES + 1] = T;
+                    hp[W2_HELP_RES + 2] = V;
+                }
+                RMX_WG_BAR();
+                continue;
+            }
             double h1[4][2][4];
             hess64_tiles<NP, 1>(lane, sAcc, cRel, h1);
             RMX_WG_BAR();
@@ -125,6 +147,178 @@ __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict_
         }
     }
 }
+#if RMX_W2
+// BDF1 steps s, s + 1, ... of a tree under the guarded Newton (driverRedMaxBDF1.m:57-157), ONE loop around one call site of the front:
+// newton_rot<NP, false> and the step epilogue of k_step_bdf1, decision for decision and operation for operation, plus this.  The
+// evaluation that ENDS a solve (the accepted line-search trial whose |g| is below tol) is followed by the first evaluation of the NEXT
+// step, at a point that depends on the converged iterate alone - known before that last evaluation is run.  When the current Newton
+// iteration is the one the previous solve ended at, wave 0 hands the trial point to the helper wave (w2_helper, command 2: a
+// residual-only front on a scratch of its own - the same operations, so the same residual) and evaluates the next step's first point
+// itself; if the helper's |g|^2 ends the solve, the epilogue of the step runs here and the loop goes on as the next step's solve with
+// its first evaluation done; if not, the trial point is evaluated after all (the prediction cost one evaluation).  Returns the number
+// of steps finished (>= 1); ends at the first solve that ends on an evaluation of its own.
+template <int NP>
+__device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o, const StepArgs& a, double* sAcc, const int lane,
+                                             const int traj, const int id, const size_t off, int s, double& q, double& qd, int& iters,
+                                             int& halvings, int& status, PivotPolicy& piv, int& predict) {
+    double Hrow[NP];
+    FrontState fs;
+    NodeOut e, e0, last;
+    double q0 = q;
+    double x = q0 + o.h * qd;                    // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
+    double qA = q0, qB = x;
+    const double eta = o.h;
+    double lo = 0.0, dx = 0.0, alpha = 1.0, f0 = 0.0, g0n2 = 0.0, x0 = x, lo0 = 0.0;
+    int iter = 1, lsfail = 0, iterLs = 1, done = 0;
+    bool ls = false, spec_failed = false;
+    e0.g = e0.eT = e0.eV = 0.0;
+    last = e0;
+    double* const hp = w2_help_area<NP>(M, sAcc);
+    // the epilogue of step s (k_step_bdf1): qdot (:72), q, Scene.saveHistory; T, V: the sums of the last evaluation's energies
+    auto finish = [&](const double T, const double V) {
+        qd = ((x - q0) + lo) / o.h;
+        q = x;
+        if (a.histT && lane == 0) {
+            a.histT[(size_t)s * a.B + traj] = T;
+            a.histV[(size_t)s * a.B + traj] = V;
+        }
+        if (a.histQ && id >= 0) {
+            a.histQ[(size_t)s * a.B * M.nr + off] = q;
+            a.histQd[(size_t)s * a.B * M.nr + off] = qd;
+        }
+        ++s;
+        ++done;
+    };
+    while (true) {
+#ifndef RMX_W2_SPEC
+#define RMX_W2_SPEC 1      // 0: measurement aid, the loop without the run-ahead
+#endif
+        const bool spec = RMX_W2_SPEC && !spec_failed && ls && iter == predict && piv.streak == 0 && s + 1 < a.nsteps && !a.w2_noahead;      // (wave-uniform)
+        // (the run-ahead swaps the next step's point INTO x, lo, qA, qB: the expressions handed to the front stay newton_rot's)
+        const double sx = x, slo = lo, sqA = qA, sqB = qB;
+        if (spec) {
+            hp[W2_HELP_ARGS + lane] = x;
+            hp[W2_HELP_ARGS + 64 + lane] = ((x - qA) + lo) / eta;
+            hp[W2_HELP_ARGS + 128 + lane] = (x - qB) + lo;
+            if (lane == 0) {
+                hp[W2_HELP_ARGS + 192] = eta;
+                *w2_cmd() = 2;
+            }
+            RMX_WG_BAR();
+            const double qn = x, qdn = ((x - q0) + lo) / o.h;      // q, qdot as `finish` forms them
+            x = qn + o.h * qdn;
+            lo = 0.0;
+            qA = qn;
+            qB = x;
+        }
+        eval_front<NP, true, false, false, false>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, fs);
+        if (spec) {
+            RMX_WG_BAR();
+            const double gh = hp[W2_HELP_RES], Th = hp[W2_HELP_RES + 1], Vh = hp[W2_HELP_RES + 2];
+            const double nx = x;
+            x = sx; lo = slo; qA = sqA; qB = sqB;
+            if (!((0.5 * gh < f0 || !(iterLs < o.iterLsMax)) && sqrt(gh) < o.tol)) {
+                spec_failed = true;              // not the end of this solve: the trial point is evaluated here after all
+                continue;
+            }
+            // the solve of step s ends at x (newton_rot: halvings, pivot policy; then the step's epilogue) ...
+            halvings += iterLs - 1;
+            predict = iter;
+            pivot_policy_update(piv);
+            finish(Th, Vh);
+            // ... and this is the solve of the next step after its first evaluation
+            q0 = q;
+            x = nx;
+            qA = q0;
+            qB = x;
+            lo = 0.0; dx = 0.0; alpha = 1.0; f0 = 0.0; g0n2 = 0.0; x0 = x; lo0 = 0.0;
+            iter = 1; lsfail = 0; iterLs = 1;
+            ls = false;
+        }
+        spec_failed = false;
+        const double gn2 = wave_sum_np<NP>(e.g * e.g);
+        if (ls) {                                        // this was a trial point of the line search (:124-138)
+            if (!(0.5 * gn2 < f0) && iterLs < o.iterLsMax) {
+                alpha *= 0.5;
+                ++iterLs;
+                two_sum(x0, fma(alpha, dx, lo0), x, lo);
+                lo *= o.comp;
+                if (__all(x == x0 && lo == lo0)) {        // see newton_impl: every further halving re-evaluates g(x0)
+                    last = e0;
+                    halvings += o.iterLsMax - 1;
+                    if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+                    break;
+                }
+                continue;
+            }
+            last = e;
+            halvings += iterLs - 1;
+            if (sqrt(gn2) < o.tol) break;
+            if (iter >= o.iterMax) {
+                status |= 2;
+                break;
+            }
+            lsfail += (0.5 * gn2 < f0) ? 0 : 1;
+            if (o.lsFailLimit > 0 && lsfail >= o.lsFailLimit) {
+                status |= 2 | ST_LS_CUT;
+                break;
+            }
+            ++iter;
+        }
+        (void)eval_hess<NP, false, false, false>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
+        e0 = e;
+        last = e;
+        ++iters;
+        {
+            const W2Lu r = w2_lu_call();
+            dx = r.dx;
+            RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+            if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+            RMX_SYNC();
+            if (r.ok != 0) {
+                piv.streak = 0;
+            } else {             // growth guard tripped: redo this solve with partial pivoting (see newton_impl)
+                ++piv.streak;
+                status |= 16;
+                NodeOut e2;
+                eval_front<NP, true, false, false, false>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e2, fs);
+                eval_hess<NP, false, false>(M, lane, fs, Hrow, nullptr, sAcc);
+                dx = lu_solve_neg<NP>(M.n, lane, Hrow, e.g);
+            }
+        }
+        const double dxn2 = wave_sum_np<NP>(dx * dx);
+        if (!(dxn2 == dxn2)) {
+            status |= 4;
+            break;
+        }
+        if (sqrt(dxn2) > o.dxMax) {
+            status |= 1;
+            break;
+        }
+        alpha = 1.0;
+        g0n2 = gn2;
+        f0 = 0.5 * g0n2;
+        x0 = x;
+        lo0 = lo;
+        iterLs = 1;
+        two_sum(x0, fma(alpha, dx, lo0), x, lo);
+        lo *= o.comp;
+        if (__all(x == x0 && lo == lo0)) {
+            last = e0;
+            halvings += o.iterLsMax - 1;
+            if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
+            break;
+        }
+        ls = true;
+    }
+    // a solve that ended on an evaluation of its own
+    predict = iter;
+    pivot_policy_update(piv);
+    finish(wave_sum(last.eT), wave_sum(last.eV));
+    return done;
+}
+#endif
+
 __device__ __forceinline__ void w2_release(const int lane) {
     if (lane == 0) *w2_cmd() = 0;
     RMX_WG_BAR();
@@ -188,14 +382,39 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
         if (M.nsph) sph_setup<NP>(M, sCol, lane, chart);
     }
     int stop = a.nsteps;
+#if RMX_W2
+    int w2_predict = 0;                            // (w2_steps_bdf1: the Newton iteration the last solve ended at)
+#endif
     for (int s = sfirst; s < a.nsteps; ++s) {
+#if RMX_W2
+        if constexpr (tag_w2(TAG) && !FULLCHAIN) {
+            // guarded solves of a tree: the loop that runs ahead into the next step (w2_steps_bdf1); pivoting solves and serial chains
+            // (whose residual-only front sums by another scan) keep newton_node
+            if (!M.is_chain && o.lu_mode == 0 && piv.hold == 0) {
+                s += w2_steps_bdf1<NP>(M, o, a, sAcc, lane, traj, id, off, s, q, qd, iters, halv, status, piv, w2_predict) - 1;
+                continue;
+            }
+        }
+#endif
         const double q0 = q, qd0 = qd;
         const double xg = q0 + o.h * qd0;          // initial guess (:70) and q0 + h qdot0 of dqtmp (:169)
         NodeOut last;
         double xlo;
         const int it_in = iters, hv_in = halv, st_in = status;
         const PivotPolicy piv_in = piv;
+#if RMX_W2
+        // (a full tree gets here for its pivoting solves only - newton_policy's first branch: the guarded loop is w2_steps_bdf1)
+        double x;
+        if constexpr (TAG == TAG_W2 && !FULLCHAIN) {
+            if (piv.hold > 0) --piv.hold;
+            xlo = 0.0;
+            x = newton_rot<NP, true>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo);
+        } else {
+            x = newton_node<NP, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo, cx);
+        }
+#else
         const double x = newton_node<NP, CT, LEAN, COOP>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo, cx);
+#endif
         if (LEAN && (status & ST_LEFT_LEAN)) {
             status &= ~ST_LEFT_LEAN;
             stop = s;
@@ -1268,18 +1487,19 @@ void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, cons
 
 void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(128);
+    const size_t smem_bytes = m->smem_bytes + ((sizeof(double) * W2_HELP_DOUBLES + 15) & ~(size_t)15);      // + the helper wave's own area
     if (m->dm.is_chain && m->dm.n == RMX_NP) {      // a serial chain that fills every node slot: FULLCHAIN (no tree paths in the front)
-        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
-        else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, true, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
+        else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, true, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
         return;
     }
     if (m->dm.n == RMX_NP) {          // every node slot in use: the n == NP instantiation
-        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
-        else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
+        else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
         return;
     }
-    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2 + 1>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
-    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2 + 1>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2 + 1>), grid, block, smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2 + 1>), grid, block, smem_bytes, b->stream, m->dm, o, a);
 }
 
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size

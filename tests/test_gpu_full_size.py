@@ -200,45 +200,67 @@ def test_tree64_global_constants_kernels(oracle_lib, monkeypatch):
 
 @pytest.mark.parametrize("nodes", [64, 41, -64])
 def test_tree64_two_wave_kernels(monkeypatch, nodes):
-    """Batches of at most one rollout per two SIMDs give a full 64-node tree TWO wavefronts (rmx_kernels.hip RMX_PART 5): the second
+    """Batches of at most one rollout per two SIMDs give a 33..64-node tree TWO wavefronts (rmx_kernels.hip RMX_PART 5): the second
     one takes the odd columns of the Hessian tiles and its share of the later column blocks in every phase of the block-column
     elimination.  Every matrix entry sees the same operations on the same values in the same order as in the one-wave kernels:
-    bit-identical states, iteration counts and status words (RMX_W2_MAX moves the threshold, read at model creation) - BDF1 and BDF2,
-    the guarded solve, pivoting throughout (lu_mode 1: wave 0 alone, the helper released at the end), history on, and states wild
-    enough for line searches and failed steps.  41 nodes: the instantiation for partly filled trees (n at run time); -64: the
-    64-link serial chain (FULLCHAIN front)."""
+    bit-identical states, iteration counts and status words (RMX_W2_MAX moves the threshold, read at model creation) - BDF2, pivoting
+    throughout (lu_mode 1: wave 0 alone, the helper released at the end), serial chains (-64: the 64-link chain, FULLCHAIN front),
+    history on, and states wild enough for line searches and failed steps.  41 nodes: partly filled trees (n at run time).
+    The guarded BDF1 steps of a TREE run the loop that evaluates the next step's first point ahead (w2_steps_bdf1): (i) with the
+    run-ahead switched off (RMX_W2_RUNAHEAD=0) the results are the same bits - what is run ahead is exactly what would have been run;
+    (ii) against the one-wave kernels that loop is a different compilation of the same operations: the compiler contracts a few of
+    them differently, the states agree to rounding (1e-11 after 14 steps) with equal Newton counts."""
     from redmax_amd import BatchSim
     from redmax_amd.scenes import sceneChain, sceneTree
-    sc = sceneTree(nodes) if nodes > 0 else sceneChain(-nodes)       # (-64: the 64-link serial chain, the FULLCHAIN instantiation)
+    sc = sceneTree(nodes) if nodes > 0 else sceneChain(-nodes)
     sc.init()
     B, K = 12, 12
     q, qd = _tree_states(sc, B)
     rng = np.random.default_rng(7)
     wild_q = q + rng.uniform(-1.5, 1.5, q.shape)
     wild_qd = rng.uniform(-40.0, 40.0, qd.shape)
+
+    def run(integ, lu_mode, qq, qqd, tol, w2, ahead="1"):
+        monkeypatch.setenv("RMX_W2_MAX", w2)
+        monkeypatch.setenv("RMX_W2_RUNAHEAD", ahead)
+        sim = BatchSim(sc, batch=B)
+        sim.opts.lu_mode = lu_mode
+        sim.opts.tol = tol
+        sim.set_state(qq, qqd)
+        step = sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2
+        step(2, h=1e-2)                                          # (BDF2: the second call runs on history)
+        out = step(K, h=1e-2, stats=True, history=True)
+        res = (sim.get_state(), out)
+        sim.close()
+        return res
+
+    def same_bits(ra, rb, what):
+        ((qa, qda), oa), ((qb, qdb), ob) = ra, rb
+        assert np.array_equal(qa, qb, equal_nan=True) and np.array_equal(qda, qdb, equal_nan=True), what
+        for k in ("newton_iters", "ls_halvings", "status", "T", "V"):
+            assert np.array_equal(oa[k], ob[k], equal_nan=True), (what, k)
+
     for integ in ("bdf1", "bdf2"):
         for lu_mode, (qq, qqd), tol in ((0, (q, qd), 1e-9), (1, (q, qd), 1e-9), (0, (wild_q, wild_qd), 1e-6)):
-            res = []
-            for w2 in ("0", "100000"):       # never / always
-                monkeypatch.setenv("RMX_W2_MAX", w2)
-                sim = BatchSim(sc, batch=B)
-                sim.opts.lu_mode = lu_mode
-                sim.opts.tol = tol
-                sim.set_state(qq, qqd)
-                step = sim.step_bdf1 if integ == "bdf1" else sim.step_bdf2
-                step(2, h=1e-2)                                          # (BDF2: the second call runs on history)
-                out = step(K, h=1e-2, stats=True, history=True)
-                res.append((sim.get_state(), out))
-                sim.close()
-            ((qa, qda), oa), ((qb, qdb), ob) = res
-            assert np.array_equal(qa, qb, equal_nan=True) and np.array_equal(qda, qdb, equal_nan=True), (integ, lu_mode, tol)
-            for k in ("newton_iters", "ls_halvings", "status", "T", "V"):
-                assert np.array_equal(oa[k], ob[k], equal_nan=True), (integ, lu_mode, tol, k)
+            one = run(integ, lu_mode, qq, qqd, tol, "0")
+            two = run(integ, lu_mode, qq, qqd, tol, "100000")
+            runs_ahead = integ == "bdf1" and lu_mode == 0 and nodes > 0
+            if not runs_ahead:
+                same_bits(one, two, (integ, lu_mode, tol))
+            else:
+                same_bits(two, run(integ, lu_mode, qq, qqd, tol, "100000", ahead="0"), (integ, lu_mode, tol, "run-ahead on / off"))
+                if tol == 1e-9:
+                    ((qa, qda), oa), ((qb, qdb), ob) = one, two
+                    assert _rel(qb, qa) <= 1e-11 and _rel(qdb, qda) <= 1e-9, (_rel(qb, qa), _rel(qdb, qda))
+                    assert np.array_equal(oa["newton_iters"], ob["newton_iters"]) and np.array_equal(oa["status"], ob["status"])
+                    assert np.allclose(oa["T"], ob["T"], rtol=1e-10, atol=0) and np.allclose(oa["V"], ob["V"], rtol=1e-10, atol=0)
+            oa = one[1]
             if tol == 1e-9:
                 assert (oa["status"] & 15 == 0).all()
             else:
                 assert oa["ls_halvings"].sum() > 0 or (oa["status"] & 15).any(), "no line search ran: the wild states are too tame"
     monkeypatch.delenv("RMX_W2_MAX")
+    monkeypatch.delenv("RMX_W2_RUNAHEAD")
 
 
 def test_max_valid_amplitude_sample(oracle_lib):

@@ -35,7 +35,7 @@ def main():
     vdir = os.path.join(ROOT, "build", "variants")
     os.makedirs(vdir, exist_ok=True)
     obj = os.path.join(vdir, "%s.o" % a.name)
-    part_flags = {3: ["-DRMX_GLOBAL_CONSTS"], 5: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()"]}.get(a.part, [])
+    part_flags = {3: ["-DRMX_GLOBAL_CONSTS"], 5: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()", "-DRMX_CONSTS(sAcc,n,NP)=(rmx_smem_base()+acc_doubles((n),(NP)))"]}.get(a.part, [])
     tu = ["-DRMX_NP=%d" % a.np, "-DRMX_PART=%d" % a.part] + part_flags + [ge.HIP_KERNEL_SRC]
     procs = [subprocess.Popen([hipcc] + flags + ilp + extra + ["-c", "-o", obj] + tu)]
     if a.asm:
