@@ -404,6 +404,14 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
         const char* w2 = getenv("RMX_W2_MAX");
         m->w2_max_batch = w2 ? atoi(w2) : (m->n_simd > 0 ? m->n_simd / 2 : 512);
     }
+    if (m->NP == 32 && nsph == 0 && m->dm.is_chain && m->dm.n == 32) {
+        // the full 32-link chain (BASELINE.json configs[1]) in shards of 128 .. one rollout per two SIMDs: the two-wave kernel of
+        // rmx_kernels.hip RMX_PART 6 (RMX_W2_MAX / RMX_W2C_MIN move the bounds)
+        const char* w2 = getenv("RMX_W2_MAX");
+        const char* w2m = getenv("RMX_W2C_MIN");
+        m->w2_max_batch = w2 ? atoi(w2) : (m->n_simd > 0 ? m->n_simd / 2 : 512);
+        m->w2_min_batch = w2m ? atoi(w2m) : 128;
+    }
     *out = m;
     return RMX_OK;
 }

@@ -1885,6 +1885,11 @@ constexpr int W2_HELP_AS = 7;
 constexpr int W2_HELP_ARGS = (MAXN + 1) * W2_HELP_AS + 1;
 constexpr int W2_HELP_RES = W2_HELP_ARGS + 3 * 64 + 2;         // |g|^2, T, V
 constexpr int W2_HELP_DOUBLES = W2_HELP_RES + 4;
+// ... and of a workgroup of chains of <= 32 nodes (rmx_kernels.hip RMX_PART 6), whose helper runs the FULL evaluation (the chain's
+// residual-only front sums by a register scan: other last bits) on a full-stride scratch
+constexpr int W2C_HELP_ARGS = (32 + 1) * ACC_STRIDE + 1;
+constexpr int W2C_HELP_RES = W2C_HELP_ARGS + 3 * 64 + 2;
+constexpr int W2C_HELP_DOUBLES = W2C_HELP_RES + 4;
 // RMX_W2: the command word of a two-wave workgroup (1: a Hessian stage and a guarded solve follow, 2: one residual-only evaluation,
 // 0: the rollout is over)
 __device__ __forceinline__ volatile int* w2_cmd() {

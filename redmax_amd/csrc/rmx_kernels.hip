@@ -147,6 +147,31 @@ __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict_
         }
     }
 }
+// RMX_W2, chains of <= 32 nodes (RMX_PART 6): the helper wave only evaluates - the point wave 0 posts, with the FULL front (see W2C_HELP_*)
+template <int NP>
+__device__ __forceinline__ void w2c_helper(const DevModel& M, double* __restrict__ sAcc, const int lane) {
+    if constexpr (NP == 32 && RMX_W2) {
+        double* const hp = w2_help_area<NP>(M, sAcc);
+        if (lane < ACC_STRIDE) hp[M.n * ACC_STRIDE + lane] = 0.0;                    // (row n of an accumulation scratch stays zero)
+        for (;;) {
+            RMX_WG_BAR();
+            if (*w2_cmd() == 0) break;
+            const double x = hp[W2C_HELP_ARGS + lane], xqd = hp[W2C_HELP_ARGS + 64 + lane], xv = hp[W2C_HELP_ARGS + 128 + lane];
+            const double eta = hp[W2C_HELP_ARGS + 192];
+            NodeOut e;
+            FrontState f2;
+            eval_front_e2<NP, true, false, false, false>(M, hp, lane, x, xqd, xv, eta, eta * eta, e, f2);
+            const double gn2 = wave_sum_np<NP>(e.g * e.g), T = wave_sum(e.eT), V = wave_sum(e.eV);
+            if (lane == 0) {
+                hp[W2C_HELP_RES] = gn2;
+                hp[W2C_HELP_RES + 1] = T;
+                hp[W2C_HELP_RES + 2] = V;
+            }
+            RMX_WG_BAR();
+        }
+    }
+}
+
 #if RMX_W2
 // BDF1 steps s, s + 1, ... of a tree under the guarded Newton (driverRedMaxBDF1.m:57-157), ONE loop around one call site of the front:
 // newton_rot<NP, false> and the step epilogue of k_step_bdf1, decision for decision and operation for operation, plus this.  The
@@ -174,6 +199,7 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
     e0.g = e0.eT = e0.eV = 0.0;
     last = e0;
     double* const hp = w2_help_area<NP>(M, sAcc);
+    constexpr int HARGS = NP == 64 ? W2_HELP_ARGS : W2C_HELP_ARGS, HRES = NP == 64 ? W2_HELP_RES : W2C_HELP_RES;
     // the epilogue of step s (k_step_bdf1): qdot (:72), q, Scene.saveHistory; T, V: the sums of the last evaluation's energies
     auto finish = [&](const double T, const double V) {
         qd = ((x - q0) + lo) / o.h;
@@ -193,15 +219,15 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
 #ifndef RMX_W2_SPEC
 #define RMX_W2_SPEC 1      // 0: measurement aid, the loop without the run-ahead
 #endif
-        const bool spec = RMX_W2_SPEC && !spec_failed && ls && iter == predict && piv.streak == 0 && s + 1 < a.nsteps && !a.w2_noahead;      // (wave-uniform)
+                const bool spec = RMX_W2_SPEC && !spec_failed && ls && iter == predict && piv.streak == 0 && s + 1 < a.nsteps && !a.w2_noahead;      // (wave-uniform)
         // (the run-ahead swaps the next step's point INTO x, lo, qA, qB: the expressions handed to the front stay newton_rot's)
         const double sx = x, slo = lo, sqA = qA, sqB = qB;
         if (spec) {
-            hp[W2_HELP_ARGS + lane] = x;
-            hp[W2_HELP_ARGS + 64 + lane] = ((x - qA) + lo) / eta;
-            hp[W2_HELP_ARGS + 128 + lane] = (x - qB) + lo;
+            hp[HARGS + lane] = x;
+            hp[HARGS + 64 + lane] = ((x - qA) + lo) / eta;
+            hp[HARGS + 128 + lane] = (x - qB) + lo;
             if (lane == 0) {
-                hp[W2_HELP_ARGS + 192] = eta;
+                hp[HARGS + 192] = eta;
                 *w2_cmd() = 2;
             }
             RMX_WG_BAR();
@@ -214,7 +240,7 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
         eval_front<NP, true, false, false, false>(M, sAcc, lane, x, ((x - qA) + lo) / eta, (x - qB) + lo, eta, e, fs);
         if (spec) {
             RMX_WG_BAR();
-            const double gh = hp[W2_HELP_RES], Th = hp[W2_HELP_RES + 1], Vh = hp[W2_HELP_RES + 2];
+            const double gh = hp[HRES], Th = hp[HRES + 1], Vh = hp[HRES + 2];
             const double nx = x;
             x = sx; lo = slo; qA = sqA; qB = sqB;
             if (!((0.5 * gh < f0 || !(iterLs < o.iterLsMax)) && sqrt(gh) < o.tol)) {
@@ -270,12 +296,19 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
         last = e;
         ++iters;
         {
-            const W2Lu r = w2_lu_call();
-            dx = r.dx;
-            RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
-            if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
-            RMX_SYNC();
-            if (r.ok != 0) {
+            bool lu_ok;
+            if constexpr (NP == 64) {
+                const W2Lu r = w2_lu_call();
+                dx = r.dx;
+                lu_ok = r.ok != 0;
+                RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
+                if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+                RMX_SYNC();
+            } else {
+                static_assert(NP == 64 || (NP == 32 && LU_SPLIT32), "the sizes newton_rot solves from the staging area");
+                dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
+            }
+            if (lu_ok) {
                 piv.streak = 0;
             } else {             // growth guard tripped: redo this solve with partial pivoting (see newton_impl)
                 ++piv.streak;
@@ -353,7 +386,8 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
     const int lane = threadIdx.x;
     if constexpr (tag_w2(TAG)) {
         if (threadIdx.x >= 64) {
-            w2_helper<NP>(M, sAcc, lane - 64);
+            if constexpr (NP == 64) w2_helper<NP>(M, sAcc, lane - 64);
+            else w2c_helper<NP>(M, sAcc, lane - 64);
             return;
         }
     }
@@ -387,10 +421,11 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
 #endif
     for (int s = sfirst; s < a.nsteps; ++s) {
 #if RMX_W2
-        if constexpr (tag_w2(TAG) && !FULLCHAIN) {
-            // guarded solves of a tree: the loop that runs ahead into the next step (w2_steps_bdf1); pivoting solves and serial chains
-            // (whose residual-only front sums by another scan) keep newton_node
-            if (!M.is_chain && o.lu_mode == 0 && piv.hold == 0) {
+        if constexpr (tag_w2(TAG) && (!FULLCHAIN || NP == 32)) {
+            // guarded solves of a tree: the loop that runs ahead into the next step (w2_steps_bdf1); pivoting solves and the 64-lane serial
+            // chains (whose residual-only front sums by another scan) keep newton_node.  NP == 32: the chains of RMX_PART 6, whose helper
+            // runs the full front
+            if ((NP == 32 || !M.is_chain) && o.lu_mode == 0 && piv.hold == 0) {
                 s += w2_steps_bdf1<NP>(M, o, a, sAcc, lane, traj, id, off, s, q, qd, iters, halv, status, piv, w2_predict) - 1;
                 continue;
             }
@@ -405,7 +440,7 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
 #if RMX_W2
         // (a full tree gets here for its pivoting solves only - newton_policy's first branch: the guarded loop is w2_steps_bdf1)
         double x;
-        if constexpr (TAG == TAG_W2 && !FULLCHAIN) {
+        if constexpr (TAG == TAG_W2 && (!FULLCHAIN || NP == 32)) {
             if (piv.hold > 0) --piv.hold;
             xlo = 0.0;
             x = newton_rot<NP, true>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo);
@@ -500,7 +535,8 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf2(const DevM
     const int lane = threadIdx.x;
     if constexpr (tag_w2(TAG)) {
         if (threadIdx.x >= 64) {
-            w2_helper<NP>(M, sAcc, lane - 64);
+            if constexpr (NP == 64) w2_helper<NP>(M, sAcc, lane - 64);
+            else w2c_helper<NP>(M, sAcc, lane - 64);
             return;
         }
     }
@@ -1502,6 +1538,17 @@ void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const 
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2 + 1>), grid, block, smem_bytes, b->stream, m->dm, o, a);
 }
 
+#elif RMX_PART == 6      // full 32-link serial chains, BDF1, two wavefronts per rollout: the second one evaluates the point that may end a solve
+#if RMX_NP != 32 || !RMX_W2
+#error "RMX_PART 6 is compiled for RMX_NP = 32 with -DRMX_W2=1 and a wave-local RMX_SYNC()"
+#endif
+
+void launch_step_w2c_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(128);
+    const size_t smem_bytes = m->smem_bytes + ((sizeof(double) * W2C_HELP_DOUBLES + 15) & ~(size_t)15);      // + the helper wave's own area
+    RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
+}
+
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
 
 void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
@@ -1569,6 +1616,12 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
 #if RMX_NP == 64
     // 33..64 nodes in a batch of at most one rollout per two SIMDs: a second wavefront per rollout for the Hessian and the solve
     if (m->w2_max_batch > 0 && b->B <= m->w2_max_batch) return launch_step_w2_64(m, b, integ, o, a);
+#endif
+#if RMX_NP == 32
+    // the full 32-link chain in a shard of one rollout per two SIMDs or fewer (the 1024-rollout batch on two or more GPUs): a second
+    // wavefront per rollout evaluates the point that may end a step's solve while the first evaluates the next step's first point
+    if (m->dm.is_chain && m->dm.n == RMX_NP && integ == INTEG_BDF1 && m->w2_max_batch > 0 && b->B >= m->w2_min_batch && b->B <= m->w2_max_batch)
+        return launch_step_w2c_32(m, b, o, a);
 #endif
 #if RMX_NP >= 16 && !defined(RMX_NO_FULLCHAIN)      // (the macro: development aid, tools/build_variant.py)
     if (m->dm.is_chain && m->dm.n == RMX_NP) return RMX_CAT(launch_step_fullchain_, RMX_NP)(m, b, integ, o, a);

@@ -263,6 +263,44 @@ def test_tree64_two_wave_kernels(monkeypatch, nodes):
     monkeypatch.delenv("RMX_W2_RUNAHEAD")
 
 
+def test_chain32_two_wave_kernel(monkeypatch):
+    """Shards of 128 .. 512 rollouts of the full 32-link chain (the 1024-rollout batch of BASELINE.json configs[1] on two or more GPUs) run
+    BDF1 with a second wavefront per rollout that evaluates the point which may end a step's solve while the first one evaluates the
+    next step's first point (rmx_kernels.hip RMX_PART 6, w2_steps_bdf1).  The helper runs the full front, every decision is
+    newton_rot's: states, Newton counts, status words and histories equal the one-wave headline kernel's bit for bit, with the run-ahead
+    on and off, on the bench states and on states wild enough for line searches."""
+    from redmax_amd import BatchSim, sceneChain, syntheticStates
+    sc = sceneChain(32)
+    sc.init()
+    B, K = 128, 12
+    q, qd = syntheticStates(sc.nr, B)
+    wq, wqd = syntheticStates(sc.nr, B, sq=0.6, sv=4.0)
+
+    def run(qq, qqd, tol, w2, ahead="1"):
+        monkeypatch.setenv("RMX_W2_MAX", w2)
+        monkeypatch.setenv("RMX_W2_RUNAHEAD", ahead)
+        sim = BatchSim(sc, batch=B)
+        sim.opts.tol = tol
+        sim.set_state(qq, qqd)
+        sim.step_bdf1(2, h=1e-2)
+        out = sim.step_bdf1(K, h=1e-2, stats=True, history=True)
+        res = (sim.get_state(), out)
+        sim.close()
+        return res
+
+    for qq, qqd, tol in ((q, qd, 1e-9), (wq, wqd, 1e-6)):
+        one = run(qq, qqd, tol, "0")
+        for ahead in ("1", "0"):
+            ((qa, qda), oa), ((qb, qdb), ob) = one, run(qq, qqd, tol, "100000", ahead)
+            assert np.array_equal(qa, qb, equal_nan=True) and np.array_equal(qda, qdb, equal_nan=True), (tol, ahead)
+            for k in ("newton_iters", "ls_halvings", "status", "T", "V"):
+                assert np.array_equal(oa[k], ob[k], equal_nan=True), (tol, ahead, k)
+        if tol == 1e-6:
+            assert one[1]["ls_halvings"].sum() > 0 or (one[1]["status"] & 15).any(), "no line search ran: the wild states are too tame"
+    monkeypatch.delenv("RMX_W2_MAX")
+    monkeypatch.delenv("RMX_W2_RUNAHEAD")
+
+
 def test_max_valid_amplitude_sample(oracle_lib):
     """The headline workload at the LARGEST initial-state amplitude the reference algorithm survives (q, qdot ~ U(-0.1856, 0.1856):
     found by tools/max_valid_amplitude.py on the literal oracle, profiles/r04_max_valid_amplitude.json): 1024 rollouts x 100 BDF1
