@@ -408,6 +408,12 @@ def roofline(kernel_ms, iters_rank, halv_rank, steps_rank, K, W, B_local, n, wl,
     if wl == "chain" and n == 32:
         alg = (iters_rank * (F_H + F_LU) + (iters_rank + halv_rank) * F_G) / sec / 1e12
         out["algorithmic_equiv_tflops"] = round(alg, 2)
+        if 128 <= B_local <= 512 and os.environ.get("RMX_W2_MAX", "512") != "0":
+            # shards of 128 .. 512 rollouts run the two-wave kernel of the full 32-link chain (rmx_kernels.hip RMX_PART 6)
+            out["kernel"] = "k_step_bdf1<32, false, false, true, 16>"
+            out["kernel_note"] = ("two wavefronts per rollout: the second evaluates the point that may end a step's solve.  The executed-work "
+                                  "figures below use the one-wave kernel's per-stage counts (the same stages on the first wavefront); the second "
+                                  "wavefront's evaluations are not counted")
     af = algorithm_flops(key)
     if af is not None:
         useful = fronts * af[0] + iters_rank * af[1] + extra_useful
