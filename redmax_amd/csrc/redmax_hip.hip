@@ -914,6 +914,8 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
     {
         const char* ra = getenv("RMX_W2_RUNAHEAD");
         a.w2_noahead = (ra && atoi(ra) == 0) ? 1 : 0;
+        const char* pc = getenv("RMX_PAIRC");        // (read at every call, like the others: tests switch it inside one process)
+        a.pairc = (pc && atoi(pc) == 0) ? 0 : 1;
     }
     if (m->pair32) {
         // RMX_GROUND_FUSED: 1 (default) ONE launch for the whole call - the rollouts (free flight, then the steps with the contact terms)

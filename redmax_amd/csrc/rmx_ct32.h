@@ -66,28 +66,84 @@ __device__ __forceinline__ void chain_suffix_sum_pair(const int lane, double (&S
     }
 }
 
+// The same sums for a FULL chain of 32 nodes through the accumulation scratch, in the order of the one-point front
+// (eval_front_e2<32, true>: per component the serial suffix over nodes 31..16, the serial suffix over nodes 15..0, and the upper
+// half's total added to every lower node): each half's sums carry the bits that front produces for the same point.  Trial point
+// t = lane >> 5 owns rows [32 t, 32 t + 32) of the scratch (2 x 32 x ACC_STRIDE doubles <= acc_doubles(32, 32)); lane = node writes
+// its 28 numbers, lane = component (of its own trial point) scans the 32 nodes in registers, lane = node reads the sums back.
+template <int NS>
+__device__ __forceinline__ void chain_suffix_sum_pair_lds(double* __restrict__ sAcc, const int lane, double (&S)[NACC]) {
+    static_assert(2 * 32 * ACC_STRIDE <= acc_doubles(32, 32), "the pair scan needs two blocks of 32 accumulation rows");
+    constexpr int AS = ACC_STRIDE;
+    const int jc = lane & 31;
+    double* const blk = sAcc + (lane >> 5) * (32 * AS);
+    {
+        double* A = blk + jc * AS;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) A[c] = S[c];
+    }
+    RMX_SYNC();
+    {
+        double a[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) a[t] = blk[t * AS + jc];      // components >= NS: finite junk, never stored
+        // every read in flight before the first addition: left alone, the scheduler issues the reads two ahead of the serial chains
+        // that consume them, and the lone wavefront pays one LDS round trip per pair of nodes
+#ifndef RMX_PAIR_SCAN_NOSB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        double up = 0.0, dn = 0.0;
+#pragma unroll
+        for (int t = 15; t >= 0; --t) {                            // (two independent serial chains)
+            up += a[16 + t];
+            a[16 + t] = up;
+            dn += a[t];
+            a[t] = dn;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) a[t] += up;
+        if (jc < NS) {
+#pragma unroll
+            for (int t = 0; t < 32; ++t) blk[t * AS + jc] = a[t];
+        }
+    }
+    RMX_SYNC();
+    {
+        const double* A = blk + jc * AS;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) S[c] = A[c];
+    }
+    RMX_SYNC();
+}
+
 // The full front of two iterates of a serial chain of n <= 32 nodes.  xq, xqd, xv: the coordinates of node lane & 31 at trial point
 // lane >> 5 (zeros where the node has no DOF).  Same formulas, in the same order, as eval_front_e2<32, true, false, CT>; the subtree
 // sums by the register scan.  out / fs: per lane, i.e. for the lane's own trial point; fs.act is lane < n (what the Hessian stage,
 // which works on lanes 0..31, expects), fs.touched is left to the caller (ta / tb: some corner of the tree penetrates at a / b).
-template <bool CT>
+// LDS_SCAN (the plain full chain, rmx_pair32.h): the 28 subtree sums through the accumulation scratch in the summation order of
+// eval_front_e2<32, true> (chain_suffix_sum_pair_lds), so that each half reproduces the one-point front bit for bit.
+// TIMED (k_phase_time_pair32): s_memtime stamps per stage, numbered as eval_front_e2's.
+// REGK (rmx_pair32.h): the lane's 57 per-node constants (PAIR_NK rows: K 36, sb 6, I4 4, prm 8, type, rel 2 - the first rows of the
+// LDS table, in its order) come from the caller's registers (rk, loaded once per rollout by pair_load_consts) instead of the wave's
+// LDS copy: 54 ds_read_b64 and 27 KB of LDS traffic less per evaluation.
+constexpr int PAIR_NK = 57;
+template <bool CT, bool LDS_SCAN = false, bool TIMED = false, bool REGK = false>
 __device__ __forceinline__ void eval_front_pair(const int n, const double* __restrict__ cK, const double (&grav)[3], const int lane,
                                                 const double xq, const double xqd, const double xv, const double eta,
-                                                NodeOut& out, FrontState& fs, bool& ta, bool& tb) {
+                                                NodeOut& out, FrontState& fs, bool& ta, bool& tb, double* __restrict__ sAcc = nullptr,
+                                                unsigned long long* stamps = nullptr, const double* rk = nullptr) {
+    static_assert(!(REGK && CT), "REGK: the plain constants only");
+#define RMX_PK(row) (REGK ? rk[(row)] : cK[(row) * CS + jc])
+    unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr int NP = 32;
     constexpr int CS = cstride(NP);
     const double e2 = eta * eta;
     const int jc = lane & 31;
-    const double* cSb = cK + 36 * CS;
-    const double* cI4 = cSb + 6 * CS;
-    const double* cPrm = cI4 + 4 * CS;
-    const double* cTyp = cPrm + 8 * CS;
-    const double* cRel = cTyp + CS;
-    const double* cCon = cRel + 2 * CS + MAXROUNDS * CS + CS;
-    const int type = (int)cTyp[jc];
+    const double* cCon = cK + (36 + 6 + 4 + 8 + 1 + 2 + MAXROUNDS + 1) * CS;
+    const int type = (int)RMX_PK(54);
     const bool dof = type != 0;
-    fs.anc_m = (unsigned long long)__double_as_longlong(cRel[jc]);
-    fs.desc_m = (unsigned long long)__double_as_longlong(cRel[CS + jc]);
+    fs.anc_m = (unsigned long long)__double_as_longlong(RMX_PK(55));
+    fs.desc_m = (unsigned long long)__double_as_longlong(RMX_PK(56));
     const double q = xq, qd = xqd, v = xv;
     double u = 0.0, w = 0.0;
     if (type == 1) {
@@ -97,17 +153,19 @@ __device__ __forceinline__ void eval_front_pair(const int n, const double* __res
     }
     double R[9], p[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) R[c] = cK[c * CS + jc] + u * cK[(12 + c) * CS + jc] + w * cK[(24 + c) * CS + jc];
+    for (int c = 0; c < 9; ++c) R[c] = RMX_PK(c) + u * RMX_PK(12 + c) + w * RMX_PK(24 + c);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) p[c] = cK[(9 + c) * CS + jc] + u * cK[(21 + c) * CS + jc] + w * cK[(33 + c) * CS + jc];
+    for (int c = 0; c < 3; ++c) p[c] = RMX_PK(9 + c) + u * RMX_PK(21 + c) + w * RMX_PK(33 + c);
+    RMX_STAMP(0)
     chain_scan_transform_dual(lane, R, p);
+    RMX_STAMP(1)
     double sbw[3], sbv[3], t3[3];
     double (&sw)[3] = fs.sw;
     double (&sv)[3] = fs.sv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        sbw[c] = cSb[c * CS + jc];
-        sbv[c] = cSb[(3 + c) * CS + jc];
+        sbw[c] = RMX_PK(36 + c);
+        sbv[c] = RMX_PK(39 + c);
     }
     mat3v(R, sbw, sw);
     mat3v(R, sbv, sv);
@@ -121,7 +179,8 @@ __device__ __forceinline__ void eval_front_pair(const int n, const double* __res
         phw[c] = sw[c] * qd;
         phv[c] = sv[c] * qd;
     }
-    chain_scan_sum6_dual(phw, phv);
+    chain_scan_sum6_dual(lane, phw, phv);
+    RMX_STAMP(2)
     double (&xiw)[3] = fs.xiw;
     double (&xiv)[3] = fs.xiv;
     double (&bw)[3] = fs.bw;
@@ -136,9 +195,10 @@ __device__ __forceinline__ void eval_front_pair(const int n, const double* __res
         bw[c] = sw[c] * v + e2 * qd * xiw[c];
         bv[c] = sv[c] * v + e2 * qd * xiv[c];
     }
-    chain_scan_sum6_dual(bw, bv);
-    const double I1 = cI4[0 * CS + jc], I2 = cI4[1 * CS + jc];
-    const double I3 = cI4[2 * CS + jc], ms = cI4[3 * CS + jc];
+    chain_scan_sum6_dual(lane, bw, bv);
+    RMX_STAMP(3)
+    const double I1 = RMX_PK(42), I2 = RMX_PK(43);
+    const double I3 = RMX_PK(44), ms = RMX_PK(45);
     double mc[3], Ib[6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) mc[c] = ms * p[c];
@@ -217,10 +277,10 @@ __device__ __forceinline__ void eval_front_pair(const int n, const double* __res
             }
         }
     }
-    const double stiff = cPrm[1 * CS + jc], damp = cPrm[2 * CS + jc];
-    const double tau = cPrm[0 * CS + jc], qRest = cPrm[3 * CS + jc];
-    const double qLimL = cPrm[4 * CS + jc], qLimU = cPrm[5 * CS + jc];
-    const double qLimK = cPrm[6 * CS + jc], qLimD = cPrm[7 * CS + jc];
+    const double stiff = RMX_PK(47), damp = RMX_PK(48);
+    const double tau = RMX_PK(46), qRest = RMX_PK(49);
+    const double qLimL = RMX_PK(50), qLimU = RMX_PK(51);
+    const double qLimK = RMX_PK(52), qLimD = RMX_PK(53);
     const double hitL = (dof && q < qLimL) ? 1.0 : 0.0, hitU = (dof && q > qLimU) ? 1.0 : 0.0;
     {
         double eT = 0.5 * (dot3(phw, ht) + dot3(phv, hf));
@@ -268,7 +328,10 @@ __device__ __forceinline__ void eval_front_pair(const int n, const double* __res
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) S[25 + c] = hf[c];
-    chain_suffix_sum_pair<NACC, NACC>(lane, S);
+    RMX_STAMP(4)
+    if constexpr (LDS_SCAN) chain_suffix_sum_pair_lds<NACC>(sAcc, lane, S);
+    else chain_suffix_sum_pair<NACC, NACC>(lane, S);
+    RMX_STAMP(6)
     const double fr = (tau + fs.tau_add) + stiff * (qRest - q) - damp * qd + hitL * (qLimK * (qLimL - q) - qLimD * qd) +
                       hitU * (qLimK * (qLimU - q) - qLimD * qd);
     out.g = dof ? (dot3(sw, &S[0]) + dot3(sv, &S[3]) - e2 * fr) : 0.0;
@@ -281,7 +344,20 @@ __device__ __forceinline__ void eval_front_pair(const int n, const double* __res
     fs.dd = damp + (hitL + hitU) * qLimD;
     fs.act = lane < n;
     fs.dof = dof;
+    RMX_STAMP(8)
+#undef RMX_PK
 }
+
+// the lane's constants for eval_front_pair<..., REGK = true>: rows 0 .. PAIR_NK - 1 of the wave's LDS table, column lane & 31
+__device__ __forceinline__ void pair_load_consts(const double* __restrict__ cK, const int lane, double (&rk)[PAIR_NK]) {
+    constexpr int CS = cstride(32);
+    const int jc = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 36 + 6 + 4 + 8 + 1; ++r) rk[r] = cK[r * CS + jc];
+    rk[55] = cK[55 * CS + jc];
+    rk[56] = cK[56 * CS + jc];
+}
+
 
 // the state of trial point b (lanes 32..63) into lanes 0..31, where the Hessian stage works
 __device__ __forceinline__ void front_take_hi(FrontState& fs, NodeOut& e) {

@@ -49,6 +49,18 @@ __device__ __forceinline__ void rmx_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 #endif
+// RMX_SYNC() for a translation unit whose workgroups are ONE wavefront (-DRMX_SYNC()=rmx_lane_sync()): the LDS executes the DS
+// instructions of a wavefront in issue order, so a read that follows a write in program order sees it whatever lanes are involved -
+// what is needed is that the COMPILER keeps the order (a wavefront-scope fence: no code), not that the wavefront waits for its own
+// writes to be acknowledged (what __syncthreads() / a workgroup-scope fence compile to: s_waitcnt lgkmcnt(0), a full LDS round trip
+// at every hand-over; the waits a read's RESULT needs are the register dependencies the compiler tracks anyway).
+__device__ __forceinline__ void rmx_lane_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifndef RMX_LANE_SYNC_NO_WB
+    __builtin_amdgcn_wave_barrier();
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // RMX_GLOBAL_CONSTS (a translation unit compiled with it, rmx_kernels.hip RMX_PART 3): the per-node constants are NOT staged in LDS
 // but read from a table in global memory (DevModel::gconst, same [row][node] layout, L2-resident and shared by the whole batch).
 // A 64-lane tree needs 33.8 KB of scratch (H for the block-column solve) plus 34.8 KB of constants per wavefront: two wavefronts
@@ -1233,14 +1245,16 @@ __device__ __forceinline__ void eval_front(const DevModel& M, double* __restrict
 // 20 trials (or accepts 2^-13 of the step) on every one of the 320 iterations of a step, ~4300 trial evaluations for one step of one
 // rollout, and the launch of the whole batch waits for it.
 //
-// lane 15 of every 16-lane row -> all lanes of the NEXT row, rows 1 and 3 only (row_mask 0xA); the other rows receive 0
-__device__ __forceinline__ double dpp_bcast15_odd_rows(const double v) {
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xA, 0xF, false);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xA, 0xF, false);
+// lane 15 of every 16-lane row -> all lanes of the NEXT row; row 0 receives 0 (bound_ctrl).  No row mask: the destination needs no
+// pre-loaded fill value (two v_mov per double in the masked form); rows 0 and 2 receive what their callers ignore - a 0 / the other
+// chain's finite total under a 0 weight, or operands of a composition only rows 1 and 3 perform
+__device__ __forceinline__ double dpp_bcast15_rows(const double v) {
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xF, 0xF, true);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 // inclusive prefix sums along the chain, two chains of 32 nodes side by side (lanes 0..31 and 32..63)
-__device__ __forceinline__ void chain_scan_sum6_dual(double (&a)[3], double (&b)[3]) {
+__device__ __forceinline__ void chain_scan_sum6_dual(const int lane, double (&a)[3], double (&b)[3]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { a[c] += dpp_shr0<1>(a[c]); b[c] += dpp_shr0<1>(b[c]); }
 #pragma unroll
@@ -1249,10 +1263,13 @@ __device__ __forceinline__ void chain_scan_sum6_dual(double (&a)[3], double (&b)
     for (int c = 0; c < 3; ++c) { a[c] += dpp_shr0<4>(a[c]); b[c] += dpp_shr0<4>(b[c]); }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { a[c] += dpp_shr0<8>(a[c]); b[c] += dpp_shr0<8>(b[c]); }
+    // rows 1 and 3 add the complete total of lane 15 / 47: one FMA with a 0/1 lane weight (exact: 1 t + a, 0 t + a), as
+    // chain_scan_sum6 hands its row totals over
+    const double w = (lane & 16) ? 1.0 : 0.0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {      // rows 1 and 3 add the complete total of lane 15 / 47
-        a[c] += dpp_bcast15_odd_rows(a[c]);
-        b[c] += dpp_bcast15_odd_rows(b[c]);
+    for (int c = 0; c < 3; ++c) {
+        a[c] = fma(w, dpp_bcast15_rows(a[c]), a[c]);
+        b[c] = fma(w, dpp_bcast15_rows(b[c]), b[c]);
     }
 }
 __device__ __forceinline__ void chain_scan_transform_dual(const int lane, double (&R)[9], double (&p)[3]) {
@@ -1262,9 +1279,9 @@ __device__ __forceinline__ void chain_scan_transform_dual(const int lane, double
     chain_compose_step<8>(lane, R, p);
     double Ra[9], pa[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) Ra[c] = dpp_bcast15_odd_rows(R[c]);
+    for (int c = 0; c < 9; ++c) Ra[c] = dpp_bcast15_rows(R[c]);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) pa[c] = dpp_bcast15_odd_rows(p[c]);
+    for (int c = 0; c < 3; ++c) pa[c] = dpp_bcast15_rows(p[c]);
     if (lane & 16) {
         double Rn[9], pn[3];
 #pragma unroll
@@ -1364,7 +1381,7 @@ RMX_DUAL_FN double eval_front_dual(const double* __restrict__ cK, const Grav3 gr
         phw[c] = sw[c] * qd;
         phv[c] = sv[c] * qd;
     }
-    chain_scan_sum6_dual(phw, phv);
+    chain_scan_sum6_dual(lane, phw, phv);
     double xiw[3], xiv[3], bw[3], bv[3];
     cross3(phw, sw, xiw);
     cross3(phv, sw, xiv);
@@ -1376,7 +1393,7 @@ RMX_DUAL_FN double eval_front_dual(const double* __restrict__ cK, const Grav3 gr
         bw[c] = sw[c] * v + e2 * qd * xiw[c];
         bv[c] = sv[c] * v + e2 * qd * xiv[c];
     }
-    chain_scan_sum6_dual(bw, bv);
+    chain_scan_sum6_dual(lane, bw, bv);
     const double I1 = cI4[0 * CS + jc], I2 = cI4[1 * CS + jc];
     const double I3 = cI4[2 * CS + jc], ms = cI4[3 * CS + jc];
     double mc[3], Ib[6];
@@ -1942,9 +1959,14 @@ __device__ __forceinline__ void hess_columns_dpp(const double (&cv)[NCV], const 
     }
 }
 
-template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true>
+// PRIMSEL (n <= 32, the pair front of rmx_pair32.h: lanes 0..31 and 32..63 hold the state of two different points, node = lane & 31):
+// the half-wave `prim` stages its operands and right-hand side; everything after the staging is the same code.
+template <int NP, bool TIMED = false, bool CT = false, bool ZERO_IDLE = true, bool PRIMSEL = false>
 __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, const FrontState& fs, double (&Hrow)[NP],
-                                          unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0) {
+                                          unsigned long long* stamps = nullptr, double* __restrict__ sAcc = nullptr, const double g_stage = 0.0,
+                                          const int prim = 0) {
+    static_assert(!PRIMSEL || (NP == 32 && HESS_MFMA && !CT), "PRIMSEL: the plain matrix-core Hessian of n <= 32");
+    (void)prim;
     unsigned long long last_ = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr int CS = cstride(NP);
     const double eta = fs.eta, e2 = eta * eta;
@@ -2139,8 +2161,14 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
         constexpr int R_RU = 0, R_RL = 8, R_CU = 8 + KL, R_CL = 16 + KL, R_HD = 16 + 2 * KL;   // operand rows in LDS
         static_assert(R_HD + 1 <= HM_ROWS, "operand rows");
         double* sOp = sAcc;
-        if (lane < NP) {
-            double* o = sOp + lane;
+        bool stage = lane < NP;          // the lanes that hold the nodes' state ...
+        int nd = lane;                   // ... and their node
+        if constexpr (PRIMSEL) {
+            stage = (lane >> 5) == prim;
+            nd = lane & 31;
+        }
+        if (stage) {
+            double* o = sOp + nd;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 o[(R_RU + c) * HM_OP_STRIDE] = sw[c];
@@ -2257,7 +2285,7 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
                 for (int r = 0; r < 4; ++r) sOp[(16 * mb + 4 * r + g) * HM_H_STRIDE + 16 * nb + j] = hv[mb][nb][r];
         // the right-hand side of the solve travels with its row (column 32 of the staging rows is spare)
         if constexpr (!ZERO_IDLE && LU_SPLIT32)
-            if (lane < NP) sOp[lane * HM_H_STRIDE + 32] = -g_stage;
+            if (stage) sOp[nd * HM_H_STRIDE + 32] = -g_stage;
         RMX_SYNC();
         // guarded diagonal solve of n <= 32 (lu_solve_neg_diag32): it reads H out of the staging area in its own layout and
         // hands sAcc back to the front itself

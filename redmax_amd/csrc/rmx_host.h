@@ -42,6 +42,7 @@ struct StepArgs {
     int fused;        // the whole call in one launch (rmx_kernels.hip k_ground32): rollouts and cooperative groups side by side
     unsigned long long* xrec;   // [ngroups][2 COOP_REC] what the winner of a line search publishes to its group (rmx_ct32.h CoopPub; zero before the launch)
     int w2_noahead;   // two-wave tree kernels (rmx_kernels.hip w2_steps_bdf1): 1 = no evaluation is run ahead (RMX_W2_RUNAHEAD=0; tests)
+    int pairc;        // the full 32-link chain under BDF1: 1 = the two-point kernel of rmx_pair32.h (default), 0 = the one-point kernel (RMX_PAIRC=0; tests)
 };
 
 struct AdjArgs {
@@ -141,6 +142,9 @@ void launch_step_gconst_64(const rmx_model* m, const rmx_batch* b, int integ, co
 void launch_step_fulln_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a);
 void launch_step_w2c_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a);
+// rmx_kernels.hip RMX_PART 7: the full 32-link chain, BDF1, two points per evaluation (rmx_pair32.h)
+void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a);
+void launch_phase_pairchain_32(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d);
 // rmx_kernels.hip RMX_PART 4 (32 lanes): serial chains with ground contact - the launch with the contact terms around newton_pair
 // (rmx_ct32.h) and the cooperative launch that finishes the rollouts it parked
 void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a, bool fused);

@@ -1097,8 +1097,9 @@ __global__ void __launch_bounds__(64) k_energy(const DevModel M, const int B, co
     }
 }
 
-// Profiling hook: shader-clock cycles (s_memtime) of the phases of one Newton iteration, measured in place with the
-// production device functions at the production occupancy (one wavefront per trajectory).
+// Profiling hook: shader-clock cycles (s_memtime) of the phases of one Newton iteration with the GENERIC device functions (eval_node,
+// the pivoting solve / the 64-row guarded solve) at the production occupancy (one wavefront per trajectory).  The full 32-link chain
+// is timed by k_phase_time_pair32 instead (the functions its step kernel runs).
 template <int NP>
 __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int reps, const double* __restrict__ q,
                                                    const double* __restrict__ qd, const double h, unsigned long long* __restrict__ out) {
@@ -1549,6 +1550,115 @@ void launch_step_w2c_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o
     RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
 }
 
+#elif RMX_PART == 7      // the full 32-link serial chain, BDF1: two points per evaluation of the front (rmx_pair32.h)
+#if RMX_NP != 32
+#error "RMX_PART 7 is compiled for RMX_NP = 32"
+#endif
+#include "rmx_pair32.h"
+
+__global__ void __launch_bounds__(64) k_step_bdf1_pair32(const DevModel Min, const DevOpts o, const StepArgs a) {
+    constexpr int NP = 32;
+    const DevModel M = model_view<NP, true>(Min);
+    const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
+    const int traj = blockIdx.x;
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x;
+    const int id = M.idx[lane & 31];             // both half-waves hold the chain: node = lane & 31
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    double q = id >= 0 ? a.q[off] : 0.0;
+    double qd = id >= 0 ? a.qd[off] : 0.0;
+    int iters = 0, halv = 0, status = 0;
+    PivotPolicy piv;
+    pair_rollout_bdf1(M, o, a, sAcc, lane, traj, id, off, q, qd, iters, halv, status, piv);
+    if (id >= 0 && lane < 32) {
+        a.q[off] = q;
+        a.qd[off] = qd;
+    }
+    if (lane == 0 && a.it) {
+        a.it[traj] += iters;
+        a.ls[traj] += halv;
+        a.status[traj] |= status;
+    }
+    if (lane == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;
+}
+
+// Profiling hook (rmx_profile_phases) for the full 32-link chain: shader-clock cycles of the stages of one Newton iteration of the
+// kernel above, measured in place with ITS device functions (the pair front with the LDS scan, the matrix-core Hessian stage staged
+// from a half-wave, the guarded column-split solve) at the production occupancy.  out[16 traj + ..]: 0 one front, 1 front + Hessian
+// stage, 2 solve, 3 the loop's own arithmetic (the two points, both norms, the compensated update); 4.. stamps inside the front and the
+// Hessian stage (numbered as eval_front_e2 / eval_hess number them).
+__global__ void __launch_bounds__(64) k_phase_time_pair32(const DevModel Min, const int reps, const double* __restrict__ q,
+                                                          const double* __restrict__ qd, const double h, unsigned long long* __restrict__ out) {
+    constexpr int NP = 32;
+    const DevModel M = model_view<NP, true>(Min);
+    double *sAcc, *sCol;
+    smem_setup<NP>(M, sAcc, sCol);
+    const int lane = threadIdx.x, traj = blockIdx.x;
+    const int id = M.idx[lane & 31];
+    const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
+    const double q0 = id >= 0 ? q[off] : 0.0, qd0 = id >= 0 ? qd[off] : 0.0;
+    const double* cK = RMX_CONSTS(sAcc, M.n, NP);
+    const double grav[3] = {M.grav[0], M.grav[1], M.grav[2]};
+    double x = fma(h, qd0, q0), lo = 0.0;
+    const double qB = x;
+    unsigned long long tg = 0, tH = 0, tLU = 0, tred = 0;
+    unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double sink = 0.0;
+    int prim = 0;
+    for (int r = 0; r < reps; ++r) {
+        NodeOut e;
+        FrontState fs;
+        bool ta, tb;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const double qdn = ((x - q0) + lo) / h;
+        const double xn = fma(h, qdn, x);
+        const bool isQ = (lane >> 5) != prim;
+        const double xe = isQ ? xn : x;
+        const double xqd = isQ ? ((xn - x) + 0.0) / h : qdn;
+        const double xv = isQ ? ((xn - xn) + 0.0) : ((x - qB) + lo);
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        eval_front_pair<false, true>(M.n, cK, grav, lane, xe, xqd, xv, h, e, fs, ta, tb, sAcc);
+        sink += e.g;
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        eval_front_pair<false, true, true>(M.n, cK, grav, lane, xe, xqd, xv, h, e, fs, ta, tb, sAcc, stamps);
+        double Hdummy[NP];
+        (void)eval_hess<NP, true, false, false, true>(M, lane, fs, Hdummy, stamps, sAcc, e.g, prim);
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        bool lu_ok;
+        double dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
+        sink += lu_ok ? 0.0 : 1.0;
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        dx = dup_lo(dx);
+        double ga2, gb2;
+        wave_sum_dual(e.g * e.g, ga2, gb2);
+        const double dxn2 = wave_sum_np<NP>(dx * dx);
+        sink += (prim ? gb2 : ga2) + dxn2;
+        double xs, ls;
+        two_sum(x, fma(1e-3, dx, lo), xs, ls);      // keep the iterations data dependent
+        x = xs;
+        lo = ls;
+        prim ^= 1;
+        const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+        tg += t2 - t1; tH += t3 - t2; tLU += t4 - t3; tred += (t1 - t0) + (t5 - t4);
+    }
+    if (lane == 0) {
+        out[16 * traj + 0] = tg; out[16 * traj + 1] = tH; out[16 * traj + 2] = tLU; out[16 * traj + 3] = tred;
+        for (int k = 0; k < 12; ++k) out[16 * traj + 4 + k] = stamps[k];
+    }
+    if (sink == 1.2345e301) out[0] = 0;   // keep the results live
+}
+
+void launch_phase_pairchain_32(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d) {
+    const dim3 grid(b->B), block(64);
+    RMX_LAUNCH(k_phase_time_pair32, grid, block, m->smem_bytes, b->stream, m->dm, reps, b->q, b->qd, h, d);
+}
+
+void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
+    const dim3 grid(b->B), block(64);
+    RMX_LAUNCH(k_step_bdf1_pair32, grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+}
+
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
 
 void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
@@ -1618,6 +1728,9 @@ void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     if (m->w2_max_batch > 0 && b->B <= m->w2_max_batch) return launch_step_w2_64(m, b, integ, o, a);
 #endif
 #if RMX_NP == 32
+    // the full 32-link chain under BDF1 (BASELINE.json configs[1]): two points per evaluation, the second one the next step's first
+    // (rmx_pair32.h; bit-identical to the one-point kernels below, which RMX_PAIRC=0 keeps reachable)
+    if (m->dm.is_chain && m->dm.n == RMX_NP && integ == INTEG_BDF1 && a.pairc) return launch_step_pairchain_32(m, b, o, a);
     // the full 32-link chain in a shard of one rollout per two SIMDs or fewer (the 1024-rollout batch on two or more GPUs): a second
     // wavefront per rollout evaluates the point that may end a step's solve while the first evaluates the next step's first point
     if (m->dm.is_chain && m->dm.n == RMX_NP && integ == INTEG_BDF1 && m->w2_max_batch > 0 && b->B >= m->w2_min_batch && b->B <= m->w2_max_batch)
@@ -1674,6 +1787,10 @@ void launch_stage_consts_64(const rmx_model* m, double* dst, hipStream_t stream)
 
 void RMX_CAT(launch_phase_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d) {
     const dim3 grid(b->B), block(64);
+#if RMX_NP == 32
+    // the full 32-link chain: the stages of the kernel that runs it (RMX_PART 7); everything else: the generic device functions below
+    if (m->dm.is_chain && m->dm.n == RMX_NP && !m->dm.con && !m->dm.nsph) return launch_phase_pairchain_32(m, b, reps, h, d);
+#endif
     RMX_LAUNCH((k_phase_time<RMX_NP>), grid, block, m->smem_bytes, b->stream, m->dm, reps, b->q, b->qd, h, d);
 }
 

@@ -301,6 +301,45 @@ def test_chain32_two_wave_kernel(monkeypatch):
     monkeypatch.delenv("RMX_W2_RUNAHEAD")
 
 
+def test_chain32_pair_kernel(monkeypatch):
+    """The headline kernel (rmx_pair32.h, RMX_PART 7): every evaluation of the front carries the next step's first point beside the
+    line-search trial, in the half-wave a 32-node tree leaves idle; a trial that ends a step's solve hands the next solve its first
+    evaluation.  Every decision and every operation per point is the one-point kernel's (RMX_PAIRC=0): states, Newton counts, halvings,
+    status words and per-step energies must be equal bit for bit - on the bench states at the reference's tol, on states wild enough for
+    line searches and diverging rollouts, with the pivoting solve (lu_mode 1), on plain doubles (compensated 0),
+    and for a single step and a single rollout."""
+    from redmax_amd import BatchSim, sceneChain, syntheticStates
+    sc = sceneChain(32)
+    sc.init()
+    monkeypatch.setenv("RMX_W2_MAX", "0")
+
+    def run(pair, B, K, tol=1e-9, wild=False, lu_mode=0, comp=1):
+        monkeypatch.setenv("RMX_PAIRC", pair)
+        q, qd = syntheticStates(sc.nr, B, sq=0.6, sv=4.0) if wild else syntheticStates(sc.nr, B)
+        sim = BatchSim(sc, batch=B)
+        sim.opts.tol = tol
+        sim.opts.lu_mode = lu_mode
+        sim.opts.compensated = comp
+        sim.set_state(q, qd)
+        sim.step_bdf1(2, h=1e-2)
+        out = sim.step_bdf1(K, h=1e-2, stats=True, history=True)
+        res = (sim.get_state(), out)
+        sim.close()
+        return res
+
+    cases = (dict(B=128, K=12), dict(B=128, K=12, tol=1e-6, wild=True), dict(B=64, K=6, lu_mode=1), dict(B=64, K=8, comp=0),
+             dict(B=64, K=6, tol=1e-6, wild=True, lu_mode=1), dict(B=1, K=1), dict(B=3, K=2))
+    for kw in cases:
+        ((qa, qda), oa), ((qb, qdb), ob) = run("0", **kw), run("1", **kw)
+        assert np.array_equal(qa, qb, equal_nan=True) and np.array_equal(qda, qdb, equal_nan=True), kw
+        for k in ("newton_iters", "ls_halvings", "status", "T", "V"):
+            assert np.array_equal(oa[k], ob[k], equal_nan=True), (kw, k)
+        if kw.get("wild") and not kw.get("lu_mode"):
+            assert oa["ls_halvings"].sum() > 0 or (oa["status"] & 15).any(), "no line search ran: the wild states are too tame"
+    monkeypatch.delenv("RMX_PAIRC")
+    monkeypatch.delenv("RMX_W2_MAX")
+
+
 def test_max_valid_amplitude_sample(oracle_lib):
     """The headline workload at the LARGEST initial-state amplitude the reference algorithm survives (q, qdot ~ U(-0.1856, 0.1856):
     found by tools/max_valid_amplitude.py on the literal oracle, profiles/r04_max_valid_amplitude.json): 1024 rollouts x 100 BDF1

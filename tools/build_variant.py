@@ -36,6 +36,8 @@ def main():
     os.makedirs(vdir, exist_ok=True)
     obj = os.path.join(vdir, "%s.o" % a.name)
     part_flags = {3: ["-DRMX_GLOBAL_CONSTS"], 6: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()", "-DRMX_CONSTS(sAcc,n,NP)=(rmx_smem_base()+acc_doubles((n),(NP)))"], 5: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()", "-DRMX_CONSTS(sAcc,n,NP)=(rmx_smem_base()+acc_doubles((n),(NP)))"]}.get(a.part, [])
+    if a.part == 7 and not any(x.startswith("-DRMX_SYNC") for x in extra):
+        part_flags = ["-DRMX_SYNC()=rmx_lane_sync()"]      # (the in-tree default of that part, __graft_entry__._build_hip)
     tu = ["-DRMX_NP=%d" % a.np, "-DRMX_PART=%d" % a.part] + part_flags + [ge.HIP_KERNEL_SRC]
     procs = [subprocess.Popen([hipcc] + flags + ilp + extra + ["-c", "-o", obj] + tu)]
     if a.asm:
@@ -50,7 +52,7 @@ def main():
             if part == 2 and n < 16:
                 continue
             objs.append(obj if (n == a.np and part == a.part) else os.path.join(ge.OBJ_DIR, "rmx_kernels_np%d_p%d.o" % (n, part)))
-    for n, part in ((64, 3), (32, 4), (64, 5), (32, 6)):      # the one-size parts
+    for n, part in ((64, 3), (32, 4), (64, 5), (32, 6), (32, 7)):      # the one-size parts
         objs.append(obj if (n == a.np and part == a.part) else os.path.join(ge.OBJ_DIR, "rmx_kernels_np%d_p%d.o" % (n, part)))
     out = os.path.join(ROOT, "redmax_amd", "variants", "libredmax_hip_%s.so" % a.name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs)
