@@ -215,6 +215,10 @@ class GpuStepper:
         """s_memtime ticks every rollout's wavefront spent in the last launch (the launch ends with its slowest rollout)."""
         return self.sim.step_ticks()
 
+    def step_kernel(self):
+        """label of the step kernel the library chose for the last launch (rmx_last_step_kernel)"""
+        return self.sim.last_step_kernel()
+
     def state_tensors(self, torch, on_device):
         """(q, qdot) of this rank as torch tensors for the gather: device tensors (RCCL) or host tensors (gloo)."""
         if on_device:
@@ -351,6 +355,7 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
         "gathered_rows": int(gathered[0].shape[0]) if gathered is not None else shard.count,
         "local_iters": s["newton_iters"].copy(),
         "burned": burned,
+        "step_kernel": st.step_kernel() if hasattr(st, "step_kernel") else None,
     }
     if hasattr(st, "rollout_ticks"):      # how the launch time is spread over this rank's rollouts (all run concurrently, one wavefront each)
         tk = st.rollout_ticks().astype(np.float64)
@@ -387,7 +392,8 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
     return out
 
 
-def roofline(kernel_ms, iters_rank, halv_rank, steps_rank, K, W, B_local, n, wl, tol, local_iters=None, fronts=None, extra_useful=0.0):
+def roofline(kernel_ms, iters_rank, halv_rank, steps_rank, K, W, B_local, n, wl, tol, local_iters=None, fronts=None, extra_useful=0.0,
+             step_kernel=None):
     """Executed-work roofline of one rank's timed launch (rank 0's counters stand for all: identical work distribution by
     construction).  bound = "valu-issue": every step kernel of this library runs one wavefront per SIMD (or per rollout) through
     a sequential Newton chain, so what bounds it is the issue rate of a lone wavefront against the fp64 peak - not HBM (the state
@@ -398,25 +404,33 @@ def roofline(kernel_ms, iters_rank, halv_rank, steps_rank, K, W, B_local, n, wl,
         return None
     key = workload_key(wl, n, B_local)
     ent, stale = load_calibration(key)
+    alg_fronts = fronts
     if fronts is None:
-        fronts = steps_rank + iters_rank + halv_rank          # one per step (initial guess) + one per line-search trial
+        alg_fronts = fronts = steps_rank + iters_rank + halv_rank          # one per step (initial guess) + one per line-search trial
+        if step_kernel == "k_step_bdf1_pair32":
+            # the two-point kernel (rmx_pair32.h): the EXECUTED evaluations of the front are the line-search trials plus the first evaluation
+            # of each rollout's launch - every later step's first point rides in the idle half-wave of the trial that ends the step before
+            # it (the rare solves that end on a stall / a diverged update re-evaluate: not counted).  The algorithm's evaluations
+            # (useful_frac) stay one per step + one per trial: the riding point IS that evaluation.
+            fronts = iters_rank + halv_rank + B_local
     sec = kernel_ms * 1e-3
     out = {"bound": "valu-issue", "achieved": None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "useful_frac": None, "traffic": None,
            "kernel": ", ".join(k.split("(")[0].replace("void ", "") for k in ent["kernels"]) if ent else None, "kernel_ms": round(kernel_ms, 4),
            "newton_iters_per_step": round(iters_rank / max(steps_rank, 1), 3), "ls_halvings_per_step": round(halv_rank / max(steps_rank, 1), 4),
            "front_evals": fronts, "newton_iters": iters_rank}
+    if step_kernel:
+        out["kernel"] = step_kernel      # what the library says it launched (rmx_last_step_kernel), not a guess from batch thresholds
+        if ent and not any(step_kernel.split("<")[0] in k for k in ent["kernels"]):
+            stale = "calibrated on %s, the library launched %s" % (", ".join(ent["kernels"]), step_kernel)
     if wl == "chain" and n == 32:
         alg = (iters_rank * (F_H + F_LU) + (iters_rank + halv_rank) * F_G) / sec / 1e12
         out["algorithmic_equiv_tflops"] = round(alg, 2)
-        if 128 <= B_local <= 512 and os.environ.get("RMX_W2_MAX", "512") != "0":
-            # shards of 128 .. 512 rollouts run the two-wave kernel of the full 32-link chain (rmx_kernels.hip RMX_PART 6)
-            out["kernel"] = "k_step_bdf1<32, false, false, true, 16>"
-            out["kernel_note"] = ("two wavefronts per rollout: the second evaluates the point that may end a step's solve.  The executed-work "
-                                  "figures below use the one-wave kernel's per-stage counts (the same stages on the first wavefront); the second "
-                                  "wavefront's evaluations are not counted")
+        if fronts != alg_fronts:
+            out["front_evals_note"] = ("front_evals = EXECUTED evaluations (each carries two points: the trial and the next step's first point); the "
+                                       "algorithm's %d evaluations (one per step + one per trial) price useful_frac" % int(alg_fronts))
     af = algorithm_flops(key)
     if af is not None:
-        useful = fronts * af[0] + iters_rank * af[1] + extra_useful
+        useful = alg_fronts * af[0] + iters_rank * af[1] + extra_useful
         out["useful_tflops"] = round(useful / sec / 1e12, 3)
         out["useful_frac"] = round(useful / sec / 1e12 / FP64_PEAK_TFLOPS, 4)
         out["useful_note"] = ("flops the ALGORITHM needs (scalar CPU twin compiled with a counting double, tests/flop_count.py -> "
@@ -433,8 +447,10 @@ def roofline(kernel_ms, iters_rank, halv_rank, steps_rank, K, W, B_local, n, wl,
     if same:
         flops, valu, how = ent["launch"]["flops"], ent["launch"]["SQ_INSTS_VALU"], "counter totals of this very launch (same signature, same Newton iteration count: the workload is deterministic)"
     elif ex:
-        flops = fronts * ex["flops"]["front"] + iters_rank * ex["flops"]["newton"]
-        valu = fronts * ex["SQ_INSTS_VALU"]["front"] + iters_rank * ex["SQ_INSTS_VALU"]["newton"]
+        # (two-point kernel: NEWTON is a whole iteration including its one front, FRONT prices the evaluations beyond one per iteration)
+        xf = fronts - iters_rank if ent.get("per_wave_basis") == "fronts_beyond_iters" else fronts
+        flops = xf * ex["flops"]["front"] + iters_rank * ex["flops"]["newton"]
+        valu = xf * ex["SQ_INSTS_VALU"]["front"] + iters_rank * ex["SQ_INSTS_VALU"]["newton"]
         how = "per-stage counts (front evaluation / Newton iteration, fitted on two counter passes) x the counts of this launch"
     else:
         scale = iters_rank / max(ent.get("newton_iters") or 1, 1)
@@ -464,7 +480,11 @@ def roofline(kernel_ms, iters_rank, halv_rank, steps_rank, K, W, B_local, n, wl,
                 "measured with HIP events on the kernel's stream; peak = 78.6 TF (fp64 vector = fp64 matrix on MI355X); bound = issue rate of a lone "
                 "wavefront, not a pipe.  useful_frac prices the same launch with the scalar algorithm's flops",
     })
-    if ex:
+    if ex and ent.get("per_wave_basis") == "fronts_beyond_iters":
+        out.update({"executed_flops_per_newton_iter_incl_front": round(ex["flops"]["newton"], 1),
+                    "valu_insts_per_newton_iter_incl_front": round(ex["SQ_INSTS_VALU"]["newton"], 1),
+                    "valu_insts_per_extra_front_eval": round(ex["SQ_INSTS_VALU"]["front"], 1)})
+    elif ex:
         out.update({"executed_flops_per_front_eval": round(ex["flops"]["front"], 1), "executed_flops_per_newton_iter": round(ex["flops"]["newton"], 1),
                     "valu_insts_per_front_eval": round(ex["SQ_INSTS_VALU"]["front"], 1),
                     "valu_insts_per_newton_iter_beyond_its_front": round(ex["SQ_INSTS_VALU"]["newton"], 1)})
@@ -559,7 +579,8 @@ def rank_main(args, make_stepper=None, backend=None):
                            "; ranks share a device, so the gather runs on gloo with host tensors" if (on_gpu and shared) else ""),
                        "steps_per_launch": K, "untimed_burn_in": {"ms": burn, "launches": m.get("burned", 0)}, "not_converged_trajectories": m["bad"], "trajectories_with_pivoted_fallback": m["pivoted"],
                        "all_finite": m["finite"], "gathered_rows": m["gathered_rows"]},
-            "roofline": roofline(m["kernel_ms"], m["iters"] / world, m["halvings"] / world, B * K, K, W, B, n, wl, args.tol, m["local_iters"]) if on_gpu else None,
+            "roofline": roofline(m["kernel_ms"], m["iters"] / world, m["halvings"] / world, B * K, K, W, B, n, wl, args.tol, m["local_iters"],
+                                 step_kernel=m.get("step_kernel")) if on_gpu else None,
         }
         if "repeat" in m:
             out["repeat"] = m["repeat"]

@@ -17,6 +17,10 @@ extern "C" {
 /* Timing hook for benchmarks: milliseconds spent in the kernels of the last rmx_step_* call, measured
  * with hipEvents on the batch's own stream. */
 double rmx_last_step_ms(const rmx_batch* b);
+/* The step kernel the last rmx_step_* call of this batch launched, as a short label ("k_step_bdf1_pair32", "k_step_bdf1<32,fullchain>",
+ * "k_step_bdf1<64,w2>", "k_ground32", "k_big_step", ...): which of the size / batch / environment dependent variants the library chose.
+ * A static string (never null; "" before the first step call).  What bench.py labels its roofline object with. */
+const char* rmx_last_step_kernel(const rmx_batch* b);
 /* Profiling hook: mean shader-clock cycles per wavefront of {residual evaluation, residual+Hessian evaluation,
  * LU solve, the two norm reductions} of one Newton iteration at the current state (reps repetitions per trajectory)
  * in cycles16[0..3]; cycles16[4..15] split the residual+Hessian evaluation into its 12 stages (rmx_device.h RMX_STAMP). */

@@ -24,7 +24,7 @@ SYMBOLS = (
     "rmx_batch_create", "rmx_batch_destroy", "rmx_batch_size",
     "rmx_set_state", "rmx_get_state", "rmx_set_state_device", "rmx_get_state_device",
     "rmx_eval", "rmx_eval_mfd", "rmx_compute_values", "rmx_step_bdf1", "rmx_step_bdf2", "rmx_step_history", "rmx_step_euler", "rmx_adjoint_bdf1", "rmx_adjoint_bdf2", "rmx_adjoint_bdf1_device", "rmx_adjoint_bdf2_device", "rmx_energy",
-    "rmx_last_step_ms", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_step_bdf2_async", "rmx_step_history_async", "rmx_sync",
+    "rmx_last_step_ms", "rmx_last_step_kernel", "rmx_batch_stream", "rmx_step_bdf1_async", "rmx_step_bdf2_async", "rmx_step_history_async", "rmx_sync",
     "rmx_history_read", "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases", "rmx_step_ticks",
     "rmx_group_create", "rmx_group_destroy", "rmx_group_batch_size", "rmx_group_nshards", "rmx_group_shard", "rmx_group_shard_batch",
     "rmx_group_shard_model", "rmx_group_set_state", "rmx_group_get_state", "rmx_group_step", "rmx_group_step_async", "rmx_group_sync",
@@ -122,6 +122,8 @@ def lib():
     L.rmx_energy.argtypes = [vp, _dp, _dp]
     L.rmx_last_step_ms.argtypes = [vp]
     L.rmx_last_step_ms.restype = C.c_double
+    L.rmx_last_step_kernel.argtypes = [vp]
+    L.rmx_last_step_kernel.restype = C.c_char_p
     L.rmx_batch_stream.argtypes = [vp]
     L.rmx_batch_stream.restype = vp
     L.rmx_step_bdf1_async.argtypes = [vp, C.POINTER(Opts), C.c_int]

@@ -252,6 +252,11 @@ class BatchSim:
     def adjoint_bdf2_device(self, nsteps, h, task, p_ptr, P_ptr, dPdp_ptr, stats=False):
         return self.adjoint_bdf1_device(nsteps, h, task, p_ptr, P_ptr, dPdp_ptr, stats=stats, _fn="rmx_adjoint_bdf2_device")
 
+    def last_step_kernel(self):
+        """Label of the step kernel the last step call launched (rmx_last_step_kernel): which size / batch / environment dependent
+        variant the library chose."""
+        return self._L.rmx_last_step_kernel(self._batch).decode()
+
     def step_ticks(self):
         """Shader-clock ticks each rollout's wavefront spent in the kernel(s) of the last step call (rmx_step_ticks): [B] uint64."""
         t = np.zeros(self.B, dtype=np.uint64)

@@ -1871,6 +1871,7 @@ static void big_step_launch(const rmx_model* m, const rmx_batch* b, const DevOpt
     k_big_step<INTEG, HL, CT><<<dim3(b->B), dim3(BT), lds, b->stream>>>(m->dm, o, a, b->bigws, b->bigws_stride);
 }
 void launch_big_step(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
+    b->last_kernel = "k_big_step";
     const bool hl = big_hl(m), ct = m->dm.con != nullptr, b1 = integ == INTEG_BDF1;
     const size_t lds = big_dyn_lds(m, hl);
     if (ct) {

@@ -103,6 +103,7 @@ struct rmx_batch {
     void* adjws = nullptr;          // rmx_adjoint_*: H, M, D of every step and rollout, dP/dq, P, dP/dp - one allocation that is kept
     size_t adjws_bytes = 0;         // between calls and only ever grows (hipMalloc + hipFree of 3 x 20 MB cost more than the kernels)
     double last_ms = 0.0;
+    mutable const char* last_kernel = "";   // label of the step kernel the last step call launched (rmx_last_step_kernel; set by the launchers)
     bool async_pending = false;     // an rmx_step_*_async launch nobody has waited for yet (see pending_error_check)
     // per-step record of the last step call (Scene.saveHistory): device buffers, kept until the next step call so that an
     // asynchronous launch can be read back after rmx_sync (rmx_history_read)

@@ -1156,6 +1156,8 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
 // More than 64 KiB of dynamic LDS (trees of 33..64 nodes: 34 KiB of per-node constants + H row-major for the block-column solve)
 // is an opt-in per kernel and device; it costs microseconds, so it is set at every launch rather than cached (a process may
 // drive several devices from several threads).
+#define RMX_STR_(x) #x
+#define RMX_STR(x) RMX_STR_(x)
 #define RMX_LAUNCH(kernel, grid, block, bytes, stream, ...)                                                                         \
     do {                                                                                                                            \
         if ((bytes) > 64 * 1024)                                                                                                    \
@@ -1170,6 +1172,7 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
 
 void RMX_CAT(launch_step_gconst_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+    b->last_kernel = integ == INTEG_BDF1 ? "k_step_bdf1<64,gconst>" : "k_step_bdf2<64,gconst>";
     const size_t bytes = sizeof(double) * (size_t)acc_doubles(m->n, RMX_NP);
     if (m->dm.n == RMX_NP) {          // every node slot in use: the n == NP instantiation
         if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_FULLN + 1>), grid, block, bytes, b->stream, m->dm, o, a);
@@ -1490,6 +1493,7 @@ __global__ void __launch_bounds__(64) k_ground32(const GroundArgs* __restrict__ 
 
 // the steps with the contact terms of a chain of <= 32 nodes: fused (one launch for everything) or behind the lean launch of launch_step_ct_32
 void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a, bool fused) {
+    b->last_kernel = fused ? "k_ground32" : "k_step_pair";
     if (fused) {
         // a.fused 1: rollouts and cooperative groups in one launch; 2: the rollouts (free flight + contact terms) in one launch, the groups in a second
         const int inline_groups = a.fused == 1 ? a.ngroups : 0;
@@ -1524,6 +1528,7 @@ void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, cons
 
 void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(128);
+    b->last_kernel = integ == INTEG_BDF1 ? "k_step_bdf1<64,w2>" : "k_step_bdf2<64,w2>";
     const size_t smem_bytes = m->smem_bytes + ((sizeof(double) * W2_HELP_DOUBLES + 15) & ~(size_t)15);      // + the helper wave's own area
     if (m->dm.is_chain && m->dm.n == RMX_NP) {      // a serial chain that fills every node slot: FULLCHAIN (no tree paths in the front)
         if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
@@ -1546,6 +1551,7 @@ void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const 
 
 void launch_step_w2c_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(128);
+    b->last_kernel = "k_step_bdf1<32,fullchain,w2>";
     const size_t smem_bytes = m->smem_bytes + ((sizeof(double) * W2C_HELP_DOUBLES + 15) & ~(size_t)15);      // + the helper wave's own area
     RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
 }
@@ -1580,7 +1586,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1_pair32(const DevModel Min, con
         a.ls[traj] += halv;
         a.status[traj] |= status;
     }
-    if (lane == 0 && a.ticks) a.ticks[traj] += __builtin_amdgcn_s_memtime() - tick0;
+    if (lane == 0 && a.ticks) a.ticks[traj] = __builtin_amdgcn_s_memtime() - tick0;      // (stored, not added: launch_step skips the fill for this kernel)
 }
 
 // Profiling hook (rmx_profile_phases) for the full 32-link chain: shader-clock cycles of the stages of one Newton iteration of the
@@ -1656,6 +1662,7 @@ void launch_phase_pairchain_32(const rmx_model* m, const rmx_batch* b, int reps,
 
 void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+    b->last_kernel = "k_step_bdf1_pair32";
     RMX_LAUNCH(k_step_bdf1_pair32, grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
 
@@ -1663,6 +1670,7 @@ void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevO
 
 void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+    b->last_kernel = integ == INTEG_BDF1 ? "k_step_bdf1<" RMX_STR(RMX_NP) ",fullchain>" : "k_step_bdf2<" RMX_STR(RMX_NP) ",fullchain>";
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
@@ -1670,6 +1678,7 @@ void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch
 // a tree that fills all 64 node slots (n == NP at compile time; LDS-resident constants)
 void launch_step_fulln_64(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+    b->last_kernel = integ == INTEG_BDF1 ? "k_step_bdf1<64,fulln>" : "k_step_bdf2<64,fulln>";
     if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_FULLN>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
     else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_FULLN>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
@@ -1688,6 +1697,7 @@ void RMX_CAT(launch_mfd_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, dou
 }
 void RMX_CAT(launch_step_ct_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+    b->last_kernel = integ == INTEG_BDF1 ? "k_step_bdf1<" RMX_STR(RMX_NP) ",ct>" : "k_step_bdf2<" RMX_STR(RMX_NP) ",ct>";      // (lean launch + launch with the contact terms)
 #if RMX_NP == 32
     // serial chains with ForceGroundCuboid (no Euler-chart joints): free flight, contact and the cooperative groups in ONE launch
     if (m->pair32 && m->dm.con && a.fused) return launch_step_pair_32(m, b, integ, o, a, true);
@@ -1722,6 +1732,7 @@ void RMX_CAT(launch_eval_, RMX_NP)(const rmx_model* m, const rmx_batch* b, bool 
 
 void RMX_CAT(launch_step_np_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
+    b->last_kernel = integ == INTEG_BDF1 ? "k_step_bdf1<" RMX_STR(RMX_NP) ">" : "k_step_bdf2<" RMX_STR(RMX_NP) ">";      // (the launchers taken below overwrite it)
     if (m->dm.con != nullptr || m->dm.nsph > 0) return RMX_CAT(launch_step_ct_, RMX_NP)(m, b, integ, o, a);
 #if RMX_NP == 64
     // 33..64 nodes in a batch of at most one rollout per two SIMDs: a second wavefront per rollout for the Hessian and the solve

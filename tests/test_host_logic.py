@@ -106,6 +106,9 @@ def test_roofline_calibration_matches_the_built_kernel():
         assert cal["launch"]["flops"] > 0 and cal["launch"]["SQ_INSTS_VALU"] > 0 and cal["newton_iters"] > 0
         assert bench.algorithm_flops(key) is not None
     cal, _ = bench.load_calibration("chain")
+    # the headline workload is calibrated on the kernel that runs it: the two-point kernel of rmx_pair32.h
+    assert cal["kernels"] == ["k_step_bdf1_pair32"] and cal.get("per_wave_basis") == "fronts_beyond_iters"
+    assert any("k_step_bdf1_pair32" in v["name"] and v["scratch_bytes"] == 0 for v in fp.values())
     for k in ("flops", "SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
         assert cal["per_wave"][k]["front"] >= 0 and cal["per_wave"][k]["newton"] > 0
     assert abs(cal["per_wave"]["SQ_INSTS_VALU_MFMA_MOPS_F64"]["newton"] - 60.0) < 0.5      # 15 v_mfma_f64_16x16x4_f64 per Newton iteration

@@ -37,7 +37,7 @@ F64 = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_IN
 
 # kernels of the timed step call, per workload: name fragments as rocprofv3 prints them (demangled)
 KERNELS = {
-    "chain": ("k_step_bdf1<32",), "tree64": ("k_step_bdf1<64",), "tree64x": ("k_step_bdf1<64",), "ground": ("k_ground32", "k_step_pair<"),
+    "chain": ("k_step_bdf1_pair32", "k_step_bdf1<32"), "tree64": ("k_step_bdf1<64",), "tree64x": ("k_step_bdf1<64",), "ground": ("k_ground32", "k_step_pair<"),
     "adjoint": ("k_adjoint_fwd<16", "k_adjoint_bwd<16"), "chain128": ("k_big_step",),
 }
 
@@ -97,6 +97,13 @@ def main():
     fp_all = json.load(open(os.path.join(here, "redmax_amd", "kernel_fingerprint.json")))
     by_name = {v["name"]: (k, v) for k, v in fp_all.items()}
     out = {"schema": 2, "source": "tools/roofline_from_pmc.py %s" % root, "workloads": {}}
+    if len(sys.argv) > 2 and os.path.exists(sys.argv[2]):      # a session that profiled some of the workloads: the others keep their entries
+        try:
+            old = json.load(open(sys.argv[2]))
+            out["workloads"] = dict(old.get("workloads") or {})
+            out["source"] = "%s; %s" % (old.get("source", ""), out["source"])
+        except (OSError, ValueError):
+            pass
     for wl in KERNELS:
         p = read_pass(root, wl, "f64")
         if p is None:
@@ -131,6 +138,12 @@ def main():
             tot3, _, line3 = p3
             f3, i3 = counts(line3)
             A = np.array([[fronts, iters], [f3, i3]], dtype=float)
+            if "pair32" in " ".join(knames):
+                # the two-point kernel: every Newton iteration executes exactly one evaluation of the front (its line-search trial), so
+                # front_evals - newton_iters (rejected trials + the first evaluation of each rollout's launch) is the second regressor:
+                # counts = (front_evals - newton_iters) x FRONT + newton_iters x NEWTON, NEWTON = a whole iteration INCLUDING its front
+                A = np.array([[fronts - iters, iters], [f3 - i3, i3]], dtype=float)
+                ent["per_wave_basis"] = "fronts_beyond_iters"
             ent["model_condition_number"] = float(np.linalg.cond(A))
             ent["model_passes"] = [{"tol": signature(line)["tol"], "front_evals": fronts, "newton_iters": iters},
                                    {"tol": signature(line3)["tol"], "front_evals": f3, "newton_iters": i3}]
