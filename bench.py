@@ -107,6 +107,20 @@ def algorithm_flops(key):
     return (e["per_front"], e["per_newton"], e.get("note"), e.get("n")) if e else None
 
 
+# The ceiling of newton_count_agreement.vs_oracle at the reference's tol: the literal oracle against ITSELF from initial states one unit in
+# the last place apart (tools/newton_count_dither.py, profiles/r06_newton_count_dither.txt: 64 rollouts x 23 steps of this workload).  At
+# tol 1e-9 the last iterations of a step test |g| against tol at the resolution of doubles, so the count of a step is decided by
+# rounding: no implementation of the same mathematics can agree with the oracle more often than the oracle agrees with itself.
+ORACLE_SELF_AGREEMENT = {"frac": None, "frac_at_tol_1e-8": None, "source": "profiles/r06_newton_count_dither.txt"}
+try:
+    for _ln in open(os.path.join(ROOT, "profiles", "r06_newton_count_dither.txt")):
+        if _ln.startswith("{"):
+            _d = json.loads(_ln)["tols"]
+            ORACLE_SELF_AGREEMENT["frac"] = _d["1e-09"]["frac"]
+            ORACLE_SELF_AGREEMENT["frac_at_tol_1e-8"] = _d["1e-08"]["frac"]
+except (OSError, ValueError, KeyError):
+    pass
+
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the microarch guide has no fp64 row)
 SHADER_CLOCK_GHZ = 2.4    # max clock (guide); the effective clock under load is lower, so cycle counts below are upper bounds
 N_SIMD = 1024             # 256 CUs x 4 SIMDs
@@ -667,6 +681,10 @@ def rank_main(args, make_stepper=None, backend=None):
                         "batch (SIMDs idle): expect a flat curve (SURVEY.md §8(e))" % (strong["rollouts"], world)}
         if on_gpu and world == 1 and not args.no_cpu_baseline and wl == "chain":
             out.update(cpu_baselines(scene, args, h))
+            # the numbers that decide SURVEY.md 8(d)'s Newton-count statement, at the top level of the line (round-5 review)
+            nca = out.get("newton_count_agreement") or {}
+            out["newton_count_agreement_frac"] = {k: (nca.get(k) or {}).get("frac") for k in ("vs_oracle", "vs_oracle_at_tol_1e-8", "vs_tensor_free")}
+            out["newton_count_agreement_frac"]["oracle_vs_itself_1ulp_apart_at_tol_1e-9"] = ORACLE_SELF_AGREEMENT
         line = json.dumps(out)
         print(line, flush=True)
         if args.json_out:

@@ -177,7 +177,7 @@ def test_full_size_batch_properties():
     q, qd = syntheticStates(32, B)
     sim = BatchSim(sc, batch=B)
     sim.set_state(q, qd)
-    sim.opts.tol = 1e-8                            # the bench setting: every trajectory-step converges
+    sim.opts.tol = 1e-9                            # the bench setting = the reference's tol (driverRedMaxBDF1.m:95): every trajectory-step converges
     out = sim.step_bdf1(K, h=1e-2, stats=True, history=True)
     qa, qda = sim.get_state()
     assert (out["status"] & 15 == 0).all()
@@ -187,7 +187,7 @@ def test_full_size_batch_properties():
     assert np.allclose(V, out["V"][-1], rtol=1e-12, atol=1e-9)
     # shard invariance: rows 256..383 recomputed alone give bit-identical results
     sub = BatchSim(sc, batch=128)
-    sub.opts.tol = 1e-8
+    sub.opts.tol = 1e-9
     sub.set_state(q[256:384], qd[256:384])
     sub.step_bdf1(K, h=1e-2)
     qs, qds = sub.get_state()
