@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RMX_VERSION 110
+#define RMX_VERSION 111
 
 enum {
     RMX_OK = 0,
@@ -371,6 +371,27 @@ int rmx_group_step(rmx_group* g, const rmx_opts* opts, int nsteps, int integrato
 int rmx_group_step_async(rmx_group* g, const rmx_opts* opts, int nsteps, int integrator, int record);
 int rmx_group_sync(rmx_group* g, rmx_stats* stats, const rmx_history* hist);
 int rmx_group_energy(rmx_group* g, double* T, double* V);                      /* [batch], as rmx_energy */
+/* The final gather with DEVICE-resident destinations (ABI 111) - BASELINE.json north_star: "the batch axis shards naturally across GPUs
+ * with RCCL over xGMI only for the final gather"; SURVEY.md 8(e): one collective at the end of the rollout, [B/N][nr] x 2 per shard.
+ * d_q[s], d_qdot[s] (s < nshards): device pointers to [batch][nr] arrays ON SHARD s's DEVICE (a shard that receives nothing may pass
+ * NULL).  root_or_all = RMX_GATHER_ALL: every shard's device receives the whole batch; a shard index: that shard's device alone.
+ * Groups whose devices are pairwise distinct form a single-process RCCL clique at the first call (ncclCommInitAll on the device list;
+ * librccl is bound at run time, the library itself links the HIP runtime only) and run ncclAllGather (equal shards), one
+ * ncclBroadcast per shard inside a group call (shards that differ by one rollout) or ncclSend / ncclRecv (one root), enqueued on
+ * the shards' own streams behind their step kernels.  A group that lists a device more than once - RCCL refuses such a clique -
+ * exchanges by device-to-device / peer copies on the same streams (RMX_GROUP_GATHER=copy in the environment forces that path).
+ * Returns when the destinations are complete.  rmx_group_gather_path: how the last gather travelled ("rccl:allgather",
+ * "rccl:broadcast", "rccl:sendrecv", "copy"; "" before the first). */
+enum { RMX_GATHER_ALL = -1 };
+int rmx_group_gather_device(rmx_group* g, double* const* d_q, double* const* d_qdot, int root_or_all);
+const char* rmx_group_gather_path(const rmx_group* g);
+/* The same gather into [batch][nr] destinations the GROUP owns on every receiving shard's device (allocated at the first call; for
+ * hosts that cannot allocate device memory themselves - the MEX gateway's 'gather').  rmx_group_gathered: the device pointers of shard
+ * s's copy (valid until the group is destroyed; what a MATLAB host would wrap as gpuArray); rmx_group_gathered_read: that copy into host
+ * arrays ([batch][nr]; either pointer may be NULL). */
+int rmx_group_gather(rmx_group* g, int root_or_all);
+int rmx_group_gathered(rmx_group* g, int s, const double** d_q, const double** d_qdot);
+int rmx_group_gathered_read(rmx_group* g, int s, double* q, double* qdot);
 /* Timing of the last rmx_group_step / rmx_group_step_async + rmx_group_sync: wall_ms = host wall clock from the first launch to
  * the last shard's completion; per shard (arrays [nshards], any may be NULL) kernel_ms = HIP-event time of its launch, start_ms /
  * end_ms = when its launch began / ended relative to the start of the FIRST shard on the same device (HIP events of one device

@@ -105,6 +105,16 @@ classdef HipSim < handle
 			[T, V] = redmax_hip_mex('energy', this.h);
 		end
 
+		function [q, qdot, path] = gather(this, root)
+			% the final gather of the sharded batch with device-resident destinations (rmx_group_gather: RCCL over the group's devices):
+			% every shard's device (root omitted) or shard `root`'s device alone (0-based) ends up with the whole batch; q, qdot (nr x batch):
+			% that copy read back; path: 'rccl:allgather' | 'rccl:broadcast' | 'rccl:sendrecv' | 'copy'
+			if nargin < 2
+				root = -1;
+			end
+			[q, qdot, path] = redmax_hip_mex('gather', this.h, root);
+		end
+
 		function c = getCharts(this)
 			c = redmax_hip_mex('getcharts', this.h);
 		end

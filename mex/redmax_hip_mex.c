@@ -510,7 +510,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     /* include/redmax_hip.h "Asynchronous stepping": between a 'step_async' and its 'sync' only 'sync', 'timing', 'info' and 'destroy'
      * may name the handle ('step' / 'step_async' refuse with their own text).  Everything below reads or writes the state, the
      * scratch buffers or the counters of a launch in flight, and would clear its pending mark without taking the event time. */
-    static const char* const needs_idle[] = {"set", "get", "euler", "eval", "values", "energy", "getcharts", "setcharts", "ticks",
+    static const char* const needs_idle[] = {"set", "get", "gather", "euler", "eval", "values", "energy", "getcharts", "setcharts", "ticks",
                                              "adjoint", NULL};
     for (int i = 0; needs_idle[i]; ++i)
         if (!strcmp(cmd, needs_idle[i]) && get_handle(nrhs, prhs)->pending)
@@ -566,6 +566,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (rmx_group_energy(h->g, mxGetPr(T), mxGetPr(V))) die_rmx("rmx_group_energy");
         plhs[0] = T;
         if (nlhs > 1) plhs[1] = V;
+    } else if (!strcmp(cmd, "gather")) {
+        /* [q, qdot, path] = redmax_hip_mex('gather', h [, root]): the final gather of the sharded batch with DEVICE-resident destinations
+         * (rmx_group_gather: RCCL over the group's devices, copies when a device is listed twice) - every shard's device (root omitted or
+         * < 0) or shard `root`'s device alone ends up with the whole batch; q, qdot: that device copy read back (nr x batch), what a host
+         * with gpuArray support would wrap in place (rmx_group_gathered); path: how the gather travelled (rmx_group_gather_path) */
+        handle_t* h = get_handle(nrhs, prhs);
+        const int root = (nrhs > 2 && mxGetScalar(prhs[2]) >= 0.0) ? (int)mxGetScalar(prhs[2]) : RMX_GATHER_ALL;
+        if (rmx_group_gather(h->g, root)) die_rmx("rmx_group_gather");
+        mxArray* q = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
+        mxArray* qd = mxCreateDoubleMatrix((size_t)h->nr, (size_t)h->B, mxREAL);
+        if (rmx_group_gathered_read(h->g, root >= 0 ? root : 0, mxGetPr(q), mxGetPr(qd))) die_rmx("rmx_group_gathered_read");
+        plhs[0] = q;
+        if (nlhs > 1) plhs[1] = qd;
+        if (nlhs > 2) plhs[2] = mxCreateString(rmx_group_gather_path(h->g));
     } else if (!strcmp(cmd, "getcharts")) {
         handle_t* h = get_handle(nrhs, prhs);
         mxArray* c = new_i32((size_t)h->nsph, (size_t)h->B);

@@ -28,7 +28,8 @@ SYMBOLS = (
     "rmx_history_read", "rmx_stats_reset", "rmx_stats_read", "rmx_profile_phases", "rmx_step_ticks",
     "rmx_group_create", "rmx_group_destroy", "rmx_group_batch_size", "rmx_group_nshards", "rmx_group_shard", "rmx_group_shard_batch",
     "rmx_group_shard_model", "rmx_group_set_state", "rmx_group_get_state", "rmx_group_step", "rmx_group_step_async", "rmx_group_sync",
-    "rmx_group_energy", "rmx_group_timing",
+    "rmx_group_energy", "rmx_group_timing", "rmx_group_gather_device", "rmx_group_gather_path", "rmx_group_gather", "rmx_group_gathered",
+    "rmx_group_gathered_read",
 )
 REC_ENERGY, REC_STATE, REC_CHARTS = 1, 2, 4      # RMX_REC_*
 
@@ -146,6 +147,12 @@ def lib():
     L.rmx_group_step_async.argtypes = [vp, C.POINTER(Opts), C.c_int, C.c_int, C.c_int]
     L.rmx_group_sync.argtypes = [vp, C.POINTER(Stats), C.POINTER(History)]
     L.rmx_group_energy.argtypes = [vp, _dp, _dp]
+    L.rmx_group_gather_device.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]
+    L.rmx_group_gather_path.argtypes = [vp]
+    L.rmx_group_gather_path.restype = C.c_char_p
+    L.rmx_group_gather.argtypes = [vp, C.c_int]
+    L.rmx_group_gathered.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.rmx_group_gathered_read.argtypes = [vp, C.c_int, _dp, _dp]
     L.rmx_group_timing.argtypes = [vp, _dp, _dp, _dp, _dp]
     L.rmx_stats_reset.argtypes = [vp]
     L.rmx_profile_phases.argtypes = [vp, C.c_int, C.c_double, _dp]

@@ -381,6 +381,35 @@ class GroupSim:
         _abi.check(self._L.rmx_group_get_state(self._g, _abi.dptr(q), _abi.dptr(qd)), "rmx_group_get_state")
         return q, qd
 
+    GATHER_ALL = -1      # RMX_GATHER_ALL
+
+    def gather_device(self, d_q, d_qdot, root=GATHER_ALL):
+        """The final gather with device-resident destinations (rmx_group_gather_device): d_q[s], d_qdot[s] = raw device pointers
+        (ints; e.g. torch tensor.data_ptr()) of [batch][nr] float64 arrays on shard s's device, None for a shard that receives nothing.
+        root: a shard index, or GATHER_ALL.  RCCL (single-process clique over the group's devices) when the devices are pairwise
+        distinct, device-to-device copies when a device is listed twice.  Returns how the gather travelled (rmx_group_gather_path)."""
+        P = C.c_void_p * self.nshards
+        pq = P(*[C.c_void_p(int(p)) if p else None for p in d_q])
+        pqd = P(*[C.c_void_p(int(p)) if p else None for p in d_qdot])
+        _abi.check(self._L.rmx_group_gather_device(self._g, pq, pqd, int(root)), "rmx_group_gather_device")
+        return self._L.rmx_group_gather_path(self._g).decode()
+
+    def gather(self, root=GATHER_ALL):
+        """The same gather into destinations the group owns on the receiving shards' devices (rmx_group_gather)."""
+        _abi.check(self._L.rmx_group_gather(self._g, int(root)), "rmx_group_gather")
+        return self._L.rmx_group_gather_path(self._g).decode()
+
+    def gathered_read(self, shard=0):
+        """Host copy of shard `shard`'s gathered (q, qdot) ([batch][nr]); gathered_ptrs: its device pointers."""
+        q, qd = np.empty((self.B, self.nr)), np.empty((self.B, self.nr))
+        _abi.check(self._L.rmx_group_gathered_read(self._g, int(shard), _abi.dptr(q), _abi.dptr(qd)), "rmx_group_gathered_read")
+        return q, qd
+
+    def gathered_ptrs(self, shard=0):
+        a, b = C.c_void_p(), C.c_void_p()
+        _abi.check(self._L.rmx_group_gathered(self._g, int(shard), C.byref(a), C.byref(b)), "rmx_group_gathered")
+        return a.value, b.value
+
     def _outputs(self, nsteps, record):
         out = {k: np.zeros(self.B, dtype=np.int32) for k in ("newton_iters", "ls_halvings", "status")}
         st = _abi.Stats(_abi.iptr(out["newton_iters"]), _abi.iptr(out["ls_halvings"]), _abi.iptr(out["status"]))

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -1377,6 +1378,56 @@ extern "C" int rmx_energy(rmx_batch* b, double* T, double* V) {
 // ============================================================================ multi-device groups (include/redmax_hip.h, ABI 107)
 #include <chrono>
 
+// ---- RCCL, bound at run time.  libredmax_hip.so links the HIP runtime only; the one collective of the path (north_star: "RCCL over
+// xGMI only for the final gather") needs librccl when a group spans several DISTINCT devices, and a host without it still simulates
+// (rmx_group_gather_device then says so).  The entry points are resolved from librccl.so(.1) on first use; the types come from rccl.h.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    bool tried = false;
+    std::string why;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+bool rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.tried) return g_rccl.lib != nullptr;
+    g_rccl.tried = true;
+    const char* env = getenv("RMX_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        if (!nm || !*nm) continue;
+        g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) break;
+        g_rccl.why = dlerror() ? dlerror() : "dlopen failed";
+    }
+    if (!g_rccl.lib) return false;
+    bool ok = true;
+#define RMX_SYM(field, name) ok = ok && ((g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, name))) != nullptr)
+    RMX_SYM(CommInitAll, "ncclCommInitAll"); RMX_SYM(CommDestroy, "ncclCommDestroy"); RMX_SYM(GetErrorString, "ncclGetErrorString");
+    RMX_SYM(AllGather, "ncclAllGather"); RMX_SYM(Broadcast, "ncclBroadcast"); RMX_SYM(Send, "ncclSend"); RMX_SYM(Recv, "ncclRecv");
+    RMX_SYM(GroupStart, "ncclGroupStart"); RMX_SYM(GroupEnd, "ncclGroupEnd");
+#undef RMX_SYM
+    if (!ok) {
+        g_rccl.why = "librccl lacks an entry point this library binds";
+        dlclose(g_rccl.lib);
+        g_rccl.lib = nullptr;
+    }
+    return ok;
+}
+}  // namespace
+
 struct rmx_group {
     int B = 0, nr = 0;
     std::vector<rmx_model*> models;
@@ -1385,10 +1436,23 @@ struct rmx_group {
     std::chrono::steady_clock::time_point t0;
     double wall_ms = 0.0;
     bool in_flight = false;
+    // rmx_group_gather_device: one RCCL communicator per shard (a single-process clique, ncclCommInitAll on the device list), created
+    // at the first gather of a group whose devices are pairwise distinct; a group that lists a device twice gathers by peer copies
+    std::vector<ncclComm_t> comms;
+    int gather_path = 0;            // 0 not decided, 1 RCCL, 2 peer copies (a device is listed more than once, or RMX_GROUP_GATHER=copy)
+    const char* last_gather = "";   // "rccl:allgather" | "rccl:broadcast" | "rccl:sendrecv" | "copy" (rmx_group_gather_path)
+    std::vector<double*> gq, gqd;   // rmx_group_gather: the group's own [batch][nr] destinations, one pair per shard's device (on demand)
 };
 
 extern "C" void rmx_group_destroy(rmx_group* g) {
     if (!g) return;
+    for (ncclComm_t c : g->comms)
+        if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
+    for (size_t s = 0; s < g->gq.size(); ++s) {
+        if (g->gq[s] || g->gqd[s]) (void)hipSetDevice(g->device[s]);
+        if (g->gq[s]) (void)hipFree(g->gq[s]);
+        if (g->gqd[s]) (void)hipFree(g->gqd[s]);
+    }
     for (rmx_batch* b : g->batches) rmx_batch_destroy(b);
     for (rmx_model* m : g->models) rmx_model_destroy(m);
     delete g;
@@ -1459,6 +1523,140 @@ extern "C" int rmx_group_get_state(rmx_group* g, double* q, double* qdot) {
     }
     return RMX_OK;
 }
+// The final gather of the path with DEVICE-resident destinations (north_star: "RCCL over xGMI only for the final gather"; SURVEY.md
+// 8(e): one collective at the end of the rollout, [B/N][nr] x 2 per shard).  d_q[s], d_qdot[s]: [batch][nr] arrays on shard s's device
+// (null for a shard that receives nothing).  root_or_all = RMX_GATHER_ALL: every shard's device ends up with the whole batch
+// (ncclAllGather when the shards are equal, one ncclBroadcast per shard inside a group call otherwise); a shard index: that shard's
+// device alone (ncclSend / ncclRecv).  The collective is enqueued on the shards' own streams, behind their step kernels - no host
+// synchronisation between the rollout and the gather -, and the call returns when every stream has drained.
+static int gather_fail(rmx_group* g, ncclResult_t r, const char* what) {
+    (void)g;
+    return fail(RMX_E_HIP, std::string("rmx_group_gather_device: ") + what + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+extern "C" int rmx_group_gather_device(rmx_group* g, double* const* d_q, double* const* d_qdot, int root_or_all) {
+    if (!g || !d_q || !d_qdot) return fail(RMX_E_INVALID, "null argument");
+    const int S = (int)g->batches.size();
+    const bool all = root_or_all == RMX_GATHER_ALL;
+    if (!all && (root_or_all < 0 || root_or_all >= S)) return fail(RMX_E_INVALID, "rmx_group_gather_device: root must be a shard index or RMX_GATHER_ALL");
+    for (int s = 0; s < S; ++s)
+        if ((all || s == root_or_all) && (!d_q[s] || !d_qdot[s])) return fail(RMX_E_INVALID, "rmx_group_gather_device: a receiving shard has no destination");
+    if (g->gather_path == 0) {
+        bool dup = false;
+        for (int a = 0; a < S; ++a)
+            for (int c = a + 1; c < S; ++c) dup = dup || g->device[a] == g->device[c];
+        const char* force = getenv("RMX_GROUP_GATHER");
+        if (dup || (force && !strcmp(force, "copy"))) {
+            g->gather_path = 2;       // RCCL refuses a clique that names a GPU twice: such shards exchange by (peer) copies
+        } else {
+            if (!rccl_load()) return fail(RMX_E_HIP, "rmx_group_gather_device: librccl could not be loaded (" + g_rccl.why + "); RMX_GROUP_GATHER=copy gathers by peer copies");
+            g->comms.assign(S, nullptr);
+            const ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), S, g->device.data());
+            if (r != ncclSuccess) { g->comms.clear(); return gather_fail(g, r, "ncclCommInitAll"); }
+            g->gather_path = 1;
+        }
+    }
+    const size_t nr = (size_t)g->nr;
+    if (g->gather_path == 2) {
+        g->last_gather = "copy";
+        for (int src = 0; src < S; ++src) {
+            rmx_batch* b = g->batches[src];
+            const size_t off = (size_t)g->first[src] * nr, bytes = (size_t)g->count[src] * nr * sizeof(double);
+            for (int dst = 0; dst < S; ++dst) {
+                if (!(all || dst == root_or_all)) continue;
+                // on the SOURCE shard's stream, behind its step kernel; the destination is idle memory of the caller's
+                HIPCHK(hipSetDevice(g->device[src]));
+                if (g->device[src] == g->device[dst]) {
+                    HIPCHK(hipMemcpyAsync(d_q[dst] + off, b->q, bytes, hipMemcpyDeviceToDevice, b->stream));
+                    HIPCHK(hipMemcpyAsync(d_qdot[dst] + off, b->qd, bytes, hipMemcpyDeviceToDevice, b->stream));
+                } else {
+                    HIPCHK(hipMemcpyPeerAsync(d_q[dst] + off, g->device[dst], b->q, g->device[src], bytes, b->stream));
+                    HIPCHK(hipMemcpyPeerAsync(d_qdot[dst] + off, g->device[dst], b->qd, g->device[src], bytes, b->stream));
+                }
+            }
+        }
+    } else {
+        bool equal = true;
+        for (int s = 1; s < S; ++s) equal = equal && g->count[s] == g->count[0];
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return gather_fail(g, r, "ncclGroupStart");
+        if (all && equal) {
+            g->last_gather = "rccl:allgather";
+            const size_t cnt = (size_t)g->count[0] * nr;
+            for (int s = 0; s < S && r == ncclSuccess; ++s) {
+                r = g_rccl.AllGather(g->batches[s]->q, d_q[s], cnt, ncclDouble, g->comms[s], g->batches[s]->stream);
+                if (r == ncclSuccess) r = g_rccl.AllGather(g->batches[s]->qd, d_qdot[s], cnt, ncclDouble, g->comms[s], g->batches[s]->stream);
+            }
+        } else if (all) {
+            g->last_gather = "rccl:broadcast";      // shards that differ by one rollout: the all-gather as one broadcast per shard
+            for (int root = 0; root < S && r == ncclSuccess; ++root) {
+                const size_t off = (size_t)g->first[root] * nr, cnt = (size_t)g->count[root] * nr;
+                for (int s = 0; s < S && r == ncclSuccess; ++s) {
+                    r = g_rccl.Broadcast(g->batches[root]->q, d_q[s] + off, cnt, ncclDouble, root, g->comms[s], g->batches[s]->stream);
+                    if (r == ncclSuccess) r = g_rccl.Broadcast(g->batches[root]->qd, d_qdot[s] + off, cnt, ncclDouble, root, g->comms[s], g->batches[s]->stream);
+                }
+            }
+        } else {
+            g->last_gather = "rccl:sendrecv";
+            const int root = root_or_all;
+            for (int s = 0; s < S && r == ncclSuccess; ++s) {
+                const size_t off = (size_t)g->first[s] * nr, cnt = (size_t)g->count[s] * nr;
+                if (s == root) {      // the root's own slice: a copy on its stream
+                    if (hipSetDevice(g->device[s]) != hipSuccess ||
+                        hipMemcpyAsync(d_q[root] + off, g->batches[s]->q, cnt * sizeof(double), hipMemcpyDeviceToDevice, g->batches[s]->stream) != hipSuccess ||
+                        hipMemcpyAsync(d_qdot[root] + off, g->batches[s]->qd, cnt * sizeof(double), hipMemcpyDeviceToDevice, g->batches[s]->stream) != hipSuccess) {
+                        (void)g_rccl.GroupEnd();
+                        return fail(RMX_E_HIP, "rmx_group_gather_device: copying the root's own slice failed");
+                    }
+                    continue;
+                }
+                r = g_rccl.Send(g->batches[s]->q, cnt, ncclDouble, root, g->comms[s], g->batches[s]->stream);
+                if (r == ncclSuccess) r = g_rccl.Send(g->batches[s]->qd, cnt, ncclDouble, root, g->comms[s], g->batches[s]->stream);
+                if (r == ncclSuccess) r = g_rccl.Recv(d_q[root] + off, cnt, ncclDouble, s, g->comms[root], g->batches[root]->stream);
+                if (r == ncclSuccess) r = g_rccl.Recv(d_qdot[root] + off, cnt, ncclDouble, s, g->comms[root], g->batches[root]->stream);
+            }
+        }
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return gather_fail(g, r, g->last_gather);
+        if (re != ncclSuccess) return gather_fail(g, re, "ncclGroupEnd");
+    }
+    for (int s = 0; s < S; ++s) {
+        HIPCHK(hipSetDevice(g->device[s]));
+        HIPCHK(hipStreamSynchronize(g->batches[s]->stream));
+    }
+    return RMX_OK;
+}
+extern "C" const char* rmx_group_gather_path(const rmx_group* g) { return g ? g->last_gather : ""; }
+// the same gather into destinations the GROUP owns (for hosts that cannot allocate device memory themselves: the MEX gateway)
+extern "C" int rmx_group_gather(rmx_group* g, int root_or_all) {
+    if (!g) return fail(RMX_E_INVALID, "null group");
+    const int S = (int)g->batches.size();
+    if (root_or_all != RMX_GATHER_ALL && (root_or_all < 0 || root_or_all >= S)) return fail(RMX_E_INVALID, "rmx_group_gather: root must be a shard index or RMX_GATHER_ALL");
+    if (g->gq.empty()) { g->gq.assign(S, nullptr); g->gqd.assign(S, nullptr); }
+    const size_t bytes = (size_t)g->B * g->nr * sizeof(double);
+    for (int s = 0; s < S; ++s) {
+        if (!(root_or_all == RMX_GATHER_ALL || s == root_or_all)) continue;
+        HIPCHK(hipSetDevice(g->device[s]));
+        if (!g->gq[s]) HIPCHK(hipMalloc((void**)&g->gq[s], bytes ? bytes : 8));
+        if (!g->gqd[s]) HIPCHK(hipMalloc((void**)&g->gqd[s], bytes ? bytes : 8));
+    }
+    return rmx_group_gather_device(g, g->gq.data(), g->gqd.data(), root_or_all);
+}
+extern "C" int rmx_group_gathered(rmx_group* g, int s, const double** d_q, const double** d_qdot) {
+    if (!g || s < 0 || s >= (int)g->gq.size() || !g->gq[s] || !g->gqd[s]) return fail(RMX_E_INVALID, "rmx_group_gathered: shard holds no gathered state (rmx_group_gather first)");
+    if (d_q) *d_q = g->gq[s];
+    if (d_qdot) *d_qdot = g->gqd[s];
+    return RMX_OK;
+}
+extern "C" int rmx_group_gathered_read(rmx_group* g, int s, double* q, double* qdot) {
+    const double *dq = nullptr, *dqd = nullptr;
+    if (int rc = rmx_group_gathered(g, s, &dq, &dqd)) return rc;
+    const size_t bytes = (size_t)g->B * g->nr * sizeof(double);
+    HIPCHK(hipSetDevice(g->device[s]));
+    if (q) HIPCHK(hipMemcpy(q, dq, bytes, hipMemcpyDeviceToHost));
+    if (qdot) HIPCHK(hipMemcpy(qdot, dqd, bytes, hipMemcpyDeviceToHost));
+    return RMX_OK;
+}
+
 extern "C" int rmx_group_energy(rmx_group* g, double* T, double* V) {
     if (!g || !T || !V) return fail(RMX_E_INVALID, "null argument");
     for (size_t s = 0; s < g->batches.size(); ++s)

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_abi.LIB_PATH)
     for name in _declared():
         assert hasattr(L, name), name
-    assert _abi.lib().rmx_version() == 110
+    assert _abi.lib().rmx_version() == 111
 
 
 def test_no_device_fails_loudly():

@@ -200,6 +200,76 @@ def test_async_entries_on_two_batches_of_one_host_thread():
         s.close()
 
 
+class _DevBuf:
+    """[rows][cols] float64 device array through the HIP runtime the library itself is linked against (torch brings its own copy of the
+    runtime: once the library has initialised the system one in this process, torch's no longer finds the GPU)."""
+    _hip = None
+
+    def __init__(self, rows, cols, fill=np.nan):
+        import ctypes as C
+        if _DevBuf._hip is None:
+            _DevBuf._hip = C.CDLL("libamdhip64.so")
+        self.C, self.shape = C, (rows, cols)
+        self.ptr = C.c_void_p()
+        self.nbytes = rows * cols * 8
+        assert self._hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(self.nbytes, 8))) == 0
+        self.fill(fill)
+
+    def fill(self, v):
+        h = np.full(self.shape, v)
+        assert self._hip.hipMemcpy(self.ptr, h.ctypes.data_as(self.C.c_void_p), self.C.c_size_t(self.nbytes), 1) == 0    # hipMemcpyHostToDevice
+
+    def get(self):
+        out = np.empty(self.shape)
+        assert self._hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.ptr, self.C.c_size_t(self.nbytes), 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        self._hip.hipFree(self.ptr)
+
+
+def test_group_gather_device_rccl_and_copy_paths():
+    """ABI 111, north_star's "RCCL over xGMI only for the final gather" inside the library: rmx_group_gather_device enqueues the gather
+    of (q, qdot) on the shards' own streams behind their step kernels, with device-resident destinations.  On the one-GPU box: a
+    ONE-shard group forms a one-rank RCCL communicator (ncclCommInitAll + ncclAllGather / the root form); a group that lists device 0
+    twice takes the copy path (RCCL refuses duplicate GPUs), equal and unequal shards; the caller's buffers and the group's own
+    (rmx_group_gather) must both hold exactly what rmx_group_get_state returns."""
+    from redmax_amd import GroupSim, sceneChain, syntheticStates
+    sc = sceneChain(8)
+    sc.init()
+    for B, devices, want_all, want_root in ((64, (0,), "rccl:allgather", "rccl:sendrecv"), (64, (0, 0), "copy", "copy"), (65, (0, 0, 0), "copy", "copy")):
+        q, qd = syntheticStates(sc.nr, B)
+        g = GroupSim(sc, B, devices=devices)
+        g.set_state(q, qd)
+        dq = [_DevBuf(B, sc.nr) for _ in devices]
+        dqd = [_DevBuf(B, sc.nr) for _ in devices]
+        g.step_async(6, integrator=1, h=sc.h, record=0)      # the gather is enqueued BEHIND the launches that are still in flight
+        path = g.gather_device([t.ptr.value for t in dq], [t.ptr.value for t in dqd])
+        g.sync()
+        qf, qdf = g.get_state()
+        assert path == want_all, (path, devices)
+        assert not np.array_equal(qf, q)
+        for t, u in zip(dq, dqd):
+            assert np.array_equal(t.get(), qf) and np.array_equal(u.get(), qdf), devices
+        # one root: only its destination is written
+        root = len(devices) - 1
+        for t in dq + dqd:
+            t.fill(np.nan)
+        ptr_q = [dq[s].ptr.value if s == root else None for s in range(len(devices))]
+        ptr_qd = [dqd[s].ptr.value if s == root else None for s in range(len(devices))]
+        assert g.gather_device(ptr_q, ptr_qd, root=root) == want_root
+        assert np.array_equal(dq[root].get(), qf) and np.array_equal(dqd[root].get(), qdf)
+        assert all(np.isnan(dq[s].get()).all() for s in range(len(devices)) if s != root)
+        # the group's own destinations
+        assert g.gather() == want_all
+        for s in range(len(devices)):
+            a, b = g.gathered_read(s)
+            assert np.array_equal(a, qf) and np.array_equal(b, qdf)
+        for t in dq + dqd:
+            t.free()
+        g.close()
+
+
 def test_group_refuses_bad_plans():
     from redmax_amd import GroupSim, sceneChain
     from redmax_amd._abi import RedMaxHipError

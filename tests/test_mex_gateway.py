@@ -99,8 +99,11 @@ class Gateway:
         if cls == 2:          # struct: only the fields the gateway's 'info' returns
             return {k: self.from_mx(L.mxGetField(m, 0, k.encode())) for k in ("nr", "nm", "nsph", "batch", "idxR", "nshards", "devices",
                                                                                "shard_first", "shard_count")}
-        dt = {mxDOUBLE: np.float64, mxINT32: np.int32, mxUINT64: np.uint64}[cls]
         n = int(np.prod(shape))
+        if cls == 4:          # char array (mxCreateString: 16-bit code units) -> str
+            buf = (C.c_char * (2 * n)).from_address(L.mxGetData(m)) if n else b""
+            return "".join(chr(c) for c in np.frombuffer(bytes(buf), dtype=np.uint16))
+        dt = {mxDOUBLE: np.float64, mxINT32: np.int32, mxUINT64: np.uint64}[cls]
         buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(L.mxGetData(m)) if n else b""
         return np.frombuffer(bytes(buf), dtype=dt).reshape(shape, order="F").copy()
 
@@ -145,7 +148,7 @@ def flatten(scene):
 
 
 def test_gateway_builds_warning_free_and_answers_version(gw):
-    assert gw.call(1, "version") == 110
+    assert gw.call(1, "version") == 111
 
 
 def test_gateway_reports_errors_the_matlab_way(gw):
@@ -315,7 +318,7 @@ def test_two_shards_through_the_gateway_async_and_sync(gw):
                 gw.call(1, "step", h, 1.0, 1e-2, 1.0)
             # every command that touches the state, the scratch buffers or the counters waits for 'sync' too (round-4 advice);
             # 'info' and 'timing' stay available
-            for cmd in (("get",), ("set", q.T, qd.T), ("energy",), ("ticks",), ("eval", q.T, q.T, q.T, 1e-2), ("values", q.T, qd.T)):
+            for cmd in (("get",), ("set", q.T, qd.T), ("gather",), ("energy",), ("ticks",), ("eval", q.T, q.T, q.T, 1e-2), ("values", q.T, qd.T)):
                 with pytest.raises(MexError, match="in flight"):
                     gw.call(1, cmd[0], h, *cmd[1:])
             gw.call(1, "info", h)
@@ -324,6 +327,13 @@ def test_two_shards_through_the_gateway_async_and_sync(gw):
         else:
             T, V, st, Q, Qd = gw.call(5, "step", h, 1.0, 1e-2, float(K))
         q1, qd1 = gw.call(2, "get", h)
+        # 'gather' (ABI 111): the final gather with device-resident destinations - a one-rank RCCL communicator for the one-shard handle,
+        # device-to-device copies for the two shards that share device 0 (RCCL refuses a clique that names a GPU twice) - every shard's
+        # device, and shard 0's alone, must hold exactly what 'get' returns
+        for root in ((), (0.0,)):
+            gq, gqd, path = gw.call(3, "gather", h, *root)
+            assert np.array_equal(gq, q1) and np.array_equal(gqd, qd1), (devs, root)
+            assert path == ("copy" if devs.size == 2 else ("rccl:allgather" if not root else "rccl:sendrecv")), (path, devs, root)
         wall, k, t0, t1 = gw.call(4, "timing", h)
         gw.call(0, "destroy", h)
         outs.append((T, V, st, Q, Qd, q1, qd1))
