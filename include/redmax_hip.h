@@ -63,7 +63,11 @@ enum {
  * with full partial pivoting (see rmx_device.h lu_solve_neg_diag). */
 enum { RMX_ST_DIVERGED = 1, RMX_ST_MAXITER = 2, RMX_ST_NAN = 4, RMX_ST_STALLED = 8, RMX_ST_PIVOTED = 16,
        RMX_ST_CHART = 32 /* informational: a JointSpherical changed its Euler chart (the reference prints 'XYZ->YXZ') */,
-       RMX_ST_LS_CUT = 128 /* with RMX_ST_MAXITER: rmx_opts.ls_fail_limit ended the Newton loop of a step (off by default) */ };
+       RMX_ST_LS_CUT = 128 /* with RMX_ST_MAXITER: rmx_opts.ls_fail_limit ended the Newton loop of a step (off by default) */,
+       RMX_ST_COOP_FAULT = 512 /* with RMX_ST_NAN, chains with ForceGroundCuboid only: the wavefronts that share a creeping line search
+                                  (DESIGN.md "Chains with ground contact") waited in vain for each other, or a rollout handed to them was
+                                  never picked up; the rollout's state is NaN.  Never observed: a guard, not a code path of the method.
+                                  (Bits 64 and 256 are internal to the kernels and never reach rmx_stats.status.) */ };
 
 /* Scene listing, one entry per joint/body pair in the order the scene file lists them
  * (parent before child; scenesRedMax.m).  Replaces the handle-object graph that Scene.init()

@@ -345,6 +345,10 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
             m->n_simd = 4 * prop.multiProcessorCount;
             m->lds_limit = (int)prop.sharedMemPerBlock;
+            // the cooperative groups' timeout, ~2 s in s_memtime ticks: on gfx950 the counter runs at the shader clock (8.9 M ticks per
+            // 3.75 ms launch, tools/pairc_ticks.py), on gfx90a / gfx942 at the constant 100 MHz reference clock
+            const bool shader_rate = strncmp(prop.gcnArchName, "gfx950", 6) == 0 && prop.clockRate > 0;
+            m->coop_ticks = shader_rate ? 2000ull * (unsigned long long)prop.clockRate : 200000000ull;
         }
         if (const char* lim = getenv("RMX_BIG_LDS_LIMIT")) m->lds_limit = atoi(lim);     // development aid (0: H of large trees stays in HBM)
     }
@@ -591,6 +595,19 @@ extern "C" int rmx_model_idxR(const rmx_model* m, int* idx) {
     return RMX_OK;
 }
 
+// Batches that hold cooperative-group buffers (launch_step: serial chains of <= 32 nodes with ForceGroundCuboid), process-wide: the groups of
+// ONE launch spin on each other through global memory and must all be resident together, so the SIMDs of a device are DIVIDED among the
+// live batches that may run such a launch on it at the same time (two shards of a group on one device, asynchronous BatchSims) - each
+// sized as if it owned the device, the partly resident groups of two launches could wait for each other's missing members for ever.
+static std::mutex g_coop_mu;
+static std::vector<rmx_batch*> g_coop_batches;
+static int coop_batches_on_device(int device) {
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    int n = 0;
+    for (const rmx_batch* b : g_coop_batches) n += (b->m->device == device) ? 1 : 0;
+    return n;
+}
+
 extern "C" int rmx_batch_create(rmx_model* m, int batch, rmx_batch** out) {
     if (!m || !out || batch < 1) return fail(RMX_E_INVALID, "bad argument");
     *out = nullptr;
@@ -633,6 +650,10 @@ extern "C" void rmx_batch_destroy(rmx_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->m->device);
     b->m->batches.erase(std::remove(b->m->batches.begin(), b->m->batches.end(), b), b->m->batches.end());
+    {
+        std::lock_guard<std::mutex> lk(g_coop_mu);
+        g_coop_batches.erase(std::remove(g_coop_batches.begin(), g_coop_batches.end(), b), g_coop_batches.end());
+    }
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     hist_free(b);
     for (void* p : {(void*)b->q, (void*)b->qd, (void*)b->qp, (void*)b->qdp, (void*)b->tmpA, (void*)b->tmpB, (void*)b->tmpC,
@@ -865,6 +886,7 @@ static int make_opts(const rmx_batch* b, const rmx_opts* o, DevOpts& d) {
     if (o->ls_fail_limit < 0) return fail(RMX_E_INVALID, "opts.ls_fail_limit must be >= 0");
     d.lsFailLimit = o->ls_fail_limit;
     d.parkHalv = 0;
+    d.coopTicks = b->m->coop_ticks;
     return RMX_OK;
 }
 
@@ -897,12 +919,19 @@ static int launch_step(rmx_batch* b, const rmx_opts* opts, int nsteps, int integ
         o.parkHalv = e ? atoi(e) : 24;
     }
     if (o.parkHalv > 0) {
-        if (!b->park) {
-            b->ngroups = std::min(b->B, m->n_simd / COOP_G);     // all groups resident at once: one 512-register wavefront per SIMD
-            HIPCHK(hipMalloc((void**)&b->park, sizeof(int) * (2 + 4 * (size_t)b->B)));
-            HIPCHK(hipMalloc((void**)&b->xch, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups));
-            HIPCHK(hipMalloc((void**)&b->xrec, sizeof(unsigned long long) * 2 * COOP_REC * (size_t)b->ngroups));
+        // buffers for the most groups a launch of this batch can ever hold (it alone on the device); each under its own check, so that a
+        // failed allocation leaves nothing half set up for the next call
+        const int cap = std::min(b->B, m->n_simd / COOP_G);
+        if (!b->park) HIPCHK(hipMalloc((void**)&b->park, sizeof(int) * (2 + 4 * (size_t)b->B)));
+        if (!b->xch) HIPCHK(hipMalloc((void**)&b->xch, sizeof(unsigned) * COOP_WORDS * (size_t)cap));
+        if (!b->xrec) HIPCHK(hipMalloc((void**)&b->xrec, sizeof(unsigned long long) * 2 * COOP_REC * (size_t)cap));
+        {
+            std::lock_guard<std::mutex> lk(g_coop_mu);
+            if (std::find(g_coop_batches.begin(), g_coop_batches.end(), b) == g_coop_batches.end()) g_coop_batches.push_back(b);
         }
+        // the groups of this launch: all resident at once (one 512-register wavefront per SIMD) beside those of every other live batch that
+        // may be stepping on this device at the same time
+        b->ngroups = std::max(1, std::min(cap, (m->n_simd / COOP_G) / std::max(1, coop_batches_on_device(m->device))));
         HIPCHK(hipMemsetAsync(b->park, 0, sizeof(int) * (2 + 4 * (size_t)b->B), b->stream));
         HIPCHK(hipMemsetAsync(b->xch, 0, sizeof(unsigned) * COOP_WORDS * (size_t)b->ngroups, b->stream));
         HIPCHK(hipMemsetAsync(b->xrec, 0, sizeof(unsigned long long) * 2 * COOP_REC * (size_t)b->ngroups, b->stream));

@@ -431,7 +431,7 @@ __device__ __forceinline__ bool coop_collect(const CoopPub& pb, const CoopCtx& c
         if (__all(mine)) break;
         unsigned ab = 0u;
         if (lane == 0) ab = coop_load(cx.words + 2 * COOP_G);
-        if (__any(ab != 0u) || __builtin_amdgcn_s_memtime() - t0 > 5000000000ull) {
+        if (__any(ab != 0u) || __builtin_amdgcn_s_memtime() - t0 > cx.ticks) {
             if (lane == 0) coop_store(cx.words + 2 * COOP_G, 1u);
             return false;
         }
@@ -470,7 +470,7 @@ __device__ __forceinline__ bool coop_wait_acks(const CoopCtx& cx, const int lane
         if (__all((int)(w - seq) >= 0)) return true;
         unsigned ab = 0u;
         if (lane == 0) ab = coop_load(cx.words + 2 * COOP_G);
-        if (__any(ab != 0u) || __builtin_amdgcn_s_memtime() - t0 > 5000000000ull) {
+        if (__any(ab != 0u) || __builtin_amdgcn_s_memtime() - t0 > cx.ticks) {
             if (lane == 0) coop_store(cx.words + 2 * COOP_G, 1u);
             return false;
         }

@@ -148,6 +148,9 @@ struct DevOpts {
     int lu_mode;      // 0: diagonal pivots under a growth guard, partial pivoting on demand; 1: always partial pivoting
     double comp;      // 1.0: compensated Newton iterate (x + xlo, see newton_impl); 0.0: plain doubles (the reference's lattice)
     int lsFailLimit;  // rmx_opts.ls_fail_limit: > 0 ends a step's Newton loop at its N-th failed line search
+    unsigned long long coopTicks;   // how long a member of a cooperative group waits for its group before it gives the rollout up: ~2 s in
+                      // s_memtime ticks of THIS device (rmx_model::coop_ticks - the counter runs at the shader clock on gfx950, at a
+                      // constant 100 MHz on older parts: the host derives the budget, the kernels do not assume a rate)
     int parkHalv;     // > 0 (contact kernels of serial chains of <= 32 nodes): a solve whose line searches have spent more than this many
                       // halvings parks its rollout at the start of the step for the cooperative launch (newton_impl COOP); 0: never
 };
@@ -3423,7 +3426,7 @@ __device__ __forceinline__ void pivot_policy_update(PivotPolicy& piv) {   // aft
 constexpr int ST_LEFT_LEAN = 64;
 constexpr int ST_LS_CUT = 128;     // RMX_ST_LS_CUT
 constexpr int ST_PARK = 256;       // internal, like ST_LEFT_LEAN: the solve gave its rollout up to the cooperative launch
-constexpr int ST_COOP_FAULT = 512; // RMX_ST_COOP_FAULT: a member of a cooperative group waited in vain (never seen; the rollout is invalid)
+constexpr int ST_COOP_FAULT = 512; // RMX_ST_COOP_FAULT (include/redmax_hip.h): a member of a cooperative group waited in vain, or a parked rollout was never picked up; the rollout is invalid
 //
 // The cooperative line search (BASELINE.json configs[4]; DESIGN.md section 4 "park and relaunch").  At a stick / slip kink of the ground
 // contact the reference's backtracking (driverRedMaxBDF2.m newton, the same as driverRedMaxBDF1.m:123-141) runs out its 20 trials - or
@@ -3453,6 +3456,7 @@ struct CoopCtx {
     unsigned round = 0;                          // decision-word exchanges this group has gone through (the tag of the next one)
     unsigned rseq = 0;                           // records the group has passed on (rmx_ct32.h CoopPub: the tag of the next one)
     bool wide = false;                           // the line search in progress / the next one takes the whole group (rmx_ct32.h newton_pair)
+    unsigned long long ticks = 5000000000ull;    // the longest wait for the group, in s_memtime ticks (DevOpts::coopTicks: ~2 s on this device)
 #ifdef RMX_TICK_PHASE                            // measurement build (rmx_ct32.h RMX_PH_BEGIN): ticks of one phase of newton_pair
     unsigned long long phase = 0;
 #endif
@@ -3492,7 +3496,7 @@ __device__ __forceinline__ bool coop_gather(CoopCtx& cx, const int lane, unsigne
             break;
         }
         const bool aborted = __any(lane == COOP_G && !mine);                          // ... and ends the wait at once
-        if (aborted || __builtin_amdgcn_s_memtime() - t0 > 5000000000ull) {
+        if (aborted || __builtin_amdgcn_s_memtime() - t0 > cx.ticks) {
             if (lane == 0) coop_store(cx.words + 2 * COOP_G, 1u);
             ok = false;
             break;

@@ -70,6 +70,7 @@ struct rmx_model {
     DevModel dm{};
     size_t smem_bytes = 0;
     int n_simd = 0;                 // SIMDs of the device (4 per CU)
+    unsigned long long coop_ticks = 5000000000ull;   // ~2 s in s_memtime ticks of this device (DevOpts::coopTicks): measured at model creation
     int lds_limit = 0;              // LDS bytes one workgroup may hold (hipDeviceProp_t::sharedMemPerBlock); RMX_BIG_LDS_LIMIT overrides
     void* dgconst = nullptr;        // 64-lane plain models: the staged per-node constants in global memory (DevModel::gconst)
     int gconst_min_batch = 0;       // batches of at least this many rollouts run the global-constants kernels (0: never)

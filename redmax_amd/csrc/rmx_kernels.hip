@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
     unsigned long long tick0 = __builtin_amdgcn_s_memtime();
     int traj = blockIdx.x;
     CoopCtx cx;
+    cx.ticks = o.coopTicks;
     int pk = 0, npark = 1, pstride = 1;
     if constexpr (COOP) {
         pk = blockIdx.x / COOP_G;
@@ -518,6 +519,7 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf2(const DevM
     unsigned long long tick0 = __builtin_amdgcn_s_memtime();
     int traj = blockIdx.x;
     CoopCtx cx;
+    cx.ticks = o.coopTicks;
     int pk = 0, npark = 1, pstride = 1;
     if constexpr (COOP) {
         pk = blockIdx.x / COOP_G;
@@ -1308,6 +1310,10 @@ __device__ __forceinline__ int run_rollout(const DevModel& M, const DevOpts& o, 
             a.qdp[off] = qdp;
         }
     }
+    if constexpr (COOP) {
+        // a parked rollout a group has taken to its end: k_park_audit tells it from one nobody picked up by this
+        if (lane == 0 && writer && !(status & ST_COOP_FAULT)) a.resume[traj] = a.nsteps;
+    }
     if constexpr (!COOP) {
         if (lane == 0) {
             a.resume[traj] = stop;
@@ -1339,6 +1345,7 @@ __global__ void __launch_bounds__(64) k_step_pair(const DevModel M, const DevOpt
     unsigned long long tick0 = __builtin_amdgcn_s_memtime();
     int traj = blockIdx.x;
     CoopCtx cx;
+    cx.ticks = o.coopTicks;
     CoopPub pb;
     int pk = 0, npark = 1, pstride = 1;
     if constexpr (COOP) {
@@ -1409,6 +1416,7 @@ __device__ __attribute__((noinline)) int role_lean(const GroundArgs* __restrict_
     double *sAcc, *sCol;
     role_smem(M, sAcc, sCol);
     CoopCtx cx;
+    cx.ticks = o.coopTicks;
     CoopPub pb;
     return run_rollout<RUN_LEAN>(M, o, a, integ, sAcc, sCol, threadIdx.x, traj, 0, cx, pb, __builtin_amdgcn_s_memtime());
 }
@@ -1420,6 +1428,7 @@ __device__ __attribute__((noinline)) int role_pair(const GroundArgs* __restrict_
     double *sAcc, *sCol;
     role_smem(M, sAcc, sCol);
     CoopCtx cx;
+    cx.ticks = o.coopTicks;
     CoopPub pb;
     return run_rollout<RUN_PAIR>(M, o, a, integ, sAcc, sCol, threadIdx.x, traj, sfirst, cx, pb, __builtin_amdgcn_s_memtime());
 }
@@ -1432,6 +1441,7 @@ __device__ __forceinline__ void role_coop(const GroundArgs* __restrict__ g, cons
     role_smem(M, sAcc, sCol);
     const int lane = threadIdx.x;
     CoopCtx cx;
+    cx.ticks = o.coopTicks;
     CoopPub pb;
     cx.member = member;
     cx.words = a.xch + (size_t)grp * COOP_WORDS;
@@ -1439,6 +1449,10 @@ __device__ __forceinline__ void role_coop(const GroundArgs* __restrict__ g, cons
     int* const done = a.park + 1 + 4 * a.B;
     for (int e = grp; e < a.B; e += a.ngroups) {
         int v = 0;
+        // (the wait below ends when the rollout workgroups have all finished or parked.  It relies on their being dispatched - nothing
+        // in the programming model promises that workgroups start in index order -, so it is bounded: a group that has seen no entry and
+        // no end for 16 x the group timeout leaves, and k_park_audit marks whatever stays unfinished RMX_ST_COOP_FAULT)
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
         while (true) {
             // (relaxed polls: an agent-scope ACQUIRE invalidates this XCD's L2 under every wavefront that lives in it, hundreds of
             // times per microsecond with ~500 idle members polling; the one fence below, after the entry has been seen, is what orders
@@ -1456,6 +1470,7 @@ __device__ __forceinline__ void role_coop(const GroundArgs* __restrict__ g, cons
             // every rollout has finished or parked (its list entry is written BEFORE it is counted, both by the same lane with release
             // semantics), and the count of entries, read after the count of finished rollouts, does not reach this one
             if (d >= a.B && cnt <= e) return;
+            if (__builtin_amdgcn_s_memtime() - tw0 > 16ull * cx.ticks) return;
             __builtin_amdgcn_s_sleep(127);
         }
         __threadfence();                                 // acquire
@@ -1492,7 +1507,25 @@ __global__ void __launch_bounds__(64) k_ground32(const GroundArgs* __restrict__ 
 }
 
 // the steps with the contact terms of a chain of <= 32 nodes: fused (one launch for everything) or behind the lean launch of launch_step_ct_32
+// After the launches of a call that may park rollouts: a rollout that was parked and that no group took to its end (a group that gave
+// up waiting, see role_coop; never observed) must not pass for a result - RMX_ST_COOP_FAULT | RMX_ST_NAN and a NaN state, as for a rollout
+// whose group faulted.
+__global__ void __launch_bounds__(256) k_park_audit(const StepArgs a, const int nr) {
+    const int traj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (traj >= a.B || a.resume[traj] >= a.nsteps) return;
+    if (a.status) a.status[traj] |= ST_COOP_FAULT | 4;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int i = 0; i < nr; ++i) {
+        a.q[(size_t)traj * nr + i] = nan;
+        a.qd[(size_t)traj * nr + i] = nan;
+    }
+}
+static void launch_step_pair_32_impl(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a, bool fused);
 void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a, bool fused) {
+    launch_step_pair_32_impl(m, b, integ, o, a, fused);
+    if (a.park && o.parkHalv > 0) k_park_audit<<<dim3((b->B + 255) / 256), dim3(256), 0, b->stream>>>(a, m->nr);
+}
+static void launch_step_pair_32_impl(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a, bool fused) {
     b->last_kernel = fused ? "k_ground32" : "k_step_pair";
     if (fused) {
         // a.fused 1: rollouts and cooperative groups in one launch; 2: the rollouts (free flight + contact terms) in one launch, the groups in a second
@@ -1502,13 +1535,15 @@ void launch_step_pair_32(const rmx_model* m, const rmx_batch* b, int integ, cons
         ga.a.ngroups = inline_groups;
         ga.coop_only = 0;
         static_assert(2 * sizeof(GroundArgs) <= RMX_GARGS_BYTES, "rmx_batch::gargs");
-        (void)hipMemcpyAsync(b->gargs, &ga, sizeof ga, hipMemcpyHostToDevice, b->stream);      // (pageable source: staged before the call returns)
+        // (pageable source: staged before the call returns; a failed copy must not be followed by a launch that reads the block - the
+        // sticky error surfaces in the caller's hipGetLastError)
+        if (hipMemcpyAsync(b->gargs, &ga, sizeof ga, hipMemcpyHostToDevice, b->stream) != hipSuccess) return;
         RMX_LAUNCH(k_ground32, dim3(b->B + inline_groups * COOP_G), dim3(64), m->smem_bytes, b->stream, (const GroundArgs*)b->gargs);
         if (a.fused == 3 && a.park && o.parkHalv > 0) {      // measurement aid: the groups as a second launch of the SAME kernel (its out-of-line role)
             ga.a.ngroups = a.ngroups;
             ga.coop_only = 1;
             GroundArgs* g2 = (GroundArgs*)b->gargs + 1;
-            (void)hipMemcpyAsync(g2, &ga, sizeof ga, hipMemcpyHostToDevice, b->stream);
+            if (hipMemcpyAsync(g2, &ga, sizeof ga, hipMemcpyHostToDevice, b->stream) != hipSuccess) return;
             RMX_LAUNCH(k_ground32, dim3(a.ngroups * COOP_G), dim3(64), m->smem_bytes, b->stream, (const GroundArgs*)g2);
             return;
         }

@@ -555,3 +555,10 @@ def test_one_launch_cooperative_path_at_odd_sizes(monkeypatch):
     ref = run(1200, "24")
     got = run(1200, "24", group=True)
     assert np.array_equal(ref[0], got[0]) and (got[2]["status"] & 512).max() == 0
+    # ... and the same two launches with (nearly) every rollout parked - a threshold of one halving -: the SIMDs of the device are divided
+    # among the live batches that may hold cooperative groups (launch_step), so the groups of both launches are resident together and
+    # neither waits for members the other one keeps from being dispatched (round-5 advice); one wavefront per rollout is the reference
+    ref = run(600, "0")
+    got = run(600, "1", group=True)
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
+    assert np.array_equal(ref[2]["newton_iters"], got[2]["newton_iters"]) and (got[2]["status"] & 512).max() == 0
