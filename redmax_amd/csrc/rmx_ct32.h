@@ -25,7 +25,7 @@
 
 namespace rmx {
 
-// measurement builds (tools/pair_variants.py): -DRMX_TICK_PHASE=k makes rmx_step_ticks report the shader-clock ticks of ONE phase of
+// measurement builds (tools/build_variant.py --part 4 -- -DRMX_TICK_PHASE=k): RMX_TICK_PHASE=k makes rmx_step_ticks report the shader-clock ticks of ONE phase of
 // newton_pair instead of the rollout's whole share of the launch: 1 front, 2 Hessian stage, 3 solve, 4 exchange, 5 wait for the winner,
 // 6 publish
 #ifdef RMX_TICK_PHASE
