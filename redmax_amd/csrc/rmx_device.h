@@ -3440,7 +3440,10 @@ constexpr int ST_COOP_FAULT = 512; // RMX_ST_COOP_FAULT (include/redmax_hip.h): 
 // carry it with no fence, and a reader simply polls until the tag is the current one.  Every member then walks the bits in the
 // reference's order and reaches the reference's decision: identical iterates, iteration and halving counts, one evaluation latency
 // per line search instead of ten.
-constexpr int COOP_G = 10;                       // members of a group: trials 2 .. 2 COOP_G + 1 in one evaluation (iterLsMax = 20)
+#ifndef RMX_COOP_G
+#define RMX_COOP_G 10
+#endif
+constexpr int COOP_G = RMX_COOP_G;                       // members of a group: trials 2 .. 2 COOP_G + 1 in one evaluation (iterLsMax = 20)
 constexpr int COOP_WORDS = 32;                   // exchange words per group: 2 x COOP_G decision words (even / odd exchanges: a member may
                                                  // post exchange r + 1 while a slower one still reads r), [2 COOP_G] the group's abort flag
 constexpr int COOP_REC = 40;                     // doubles per group the winner of a line search publishes (rmx_ct32.h CoopPub)
