@@ -338,7 +338,7 @@ def test_chain32_pair_kernel(monkeypatch):
         sim.opts.compensated = comp
         sim.set_state(q, qd)
         sim.step_bdf1(2, h=1e-2)
-        out = sim.step_bdf1(K, h=1e-2, stats=True, history=True)
+        out = sim.step_bdf1(K, h=1e-2, stats=True, history="full")      # T, V, q, qdot of every step (Scene.saveHistory)
         res = (sim.get_state(), out)
         sim.close()
         return res
@@ -348,7 +348,7 @@ def test_chain32_pair_kernel(monkeypatch):
     for kw in cases:
         ((qa, qda), oa), ((qb, qdb), ob) = run("0", **kw), run("1", **kw)
         assert np.array_equal(qa, qb, equal_nan=True) and np.array_equal(qda, qdb, equal_nan=True), kw
-        for k in ("newton_iters", "ls_halvings", "status", "T", "V"):
+        for k in ("newton_iters", "ls_halvings", "status", "T", "V", "q", "qdot"):
             assert np.array_equal(oa[k], ob[k], equal_nan=True), (kw, k)
         if kw.get("wild") and not kw.get("lu_mode"):
             assert oa["ls_halvings"].sum() > 0 or (oa["status"] & 15).any(), "no line search ran: the wild states are too tame"
