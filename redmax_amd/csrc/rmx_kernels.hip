@@ -1597,6 +1597,7 @@ void launch_step_w2c_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o
 #endif
 #include "rmx_pair32.h"
 
+template <bool ENERGY>
 __global__ void __launch_bounds__(64) k_step_bdf1_pair32(const DevModel Min, const DevOpts o, const StepArgs a) {
     constexpr int NP = 32;
     const DevModel M = model_view<NP, true>(Min);
@@ -1611,7 +1612,7 @@ __global__ void __launch_bounds__(64) k_step_bdf1_pair32(const DevModel Min, con
     double qd = id >= 0 ? a.qd[off] : 0.0;
     int iters = 0, halv = 0, status = 0;
     PivotPolicy piv;
-    pair_rollout_bdf1(M, o, a, sAcc, lane, traj, id, off, q, qd, iters, halv, status, piv);
+    pair_rollout_bdf1<ENERGY>(M, o, a, sAcc, lane, traj, id, off, q, qd, iters, halv, status, piv);
     if (id >= 0 && lane < 32) {
         a.q[off] = q;
         a.qd[off] = qd;
@@ -1698,7 +1699,9 @@ void launch_phase_pairchain_32(const rmx_model* m, const rmx_batch* b, int reps,
 void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a) {
     const dim3 grid(b->B), block(64);
     b->last_kernel = "k_step_bdf1_pair32";
-    RMX_LAUNCH(k_step_bdf1_pair32, grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    // (a call that records T, V per step takes the instantiation that carries the energies of the last evaluation)
+    if (a.histT) RMX_LAUNCH(k_step_bdf1_pair32<true>, grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+    else RMX_LAUNCH(k_step_bdf1_pair32<false>, grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
 
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size

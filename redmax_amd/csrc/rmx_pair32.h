@@ -32,6 +32,9 @@ __device__ __forceinline__ double half_sum(const double v, const int half) {
 }
 
 // simLoop: steps 0 .. nsteps - 1 of one rollout.  q, qd: the state of node lane & 31 (mirrored in both half-waves), in and out.
+// ENERGY: the call records T, V per step (Scene.saveHistory).  Without it - the benchmark's launch - the energies of the last
+// evaluation (`last`, `e0`: six doubles copied at every Newton iteration) and their arithmetic in the front are not carried at all.
+template <bool ENERGY>
 __device__ __forceinline__ void pair_rollout_bdf1(const DevModel& M, const DevOpts& o, const StepArgs& a, double* sAcc, const int lane,
                                                   const int traj, const int id, const size_t off, double& q, double& qd, int& iters,
                                                   int& halvings, int& status, PivotPolicy& piv) {
@@ -69,7 +72,7 @@ __device__ __forceinline__ void pair_rollout_bdf1(const DevModel& M, const DevOp
         if (!pivot_all) pivot_policy_update(piv);
         qd = ((x - q0) + lo) / h;
         q = x;
-        if (a.histT) {
+        if (ENERGY && a.histT) {
             const double T = half_sum(last.eT, lastHalf), V = half_sum(last.eV, lastHalf);
             if (lane == 0) {
                 a.histT[(size_t)s * a.B + traj] = T;
@@ -89,7 +92,7 @@ __device__ __forceinline__ void pair_rollout_bdf1(const DevModel& M, const DevOp
         iter = 1; lsfail = 0; iterLs = 1;
         ls = false;
         redo = false;
-        e0.g = e0.eT = e0.eV = 0.0;
+        if constexpr (ENERGY) e0.g = e0.eT = e0.eV = 0.0;
         pivot_all = o.lu_mode != 0 || piv.hold > 0;
         if (piv.hold > 0) --piv.hold;
         return true;
@@ -117,16 +120,20 @@ __device__ __forceinline__ void pair_rollout_bdf1(const DevModel& M, const DevOp
                 two_sum(x0, fma(alpha, dx, lo0), x, lo);
                 lo *= o.comp;
                 if (__all(x == x0 && lo == lo0)) {           // see newton_impl: every further halving re-evaluates g(x0)
-                    last = e0;
-                    lastHalf = e0Half;
+                    if constexpr (ENERGY) {
+                        last = e0;
+                        lastHalf = e0Half;
+                    }
                     halvings += o.iterLsMax - 1;
                     if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
                     if (!end_step()) break;
                 }
                 continue;
             }
-            last = e;
-            lastHalf = prim;
+            if constexpr (ENERGY) {
+                last = e;
+                lastHalf = prim;
+            }
             halvings += iterLs - 1;
             bool ends = false;
             if (sqrt(gn2) < o.tol) {
@@ -154,10 +161,12 @@ __device__ __forceinline__ void pair_rollout_bdf1(const DevModel& M, const DevOp
         // ---- the Hessian stage on P's state, dx = -H\g
         double Hdummy[NP];
         (void)eval_hess<NP, false, false, false, true>(M, lane, fs, Hdummy, nullptr, sAcc, e.g, prim);
-        e0 = e;
-        e0Half = prim;
-        last = e;
-        lastHalf = prim;
+        if constexpr (ENERGY) {
+            e0 = e;
+            e0Half = prim;
+            last = e;
+            lastHalf = prim;
+        }
         if (!redo) ++iters;
         if (pivot_all || redo) {
             double Hrow[NP];
@@ -199,8 +208,10 @@ __device__ __forceinline__ void pair_rollout_bdf1(const DevModel& M, const DevOp
         two_sum(x0, fma(alpha, dx, lo0), x, lo);
         lo *= o.comp;
         if (__all(x == x0 && lo == lo0)) {
-            last = e0;
-            lastHalf = e0Half;
+            if constexpr (ENERGY) {
+                last = e0;
+                lastHalf = e0Half;
+            }
             halvings += o.iterLsMax - 1;
             if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
             if (!end_step()) break;

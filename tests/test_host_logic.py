@@ -107,7 +107,7 @@ def test_roofline_calibration_matches_the_built_kernel():
         assert bench.algorithm_flops(key) is not None
     cal, _ = bench.load_calibration("chain")
     # the headline workload is calibrated on the kernel that runs it: the two-point kernel of rmx_pair32.h
-    assert cal["kernels"] == ["k_step_bdf1_pair32"] and cal.get("per_wave_basis") == "fronts_beyond_iters"
+    assert len(cal["kernels"]) == 1 and cal["kernels"][0].startswith("k_step_bdf1_pair32") and cal.get("per_wave_basis") == "fronts_beyond_iters"
     assert any("k_step_bdf1_pair32" in v["name"] and v["scratch_bytes"] == 0 for v in fp.values())
     for k in ("flops", "SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64"):
         assert cal["per_wave"][k]["front"] >= 0 and cal["per_wave"][k]["newton"] > 0
