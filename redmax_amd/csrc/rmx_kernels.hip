@@ -91,7 +91,10 @@ constexpr int TAG_FULLN = 4;
 constexpr int TAG_COOP = 8;      // k_step_bdf1/2<32, true, false, false, TAG_COOP>: the cooperative launch (RMX_PART 4)
 constexpr int TAG_W2 = 16;       // k_step_bdf1/2<64, false, false, false, TAG_W2>: two wavefronts per 64-node tree (RMX_PART 5, RMX_W2);
                                  // TAG_W2 + 1: the same for trees of 33..63 nodes (n at run time)
-constexpr bool tag_w2(const int tag) { return tag == TAG_W2 || tag == TAG_W2 + 1; }
+constexpr int TAG_W2_NOE = TAG_W2 + 2;      // TAG_W2 for a call that records no energies (the benchmark's launch): the energies of the last
+                                             // evaluation are neither copied per Newton iteration nor summed by the helper wave
+constexpr bool tag_w2(const int tag) { return tag == TAG_W2 || tag == TAG_W2 + 1 || tag == TAG_W2_NOE; }
+constexpr bool tag_w2_full(const int tag) { return tag == TAG_W2 || tag == TAG_W2_NOE; }
 template <int NP, bool FULLCHAIN, int TAG = 0>
 __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
     DevModel M = Min;
@@ -99,7 +102,7 @@ __device__ __forceinline__ DevModel model_view(const DevModel& Min) {
         M.n = NP;
         M.is_chain = 1;
     }
-    if constexpr ((TAG >= TAG_FULLN && TAG < TAG_COOP) || TAG == TAG_W2) M.n = NP;
+    if constexpr ((TAG >= TAG_FULLN && TAG < TAG_COOP) || tag_w2_full(TAG)) M.n = NP;
     return M;
 }
 
@@ -110,7 +113,7 @@ __device__ __forceinline__ double* w2_help_area(const DevModel& M, double* sAcc)
 // RMX_W2: wave 1 of a two-wave workgroup.  It serves wave 0's guarded Newton iterations - the odd columns of the Hessian tiles, its
 // share of the block-column elimination - and sleeps at the workgroup barrier in between (eval_hess and lu_solve_neg_diag64_staged
 // hold wave 0's side of the same barriers).
-template <int NP>
+template <int NP, bool ENERGY = true>
 __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict__ sAcc, const int lane) {
     if constexpr (NP == 64 && RMX_W2) {
         constexpr int CS = cstride(NP);
@@ -127,7 +130,12 @@ __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict_
                 NodeOut e;
                 FrontState f2;
                 eval_front_e2<NP, false, false, false, false, W2_HELP_AS>(M, hp, lane, x, xqd, xv, eta, eta * eta, e, f2);
-                const double gn2 = wave_sum_np<NP>(e.g * e.g), T = wave_sum(e.eT), V = wave_sum(e.eV);
+                const double gn2 = wave_sum_np<NP>(e.g * e.g);
+                double T = 0.0, V = 0.0;
+                if constexpr (ENERGY) {
+                    T = wave_sum(e.eT);
+                    V = wave_sum(e.eV);
+                }
                 if (lane == 0) {
                     hp[W2_HELP_RES] = gn2;
                     hp[W2_HELP_RES + 1] = T;
@@ -182,7 +190,7 @@ __device__ __forceinline__ void w2c_helper(const DevModel& M, double* __restrict
 // itself; if the helper's |g|^2 ends the solve, the epilogue of the step runs here and the loop goes on as the next step's solve with
 // its first evaluation done; if not, the trial point is evaluated after all (the prediction cost one evaluation).  Returns the number
 // of steps finished (>= 1); ends at the first solve that ends on an evaluation of its own.
-template <int NP>
+template <int NP, bool ENERGY = true>
 __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o, const StepArgs& a, double* sAcc, const int lane,
                                              const int traj, const int id, const size_t off, int s, double& q, double& qd, int& iters,
                                              int& halvings, int& status, PivotPolicy& piv, int& predict) {
@@ -204,7 +212,7 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
     auto finish = [&](const double T, const double V) {
         qd = ((x - q0) + lo) / o.h;
         q = x;
-        if (a.histT && lane == 0) {
+        if (ENERGY && a.histT && lane == 0) {
             a.histT[(size_t)s * a.B + traj] = T;
             a.histV[(size_t)s * a.B + traj] = V;
         }
@@ -270,14 +278,14 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
                 two_sum(x0, fma(alpha, dx, lo0), x, lo);
                 lo *= o.comp;
                 if (__all(x == x0 && lo == lo0)) {        // see newton_impl: every further halving re-evaluates g(x0)
-                    last = e0;
+                    if constexpr (ENERGY) last = e0;
                     halvings += o.iterLsMax - 1;
                     if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
                     break;
                 }
                 continue;
             }
-            last = e;
+            if constexpr (ENERGY) last = e;
             halvings += iterLs - 1;
             if (sqrt(gn2) < o.tol) break;
             if (iter >= o.iterMax) {
@@ -292,8 +300,10 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
             ++iter;
         }
         (void)eval_hess<NP, false, false, false>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
-        e0 = e;
-        last = e;
+        if constexpr (ENERGY) {
+            e0 = e;
+            last = e;
+        }
         ++iters;
         {
             bool lu_ok;
@@ -337,7 +347,7 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
         two_sum(x0, fma(alpha, dx, lo0), x, lo);
         lo *= o.comp;
         if (__all(x == x0 && lo == lo0)) {
-            last = e0;
+            if constexpr (ENERGY) last = e0;
             halvings += o.iterLsMax - 1;
             if (!(sqrt(g0n2) < o.tol)) status |= 2 | 8;
             break;
@@ -347,7 +357,8 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
     // a solve that ended on an evaluation of its own
     predict = iter;
     pivot_policy_update(piv);
-    finish(wave_sum(last.eT), wave_sum(last.eV));
+    if constexpr (ENERGY) finish(wave_sum(last.eT), wave_sum(last.eV));
+    else finish(0.0, 0.0);
     return done;
 }
 #endif
@@ -387,7 +398,7 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
     const int lane = threadIdx.x;
     if constexpr (tag_w2(TAG)) {
         if (threadIdx.x >= 64) {
-            if constexpr (NP == 64) w2_helper<NP>(M, sAcc, lane - 64);
+            if constexpr (NP == 64) w2_helper<NP, TAG != TAG_W2_NOE>(M, sAcc, lane - 64);
             else w2c_helper<NP>(M, sAcc, lane - 64);
             return;
         }
@@ -427,7 +438,7 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
             // chains (whose residual-only front sums by another scan) keep newton_node.  NP == 32: the chains of RMX_PART 6, whose helper
             // runs the full front
             if ((NP == 32 || !M.is_chain) && o.lu_mode == 0 && piv.hold == 0) {
-                s += w2_steps_bdf1<NP>(M, o, a, sAcc, lane, traj, id, off, s, q, qd, iters, halv, status, piv, w2_predict) - 1;
+                s += w2_steps_bdf1<NP, TAG != TAG_W2_NOE>(M, o, a, sAcc, lane, traj, id, off, s, q, qd, iters, halv, status, piv, w2_predict) - 1;
                 continue;
             }
         }
@@ -441,7 +452,7 @@ __global__ void __launch_bounds__(tag_w2(TAG) ? 128 : 64) k_step_bdf1(const DevM
 #if RMX_W2
         // (a full tree gets here for its pivoting solves only - newton_policy's first branch: the guarded loop is w2_steps_bdf1)
         double x;
-        if constexpr (TAG == TAG_W2 && (!FULLCHAIN || NP == 32)) {
+        if constexpr (tag_w2_full(TAG) && (!FULLCHAIN || NP == 32)) {
             if (piv.hold > 0) --piv.hold;
             xlo = 0.0;
             x = newton_rot<NP, true>(M, o, sAcc, sCol, lane, xg, q0, xg, o.h, last, iters, halv, status, piv, xlo);
@@ -1571,7 +1582,9 @@ void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const 
         return;
     }
     if (m->dm.n == RMX_NP) {          // every node slot in use: the n == NP instantiation
-        if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
+        // (BDF1 without an energy record - the benchmark's launch -: the instantiation that does not carry the last evaluation's energies)
+        if (integ == INTEG_BDF1 && !a.histT) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2_NOE>), grid, block, smem_bytes, b->stream, m->dm, o, a);
+        else if (integ == INTEG_BDF1) RMX_LAUNCH((k_step_bdf1<RMX_NP, false, false, false, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
         else RMX_LAUNCH((k_step_bdf2<RMX_NP, false, false, false, TAG_W2>), grid, block, smem_bytes, b->stream, m->dm, o, a);
         return;
     }

@@ -8,7 +8,8 @@ ROWS = (  # (name fragment, what it runs)
     ("k_step_bdf1_pair32", "configs[1] headline: full 32-link chain, BDF1, two points per front"),
     ("k_step_bdf1<32, false, false, true, 0>", "the one-point kernel of the same chain (RMX_PAIRC=0; bit-identity reference)"),
     ("k_step_bdf1<32, false, false, true, 16>", "the same chain, two wavefronts per rollout (RMX_PAIRC=0, 128..512 rollouts)"),
-    ("k_step_bdf1<64, false, false, false, 16>", "configs[2]: full 64-node tree, two wavefronts per rollout (<= 512 rollouts)"),
+    ("k_step_bdf1<64, false, false, false, 18>", "configs[2]: full 64-node tree, two wavefronts per rollout (<= 512 rollouts), no energy record"),
+    ("k_step_bdf1<64, false, false, false, 16>", "the same with the per-step energy record"),
     ("k_step_bdf1<64, false, false, false, 19>", "configs[2] at > 512 rollouts: constants in global memory, four wavefronts per CU"),
     ("k_ground32", "configs[4]: 32-link chain on frictional ground, BDF2, rollouts + cooperative groups in one launch"),
     ("k_step_pair<false>", "the same as separate launches: rollouts"),
