@@ -25,19 +25,22 @@ def main():
     ap.add_argument("--np", type=int, default=32)
     ap.add_argument("--part", type=int, default=0)
     ap.add_argument("--no-vform", action="store_true")
+    ap.add_argument("--no-ilp", action="store_true", help="drop -amdgpu-sched-strategy=max-ilp where the in-tree build uses it (part 1, 64-lane objects)")
     ap.add_argument("--asm", action="store_true", help="also write the device assembly to build/isa/var_<name>.s")
     a = ap.parse_args(argv)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC]
-    ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if (a.part == 1 or a.np == 64) else []
+    ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ((a.part == 1 or a.np == 64) and not a.no_ilp) else []
     if a.np >= 32 and not a.no_vform:
         ilp += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
     vdir = os.path.join(ROOT, "build", "variants")
     os.makedirs(vdir, exist_ok=True)
     obj = os.path.join(vdir, "%s.o" % a.name)
     part_flags = {3: ["-DRMX_GLOBAL_CONSTS"], 6: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()", "-DRMX_CONSTS(sAcc,n,NP)=(rmx_smem_base()+acc_doubles((n),(NP)))"], 5: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()", "-DRMX_CONSTS(sAcc,n,NP)=(rmx_smem_base()+acc_doubles((n),(NP)))"]}.get(a.part, [])
-    if a.part == 7 and not any(x.startswith("-DRMX_SYNC") for x in extra):
+    if a.part in (4, 7) and not any(x.startswith("-DRMX_SYNC") for x in extra):
         part_flags = ["-DRMX_SYNC()=rmx_lane_sync()"]      # (the in-tree default of that part, __graft_entry__._build_hip)
+    if any(x.startswith("-DRMX_SYNC") for x in extra):      # (a variant's own synchronisation macro replaces the part's)
+        part_flags = [x for x in part_flags if not x.startswith("-DRMX_SYNC")]
     tu = ["-DRMX_NP=%d" % a.np, "-DRMX_PART=%d" % a.part] + part_flags + [ge.HIP_KERNEL_SRC]
     procs = [subprocess.Popen([hipcc] + flags + ilp + extra + ["-c", "-o", obj] + tu)]
     if a.asm:
