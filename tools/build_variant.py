@@ -30,7 +30,7 @@ def main():
     a = ap.parse_args(argv)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC]
-    ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ((a.part == 1 or a.np == 64) and not a.no_ilp) else []
+    ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ((a.part == 1 or a.np == 64 or (a.np == 16 and a.part == 0)) and not a.no_ilp) else []
     if a.np >= 32 and not a.no_vform:
         ilp += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
     vdir = os.path.join(ROOT, "build", "variants")
