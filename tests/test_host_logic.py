@@ -115,3 +115,22 @@ def test_roofline_calibration_matches_the_built_kernel():
     # the headline kernel holds no scratch (kernel resources are part of the fingerprint file)
     head = [v for v in fp.values() if "k_step_bdf1<32, false, false, true" in v["name"]][0]
     assert head["scratch_bytes"] == 0 and head["vgpr"] <= 512
+
+
+def test_design_kernel_table_is_the_built_library():
+    """DESIGN.md quotes registers / scratch / instruction counts of the kernels in ONE table, generated by tools/kernel_table.py from
+    the fingerprints of the library __graft_entry__.build() linked.  A kernel change without regenerating the table fails here (the
+    round-5 review found prose figures that contradicted the traces)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    ge.build()
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_table.py")], capture_output=True, text=True, check=True).stdout
+    rows = [ln for ln in out.splitlines() if ln.startswith("| `k_")]
+    assert len(rows) >= 10
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    missing = [r for r in rows if r not in design]
+    assert not missing, "DESIGN.md's kernel table is stale (python tools/kernel_table.py):\n" + "\n".join(missing)
