@@ -450,6 +450,7 @@ def test_config5_flagged_rollouts_replay_on_the_oracle(oracle_lib):
     sim.close()
     it, ls, st = out["newton_iters"], out["ls_halvings"], out["status"]
     assert (st & 512).max() == 0                      # no cooperative group gave up
+    assert (st & (64 | 256)).max() == 0               # the launch's internal hand-over bits (left the lean solve, parked) never reach the caller
     flagged = np.nonzero(st & 2)[0]
     assert len(flagged) >= 4, len(flagged)            # the workload does have such rollouts (12 of the first 256 when written)
     pick = list(flagged[:5]) + [1, 2]

@@ -119,6 +119,7 @@ def test_config5_chain_ground_full_size(oracle_lib):
     qa, qda = sim.get_state()
     assert np.isfinite(qa).all() and np.isfinite(qda).all() and not (out["status"] & 5).any()      # nothing diverged, no NaN
     assert not (out["status"] & 512).any()                                                         # no cooperative group gave up
+    assert not (out["status"] & (64 | 256)).any()                                                  # internal hand-over bits stay inside the launch
     sub = BatchSim(sc, batch=64)
     sub.set_state(q[512:576], qd[512:576])
     sub.step_bdf2(K, h=sc.h)
