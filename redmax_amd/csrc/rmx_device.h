@@ -2743,8 +2743,12 @@ constexpr int LU_BATCH = 8;
 struct GrowGuard {
     int hi = 0;
     __device__ __forceinline__ void see(const double prod) {
+#ifdef RMX_VAR_NO_GROW_GUARD      // measurement aid (tools/build_variant.py): what the growth half of the guard costs
+        (void)prod;
+#else
         const int h = __double2hiint(prod);
         hi = h > hi ? h : hi;
+#endif
     }
     __device__ __forceinline__ void pin() { asm volatile("" : "+v"(hi)); }
     __device__ __forceinline__ bool bad(const double lim) const { return hi > __double2hiint(lim); }      // lim = 64 d_i > 0
