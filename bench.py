@@ -348,6 +348,18 @@ def measure(ctx, make_stepper, scene, gen, shard, h, tol, integ, K, W, repeats, 
         burn_ms += st.wait()
         burned += 1
     if burned:
+        # ... and ONE untimed rehearsal of the timed sequence itself (counter reset, the synchronous W warm-up steps, device sync,
+        # barrier, the K-step launch, wait, gather, barrier): the first launch behind the process's first synchronous step call pays
+        # 13 - 30 us of one-time host / runtime set-up (tools: profiles/r6n_timed_region_probe.txt), 2 - 4 % of a 0.8 ms launch
+        st.set_state(q0, qd0)
+        st.stats_reset()
+        st.warmup(W)
+        st.sync_device()
+        ctx.barrier()
+        st.launch(K)
+        st.wait()
+        ctx.gather(st, shard)
+        ctx.barrier()
         st.set_state(q0, qd0)
     st.stats_reset()
     st.warmup(W)
@@ -591,7 +603,7 @@ def rank_main(args, make_stepper=None, backend=None):
                        "parallelism": "batch-sharded x%d (redmax_amd.sharding), one %s all-gather of the final (q,qdot)%s" % (
                            world, "RCCL" if backend == "nccl" else backend,
                            "; ranks share a device, so the gather runs on gloo with host tensors" if (on_gpu and shared) else ""),
-                       "steps_per_launch": K, "untimed_burn_in": {"ms": burn, "launches": m.get("burned", 0)}, "not_converged_trajectories": m["bad"], "trajectories_with_pivoted_fallback": m["pivoted"],
+                       "steps_per_launch": K, "untimed_burn_in": {"ms": burn, "launches": m.get("burned", 0), "rehearsal": "one untimed run of the whole timed sequence (W warm-up steps, sync, K-step launch, wait, gather) before the real one" if m.get("burned", 0) else None}, "not_converged_trajectories": m["bad"], "trajectories_with_pivoted_fallback": m["pivoted"],
                        "all_finite": m["finite"], "gathered_rows": m["gathered_rows"]},
             "roofline": roofline(m["kernel_ms"], m["iters"] / world, m["halvings"] / world, B * K, K, W, B, n, wl, args.tol, m["local_iters"],
                                  step_kernel=m.get("step_kernel")) if on_gpu else None,
