@@ -1069,6 +1069,19 @@ static hipError_t set_started(rmx_batch* b, const int v) {
     b->started_host = e == hipSuccess ? v : -1;
     return e;
 }
+// Wait for a stream whose work is expected to end within a millisecond or two: by polling (hipStreamSynchronize's wake-up costs
+// ~10 us of a 0.8 ms launch); after 2 ms the host thread blocks as before.
+static hipError_t wait_stream_short(hipStream_t stream) {
+    hipError_t es = hipErrorNotReady;
+    for (const auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2);) {
+        es = hipStreamQuery(stream);
+        if (es != hipErrorNotReady) break;
+    }
+    if (es == hipErrorNotReady) es = hipStreamSynchronize(stream);
+    else (void)hipGetLastError();      // (hipStreamQuery leaves hipErrorNotReady as the thread's last error while it polls)
+    return es;
+}
+
 static void take_event_time(rmx_batch* b) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
@@ -1102,7 +1115,7 @@ static int step_sync(rmx_batch* b, const rmx_opts* opts, int nsteps, rmx_stats* 
         rc = hist_copy_out(b, &h, (size_t)b->B, 0);
         if (rc == RMX_OK) {
             if (ws) e = stats_copy_out(b, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+            if (e == hipSuccess) e = wait_stream_short(b->stream);
             if (e == hipSuccess) {
                 take_event_time(b);
                 b->async_pending = false;      // the stream has been waited for: nothing of this batch is in flight any more
@@ -1246,7 +1259,7 @@ static int adjoint_impl(rmx_batch* b, const rmx_opts* opts, int nsteps, const rm
             if (stats->newton_iters) e = hipMemcpyAsync(stats->newton_iters, b->it, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
             if (e == hipSuccess && stats->status) e = hipMemcpyAsync(stats->status, b->status, sizeof(int) * b->B, hipMemcpyDeviceToHost, b->stream);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e == hipSuccess) e = wait_stream_short(b->stream);      // (configs[3]: a launch pair of 0.9 ms)
         if (e == hipSuccess) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess) b->last_ms = ms;
@@ -1344,15 +1357,7 @@ extern "C" int rmx_step_ticks(rmx_batch* b, unsigned long long* ticks) {
 extern "C" int rmx_sync(rmx_batch* b) {
     if (!b) return fail(RMX_E_INVALID, "null batch");
     HIPCHK(hipSetDevice(b->m->device));
-    // a short launch is waited for by polling (hipStreamSynchronize's wake-up costs ~10 us of a 0.8 ms launch); after 2 ms the host
-    // thread blocks as before
-    hipError_t es = hipErrorNotReady;
-    for (const auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2);) {
-        es = hipStreamQuery(b->stream);
-        if (es != hipErrorNotReady) break;
-    }
-    if (es == hipErrorNotReady) es = hipStreamSynchronize(b->stream);
-    else (void)hipGetLastError();      // (hipStreamQuery leaves hipErrorNotReady as the thread's last error while it polls)
+    const hipError_t es = wait_stream_short(b->stream);
     b->async_pending = false;
     if (es != hipSuccess) return fail(RMX_E_HIP, std::string("rmx_sync: the asynchronous launch failed: ") + hipGetErrorString(es));
     take_event_time(b);
