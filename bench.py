@@ -212,11 +212,10 @@ class GpuStepper:
         self.sim.sync()
 
     def launch(self, K):
-        if self.integ == "bdf2":      # BDF2 has no async entry point: the synchronous call returns after the kernel
-            self._out = self.sim.step_bdf2(K, stats=True)
-        else:
-            self.sim.step_bdf1_async(K)      # all K steps of all rollouts: one kernel launch
-            self._out = None
+        # all K steps of all rollouts: one call, one kernel launch (configs[4]: rollouts and cooperative groups in one launch);
+        # the counters stay on the device until stats()
+        (self.sim.step_bdf2_async if self.integ == "bdf2" else self.sim.step_bdf1_async)(K)
+        self._out = None
 
     def wait(self):
         """kernel milliseconds of the launch (HIP events on the kernel's own stream)."""
