@@ -75,6 +75,7 @@ struct rmx_model {
     void* dgconst = nullptr;        // 64-lane plain models: the staged per-node constants in global memory (DevModel::gconst)
     int gconst_min_batch = 0;       // batches of at least this many rollouts run the global-constants kernels (0: never)
     int w2_max_batch = 0;           // 33..64-node trees / the full 32-link chain: batches of up to this many rollouts take two wavefronts each (0: never; RMX_W2_MAX)
+    int adj_help_max_batch = 0;     // trees of <= 16 nodes: adjoint batches of up to this many rollouts take a second wavefront each for M, D (rmx_kernels.hip RMX_PART 8; 0: never)
     int w2_min_batch = 0;           // the full 32-link chain: ... and of at least this many (RMX_W2C_MIN; smaller batches keep the one-wave kernel every test pins)
     bool big = false;               // more than 64 nodes: the one-workgroup-per-tree kernels of rmx_big.hip
     bool pair32 = false;            // serial chain of <= 32 nodes with ForceGroundCuboid, no Euler-chart joints: the kernels around newton_pair
@@ -146,6 +147,7 @@ void launch_step_w2_64(const rmx_model* m, const rmx_batch* b, int integ, const 
 void launch_step_w2c_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a);
 // rmx_kernels.hip RMX_PART 7: the full 32-link chain, BDF1, two points per evaluation (rmx_pair32.h)
 void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevOpts& o, const StepArgs& a);
+void launch_adjoint_help_16(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const AdjArgs& a);
 void launch_phase_pairchain_32(const rmx_model* m, const rmx_batch* b, int reps, double h, unsigned long long* d);
 // rmx_kernels.hip RMX_PART 4 (32 lanes): serial chains with ground contact - the launch with the contact terms around newton_pair
 // (rmx_ct32.h) and the cooperative launch that finishes the rollouts it parked

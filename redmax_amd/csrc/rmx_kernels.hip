@@ -729,10 +729,87 @@ __global__ void __launch_bounds__(64) k_step_euler(const DevModel M, const doubl
 // (TaskBDF1.m:45-81) / TaskBDF2.calcFinal (TaskBDF2.m:45-107).  Every forward solve is the common residual
 //     qdot = (x - qA)/eta,  v = x - qB,  g = M v - eta^2 f,  H = dg/dx      (evalBDF1, evalSDIRK2a/b, evalBDF2).
 
-template <int NP, int INTEG>
-__global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+// HELP (RMX_PART 8, trees of <= 16 nodes in batches of at most one rollout per two SIMDs - configs[3]'s 512 rollouts): a workgroup of
+// TWO wavefronts per rollout.  M and D of a step do not enter the Newton iteration; forming and storing them is 9.5 % of the launch
+// pair (profiles/r05w_adjoint_md_bound.txt).  Wave 0 - the rollout - leaves the 39 numbers per node that eval_MD reads in a
+// double-buffered hand-over area of the workgroup's LDS at the end of each step and goes on with the next step; wave 1 forms M, D
+// from them and stores them.  One workgroup barrier per step: wave 1 reaches barrier s + 1 after it has finished step s, so it has
+// read buffer s & 1 before wave 0 (which writes that buffer again only behind barrier s + 1) can touch it.  Same function on the same
+// numbers: M, D are bit-identical to the one-wave kernel's.
+constexpr int ADJ_HAND = 40;      // doubles per node and buffer
+__host__ __device__ constexpr size_t adj_hand_doubles(const int NP) { return (size_t)2 * ADJ_HAND * NP; }
+template <int NP>
+__device__ __forceinline__ void adj_hand_put(double* __restrict__ hb, const int lane, const FrontState& fs) {
+    if (lane < NP) {
+        double* o = hb + lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o[c * NP] = fs.sw[c];
+            o[(3 + c) * NP] = fs.sv[c];
+            o[(6 + c) * NP] = fs.xiw[c];
+            o[(9 + c) * NP] = fs.xiv[c];
+        }
+#pragma unroll
+        for (int c = 6; c < NACC; ++c) o[(12 + c - 6) * NP] = fs.S[c];
+        static_assert(12 + NACC - 6 + 5 <= ADJ_HAND, "hand-over rows");
+        o[(12 + NACC - 6) * NP] = fs.dd;
+        o[(13 + NACC - 6) * NP] = __longlong_as_double((long long)fs.anc_m);
+        o[(14 + NACC - 6) * NP] = __longlong_as_double((long long)fs.desc_m);
+        o[(15 + NACC - 6) * NP] = fs.act ? 1.0 : 0.0;
+        o[(16 + NACC - 6) * NP] = fs.dof ? 1.0 : 0.0;
+    }
+}
+template <int NP>
+__device__ __forceinline__ void adj_md_helper(const DevModel& M, const AdjArgs& a, const double* __restrict__ hand, const int lane, const int traj) {
+    const int n = M.n;
+    const size_t nn = (size_t)n * n;
+    const int l = lane < NP ? lane : 0;      // (lanes beyond the tree's DPP row read node 0's numbers: their results are not stored)
+    for (int s = 1; s <= a.nsteps; ++s) {
+        __syncthreads();
+        const double* o = hand + (size_t)(s & 1) * (ADJ_HAND * NP) + l;
+        FrontState fs;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            fs.sw[c] = o[c * NP];
+            fs.sv[c] = o[(3 + c) * NP];
+            fs.xiw[c] = o[(6 + c) * NP];
+            fs.xiv[c] = o[(9 + c) * NP];
+        }
+#pragma unroll
+        for (int c = 6; c < NACC; ++c) fs.S[c] = o[(12 + c - 6) * NP];
+        fs.dd = o[(12 + NACC - 6) * NP];
+        fs.anc_m = (unsigned long long)__double_as_longlong(o[(13 + NACC - 6) * NP]);
+        fs.desc_m = (unsigned long long)__double_as_longlong(o[(14 + NACC - 6) * NP]);
+        fs.act = lane < NP && o[(15 + NACC - 6) * NP] != 0.0;
+        fs.dof = o[(16 + NACC - 6) * NP] != 0.0;
+        double Mrow[NP], Drow[NP];
+        eval_MD<NP>(M, lane, fs, Mrow, Drow);
+        double* Mk = a.Ms + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        double* Dk = a.Ds + ((size_t)traj * a.nsteps + (s - 1)) * nn;
+        if (lane < n) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (i < n) {
+                    Mk[(size_t)i * n + lane] = Mrow[i];
+                    Dk[(size_t)i * n + lane] = Drow[i];
+                }
+        }
+    }
+}
+
+template <int NP, int INTEG, bool HELP = false>
+__global__ void __launch_bounds__(HELP ? 128 : 64) k_adjoint_fwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+    static_assert(!HELP || NP <= 16, "the helper-wave form: trees of one DPP row");
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
+    double* hand = nullptr;
+    if constexpr (HELP) {
+        hand = sAcc + acc_doubles(M.n, NP) + (size_t)(NCONST + NGROUND) * cstride(NP);      // behind the wave's scratch and the constants
+        if (threadIdx.x >= 64) {
+            adj_md_helper<NP>(M, a, hand, (int)threadIdx.x - 64, (int)blockIdx.x);
+            return;
+        }
+    }
     const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
     const int id = (lane < n) ? M.idx[lane] : -1;
     const size_t off = (size_t)traj * M.nr + (id >= 0 ? id : 0);
@@ -874,6 +951,14 @@ __global__ void __launch_bounds__(64) k_adjoint_fwd(const DevModel M, const DevO
                         for (int i = 0; i < NP; ++i)
                             if (i < n) Hk[(size_t)i * n + lane] = Hs[i];
                     }
+                }
+            } else if (HELP && last_solve) {
+                adj_hand_put<NP>(hand + (size_t)(s & 1) * (ADJ_HAND * NP), lane, fs);      // fs: the state of the last evaluated iterate
+                __syncthreads();                                                            // (the one barrier of the step: see above)
+                if (lane < n) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        if (i < n) Hk[(size_t)i * n + lane] = Hs[i];
                 }
             } else if (last_solve) {
                 double Mrow[NP], Drow[NP];
@@ -1717,6 +1802,23 @@ void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevO
     else RMX_LAUNCH(k_step_bdf1_pair32<false>, grid, block, m->smem_bytes, b->stream, m->dm, o, a);
 }
 
+#elif RMX_PART == 8      // adjoint forward sweep of trees of <= 16 nodes with a second wavefront per rollout for M, D (k_adjoint_fwd HELP)
+#if RMX_NP != 16
+#error "RMX_PART 8 is compiled for RMX_NP = 16 with a wave-local RMX_SYNC()"
+#endif
+
+void launch_adjoint_help_16(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const AdjArgs& a) {
+    const dim3 grid(b->B);
+    const size_t smem_bytes = m->smem_bytes + sizeof(double) * adj_hand_doubles(RMX_NP);
+    if (integ == INTEG_BDF1) {
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 1, true>), grid, dim3(128), smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 1><<<grid, dim3(64), 0, b->stream>>>(m->dm, o, a);
+    } else {
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 2, true>), grid, dim3(128), smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 2><<<grid, dim3(64), 0, b->stream>>>(m->dm, o, a);
+    }
+}
+
 #elif RMX_PART == 2      // the FULLCHAIN instantiations of the plain step kernels (sizes 16, 32, 64), one object per size
 
 void RMX_CAT(launch_step_fullchain_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const StepArgs& a) {
@@ -1826,6 +1928,13 @@ void RMX_CAT(launch_energy_, RMX_NP)(const rmx_model* m, const rmx_batch* b, dou
 
 void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const AdjArgs& a) {
     const dim3 grid(b->B), block(64);
+#if RMX_NP == 16
+    // up to one rollout per two SIMDs: a second wavefront per rollout forms and stores M, D (RMX_PART 8; RMX_ADJ_HELP=0: tests)
+    {
+        const char* ah = getenv("RMX_ADJ_HELP");      // (read at every call: tests switch it inside one process)
+        if (!(ah && atoi(ah) == 0) && m->adj_help_max_batch > 0 && b->B <= m->adj_help_max_batch) return launch_adjoint_help_16(m, b, integ, o, a);
+    }
+#endif
     if (integ == INTEG_BDF1) {
         RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 1>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
         k_adjoint_bwd<RMX_NP, 1><<<grid, block, 0, b->stream>>>(m->dm, o, a);

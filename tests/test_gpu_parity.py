@@ -380,6 +380,31 @@ def test_adjoint_with_device_arrays_equals_the_host_call(integ):
     sim.close()
 
 
+@pytest.mark.parametrize("n,B,K,integ", [(16, 96, 12, 1), (16, 96, 12, 2), (11, 33, 9, 1), (16, 1, 5, 2)])
+def test_adjoint_helper_wave_equals_one_wave(n, B, K, integ, monkeypatch):
+    """Trees of <= 16 nodes in batches of up to one rollout per two SIMDs: a second wavefront per rollout forms and stores M, D of every
+    step from the numbers the rollout's wavefront leaves in LDS (rmx_kernels.hip RMX_PART 8, k_adjoint_fwd HELP) - the same function on
+    the same numbers: P, dP/dp, the final state and the counters equal the one-wave kernel's (RMX_ADJ_HELP=0) bit for bit."""
+    from redmax_amd import BatchSim
+    from redmax_amd.scenes import sceneAdjointChain
+    sc = sceneAdjointChain(n)
+    sc.init()
+    p = 0.1 * np.random.default_rng(5).standard_normal((B, sc.nr))
+    task = dict(sc.task, t=K * sc.h)
+    q0, qd0 = sc.getQ()
+    res = []
+    for helper in ("0", "1"):
+        monkeypatch.setenv("RMX_ADJ_HELP", helper)
+        sim = BatchSim(sc, batch=B)
+        sim.set_state(q0[None, :], qd0[None, :])
+        P, dPdp, info = (sim.adjoint_bdf1 if integ == 1 else sim.adjoint_bdf2)(K, sc.h, task, p, stats=True)
+        res.append((P, dPdp, info["newton_iters"], info["status"]) + sim.get_state())
+        sim.close()
+    assert np.isfinite(res[0][0]).all() and np.abs(res[0][1]).sum() > 0
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 def test_adjoint_scene100_at_its_own_horizon(oracle_lib):
     """The reference's own adjoint scene (scene 100, scenesRedMax.m:402-436: 2 links, tEnd = 1, h = 1e-2) for its full 100 steps:
     forward + backward sweep against the oracle (P, dP/dp, final state, Newton counts), and the reference's testGrad identity

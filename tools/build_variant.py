@@ -30,14 +30,14 @@ def main():
     a = ap.parse_args(argv)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC]
-    ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ((a.part == 1 or a.np == 64 or (a.np == 16 and a.part == 0)) and not a.no_ilp) else []
+    ilp = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if ((a.part == 1 or a.np == 64 or (a.np == 16 and a.part in (0, 8))) and not a.no_ilp) else []
     if a.np >= 32 and not a.no_vform:
         ilp += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
     vdir = os.path.join(ROOT, "build", "variants")
     os.makedirs(vdir, exist_ok=True)
     obj = os.path.join(vdir, "%s.o" % a.name)
     part_flags = {3: ["-DRMX_GLOBAL_CONSTS"], 6: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()", "-DRMX_CONSTS(sAcc,n,NP)=(rmx_smem_base()+acc_doubles((n),(NP)))"], 5: ["-DRMX_W2=1", "-DRMX_SYNC()=rmx_wave_sync()", "-DRMX_CONSTS(sAcc,n,NP)=(rmx_smem_base()+acc_doubles((n),(NP)))"]}.get(a.part, [])
-    if a.part in (4, 7) and not any(x.startswith("-DRMX_SYNC") for x in extra):
+    if a.part in (4, 7, 8) and not any(x.startswith("-DRMX_SYNC") for x in extra):
         part_flags = ["-DRMX_SYNC()=rmx_lane_sync()"]      # (the in-tree default of that part, __graft_entry__._build_hip)
     if any(x.startswith("-DRMX_SYNC") for x in extra):      # (a variant's own synchronisation macro replaces the part's)
         part_flags = [x for x in part_flags if not x.startswith("-DRMX_SYNC")]
@@ -55,7 +55,7 @@ def main():
             if part == 2 and n < 16:
                 continue
             objs.append(obj if (n == a.np and part == a.part) else os.path.join(ge.OBJ_DIR, "rmx_kernels_np%d_p%d.o" % (n, part)))
-    for n, part in ((64, 3), (32, 4), (64, 5), (32, 6), (32, 7)):      # the one-size parts
+    for n, part in ((64, 3), (32, 4), (64, 5), (32, 6), (32, 7), (16, 8)):      # the one-size parts
         objs.append(obj if (n == a.np and part == a.part) else os.path.join(ge.OBJ_DIR, "rmx_kernels_np%d_p%d.o" % (n, part)))
     out = os.path.join(ROOT, "redmax_amd", "variants", "libredmax_hip_%s.so" % a.name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs)
