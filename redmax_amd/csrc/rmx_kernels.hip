@@ -1049,6 +1049,9 @@ __device__ __forceinline__ void adj_block(double& y, const double* __restrict__ 
     }
 }
 
+#ifndef RMX_ADJ_BWD_PIVOT
+#define RMX_ADJ_BWD_PIVOT 0          // 1: the backward sweep's solves with the pivot search always (build variants)
+#endif
 template <int NP, int INTEG>
 __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevOpts o, const AdjArgs a) {
     const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
@@ -1082,7 +1085,21 @@ __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevO
         const double* Hc = a.Hs + ((size_t)traj * a.nsteps + (k - 1)) * nn + (size_t)col * n;
 #pragma unroll
         for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? Hc[i] : ((i == lane) ? 1.0 : 0.0);
-        const double z = lu_solve_neg<NP, true>(n, lane, Hrow, -y);
+        double z;
+        if constexpr (NP <= 32 && !RMX_ADJ_BWD_PIVOT) {
+            // as in the forward sweep: diagonal pivots under the growth guard first (a third of the instructions of the pivot search; H'
+            // is as close to symmetric positive definite as H), partial pivoting on a fresh copy of the rows when the guard trips
+            const double hd = lane < n ? Hc[col] : 1.0;
+            bool lu_ok;
+            z = lu_solve_neg_diag<NP>(lane, Hrow, -y, hd, lu_ok);
+            if (!lu_ok) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? Hc[i] : ((i == lane) ? 1.0 : 0.0);
+                z = lu_solve_neg<NP, true>(n, lane, Hrow, -y);
+            }
+        } else {
+            z = lu_solve_neg<NP, true>(n, lane, Hrow, -y);
+        }
         zs += z;
         z4 = z3;
         z3 = z2;
