@@ -1070,11 +1070,13 @@ static hipError_t set_started(rmx_batch* b, const int v) {
     b->started_host = e == hipSuccess ? v : -1;
     return e;
 }
-// Wait for a stream whose work is expected to end within a millisecond or two: by polling (hipStreamSynchronize's wake-up costs
-// ~10 us of a 0.8 ms launch); after 2 ms the host thread blocks as before.
+// Wait for a stream by polling (hipStreamSynchronize's wake-up costs ~10 us: 1 - 2 % of the 0.8 ms launches of configs[1] and [3]);
+// after RMX_WAIT_SPIN_MS milliseconds (default 2; polling through the 5.8 / 16.6 ms launches of configs[2] / [4] gained nothing
+// measurable) the host thread blocks as before.
 static hipError_t wait_stream_short(hipStream_t stream) {
+    static const int spin_ms = [] { const char* e = getenv("RMX_WAIT_SPIN_MS"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : v; }();
     hipError_t es = hipErrorNotReady;
-    for (const auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2);) {
+    for (const auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(spin_ms);) {
         es = hipStreamQuery(stream);
         if (es != hipErrorNotReady) break;
     }
