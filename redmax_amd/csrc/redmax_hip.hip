@@ -353,8 +353,39 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
         if (const char* lim = getenv("RMX_BIG_LDS_LIMIT")) m->lds_limit = atoi(lim);     // development aid (0: H of large trees stays in HBM)
     }
     if (hipSetDevice(device) != hipSuccess) { delete m; return fail(RMX_E_HIP, "hipSetDevice failed"); }
+    // the tree as the multifrontal solve of 33..64-node branching trees walks it (DevModel::tree, tree_solve64 in rmx_device.h)
+    std::vector<int> tree((size_t)TREE_ROWS * NS, -1);
+    int tree_dmax = 0, tree_cmax = 0;
+    if (!big && n > 32 && nsph == 0) {
+        std::vector<int> dep(n, 0), nch(n, 0);
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {
+            dep[k] = par[k] >= 0 ? dep[par[k]] + 1 : 0;
+            if (par[k] >= k) ok = false;                       // (parents first: the depth-first order the kernels rely on)
+            if (dep[k] > TREE_DMAX) ok = false;
+            tree_dmax = std::max(tree_dmax, dep[k]);
+            if (par[k] >= 0) {
+                if (nch[par[k]] >= TREE_CMAX) ok = false;
+                else tree[(size_t)(1 + TREE_DMAX + nch[par[k]]++) * NS + par[k]] = k;
+                tree_cmax = std::max(tree_cmax, nch[par[k]]);
+            }
+        }
+        int roots = 0;
+        for (int k = 0; k < n; ++k) roots += par[k] < 0;
+        if (roots != 1) ok = false;                            // (one tree: every frontal matrix ends at the same root)
+        if (ok) {
+            for (int k = 0; k < n; ++k) {
+                tree[k] = dep[k];
+                for (int t = par[k]; t >= 0; t = par[t]) tree[(size_t)(1 + dep[t]) * NS + k] = t;
+                tree[(size_t)(1 + TREE_DMAX + TREE_CMAX) * NS + k] = par[k];
+            }
+        }
+        if (!ok || tree_dmax < 1) tree_dmax = 0;
+        const char* ts = getenv("RMX_TREE_SOLVE");             // 0: the dense guarded solve for every tree (tests)
+        if (ts && atoi(ts) == 0) tree_dmax = 0;
+    }
     const size_t nd = K.size() + sb.size() + I4.size() + prm.size();
-    const size_t ni = type.size() + idx.size() + endd.size() + anc.size();
+    const size_t ni = type.size() + idx.size() + endd.size() + anc.size() + tree.size();
     const size_t bytes = nd * sizeof(double) + rel.size() * sizeof(unsigned long long) + ni * sizeof(int);
     hipError_t e = hipMalloc(&m->dbuf, bytes);
     if (e != hipSuccess) { delete m; return fail(RMX_E_NOMEM, std::string("hipMalloc(model): ") + hipGetErrorString(e)); }
@@ -376,6 +407,9 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
     m->dm.idx = (const int*)put(idx.data(), idx.size() * sizeof(int));
     m->dm.end = (const int*)put(endd.data(), endd.size() * sizeof(int));
     m->dm.anc = (const int*)put(anc.data(), anc.size() * sizeof(int));
+    m->dm.tree = (const int*)put(tree.data(), tree.size() * sizeof(int));
+    m->dm.tree_dmax = tree_dmax;
+    m->dm.tree_cmax = tree_cmax;
     for (int c = 0; c < 3; ++c) m->dm.grav[c] = d->grav[c];
     e = hipMemcpy(m->dbuf, host.data(), bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(m->dbuf); delete m; return fail(RMX_E_HIP, std::string("hipMemcpy(model): ") + hipGetErrorString(e)); }

@@ -140,7 +140,15 @@ struct DevModel {
     int nsph;
     const double* sphV;  // [nsph][3 nodes][3 axes][SPH_ROWS]  K and sb of each group node for axis x, y, z
     short sph_first[MAXSPH + 3];
+    // Branching trees of 33..64 nodes and depth <= TREE_DMAX: the structure the multifrontal solve walks (tree_solve64).  tree: [TREE_ROWS][MAXN]
+    // ints - row 0 depth (-1: no node), rows 1 .. TREE_DMAX the ancestor at depth 0 .. TREE_DMAX - 1 (or -1), then the children, then
+    // the parent; tree_dmax = 0: the dense solve (serial chains, deep trees, other sizes)
+    const int* tree;
+    int tree_dmax, tree_cmax;
 };
+constexpr int TREE_DMAX = 7;       // deepest node of a tree the multifrontal solve takes (levels 0 .. 7: frontal matrices of up to 8 x 9)
+constexpr int TREE_CMAX = 4;       // most children of a node
+constexpr int TREE_ROWS = 1 + TREE_DMAX + TREE_CMAX + 1;
 
 struct DevOpts {
     double h, tol, dxMax;
@@ -3295,6 +3303,182 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
     return dx;
 }
 
+// ---- 33..64 rows of a BRANCHING tree: the guarded solve as a multifrontal elimination along the tree.
+// H(i, j) is non-zero only where one of the nodes i, j is an ancestor of the other (the Hessian stage's relation masks), so in
+// leaves-first order the elimination creates no fill outside the root paths: node i owns a frontal matrix over itself and its
+// ancestors, G[k1][k2] with k = levels above i (0 = i itself) - row 0 = H(i, ancestors), column 0 = H(ancestors, i), the rest the
+// updates its subtree has accumulated for its ancestors - and the right-hand side rides along as one more column.  Lane = node; ALL
+// nodes of a depth level are eliminated at once (they share no unknown), then every parent adds its children's update matrices
+// (shifted by one level) to its own, children in listing order: depth rounds of at most (d + 1)(d + 2) fused multiply-adds and
+// lane gathers per node instead of 64 pivot steps over 64 x 64 - the 64-joint tree of configs[2] (depth 6, 592 of 4096 entries
+// non-zero): ~1.1 k instructions and 6 dependent levels against 4 k instructions and 64 dependent pivots.  The back substitution
+// walks down: a node takes its ancestors' solutions from its parent.  Guards as in the dense solve (every pivot positive and finite,
+// every multiplier of the equilibrated matrix below LU_GROWTH_MAX); a tripped guard sends the caller to the pivoting dense solve.
+// Not the dense solve's elimination order, hence not its rounding: results agree with it to roundoff, not bit for bit.
+struct TreeLane {
+    int depth, parent;
+    int up[TREE_DMAX + 1];       // up[k]: the ancestor k levels up (k = 1 .. depth), -1 beyond the root
+    int child[TREE_CMAX];
+};
+__device__ __forceinline__ TreeLane tree_lane(const DevModel& M, const int lane) {
+    TreeLane t;
+    const int* T = M.tree + lane;
+    t.depth = T[0];
+    t.parent = T[(1 + TREE_DMAX + TREE_CMAX) * MAXN];
+#pragma unroll
+    for (int c = 0; c < TREE_CMAX; ++c) t.child[c] = T[(1 + TREE_DMAX + c) * MAXN];
+    t.up[0] = lane;
+#pragma unroll
+    for (int k = 1; k <= TREE_DMAX; ++k) {
+        const int e = t.depth - k;                           // depth of that ancestor
+        t.up[k] = e >= 0 ? T[(1 + e) * MAXN] : -1;
+    }
+    return t;
+}
+constexpr int TREE_NR = TREE_DMAX + 1, TREE_RC = TREE_DMAX + 1;      // rows / columns of a frontal matrix (levels 0 .. TREE_DMAX), its right-hand-side column
+
+// level L: the nodes of depth L eliminate themselves, their parents (depth L - 1) assemble.  The update matrices travel through the
+// scratch (H itself is in registers by then and its staging area is free), two entries per 16-byte access, [pair][lane][2] - a store
+// per pair and a load per pair and child; a lane gather (two ds_bpermute per double, ~48 cycles for a lone wavefront) costs eight
+// times that.  All of it is one wavefront's own traffic: the LDS runs a wavefront's instructions in issue order, so a load behind a
+// store needs the compiler to keep the order (wavefront-scope fences, rmx_lane_sync), not a wait for the store.
+template <int L, int E>      // entry E of level L's update matrix: row E / (L + 1) + 1, column E % (L + 1) + 1 (the last one: the right-hand side)
+__device__ __forceinline__ double& tree_entry(double (&G)[TREE_NR][TREE_RC + 1], const int up) {
+    constexpr int k1 = E / (L + 1) + 1, kk = E % (L + 1);
+    return G[k1 - up][kk < L ? kk + 1 - up : TREE_RC];
+}
+template <int L, int P>
+__device__ __forceinline__ void tree_put(double (&G)[TREE_NR][TREE_RC + 1], double* __restrict__ X, const int lane) {
+    if constexpr (P < L * (L + 1) / 2) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<v2d*>(X + (P * 64 + lane) * 2) = v2d{tree_entry<L, 2 * P>(G, 0), tree_entry<L, 2 * P + 1>(G, 0)};
+        tree_put<L, P + 1>(G, X, lane);
+    }
+}
+template <int L, int P>
+__device__ __forceinline__ void tree_take(double (&G)[TREE_NR][TREE_RC + 1], const double* __restrict__ Xc, const double w) {
+    if constexpr (P < L * (L + 1) / 2) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d v = *reinterpret_cast<const v2d*>(Xc + P * 128);
+        double& a = tree_entry<L, 2 * P>(G, 1);
+        double& b = tree_entry<L, 2 * P + 1>(G, 1);
+        a = fma(w, v[0], a);
+        b = fma(w, v[1], b);
+        tree_take<L, P + 1>(G, Xc, w);
+    }
+}
+template <int L>
+__device__ __forceinline__ void tree_level(double (&G)[TREE_NR][TREE_RC + 1], const TreeLane& t, const int cmax, const int lane, double& rinv_own,
+                                           const double (&lim)[TREE_DMAX + 1], GrowGuard& gm, PivGuard& pg, double* __restrict__ X) {
+    const bool mine = t.depth == L;
+    const double piv = mine ? G[0][0] : 1.0;
+    const double rinv = recip(piv);
+    pg.see(piv, rinv);
+    rinv_own = mine ? rinv : rinv_own;
+    double l[L + 1];
+#pragma unroll
+    for (int k1 = 1; k1 <= L; ++k1) {
+        l[k1] = mine ? G[k1][0] * rinv : 0.0;
+        // l'^2 = l^2 u_kk / d_anc <= LU_GROWTH_MAX^2 with l^2 u_kk = a l (see lu_solve_neg_diag): compared per ancestor against its
+        // own bound, folded into one running maximum of the ratios' high words by scaling with 1 / lim
+        gm.see((G[k1][0] * l[k1]) * lim[k1]);
+    }
+#pragma unroll
+    for (int k1 = 1; k1 <= L; ++k1) {
+#pragma unroll
+        for (int k2 = 1; k2 <= L; ++k2) G[k1][k2] = fma(-l[k1], G[0][k2], G[k1][k2]);
+        G[k1][TREE_RC] = fma(-l[k1], G[0][TREE_RC], G[k1][TREE_RC]);
+    }
+    rmx_lane_sync();            // (behind the previous level's loads - or the reads of H)
+    tree_put<L, 0>(G, X, lane);
+    rmx_lane_sync();
+    // the parents take their children's update matrices, one level up
+    const bool par = t.depth == L - 1;
+#pragma unroll
+    for (int c = 0; c < TREE_CMAX; ++c) {
+        if (c < cmax) {
+            const bool has = par && t.child[c] >= 0;
+            tree_take<L, 0>(G, X + 2 * (has ? t.child[c] : lane), has ? 1.0 : 0.0);
+        }
+    }
+}
+// level L of the way down: every finished node's solution lies in the scratch ([lane]); the nodes of depth L read their ancestors'
+template <int L>
+__device__ __forceinline__ void tree_back(const double (&G)[TREE_NR][TREE_RC + 1], const TreeLane& t, const int lane, const double rinv_own,
+                                          double& x, double* __restrict__ X) {
+    const bool mine = t.depth == L;
+    double r = G[0][TREE_RC];
+#pragma unroll
+    for (int k = 1; k <= L; ++k) r = fma(-G[0][k], X[mine ? t.up[k] : lane], r);
+    if (mine) x = r * rinv_own;
+    rmx_lane_sync();
+    if (mine) X[lane] = x;
+    rmx_lane_sync();
+}
+// H and the right-hand side are in place: sAcc = [64][H64_STRIDE], row-major, column 64 = -g (as lu_solve_neg_diag64_staged takes them)
+__device__ __forceinline__ double tree_solve64(const DevModel& M, const int lane, double* sAcc, bool& ok) {
+    const double* sH = sAcc;                             // (H is read once, below; afterwards the scratch carries the update matrices)
+    const TreeLane t = tree_lane(M, lane);
+    const int dmax = M.tree_dmax, cmax = M.tree_cmax;
+    const bool act = t.depth >= 0;
+    double G[TREE_NR][TREE_RC + 1];
+    double lim[TREE_DMAX + 1];
+#pragma unroll
+    for (int a = 0; a < TREE_NR; ++a)
+#pragma unroll
+        for (int b = 0; b <= TREE_RC; ++b) G[a][b] = 0.0;
+    {
+        const double* row = sH + lane * H64_STRIDE;
+        G[0][0] = act ? row[lane] : 1.0;
+        G[0][TREE_RC] = act ? row[64] : 0.0;
+        lim[0] = 0.0;
+#pragma unroll
+        for (int k = 1; k <= TREE_DMAX; ++k) {
+            const int a = t.up[k];
+            const bool on = a >= 0;
+            const int aa = on ? a : lane;
+            G[0][k] = on ? row[aa] : 0.0;                                   // H(i, ancestor)
+            G[k][0] = on ? sH[aa * H64_STRIDE + lane] : 0.0;                // H(ancestor, i)
+            const double da = sH[aa * H64_STRIDE + aa];                     // the ancestor's own diagonal entry, as assembled
+            lim[k] = on ? recip((LU_GROWTH_MAX * LU_GROWTH_MAX) * da) : 0.0;
+        }
+    }
+    GrowGuard gm;
+    PivGuard pg;
+    double rinv_own = 1.0;
+    if (dmax >= 7) tree_level<7>(G, t, cmax, lane, rinv_own, lim, gm, pg, sAcc);
+    if (dmax >= 6) tree_level<6>(G, t, cmax, lane, rinv_own, lim, gm, pg, sAcc);
+    if (dmax >= 5) tree_level<5>(G, t, cmax, lane, rinv_own, lim, gm, pg, sAcc);
+    if (dmax >= 4) tree_level<4>(G, t, cmax, lane, rinv_own, lim, gm, pg, sAcc);
+    if (dmax >= 3) tree_level<3>(G, t, cmax, lane, rinv_own, lim, gm, pg, sAcc);
+    if (dmax >= 2) tree_level<2>(G, t, cmax, lane, rinv_own, lim, gm, pg, sAcc);
+    tree_level<1>(G, t, cmax, lane, rinv_own, lim, gm, pg, sAcc);
+    static_assert(TREE_DMAX == 7, "tree_solve64: one call per level");
+    // the root
+    double x = 0.0;
+    {
+        const bool root = t.depth == 0;
+        const double piv = root ? G[0][0] : 1.0;
+        const double rinv = recip(piv);
+        pg.see(piv, rinv);
+        rinv_own = root ? rinv : rinv_own;
+        x = root ? G[0][TREE_RC] * rinv : 0.0;
+        rmx_lane_sync();        // (behind level 1's loads)
+        sAcc[lane] = x;
+        rmx_lane_sync();
+    }
+    tree_back<1>(G, t, lane, rinv_own, x, sAcc);
+    if (dmax >= 2) tree_back<2>(G, t, lane, rinv_own, x, sAcc);
+    if (dmax >= 3) tree_back<3>(G, t, lane, rinv_own, x, sAcc);
+    if (dmax >= 4) tree_back<4>(G, t, lane, rinv_own, x, sAcc);
+    if (dmax >= 5) tree_back<5>(G, t, lane, rinv_own, x, sAcc);
+    if (dmax >= 6) tree_back<6>(G, t, lane, rinv_own, x, sAcc);
+    if (dmax >= 7) tree_back<7>(G, t, lane, rinv_own, x, sAcc);
+    // growth: the running maximum holds a_ik l / (64 d_anc), to stay at or below 1; pivots: every reciprocal positive and finite
+    ok = !__any(act && gm.bad(1.0)) && pg.ok();
+    return act ? x : 0.0;
+}
+
 #if RMX_W2
 // The solve as both waves of a workgroup call it (wave 0 from the Newton loop, wave 1 from w2_helper).
 struct W2Lu {
@@ -3312,6 +3496,18 @@ __device__ __forceinline__ W2Lu w2_lu_call() {
     return W2Lu{dx, ok ? 1 : 0};
 }
 #endif
+
+// the staged solve of the one-wave kernels: along the tree where the model has one to offer (DevModel::tree_dmax), else block columns
+__device__ __forceinline__ double solve64_staged(const DevModel& M, const int lane, double* sAcc, bool& ok) {
+    if (M.tree_dmax > 0) {
+        const double dx = tree_solve64(M, lane, sAcc, ok);
+        RMX_SYNC();                 // sAcc goes back to the front, whose subtree scan relies on a zero row n
+        if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
+        RMX_SYNC();
+        return dx;
+    }
+    return lu_solve_neg_diag64_staged(M.n, lane, sAcc, ok);
+}
 
 // the row-per-lane form of the interface (callers whose Hessian stage leaves H in registers)
 __device__ __forceinline__ double lu_solve_neg_diag64(const int n, const int lane, double* sAcc, const double (&Hrow)[64], const double g,
@@ -3561,7 +3757,7 @@ __device__ __forceinline__ double newton_impl(const DevModel& M, const DevOpts& 
                 // the matrix-core Hessian stage (evaluations without contact terms: eval_hess compiles it for !CT only) has left H and
                 // -g in the scratch; the v_readlane stage of the kernels with the contact terms hands the rows over in registers,
                 // whether or not a corner touches the ground at this iterate
-                if constexpr (HESS_MFMA64 && !CT) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
+                if constexpr (HESS_MFMA64 && !CT) dx = solve64_staged(M, lane, sAcc, lu_ok);
                 else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
             }
             else dx = lu_solve_neg_diag<NP>(lane, Hrow, e.g, hdiag, lu_ok);
@@ -3831,14 +4027,18 @@ __device__ __forceinline__ double newton_rot(const DevModel& M, const DevOpts& o
             if constexpr (NP == 32 && LU_SPLIT32) dx = lu_solve_neg_diag32(M.n, lane, sAcc, e.g, lu_ok);
             else if constexpr (NP == 64 && LU_SPLIT64) {
 #if RMX_W2
-                const W2Lu r = w2_lu_call();
-                dx = r.dx;
-                lu_ok = r.ok != 0;
+                if (M.tree_dmax > 0) {   // (the helper wave stays out of this one: w2_helper)
+                    dx = tree_solve64(M, lane, sAcc, lu_ok);
+                } else {
+                    const W2Lu r = w2_lu_call();
+                    dx = r.dx;
+                    lu_ok = r.ok != 0;
+                }
                 RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
                 if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
                 RMX_SYNC();
 #else
-                if constexpr (HESS_MFMA64) dx = lu_solve_neg_diag64_staged(M.n, lane, sAcc, lu_ok);
+                if constexpr (HESS_MFMA64) dx = solve64_staged(M, lane, sAcc, lu_ok);
                 else dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
 #endif
             }

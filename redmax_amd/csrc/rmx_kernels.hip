@@ -150,7 +150,7 @@ __device__ __forceinline__ void w2_helper(const DevModel& M, double* __restrict_
             w2_store_half<1>(sAcc, lane, h1);
             RMX_WG_BAR();
 #if RMX_W2
-            (void)w2_lu_call();
+            if (M.tree_dmax == 0) (void)w2_lu_call();      // (a branching tree's solve runs along the tree, on wave 0 alone: tree_solve64)
 #endif
         }
     }
@@ -308,9 +308,13 @@ __device__ __forceinline__ int w2_steps_bdf1(const DevModel& M, const DevOpts& o
         {
             bool lu_ok;
             if constexpr (NP == 64) {
-                const W2Lu r = w2_lu_call();
-                dx = r.dx;
-                lu_ok = r.ok != 0;
+                if (M.tree_dmax > 0) {   // (a branching tree: along the tree, this wave alone - w2_helper skips the solve)
+                    dx = tree_solve64(M, lane, sAcc, lu_ok);
+                } else {
+                    const W2Lu r = w2_lu_call();
+                    dx = r.dx;
+                    lu_ok = r.ok != 0;
+                }
                 RMX_SYNC();             // sAcc goes back to the front, whose subtree scan relies on a zero row n
                 if (lane < ACC_STRIDE) sAcc[M.n * ACC_STRIDE + lane] = 0.0;
                 RMX_SYNC();
@@ -1240,7 +1244,18 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
         double dx;
         if constexpr (NP == 64 && LU_SPLIT64) {      // the guarded solve the step kernels run (33..64 rows)
             bool lu_ok;
-            dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
+            if (M.tree_dmax > 0) {                    // a branching tree: along the tree (the staging of H is the Hessian stage's in the step kernels)
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                v2d* w = reinterpret_cast<v2d*>(sAcc + lane * H64_STRIDE);
+#pragma unroll
+                for (int c = 0; c < 32; ++c) w[c] = v2d{Hrow[2 * c], Hrow[2 * c + 1]};
+                sAcc[lane * H64_STRIDE + 64] = -e.g;
+                RMX_SYNC();
+                t2 = __builtin_amdgcn_s_memtime();
+                dx = solve64_staged(M, lane, sAcc, lu_ok);
+            } else {
+                dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
+            }
             sink += lu_ok ? 0.0 : 1.0;
         } else {
             dx = lu_solve_neg<NP, true>(M.n, lane, Hrow, e.g);
