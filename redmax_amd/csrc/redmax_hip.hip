@@ -376,7 +376,7 @@ static int model_create_flat(const rmx_model_desc* d, const int* idx_explicit, c
         if (ok) {
             for (int k = 0; k < n; ++k) {
                 tree[k] = dep[k];
-                for (int t = par[k]; t >= 0; t = par[t]) tree[(size_t)(1 + dep[t]) * NS + k] = t;
+                { int lv = 1; for (int t = par[k]; t >= 0; t = par[t], ++lv) tree[(size_t)lv * NS + k] = t; }      // row lv: the ancestor lv levels up
                 tree[(size_t)(1 + TREE_DMAX + TREE_CMAX) * NS + k] = par[k];
             }
         }

@@ -3329,10 +3329,7 @@ __device__ __forceinline__ TreeLane tree_lane(const DevModel& M, const int lane)
     for (int c = 0; c < TREE_CMAX; ++c) t.child[c] = T[(1 + TREE_DMAX + c) * MAXN];
     t.up[0] = lane;
 #pragma unroll
-    for (int k = 1; k <= TREE_DMAX; ++k) {
-        const int e = t.depth - k;                           // depth of that ancestor
-        t.up[k] = e >= 0 ? T[(1 + e) * MAXN] : -1;
-    }
+    for (int k = 1; k <= TREE_DMAX; ++k) t.up[k] = T[k * MAXN];      // (-1 beyond the root; every load independent of the others)
     return t;
 }
 constexpr int TREE_NR = TREE_DMAX + 1, TREE_RC = TREE_DMAX + 1;      // rows / columns of a frontal matrix (levels 0 .. TREE_DMAX), its right-hand-side column
@@ -3355,16 +3352,32 @@ __device__ __forceinline__ void tree_put(double (&G)[TREE_NR][TREE_RC + 1], doub
         tree_put<L, P + 1>(G, X, lane);
     }
 }
-template <int L, int P>
+// (the loads of a child's pairs in groups of TREE_GRP, every load of a group in flight before its first use: left alone, the compiler
+// gives every load the same destination registers and waits for each - 112 LDS round trips per solve, 14 k cycles of its 16 k)
+constexpr int TREE_GRP = 8;
+typedef double tree_v2d __attribute__((ext_vector_type(2)));
+template <int L, int P0, int I, int N>
+__device__ __forceinline__ void tree_take_fma(double (&G)[TREE_NR][TREE_RC + 1], const tree_v2d (&v)[TREE_GRP], const double w) {
+    if constexpr (I < N) {
+        double& a = tree_entry<L, 2 * (P0 + I)>(G, 1);
+        double& b = tree_entry<L, 2 * (P0 + I) + 1>(G, 1);
+        a = fma(w, v[I][0], a);
+        b = fma(w, v[I][1], b);
+        tree_take_fma<L, P0, I + 1, N>(G, v, w);
+    }
+}
+template <int L, int P0>
 __device__ __forceinline__ void tree_take(double (&G)[TREE_NR][TREE_RC + 1], const double* __restrict__ Xc, const double w) {
-    if constexpr (P < L * (L + 1) / 2) {
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        const v2d v = *reinterpret_cast<const v2d*>(Xc + P * 128);
-        double& a = tree_entry<L, 2 * P>(G, 1);
-        double& b = tree_entry<L, 2 * P + 1>(G, 1);
-        a = fma(w, v[0], a);
-        b = fma(w, v[1], b);
-        tree_take<L, P + 1>(G, Xc, w);
+    constexpr int NPAIR = L * (L + 1) / 2;
+    if constexpr (P0 < NPAIR) {
+        constexpr int N = NPAIR - P0 < TREE_GRP ? NPAIR - P0 : TREE_GRP;
+        tree_v2d v[TREE_GRP];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = *reinterpret_cast<const tree_v2d*>(Xc + (P0 + i) * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        tree_take_fma<L, P0, 0, N>(G, v, w);
+        __builtin_amdgcn_sched_barrier(0);
+        tree_take<L, P0 + TREE_GRP>(G, Xc, w);
     }
 }
 template <int L>
@@ -3407,9 +3420,13 @@ template <int L>
 __device__ __forceinline__ void tree_back(const double (&G)[TREE_NR][TREE_RC + 1], const TreeLane& t, const int lane, const double rinv_own,
                                           double& x, double* __restrict__ X) {
     const bool mine = t.depth == L;
+    double v[L + 1];
+#pragma unroll
+    for (int k = 1; k <= L; ++k) v[k] = X[mine ? t.up[k] : lane];
+    __builtin_amdgcn_sched_barrier(0);      // (every load in flight before the first use: see tree_take)
     double r = G[0][TREE_RC];
 #pragma unroll
-    for (int k = 1; k <= L; ++k) r = fma(-G[0][k], X[mine ? t.up[k] : lane], r);
+    for (int k = 1; k <= L; ++k) r = fma(-G[0][k], v[k], r);
     if (mine) x = r * rinv_own;
     rmx_lane_sync();
     if (mine) X[lane] = x;
@@ -3432,15 +3449,21 @@ __device__ __forceinline__ double tree_solve64(const DevModel& M, const int lane
         G[0][0] = act ? row[lane] : 1.0;
         G[0][TREE_RC] = act ? row[64] : 0.0;
         lim[0] = 0.0;
+        double hr[TREE_DMAX + 1], hc[TREE_DMAX + 1], hd[TREE_DMAX + 1];
 #pragma unroll
         for (int k = 1; k <= TREE_DMAX; ++k) {
-            const int a = t.up[k];
-            const bool on = a >= 0;
-            const int aa = on ? a : lane;
-            G[0][k] = on ? row[aa] : 0.0;                                   // H(i, ancestor)
-            G[k][0] = on ? sH[aa * H64_STRIDE + lane] : 0.0;                // H(ancestor, i)
-            const double da = sH[aa * H64_STRIDE + aa];                     // the ancestor's own diagonal entry, as assembled
-            lim[k] = on ? recip((LU_GROWTH_MAX * LU_GROWTH_MAX) * da) : 0.0;
+            const int aa = t.up[k] >= 0 ? t.up[k] : lane;
+            hr[k] = row[aa];                                                // H(i, ancestor)
+            hc[k] = sH[aa * H64_STRIDE + lane];                             // H(ancestor, i)
+            hd[k] = sH[aa * H64_STRIDE + aa];                               // the ancestor's own diagonal entry, as assembled
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (every load in flight before the first use: see tree_take)
+#pragma unroll
+        for (int k = 1; k <= TREE_DMAX; ++k) {
+            const bool on = t.up[k] >= 0;
+            G[0][k] = on ? hr[k] : 0.0;
+            G[k][0] = on ? hc[k] : 0.0;
+            lim[k] = on ? recip((LU_GROWTH_MAX * LU_GROWTH_MAX) * hd[k]) : 0.0;
         }
     }
     GrowGuard gm;
@@ -3475,7 +3498,8 @@ __device__ __forceinline__ double tree_solve64(const DevModel& M, const int lane
     if (dmax >= 6) tree_back<6>(G, t, lane, rinv_own, x, sAcc);
     if (dmax >= 7) tree_back<7>(G, t, lane, rinv_own, x, sAcc);
     // growth: the running maximum holds a_ik l / (64 d_anc), to stay at or below 1; pivots: every reciprocal positive and finite
-    ok = !__any(act && gm.bad(1.0)) && pg.ok();
+    // (pivots are per lane here - every node has its own -, so both halves of the verdict are taken over the wavefront)
+    ok = !__any(act && (gm.bad(1.0) || !pg.ok()));
     return act ? x : 0.0;
 }
 

@@ -1045,10 +1045,25 @@ __device__ __forceinline__ void adj_block(double& y, const double* __restrict__ 
                                           const int col, const double cm, const double cdh, const double z) {
     const double* Mc = Mj + (size_t)col * n;
     const double* Dc = Dj + (size_t)col * n;
+    // Every load of the column before its first use, none of them under a lane condition (index and column clamped into the block,
+    // the padding selected afterwards): guarded by `j < n && lane < n` each load sat in its own exec-masked block with a full wait
+    // behind it - 32 dependent round trips per block and step, most of the backward kernel's time.
+    double mc[NP], dc[NP];
+    const bool withD = cdh != 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) mc[j] = Mc[j < n ? j : 0];
+    if (withD) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dc[j] = Dc[j < n ? j : 0];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dc[j] = 0.0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         double blk = 0.0;
-        if (j < n && lane < n) blk = cdh != 0.0 ? (cm * Mc[j] + cdh * Dc[j]) : cm * Mc[j];
+        if (j < n && lane < n) blk = withD ? (cm * mc[j] + cdh * dc[j]) : cm * mc[j];
         y -= blk * readlane_d(z, j);
     }
 }
@@ -1087,13 +1102,20 @@ __global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevO
         // z_k = H_k'^-1 y_k  (zkk0(Hp) = Hl'\(Hu'\yk) :76): this lane's "row" of H' is column `lane` of H
         double Hrow[NP];
         const double* Hc = a.Hs + ((size_t)traj * a.nsteps + (k - 1)) * nn + (size_t)col * n;
+        {   // (unconditional loads, all in flight together: see adj_block)
+            double hv[NP];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? Hc[i] : ((i == lane) ? 1.0 : 0.0);
+            for (int i = 0; i < NP; ++i) hv[i] = Hc[i < n ? i : 0];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) Hrow[i] = (i < n && lane < n) ? hv[i] : ((i == lane) ? 1.0 : 0.0);
+        }
         double z;
         if constexpr (NP <= 32 && !RMX_ADJ_BWD_PIVOT) {
             // as in the forward sweep: diagonal pivots under the growth guard first (a third of the instructions of the pivot search; H'
             // is as close to symmetric positive definite as H), partial pivoting on a fresh copy of the rows when the guard trips
-            const double hd = lane < n ? Hc[col] : 1.0;
+            const double hdl = Hc[col];
+            const double hd = lane < n ? hdl : 1.0;
             bool lu_ok;
             z = lu_solve_neg_diag<NP>(lane, Hrow, -y, hd, lu_ok);
             if (!lu_ok) {
