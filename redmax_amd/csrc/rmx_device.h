@@ -1211,8 +1211,14 @@ __device__ __forceinline__ void eval_front_e2(const DevModel& M, double* __restr
             if (!M.is_chain) {
                 const int en = (int)cEnd[jc];
                 const double* E = sAcc + en * AS;
+                // (every load in flight before the first subtraction: written as S[c] -= E[c] the compiler gives the loads ONE
+                // destination register and a full wait each - 28 LDS round trips, 1.5 k cycles per evaluation of a branching tree)
+                double ev[NS];
 #pragma unroll
-                for (int c = 0; c < NS; ++c) S[c] -= E[c];
+                for (int c = 0; c < NS; ++c) ev[c] = E[c];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < NS; ++c) S[c] -= ev[c];
             }
         }
         RMX_SYNC();   // sAcc is rewritten by the next evaluation
