@@ -2411,6 +2411,16 @@ __device__ __forceinline__ double eval_hess(const DevModel& M, const int lane, c
             for (int c = 6; c < 18; ++c) o[(H64_R_CL + c - 6) * ST] = cv[c];
             o[H64_R_HD * ST] = Hdiag;
         }
+        if constexpr (!ZERO_IDLE) {
+            if (M.tree_dmax > 0) {
+                // a branching tree whose solve runs along the tree (tree_solve64): it needs H(i, ancestor) and H(ancestor, i) only -
+                // 592 of configs[2]'s 4 096 entries - and forms them from these operands itself: no matrix products, no H in
+                // LDS, and no second wavefront in the stage.  The right-hand side -g rides in the row behind the operands.
+                sOp[H64_OP_ROWS * ST + lane] = -g_stage;
+                RMX_SYNC();
+                return Hdiag;
+            }
+        }
         const double* cRel = RMX_CONSTS(sAcc, M.n, NP) + (36 + 6 + 4 + 8 + 1) * CS;
         if constexpr (RMX_W2 && !ZERO_IDLE) {
             // two waves (w2_helper is the other one): this wave takes the even columns, the helper the odd ones
@@ -3438,7 +3448,7 @@ __device__ __forceinline__ void tree_back(const double (&G)[TREE_NR][TREE_RC + 1
     if (mine) X[lane] = x;
     rmx_lane_sync();
 }
-// H and the right-hand side are in place: sAcc = [64][H64_STRIDE], row-major, column 64 = -g (as lu_solve_neg_diag64_staged takes them)
+// The Hessian stage's operands and the right-hand side are in place (eval_hess, the tree_dmax > 0 exit): sAcc = [H64_OP_ROWS + 1][H64_OP_STRIDE]
 __device__ __forceinline__ double tree_solve64(const DevModel& M, const int lane, double* sAcc, bool& ok) {
     const double* sH = sAcc;                             // (H is read once, below; afterwards the scratch carries the update matrices)
     const TreeLane t = tree_lane(M, lane);
@@ -3451,25 +3461,45 @@ __device__ __forceinline__ double tree_solve64(const DevModel& M, const int lane
 #pragma unroll
         for (int b = 0; b <= TREE_RC; ++b) G[a][b] = 0.0;
     {
-        const double* row = sH + lane * H64_STRIDE;
-        G[0][0] = act ? row[lane] : 1.0;
-        G[0][TREE_RC] = act ? row[64] : 0.0;
+        // The entries of H this node's frontal matrix starts from, straight from the Hessian stage's operands ([k][node] rows of the
+        // scratch, eval_hess): with a an ancestor of i,  H(i, a) = RL_i . CL_a  (12 terms: the `lo` product of the row of i with the
+        // column of a) and  H(a, i) = RU_a . CU_i  (6 terms: the `up` product of the row of a with the column of i); the diagonal
+        // travels as its own row.  One group of 19 loads per ancestor, all in flight before their first use.
+        constexpr int ST = H64_OP_STRIDE;
+        double rl[12], cu[6];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) rl[c] = sH[(H64_R_RL + c) * ST + lane];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cu[c] = sH[(H64_R_CU + c) * ST + lane];
+        const double hd0 = sH[H64_R_HD * ST + lane], rhs = sH[H64_OP_ROWS * ST + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        G[0][0] = act ? hd0 : 1.0;
+        G[0][TREE_RC] = act ? rhs : 0.0;
         lim[0] = 0.0;
-        double hr[TREE_DMAX + 1], hc[TREE_DMAX + 1], hd[TREE_DMAX + 1];
 #pragma unroll
         for (int k = 1; k <= TREE_DMAX; ++k) {
-            const int aa = t.up[k] >= 0 ? t.up[k] : lane;
-            hr[k] = row[aa];                                                // H(i, ancestor)
-            hc[k] = sH[aa * H64_STRIDE + lane];                             // H(ancestor, i)
-            hd[k] = sH[aa * H64_STRIDE + aa];                               // the ancestor's own diagonal entry, as assembled
-        }
-        __builtin_amdgcn_sched_barrier(0);      // (every load in flight before the first use: see tree_take)
+            if (k <= dmax) {
+                const bool on = t.up[k] >= 0;
+                const int aa = on ? t.up[k] : lane;
+                double cl[12], ru[6];
 #pragma unroll
-        for (int k = 1; k <= TREE_DMAX; ++k) {
-            const bool on = t.up[k] >= 0;
-            G[0][k] = on ? hr[k] : 0.0;
-            G[k][0] = on ? hc[k] : 0.0;
-            lim[k] = on ? recip((LU_GROWTH_MAX * LU_GROWTH_MAX) * hd[k]) : 0.0;
+                for (int c = 0; c < 12; ++c) cl[c] = sH[(H64_R_CL + c) * ST + aa];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ru[c] = sH[(H64_R_RU + c) * ST + aa];
+                const double hda = sH[H64_R_HD * ST + aa];
+                __builtin_amdgcn_sched_barrier(0);
+                double lo = rl[0] * cl[0];
+#pragma unroll
+                for (int c = 1; c < 12; ++c) lo = fma(rl[c], cl[c], lo);
+                double up = ru[0] * cu[0];
+#pragma unroll
+                for (int c = 1; c < 6; ++c) up = fma(ru[c], cu[c], up);
+                G[0][k] = on ? lo : 0.0;                                    // H(i, ancestor)
+                G[k][0] = on ? up : 0.0;                                    // H(ancestor, i)
+                lim[k] = on ? recip((LU_GROWTH_MAX * LU_GROWTH_MAX) * hda) : 0.0;
+            } else {
+                lim[k] = 0.0;
+            }
         }
     }
     GrowGuard gm;

@@ -1261,19 +1261,21 @@ __global__ void __launch_bounds__(64) k_phase_time(const DevModel M, const int r
         eval_node<NP, false>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow);
         sink += e.g;
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        eval_node<NP, true, true>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow, stamps);
+        bool staged = false;
+        if constexpr (NP == 64 && LU_SPLIT64 && HESS_MFMA64) {
+            if (M.tree_dmax > 0) {                    // a branching tree: the Hessian stage as the step kernels run it (operands staged for tree_solve64)
+                FrontState fs;
+                eval_front<NP, true, true, false>(M, sAcc, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, fs, stamps);
+                (void)eval_hess<NP, false, false, false>(M, lane, fs, Hrow, nullptr, sAcc, e.g);
+                staged = true;
+            }
+        }
+        if (!staged) eval_node<NP, true, true>(M, sAcc, sCol, lane, x, (x - q0) / h, x - (q0 + h * qd0), h, e, Hrow, stamps);
         unsigned long long t2 = __builtin_amdgcn_s_memtime();
         double dx;
         if constexpr (NP == 64 && LU_SPLIT64) {      // the guarded solve the step kernels run (33..64 rows)
             bool lu_ok;
-            if (M.tree_dmax > 0) {                    // a branching tree: along the tree (the staging of H is the Hessian stage's in the step kernels)
-                typedef double v2d __attribute__((ext_vector_type(2)));
-                v2d* w = reinterpret_cast<v2d*>(sAcc + lane * H64_STRIDE);
-#pragma unroll
-                for (int c = 0; c < 32; ++c) w[c] = v2d{Hrow[2 * c], Hrow[2 * c + 1]};
-                sAcc[lane * H64_STRIDE + 64] = -e.g;
-                RMX_SYNC();
-                t2 = __builtin_amdgcn_s_memtime();
+            if (M.tree_dmax > 0) {                    // a branching tree: along the tree
                 dx = solve64_staged(M, lane, sAcc, lu_ok);
             } else {
                 dx = lu_solve_neg_diag64(M.n, lane, sAcc, Hrow, e.g, lu_ok);
