@@ -95,7 +95,8 @@ def test_extra_workload_default_signature_uses_the_counter_totals():
     d = _run("--workload", "tree64", "--no-side-legs", "--repeats", "0")
     r = d["roofline"]
     assert "counter totals of this very launch" in r["executed_flops_from"], r["executed_flops_from"]
-    assert 0 < r["useful_frac"] < r["frac"] <= 1
+    # (<=: on this branching tree the kernels execute FEWER flops than the dense scalar twin behind `useful` needs, and bench.py caps)
+    assert 0 < r["useful_frac"] <= r["frac"] <= 1
 
 
 def test_adjoint_workload_line():
