@@ -6,12 +6,12 @@ import numpy as np
 import pytest
 
 from redmax_amd import se3
-from redmax_amd.redmax import BodyCuboid, JointPrismatic, JointRevolute, Scene
+from redmax_amd.redmax import BodyCuboid, JointFixed, JointPrismatic, JointRevolute, Scene
 
 pytestmark = pytest.mark.gpu
 
 
-def _tree_scene(seed, n, max_depth, max_children):
+def _tree_scene(seed, n, max_depth, max_children, fixed=False):
     rng = np.random.default_rng(seed)
     # the shape first (a random parent among the nodes that can still take a child), then the depth-first listing the scene needs
     par, dep, nch = [-1], [0], [0]
@@ -31,7 +31,10 @@ def _tree_scene(seed, n, max_depth, max_children):
     for i in order:
         body = BodyCuboid(float(rng.uniform(0.5, 2.0)), rng.uniform(0.5, 3.0, 3))
         parent = joint_of[par[i]] if par[i] >= 0 else None
-        if rng.random() < 0.75:
+        kind = rng.random()
+        if fixed and par[i] >= 0 and kind < 0.12:
+            j = JointFixed(parent, body)                  # (a node without a DOF: unit diagonal, no coupling)
+        elif kind < 0.75:
             j = JointRevolute(parent, body, rng.normal(size=3))
         else:
             j = JointPrismatic(parent, body, rng.normal(size=3))
@@ -40,8 +43,9 @@ def _tree_scene(seed, n, max_depth, max_children):
         body.setBodyTransform(se3.transform(R=se3.aaToMat(rng.normal(size=3), rng.uniform(-1, 1)), p=rng.uniform(-2, 2, 3)))
         if rng.random() < 0.4:
             j.setDamping(float(rng.uniform(1e1, 1e3)))
-        j.q[:1] = rng.uniform(-0.3, 0.3, 1)
-        j.qdot[:1] = rng.uniform(-1, 1, 1)
+        if j.ndof:
+            j.q[:1] = rng.uniform(-0.3, 0.3, 1)
+            j.qdot[:1] = rng.uniform(-1, 1, 1)
         joint_of[i] = j
         sc.bodies.append(body)
         sc.joints.append(j)
@@ -62,8 +66,9 @@ def _run(sc, q0, qd0, integ, K, monkeypatch, tree):
 
 @pytest.mark.parametrize("seed,n,max_depth,max_children", [(1, 64, 7, 2), (2, 64, 5, 4), (3, 33, 3, 4), (4, 50, 6, 3), (5, 47, 7, 4), (6, 64, 3, 4)])
 def test_tree_solve_agrees_with_the_dense_solve_and_the_oracle(oracle_lib, seed, n, max_depth, max_children, monkeypatch):
-    sc, dmax, cmax = _tree_scene(seed, n, max_depth, max_children)
-    assert 1 <= dmax <= 7 and cmax <= 4 and sc.nr == n
+    sc, dmax, cmax = _tree_scene(seed, n, max_depth, max_children, fixed=seed % 2 == 0)      # even seeds: some JointFixed nodes
+    assert 1 <= dmax <= 7 and cmax <= 4 and sc.nr <= n
+    n = sc.nr
     rng = np.random.default_rng(seed + 50)
     B, K = 3, 6
     q0 = np.tile(sc.getQ()[0], (B, 1)) + rng.uniform(-0.05, 0.05, (B, n))
