@@ -801,9 +801,12 @@ __device__ __forceinline__ void adj_md_helper(const DevModel& M, const AdjArgs& 
     }
 }
 
-template <int NP, int INTEG, bool HELP = false>
-__global__ void __launch_bounds__(HELP ? 128 : 64) k_adjoint_fwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+// FC: a serial chain that fills every node slot (is_chain && n == NP, decided by the launcher): the two model facts as compile-time
+// constants (model_view), as in the FULLCHAIN step kernels - no tree paths in the front, no per-row bounds
+template <int NP, int INTEG, bool HELP = false, bool FC = false>
+__global__ void __launch_bounds__(HELP ? 128 : 64) k_adjoint_fwd(const DevModel Min, const DevOpts o, const AdjArgs a) {
     static_assert(!HELP || NP <= 16, "the helper-wave form: trees of one DPP row");
+    const DevModel M = model_view<NP, FC>(Min);
     double *sAcc, *sCol;
     smem_setup<NP>(M, sAcc, sCol);
     double* hand = nullptr;
@@ -1071,8 +1074,9 @@ __device__ __forceinline__ void adj_block(double& y, const double* __restrict__ 
 #ifndef RMX_ADJ_BWD_PIVOT
 #define RMX_ADJ_BWD_PIVOT 0          // 1: the backward sweep's solves with the pivot search always (build variants)
 #endif
-template <int NP, int INTEG>
-__global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel M, const DevOpts o, const AdjArgs a) {
+template <int NP, int INTEG, bool FC = false>
+__global__ void __launch_bounds__(64) k_adjoint_bwd(const DevModel Min, const DevOpts o, const AdjArgs a) {
+    const DevModel M = model_view<NP, FC>(Min);
     const int lane = threadIdx.x, traj = blockIdx.x, n = M.n;
     const int id = (lane < n) ? M.idx[lane] : -1;
     const size_t nn = (size_t)n * n;
@@ -1866,7 +1870,13 @@ void launch_step_pairchain_32(const rmx_model* m, const rmx_batch* b, const DevO
 void launch_adjoint_help_16(const rmx_model* m, const rmx_batch* b, int integ, const DevOpts& o, const AdjArgs& a) {
     const dim3 grid(b->B);
     const size_t smem_bytes = m->smem_bytes + sizeof(double) * adj_hand_doubles(RMX_NP);
-    if (integ == INTEG_BDF1) {
+    if (integ == INTEG_BDF1 && m->dm.is_chain && m->dm.n == RMX_NP) {      // (configs[3]: the full 16-link chain)
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 1, true, true>), grid, dim3(128), smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 1, true><<<grid, dim3(64), 0, b->stream>>>(m->dm, o, a);
+    } else if (m->dm.is_chain && m->dm.n == RMX_NP) {
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 2, true, true>), grid, dim3(128), smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 2, true><<<grid, dim3(64), 0, b->stream>>>(m->dm, o, a);
+    } else if (integ == INTEG_BDF1) {
         RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 1, true>), grid, dim3(128), smem_bytes, b->stream, m->dm, o, a);
         k_adjoint_bwd<RMX_NP, 1><<<grid, dim3(64), 0, b->stream>>>(m->dm, o, a);
     } else {
@@ -1989,6 +1999,18 @@ void RMX_CAT(launch_adjoint_, RMX_NP)(const rmx_model* m, const rmx_batch* b, in
     {
         const char* ah = getenv("RMX_ADJ_HELP");      // (read at every call: tests switch it inside one process)
         if (!(ah && atoi(ah) == 0) && m->adj_help_max_batch > 0 && b->B <= m->adj_help_max_batch) return launch_adjoint_help_16(m, b, integ, o, a);
+    }
+#endif
+#if RMX_NP == 16
+    if (integ == INTEG_BDF1 && m->dm.is_chain && m->dm.n == RMX_NP) {      // the full 16-link chain: the instantiation RMX_PART 8 runs with its helper wave
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 1, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 1, true><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+        return;
+    }
+    if (m->dm.is_chain && m->dm.n == RMX_NP) {
+        RMX_LAUNCH((k_adjoint_fwd<RMX_NP, 2, false, true>), grid, block, m->smem_bytes, b->stream, m->dm, o, a);
+        k_adjoint_bwd<RMX_NP, 2, true><<<grid, block, 0, b->stream>>>(m->dm, o, a);
+        return;
     }
 #endif
     if (integ == INTEG_BDF1) {

@@ -14,10 +14,10 @@ ROWS = (  # (name fragment, what it runs)
     ("k_ground32", "configs[4]: 32-link chain on frictional ground, BDF2, rollouts + cooperative groups in one launch"),
     ("k_step_pair<false>", "the same as separate launches: rollouts"),
     ("k_step_pair<true>", "... and cooperative groups"),
-    ("k_adjoint_fwd<16, 1, true>", "configs[3]: adjoint BDF1 forward sweep, 16 nodes, second wavefront for M, D (<= 512 rollouts)"),
-    ("k_adjoint_fwd<16, 1, false>", "the same, one wavefront per rollout (larger batches)"),
-    ("k_adjoint_bwd<16, 1>", "configs[3]: backward sweep"),
-    ("k_adjoint_fwd<64, 1, false>", "adjoint forward, 33..64 nodes"),
+    ("k_adjoint_fwd<16, 1, true, true>", "configs[3]: adjoint BDF1 forward sweep, full 16-link chain, second wavefront for M, D (<= 512 rollouts)"),
+    ("k_adjoint_fwd<16, 1, false, true>", "the same, one wavefront per rollout (larger batches)"),
+    ("k_adjoint_bwd<16, 1, true>", "configs[3]: backward sweep"),
+    ("k_adjoint_fwd<64, 1, false, false>", "adjoint forward, 33..64 nodes"),
     ("k_step_bdf1<32, true, false, false, 0>", "generic contact / Euler-chart kernel, <= 32 nodes, BDF1"),
     ("k_step_bdf2<32, true, false, false, 0>", "generic contact / Euler-chart kernel, <= 32 nodes, BDF2"),
     ("k_big_step", "trees of 65..256 nodes (one workgroup per rollout)"),
