@@ -3325,10 +3325,12 @@ __device__ __forceinline__ double lu_solve_neg_diag64_staged(const int n, const 
 // ancestors, G[k1][k2] with k = levels above i (0 = i itself) - row 0 = H(i, ancestors), column 0 = H(ancestors, i), the rest the
 // updates its subtree has accumulated for its ancestors - and the right-hand side rides along as one more column.  Lane = node; ALL
 // nodes of a depth level are eliminated at once (they share no unknown), then every parent adds its children's update matrices
-// (shifted by one level) to its own, children in listing order: depth rounds of at most (d + 1)(d + 2) fused multiply-adds and
-// lane gathers per node instead of 64 pivot steps over 64 x 64 - the 64-joint tree of configs[2] (depth 6, 592 of 4096 entries
-// non-zero): ~1.1 k instructions and 6 dependent levels against 4 k instructions and 64 dependent pivots.  The back substitution
-// walks down: a node takes its ancestors' solutions from its parent.  Guards as in the dense solve (every pivot positive and finite,
+// (shifted by one level, handed over through the scratch) to its own, children in listing order: depth rounds of at most
+// (d + 1)(d + 2) fused multiply-adds per node instead of 64 pivot steps over 64 x 64 - the 64-joint tree of configs[2] (depth 6,
+// 592 of 4096 entries non-zero): ~1.1 k instructions and 6 dependent levels against 4 k instructions and 64 dependent pivots.  The
+// back substitution walks down: a node reads its ancestors' solutions from the scratch.  The entries of H themselves are formed here,
+// from the Hessian stage's staged row and column vectors (2 x depth dot products per node): no H matrix exists on this path.
+// Guards as in the dense solve (every pivot positive and finite,
 // every multiplier of the equilibrated matrix below LU_GROWTH_MAX); a tripped guard sends the caller to the pivoting dense solve.
 // Not the dense solve's elimination order, hence not its rounding: results agree with it to roundoff, not bit for bit.
 struct TreeLane {
